@@ -1,0 +1,102 @@
+"""Seeded synthetic inputs for the hot path.
+
+The reference ships no fixtures for its parsers or its engine, so parity tests and
+bench.py feed the GPU path and the CPU oracle with the SAME seeded synthetic tensors built here:
+
+* ``paf_maps``  — conf ``[B,19,H,W]`` + paf ``[B,38,H,W]`` heat-maps of N posed 18-joint COCO skeletons,
+  laid out exactly as ``hyperpose::parser::paf::process`` consumes them (reference src/paf.cpp:300-312;
+  limb/channel tables src/coco.hpp:10-51).
+* ``images_u8`` — uniform u8 HWC BGR frames, the input of ``dnn::tensorrt::inference``
+  (reference src/tensorrt.cpp:436-461).
+
+Only numpy is used; nothing here touches the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# reference src/coco.hpp:10-30 (PAF channel pairs) and :32-51 (part index pairs)
+COCOPAIRS_NET = [(12, 13), (20, 21), (14, 15), (16, 17), (22, 23), (24, 25), (0, 1), (2, 3), (4, 5), (6, 7),
+                 (8, 9), (10, 11), (28, 29), (30, 31), (34, 35), (32, 33), (36, 37), (18, 19), (26, 27)]
+COCOPAIRS = [(1, 2), (1, 5), (2, 3), (3, 4), (5, 6), (6, 7), (1, 8), (8, 9), (9, 10), (1, 11), (11, 12),
+             (12, 13), (1, 0), (0, 14), (14, 16), (0, 15), (15, 17), (2, 16), (5, 17)]
+
+# 18-joint COCO template (x right, y down), body height ~ 1.
+# nose neck Rsho Relb Rwri Lsho Lelb Lwri Rhip Rkne Rank Lhip Lkne Lank Reye Leye Rear Lear
+_TEMPLATE = np.array([
+    (0.00, -0.40), (0.00, -0.30), (-0.12, -0.30), (-0.17, -0.12), (-0.19, 0.04), (0.12, -0.30),
+    (0.17, -0.12), (0.19, 0.04), (-0.07, 0.05), (-0.08, 0.28), (-0.08, 0.50), (0.07, 0.05),
+    (0.08, 0.28), (0.08, 0.50), (-0.04, -0.44), (0.04, -0.44), (-0.08, -0.41), (0.08, -0.41),
+], dtype=np.float64)
+
+
+def rng_for(config_index: int, salt: int = 0) -> np.random.Generator:
+    """numpy.random.Generator(PCG64(20240 + config index)); ``salt`` separates streams."""
+    return np.random.Generator(np.random.PCG64(20240 + config_index + 1000 * salt))
+
+
+def skeletons(rng: np.random.Generator, n_people: int, rows: int, cols: int,
+              scale_range=(14.0, 34.0), jitter=0.03) -> np.ndarray:
+    """``[n_people,18,2]`` continuous (x=col, y=row) joint positions in feature-map pixels."""
+    out = np.zeros((n_people, 18, 2))
+    for p in range(n_people):
+        s = rng.uniform(*scale_range)
+        th = rng.uniform(-0.5, 0.5)
+        rot = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        pts = (_TEMPLATE + rng.normal(0, jitter, _TEMPLATE.shape)) @ rot.T * s
+        lo, hi = pts.min(0), pts.max(0)
+        # keep the whole skeleton inside the map with a 1.5 px margin when it fits
+        tx = rng.uniform(1.5 - lo[0], max(1.5 - lo[0] + 1e-3, cols - 2.5 - hi[0]))
+        ty = rng.uniform(1.5 - lo[1], max(1.5 - lo[1] + 1e-3, rows - 2.5 - hi[1]))
+        out[p] = pts + (tx, ty)
+    return out
+
+
+def paf_maps(rng: np.random.Generator, batch: int, rows: int = 46, cols: int = 54, people=(1, 2, 4, 8),
+             sigma: float = 1.0, band: float = 1.0, noise: float = 0.01, drop_joint_prob: float = 0.05):
+    """Synthetic (conf ``[B,19,rows,cols]``, paf ``[B,38,rows,cols]``) float32 + the joint list per frame."""
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    conf = np.zeros((batch, 19, rows, cols))
+    paf = np.zeros((batch, 38, rows, cols))
+    truth = []
+    for b in range(batch):
+        n = int(people[b % len(people)])
+        sk = skeletons(rng, n, rows, cols)
+        visible = rng.uniform(size=(n, 18)) >= drop_joint_prob
+        truth.append((sk, visible))
+        for p in range(n):
+            for k in range(18):
+                if visible[p, k]:
+                    d2 = (xx - sk[p, k, 0]) ** 2 + (yy - sk[p, k, 1]) ** 2
+                    conf[b, k] += np.exp(-d2 / (2 * sigma * sigma))
+        conf[b, 18] = 1.0 - conf[b, :18].max(0)
+        count = np.zeros((19, rows, cols))
+        for p in range(n):
+            for l, ((p1, p2), (cx, cy)) in enumerate(zip(COCOPAIRS, COCOPAIRS_NET)):
+                if not (visible[p, p1] and visible[p, p2]):
+                    continue
+                a, c = sk[p, p1], sk[p, p2]
+                v = c - a
+                ln = np.hypot(*v)
+                if ln < 1e-6:
+                    continue
+                u = v / ln
+                rx, ry = xx - a[0], yy - a[1]
+                along = rx * u[0] + ry * u[1]
+                perp = np.abs(rx * u[1] - ry * u[0])
+                m = (along >= -band) & (along <= ln + band) & (perp <= band)
+                paf[b, cx][m] += u[0]
+                paf[b, cy][m] += u[1]
+                count[l][m] += 1
+        for l, (cx, cy) in enumerate(COCOPAIRS_NET):
+            m = count[l] > 1
+            paf[b, cx][m] /= count[l][m]
+            paf[b, cy][m] /= count[l][m]
+    conf += rng.normal(0, noise, conf.shape)
+    paf += rng.normal(0, noise, paf.shape)
+    return conf.astype(np.float32), paf.astype(np.float32), truth
+
+
+def images_u8(rng: np.random.Generator, batch: int, h: int, w: int) -> np.ndarray:
+    """Uniform[0,255] u8 ``[B,h,w,3]`` HWC BGR frames (already network-sized: cv::resize is then a copy)."""
+    return rng.integers(0, 256, size=(batch, h, w, 3), dtype=np.uint8)

@@ -1,0 +1,181 @@
+"""oracle/loader.py — TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings for the CPU oracles (oracle/_build/liboracle*.so = our restatements,
+oracle/_ref/libhp_ref*.so = the reference's own sources compiled where they lie).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
+hyperpose_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OBodyPart(C.Structure):
+    _fields_ = [("has_value", C.c_int32), ("x", C.c_float), ("y", C.c_float), ("score", C.c_float)]
+
+
+class OHuman(C.Structure):
+    _fields_ = [("parts", OBodyPart * 18), ("score", C.c_float)]
+
+
+class OPeak(C.Structure):
+    _fields_ = [("part_id", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("score", C.c_float),
+                ("id", C.c_int32)]
+
+
+class OConn(C.Structure):
+    _fields_ = [("pair_id", C.c_int32), ("cid1", C.c_int32), ("cid2", C.c_int32), ("score", C.c_float)]
+
+
+HUMAN_DTYPE = np.dtype({"names": ["parts", "score"],
+                        "formats": [(np.dtype([("has_value", "<i4"), ("x", "<f4"), ("y", "<f4"), ("score", "<f4")]), 18),
+                                    "<f4"]})
+assert HUMAN_DTYPE.itemsize == C.sizeof(OHuman) == 292
+
+_FP = C.POINTER(C.c_float)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_FP)
+
+
+def build(ref: bool = True) -> None:
+    """Compile the restatements (always) and oracle/_ref (only where /root/reference is mounted)."""
+    subprocess.check_call(["make", "-s", "-C", HERE])
+    if ref and os.path.isdir(os.environ.get("HP_REFERENCE", "/root/reference")):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+_libs = {}
+
+
+def lib(fast: bool = False):
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    if name not in _libs:
+        path = os.path.join(HERE, "_build", name)
+        if not os.path.exists(path):
+            build(ref=False)
+        L = C.CDLL(path)
+        L.oracle_resize_area.restype = C.c_int
+        L.oracle_paf_process.restype = C.c_int
+        _libs[name] = L
+    return _libs[name]
+
+
+def ref_lib(fast: bool = False):
+    """The reference's own code (oracle/_ref); None when it was never built (no /root/reference)."""
+    name = "libhp_ref_fast.so" if fast else "libhp_ref.so"
+    if name not in _libs:
+        path = os.path.join(HERE, "_ref", name)
+        if not os.path.exists(path):
+            try:
+                build(ref=True)
+            except subprocess.CalledProcessError:
+                pass
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        L.ref_ppn_process.restype = C.c_int
+        L.ref_pifpaf_process.restype = C.c_int
+        _libs[name] = L
+    return _libs[name]
+
+
+# ---------------------------------------------------------------- PAF (restatement)
+def resize_area(src: np.ndarray, dh: int, dw: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.float32)
+    c, sh, sw = src.shape
+    dst = np.zeros((c, dh, dw), np.float32)
+    lib().oracle_resize_area(_fp(src), c, sh, sw, _fp(dst), dh, dw)
+    return dst
+
+
+def smooth(src: np.ndarray, ksize: int = 17) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.float32)
+    c, h, w = src.shape
+    dst = np.zeros_like(src)
+    lib().oracle_smooth(_fp(src), c, h, w, ksize, _fp(dst))
+    return dst
+
+
+def max_pool_3x3(src: np.ndarray) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.float32)
+    c, h, w = src.shape
+    dst = np.zeros_like(src)
+    lib().oracle_max_pool_3x3(_fp(src), c, h, w, _fp(dst))
+    return dst
+
+
+def gaussian_kernel(ksize: int = 17, sigma: float = 3.0) -> np.ndarray:
+    out = np.zeros(ksize, np.float32)
+    lib().oracle_gaussian_kernel(ksize, C.c_double(sigma), _fp(out))
+    return out
+
+
+def paf_process(conf: np.ndarray, paf: np.ndarray, conf_thresh: float = 0.05, paf_thresh: float = 0.05,
+                res_w: int = -1, res_h: int = -1, cap_humans: int = 128, cap_peaks: int = 8192,
+                cap_conns: int = 8192, fast: bool = False):
+    """One frame through the restated parser::paf::process; returns (humans, peaks, conns) numpy records."""
+    conf = np.ascontiguousarray(conf, np.float32)
+    paf = np.ascontiguousarray(paf, np.float32)
+    j, rows, cols = conf.shape
+    humans = (OHuman * cap_humans)()
+    peaks = (OPeak * cap_peaks)()
+    conns = (OConn * cap_conns)()
+    n_peaks, n_conns = C.c_int(0), C.c_int(0)
+    n = lib(fast).oracle_paf_process(_fp(conf), j, rows, cols, _fp(paf), paf.shape[0],
+                                     C.c_float(conf_thresh), C.c_float(paf_thresh), res_w, res_h,
+                                     humans, cap_humans, peaks, cap_peaks, C.byref(n_peaks),
+                                     conns, cap_conns, C.byref(n_conns))
+    if n < 0 or n > cap_humans or n_peaks.value > cap_peaks or n_conns.value > cap_conns:
+        raise RuntimeError(f"oracle_paf_process overflow/err: humans={n} peaks={n_peaks.value} conns={n_conns.value}")
+    h = np.frombuffer(humans, dtype=HUMAN_DTYPE, count=n).copy()
+    p = np.frombuffer(peaks, dtype=np.dtype([("part_id", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4"),
+                                             ("id", "<i4")]), count=n_peaks.value).copy()
+    c = np.frombuffer(conns, dtype=np.dtype([("pair_id", "<i4"), ("cid1", "<i4"), ("cid2", "<i4"),
+                                             ("score", "<f4")]), count=n_conns.value).copy()
+    return h, p, c
+
+
+def nhwc_u8_to_nchw_f32(images: np.ndarray, factor: float = 1.0 / 255, flip_rb: bool = True) -> np.ndarray:
+    images = np.ascontiguousarray(images, np.uint8)
+    n, h, w, _ = images.shape
+    out = np.zeros((n, 3, h, w), np.float32)
+    lib().oracle_nhwc_u8_to_nchw_f32(images.ctypes.data_as(C.POINTER(C.c_uint8)), n, h, w, C.c_double(factor),
+                                     int(flip_rb), _fp(out))
+    return out
+
+
+# ---------------------------------------------------------------- reference-compiled parsers
+def ref_ppn_process(tensors, net_w=384, net_h=384, point_thresh=0.10, limb_thresh=0.05, nms_thresh=0.3,
+                    cap=256, fast=False):
+    L = ref_lib(fast)
+    if L is None:
+        raise RuntimeError("oracle/_ref not built")
+    t = [np.ascontiguousarray(a, np.float32) for a in tensors]
+    k, gh, gw = t[0].shape
+    e, nh, nw = t[6].shape[:3]
+    out = (OHuman * cap)()
+    n = L.ref_ppn_process(net_w, net_h, C.c_float(point_thresh), C.c_float(limb_thresh), C.c_float(nms_thresh),
+                          *[_fp(a) for a in t], k, gh, gw, e, nh, nw, out, cap)
+    assert 0 <= n <= cap
+    return np.frombuffer(out, dtype=HUMAN_DTYPE, count=n).copy()
+
+
+def ref_pifpaf_process(paf, pif, net_h=385, net_w=385, thresh=0.1, cap=256, fast=False):
+    L = ref_lib(fast)
+    if L is None:
+        raise RuntimeError("oracle/_ref not built")
+    paf = np.ascontiguousarray(paf, np.float32)
+    pif = np.ascontiguousarray(pif, np.float32)
+    fh, fw = pif.shape[-2:]
+    out = (OHuman * cap)()
+    n = L.ref_pifpaf_process(net_h, net_w, C.c_float(thresh), _fp(paf), _fp(pif), fh, fw, out, cap)
+    assert 0 <= n <= cap
+    return np.frombuffer(out, dtype=HUMAN_DTYPE, count=n).copy()
