@@ -1,0 +1,74 @@
+"""Build libhp_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+    python -m hyperpose_amd.build [--force]
+
+Each translation unit is compiled separately (cached by mtime) and linked into
+``hyperpose_amd/libhp_hip.so``.  The parser kernels are compiled with ``-ffp-contract=off``: their results
+must be bit-identical to the CPU code they replace ("Parser numerics").  hipcc cross-compiles
+without a GPU, so this runs in the GPU-less build container; the .so travels to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "libhp_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+COMMON = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-I" + os.path.join(HERE, "..", "include")]
+# (source, extra flags)
+UNITS = [
+    ("hp_runtime.cpp", []),
+    ("preproc.hip", ["-ffp-contract=off"]),
+    ("paf_parser.hip", ["-ffp-contract=off"]),
+    ("ppn_parser.hip", ["-ffp-contract=off"]),
+    ("pifpaf_parser.hip", ["-ffp-contract=off"]),
+    ("conv_kernels.hip", []),
+    ("engine.cpp", []),
+    ("models.cpp", []),
+]
+
+
+def _newer(src: str, dst: str, deps) -> bool:
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(d) > t for d in [src] + deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers.append(os.path.join(HERE, "..", "include", "hp_hip.h"))
+    objs, changed = [], False
+    procs = []
+    for src, extra in UNITS:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(OBJ, src + ".o")
+        objs.append(obj)
+        if force or _newer(path, obj, headers):
+            cmd = [HIPCC, "-x", "hip", *COMMON, *extra, "-c", path, "-o", obj]
+            if verbose:
+                print("[hyperpose_amd.build]", " ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+            changed = True
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    if changed or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print("[hyperpose_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

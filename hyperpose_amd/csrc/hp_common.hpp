@@ -1,0 +1,102 @@
+// hp_common.hpp — shared host-side plumbing of libhp_hip.so: error reporting across the C ABI,
+// HIP call checking, RAII device/pinned buffers.  No reference counterpart (the reference's error
+// policy is print + std::exit, src/logging.hpp:31-37; the C ABI returns codes instead and the C++
+// mirror classes in include/hyperpose/ restore the throw/exit behaviour on top).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/hp_hip.h"
+
+namespace hp {
+
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+const char* last_error();
+
+#define HP_HIP_TRY(expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) {                                                                              \
+            ::hp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);      \
+            return HP_ERR_HIP;                                                                               \
+        }                                                                                                    \
+    } while (0)
+
+#define HP_REQUIRE(cond, code, ...)                                                                          \
+    do {                                                                                                     \
+        if (!(cond)) {                                                                                       \
+            ::hp::set_error(__VA_ARGS__);                                                                    \
+            return (code);                                                                                   \
+        }                                                                                                    \
+    } while (0)
+
+#define HP_TRY(expr)                                                                                         \
+    do {                                                                                                     \
+        int _rc = (expr);                                                                                    \
+        if (_rc != HP_OK)                                                                                    \
+            return _rc;                                                                                      \
+    } while (0)
+
+// Owning device buffer (hipMalloc / hipFree).
+struct dev_buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    dev_buf() = default;
+    dev_buf(const dev_buf&) = delete;
+    dev_buf& operator=(const dev_buf&) = delete;
+    ~dev_buf() { release(); }
+    int alloc(size_t n)
+    {
+        release();
+        if (n == 0)
+            return HP_OK;
+        HP_HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
+        return HP_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+// Owning pinned host buffer.
+struct host_buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    host_buf() = default;
+    host_buf(const host_buf&) = delete;
+    host_buf& operator=(const host_buf&) = delete;
+    ~host_buf() { release(); }
+    int alloc(size_t n)
+    {
+        release();
+        if (n == 0)
+            return HP_OK;
+        HP_HIP_TRY(hipHostMalloc(&p, n, hipHostMallocDefault));
+        bytes = n;
+        return HP_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+} // namespace hp

@@ -1,0 +1,102 @@
+// hp_runtime.cpp — runtime entry points of the C ABI (include/hp_hip.h): device selection, error
+// string, memory helpers.  Replaces the implicit CUDA context handling of the reference engine
+// (src/tensorrt.cpp:106-118 `cuda_dep`).
+#include "hp_common.hpp"
+
+namespace hp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+const char* last_error() { return g_err; }
+
+} // namespace hp
+
+extern "C" {
+
+const char* hp_last_error(void) { return hp::last_error(); }
+
+const char* hp_version(void) { return "hyperpose-mi355x 0.1 (gfx950)"; }
+
+int hp_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        hp::set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return HP_ERR_NO_DEVICE;
+    }
+    return n;
+}
+
+int hp_init(int device)
+{
+    int n = hp_device_count();
+    if (n <= 0) {
+        if (n == 0)
+            hp::set_error("no HIP device visible");
+        return HP_ERR_NO_DEVICE;
+    }
+    HP_REQUIRE(device >= 0 && device < n, HP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    HP_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HP_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        hp::set_error("device %d is %s; libhp_hip.so is built for gfx950 only", device, prop.gcnArchName);
+        return HP_ERR_NO_DEVICE;
+    }
+    return HP_OK;
+}
+
+int hp_malloc(void** dev, size_t nbytes)
+{
+    HP_REQUIRE(dev, HP_ERR_INVALID, "hp_malloc: null out pointer");
+    HP_HIP_TRY(hipMalloc(dev, nbytes));
+    return HP_OK;
+}
+
+int hp_free(void* dev)
+{
+    HP_HIP_TRY(hipFree(dev));
+    return HP_OK;
+}
+
+int hp_malloc_host(void** host, size_t nbytes)
+{
+    HP_REQUIRE(host, HP_ERR_INVALID, "hp_malloc_host: null out pointer");
+    HP_HIP_TRY(hipHostMalloc(host, nbytes, hipHostMallocDefault));
+    return HP_OK;
+}
+
+int hp_free_host(void* host)
+{
+    HP_HIP_TRY(hipHostFree(host));
+    return HP_OK;
+}
+
+int hp_memcpy_h2d(void* dev, const void* host, size_t nbytes)
+{
+    HP_HIP_TRY(hipMemcpy(dev, host, nbytes, hipMemcpyHostToDevice));
+    return HP_OK;
+}
+
+int hp_memcpy_d2h(void* host, const void* dev, size_t nbytes)
+{
+    HP_HIP_TRY(hipMemcpy(host, dev, nbytes, hipMemcpyDeviceToHost));
+    return HP_OK;
+}
+
+int hp_device_synchronize(void)
+{
+    HP_HIP_TRY(hipDeviceSynchronize());
+    return HP_OK;
+}
+
+} // extern "C"

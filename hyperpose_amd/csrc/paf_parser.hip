@@ -1,0 +1,899 @@
+// paf_parser.hip — hyperpose::parser::paf on gfx950 (replaces reference src/paf.cpp + src/post_process.hpp).
+//
+// The reference runs, per frame and on ONE CPU thread: 57 cv::resize calls (post_process.hpp:47-51),
+// 19 GaussianBlur calls (:61-68), a scalar 3x3 max-pool (:71-102), a full scan for peaks (:184-192), the
+// line-integral scoring of every peak pair of every limb (paf.cpp:93-144), a sort + greedy assignment
+// per limb (:234-272) and the sequential skeleton assembly (:146-232), materialising ~15 MB of
+// up-sampled / smoothed / pooled temporaries on the way.
+//
+// Here a whole batch of frames is parsed by four launches that never materialise the up-sampled maps:
+//   1. paf_peaks_kernel    grid (tiles, 18 parts, frames): stage the few source rows a tile needs in LDS,
+//                          up-sample (INTER_AREA semantics) -> 17-tap row filter -> symmetric column
+//                          filter -> 3x3 max / threshold, all inside LDS; append peaks with an atomic.
+//   2. paf_sort_kernel     grid (18 parts, frames): rank-sort each part's peaks into the reference's scan
+//                          order so that peak ids equal the reference's running index.
+//   3. paf_limbs_kernel    grid (19 limbs, frames): the limb's two PAF source channels live in LDS; one
+//                          thread per (peak a, peak b) pair evaluates the 10-sample line integral by
+//                          interpolating the un-up-sampled PAF on the fly; rank-sort of the surviving
+//                          candidates and a wave-ballot greedy bipartite assignment.
+//   4. paf_assemble_kernel grid (frames): one wavefront walks the connections in reference order; the
+//                          "which humans touch this connection" scan is a ballot over up to 256 humans.
+// Only `hp_human`s (<= 292 B each) come back over PCIe.
+//
+// Every floating-point expression keeps the operand order and the (non-fused) rounding of the CPU
+// code it replaces; this translation unit is compiled with -ffp-contract=off.  See DESIGN.md.
+#include "hp_common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int KSIZE = 17; // paf.cpp:331 (peak_finder ksize)
+constexpr int KR = KSIZE / 2;
+constexpr int PEAK_THREADS = 256;
+constexpr int MAXH = 256;          // humans in flight per frame in the assembly kernel
+constexpr int THRESH_VECTOR_CNT1 = 8; // paf.cpp:57
+constexpr int THRESH_PART_CNT = 4;    // paf.cpp:58
+constexpr float THRESH_HUMAN_SCORE = 0.4; // paf.cpp:59
+constexpr int STEP_PAF = 10;          // paf.cpp:60
+
+// src/coco.hpp:10-30 / :32-51
+__constant__ int c_pairs_net[19][2] = {
+    { 12, 13 }, { 20, 21 }, { 14, 15 }, { 16, 17 }, { 22, 23 }, { 24, 25 }, { 0, 1 }, { 2, 3 },
+    { 4, 5 }, { 6, 7 }, { 8, 9 }, { 10, 11 }, { 28, 29 }, { 30, 31 }, { 34, 35 }, { 32, 33 },
+    { 36, 37 }, { 18, 19 }, { 26, 27 },
+};
+__constant__ int c_pairs[19][2] = {
+    { 1, 2 }, { 1, 5 }, { 2, 3 }, { 3, 4 }, { 5, 6 }, { 6, 7 }, { 1, 8 }, { 8, 9 }, { 9, 10 },
+    { 1, 11 }, { 11, 12 }, { 12, 13 }, { 1, 0 }, { 0, 14 }, { 14, 16 }, { 0, 15 }, { 15, 17 },
+    { 2, 16 }, { 5, 17 },
+};
+
+struct gauss_t {
+    float k[KSIZE];
+};
+
+// Geometry + interpolation tables of one parser instance (device pointers into one table buffer).
+struct geom_t {
+    int J, L2;      // channels of conf / paf
+    int R, Cc;      // source rows / cols (memory order [ch][R][Cc])
+    int UH, UW;     // up-sampled rows / cols  (m_resolution_size.height / .width)
+    int vmax_x;     // first dx that uses the 1-tap copy (OpenCV's xmax)
+    int feat_height; // m_feature_size.height == Cc (paf.cpp:329)
+    const int* ofs_x;  // [UW]
+    const float* c0_x; // [UW]
+    const float* c1_x; // [UW]
+    const int* ofs_y0; // [UH]
+    const int* ofs_y1; // [UH]  min(sy+1, R-1)
+    const float* c0_y; // [UH]
+    const float* c1_y; // [UH]
+};
+
+struct dpeak {
+    int x, y;
+    float score;
+    int lin; // y * UW + x: the reference's scan position inside the channel
+};
+
+struct dconn {
+    int cid1, cid2;
+    float score;
+};
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1)
+        return 0;
+    while (p < 0 || p >= len)
+        p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+// One up-sampled sample = HResizeLinear on the two source rows, then VResizeLinear (see oracle/paf_oracle.cpp
+// for the OpenCV derivation).  `src` points at a [rows][Cc] plane whose row 0 is source row `row_base`.
+__device__ __forceinline__ float up_at(const float* __restrict__ src, int row_base, const geom_t& g, int y, int x)
+{
+    const int sx = g.ofs_x[x];
+    const int r0 = g.ofs_y0[y] - row_base, r1 = g.ofs_y1[y] - row_base;
+    float h0, h1;
+    if (x < g.vmax_x) {
+        const float a0 = g.c0_x[x], a1 = g.c1_x[x];
+        h0 = src[r0 * g.Cc + sx] * a0 + src[r0 * g.Cc + sx + 1] * a1;
+        h1 = src[r1 * g.Cc + sx] * a0 + src[r1 * g.Cc + sx + 1] * a1;
+    } else {
+        h0 = src[r0 * g.Cc + sx] * 1.f;
+        h1 = src[r1 * g.Cc + sx] * 1.f;
+    }
+    return h0 * g.c0_y[y] + h1 * g.c1_y[y];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1. peaks: resize_area + smooth + same_max_pool_3x3 + find_peak_coords (post_process.hpp:26-195), fused.
+// LDS carve (floats): src rows | U tile (re-used for S) | row-filtered tile.
+__global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __restrict__ conf, geom_t g,
+    gauss_t gk, float thresh, int TH, int TW, int tiles_x, int src_rows_cap, int Uw_cap, int Rw_cap,
+    dpeak* __restrict__ plist, int* __restrict__ pcount, int peak_cap,
+    float* __restrict__ dump_up, float* __restrict__ dump_smooth)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int k = blockIdx.y, f = blockIdx.z;
+
+    const int y0 = ty * TH, y1 = min(g.UH, y0 + TH);
+    const int x0 = tx * TW, x1 = min(g.UW, x0 + TW);
+    // smoothed values needed on the tile plus the 1-px pool halo
+    const int sy_lo = max(0, y0 - 1), sy_hi = min(g.UH, y1 + 1);
+    const int sx_lo = max(0, x0 - 1), sx_hi = min(g.UW, x1 + 1);
+    // row-filtered / up-sampled rows needed for those (reflect101 targets stay inside)
+    const int ry_lo = max(0, sy_lo - KR), ry_hi = min(g.UH, sy_hi + KR);
+    const int ux_lo = max(0, sx_lo - KR), ux_hi = min(g.UW, sx_hi + KR);
+    const int Uh = ry_hi - ry_lo, Uw = ux_hi - ux_lo, Rw = sx_hi - sx_lo, Sh = sy_hi - sy_lo;
+
+    const int row_base = g.ofs_y0[ry_lo];
+    const int row_last = g.ofs_y1[ry_hi - 1];
+    const int nrows = row_last - row_base + 1;
+
+    float* s_src = smem;                           // [src_rows_cap][Cc]
+    float* s_U = s_src + src_rows_cap * g.Cc;      // [Uh][Uw]   later S [Sh][Rw]
+    float* s_R = s_U + (TH + 2 + 2 * KR) * Uw_cap; // [Uh][Rw]
+
+    const float* plane = conf + ((size_t)f * g.J + k) * g.R * g.Cc;
+    for (int i = tid; i < nrows * g.Cc; i += PEAK_THREADS)
+        s_src[i] = plane[row_base * g.Cc + i];
+    __syncthreads();
+
+    // up-sample
+    for (int i = tid; i < Uh * Uw; i += PEAK_THREADS) {
+        const int yy = i / Uw, xx = i - yy * Uw;
+        s_U[yy * Uw + xx] = up_at(s_src, row_base, g, ry_lo + yy, ux_lo + xx);
+    }
+    __syncthreads();
+    if (dump_up) {
+        for (int i = tid; i < (y1 - y0) * (x1 - x0); i += PEAK_THREADS) {
+            const int yy = i / (x1 - x0), xx = i - yy * (x1 - x0);
+            dump_up[(((size_t)f * g.J + k) * g.UH + y0 + yy) * g.UW + x0 + xx] = s_U[(y0 + yy - ry_lo) * Uw + (x0 + xx - ux_lo)];
+        }
+    }
+
+    // RowFilter<float,float>: s = k0*S[0]; s += kk*S[kk], BORDER_REFLECT_101
+    for (int i = tid; i < Uh * Rw; i += PEAK_THREADS) {
+        const int yy = i / Rw, xx = i - yy * Rw;
+        const int x = sx_lo + xx;
+        const float* row = s_U + yy * Uw;
+        float s = gk.k[0] * row[reflect101(x - KR, g.UW) - ux_lo];
+#pragma unroll
+        for (int t = 1; t < KSIZE; ++t)
+            s += gk.k[t] * row[reflect101(x - KR + t, g.UW) - ux_lo];
+        s_R[yy * Rw + xx] = s;
+    }
+    __syncthreads();
+
+    // SymmColumnFilter<float>: s = k8*C + 0; s += kk*(S[+kk] + S[-kk])
+    float* s_S = s_U;
+    for (int i = tid; i < Sh * Rw; i += PEAK_THREADS) {
+        const int yy = i / Rw, xx = i - yy * Rw;
+        const int y = sy_lo + yy;
+        float s = gk.k[KR] * s_R[(y - ry_lo) * Rw + xx] + 0.f;
+#pragma unroll
+        for (int t = 1; t <= KR; ++t) {
+            const float a = s_R[(reflect101(y + t, g.UH) - ry_lo) * Rw + xx];
+            const float b = s_R[(reflect101(y - t, g.UH) - ry_lo) * Rw + xx];
+            s += gk.k[KR + t] * (a + b);
+        }
+        s_S[yy * Rw + xx] = s;
+    }
+    __syncthreads();
+
+    const int tw = x1 - x0, th = y1 - y0;
+    for (int i = tid; i < th * tw; i += PEAK_THREADS) {
+        const int yy = i / tw, xx = i - yy * tw;
+        const int y = y0 + yy, x = x0 + xx;
+        const float v = s_S[(y - sy_lo) * Rw + (x - sx_lo)];
+        if (dump_smooth)
+            dump_smooth[(((size_t)f * g.J + k) * g.UH + y) * g.UW + x] = v;
+        if (k < HP_COCO_N_PARTS && v > thresh) {
+            // same_max_pool_3x3_2d: max over in-range taps == v  <=>  no in-range tap exceeds v
+            bool is_max = true;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int ny = y + dy, nx = x + dx;
+                    if (ny >= 0 && ny < g.UH && nx >= 0 && nx < g.UW)
+                        is_max = is_max && !(s_S[(ny - sy_lo) * Rw + (nx - sx_lo)] > v);
+                }
+            if (is_max) {
+                const int pos = atomicAdd(&pcount[f * HP_COCO_N_PARTS + k], 1);
+                if (pos < peak_cap) {
+                    dpeak p;
+                    p.x = x;
+                    p.y = y;
+                    p.score = up_at(s_src, row_base, g, y, x); // raw up-sampled value (post_process.hpp:180)
+                    p.lin = y * g.UW + x;
+                    plist[((size_t)f * HP_COCO_N_PARTS + k) * peak_cap + pos] = p;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2. order every part's peaks by scan position (row-major), i.e. the reference's push_back order.
+__global__ __launch_bounds__(256) void paf_sort_kernel(const dpeak* __restrict__ plist, const int* __restrict__ pcount,
+    int peak_cap, dpeak* __restrict__ sorted)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_lin[];
+    const int k = blockIdx.x, f = blockIdx.y;
+    const int n = min(pcount[f * HP_COCO_N_PARTS + k], peak_cap);
+    const dpeak* in = plist + ((size_t)f * HP_COCO_N_PARTS + k) * peak_cap;
+    dpeak* out = sorted + ((size_t)f * HP_COCO_N_PARTS + k) * peak_cap;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        s_lin[i] = in[i].lin;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int me = s_lin[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j)
+            rank += (s_lin[j] < me);
+        out[rank] = in[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3. get_connection_candidates + get_connections (paf.cpp:93-144, :234-272) for one limb of one frame.
+struct cand_t {
+    float score;
+    int ab;  // (a << 16) | b, indices inside the two part lists
+    int seq; // a * n2 + b: generation order (tie-break for equal scores)
+};
+
+__global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict__ paf, geom_t g, float paf_thresh,
+    const dpeak* __restrict__ sorted, const int* __restrict__ pcount, int peak_cap, int cand_cap,
+    dconn* __restrict__ conns, int* __restrict__ conn_count, int* __restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int s_ncand;
+    const int tid = threadIdx.x;
+    const int pair_id = blockIdx.x, f = blockIdx.y;
+    const int p1 = c_pairs[pair_id][0], p2 = c_pairs[pair_id][1];
+    const int ch1 = c_pairs_net[pair_id][0], ch2 = c_pairs_net[pair_id][1];
+
+    int start1 = 0, start2 = 0;
+    for (int c = 0; c < HP_COCO_N_PARTS; ++c) {
+        const int nc = min(pcount[f * HP_COCO_N_PARTS + c], peak_cap);
+        if (c < p1)
+            start1 += nc;
+        if (c < p2)
+            start2 += nc;
+    }
+    const int n1 = min(pcount[f * HP_COCO_N_PARTS + p1], peak_cap);
+    const int n2 = min(pcount[f * HP_COCO_N_PARTS + p2], peak_cap);
+
+    const int plane = g.R * g.Cc;
+    float* s_px = smem;            // PAF x-channel of this limb, [R][Cc]
+    float* s_py = smem + plane;    // PAF y-channel
+    cand_t* s_cand = reinterpret_cast<cand_t*>(smem + 2 * plane); // [cand_cap]
+    int* s_order = reinterpret_cast<int*>(s_cand + cand_cap);     // [cand_cap] sorted position -> candidate
+
+    if (tid == 0)
+        s_ncand = 0;
+    if (n1 > 0 && n2 > 0) {
+        const float* src = paf + (size_t)f * g.L2 * plane;
+        for (int i = tid; i < plane; i += blockDim.x) {
+            s_px[i] = src[(size_t)ch1 * plane + i];
+            s_py[i] = src[(size_t)ch2 * plane + i];
+        }
+    }
+    __syncthreads();
+
+    const dpeak* A = sorted + ((size_t)f * HP_COCO_N_PARTS + p1) * peak_cap;
+    const dpeak* B = sorted + ((size_t)f * HP_COCO_N_PARTS + p2) * peak_cap;
+    const int npairs = n1 * n2;
+    for (int idx = tid; idx < npairs; idx += blockDim.x) {
+        const int ia = idx / n2, ib = idx - ia * n2;
+        const dpeak a = A[ia], b = B[ib];
+        const int dx = b.x - a.x, dy = b.y - a.y;
+        const float norm = sqrtf((float)(dx * dx + dy * dy)); // std::sqrt(int l2) narrowed to float, paf.cpp:104
+        if (norm < 1e-12)
+            continue;
+        float vx = (float)dx, vy = (float)dy;
+        vx /= norm;
+        vy /= norm;
+        const float step_x = (b.x - a.x) / float(STEP_PAF);
+        const float step_y = (b.y - a.y) / float(STEP_PAF);
+        float scores = 0.0f;
+        int criterion1 = 0;
+#pragma unroll
+        for (int i = 0; i < STEP_PAF; ++i) {
+            const int lx = static_cast<int>(a.x + i * step_x + 0.5); // roundpaf, paf.cpp:74
+            const int ly = static_cast<int>(a.y + i * step_y + 0.5);
+            const float px = up_at(s_px, 0, g, ly, lx);
+            const float py = up_at(s_py, 0, g, ly, lx);
+            const float score = vx * px + vy * py;
+            scores += score;
+            if (score > paf_thresh)
+                criterion1 += 1;
+        }
+        const float criterion2 = scores / STEP_PAF + fmin(0.0, 0.5 * g.feat_height / norm - 1.0); // paf.cpp:129
+        if (criterion1 > THRESH_VECTOR_CNT1 && criterion2 > 0) {
+            const int pos = atomicAdd(&s_ncand, 1);
+            if (pos < cand_cap) {
+                s_cand[pos].score = criterion2;
+                s_cand[pos].ab = (ia << 16) | ib;
+                s_cand[pos].seq = idx;
+            }
+        }
+    }
+    __syncthreads();
+    int n = s_ncand;
+    if (n > cand_cap) {
+        if (tid == 0)
+            atomicOr(flags, 2);
+        n = cand_cap;
+    }
+
+    // std::sort(..., std::greater) (paf.cpp:249): rank by (score desc, generation order asc)
+    for (int i = tid; i < n; i += blockDim.x) {
+        const float sc = s_cand[i].score;
+        const int sq = s_cand[i].seq;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float sj = s_cand[j].score;
+            rank += (sj > sc) || (sj == sc && s_cand[j].seq < sq);
+        }
+        s_order[rank] = i;
+    }
+    __syncthreads();
+
+    // greedy assignment (paf.cpp:252-270) by wavefront 0: "used" bitmaps live in registers, one 32-bit word
+    // per lane (covers 2048 peaks per part); conflicts inside a 64-candidate chunk are resolved leader by leader.
+    if (tid < 64) {
+        const int lane = tid;
+        unsigned used1 = 0, used2 = 0;
+        int nconn = 0;
+        dconn* out = conns + ((size_t)f * HP_COCO_N_PAIRS + pair_id) * peak_cap;
+        const int max_conn = min(n1, n2);
+        for (int base = 0; base < n && nconn < max_conn; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < n;
+            int a = 0, b = 0;
+            float sc = 0.f;
+            if (valid) {
+                const cand_t c = s_cand[s_order[i]];
+                a = c.ab >> 16;
+                b = c.ab & 0xffff;
+                sc = c.score;
+            }
+            const unsigned w1 = __shfl(used1, a >> 5), w2 = __shfl(used2, b >> 5);
+            bool alive = valid && !((w1 >> (a & 31)) & 1u) && !((w2 >> (b & 31)) & 1u);
+            unsigned long long m;
+            while ((m = __ballot(alive)) != 0ull) {
+                const int leader = __ffsll((long long)m) - 1;
+                const int la = __shfl(a, leader), lb = __shfl(b, leader);
+                const float ls = __shfl(sc, leader);
+                if (lane == 0) {
+                    dconn c;
+                    c.cid1 = start1 + la;
+                    c.cid2 = start2 + lb;
+                    c.score = ls;
+                    out[nconn] = c;
+                }
+                if (lane == (la >> 5))
+                    used1 |= 1u << (la & 31);
+                if (lane == (lb >> 5))
+                    used2 |= 1u << (lb & 31);
+                ++nconn;
+                alive = alive && lane != leader && a != la && b != lb;
+            }
+        }
+        if (lane == 0)
+            conn_count[f * HP_COCO_N_PAIRS + pair_id] = nconn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 4. get_humans (paf.cpp:146-232) + the human_t emission of paf::process (:359-372); one wavefront per frame.
+__device__ __forceinline__ dpeak peak_by_id(const dpeak* __restrict__ sorted_f, const int* s_start, int peak_cap, int id)
+{
+    dpeak z;
+    z.x = 0, z.y = 0, z.score = 0.f, z.lin = 0;
+    if (id < 0 || id >= s_start[HP_COCO_N_PARTS])
+        return z; // the reference would index out of bounds here (paf.cpp:193 can synthesise such ids)
+    int c = 0;
+    while (id >= s_start[c + 1])
+        ++c;
+    return sorted_f[(size_t)c * peak_cap + (id - s_start[c])];
+}
+
+__global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restrict__ sorted, const int* __restrict__ pcount,
+    int peak_cap, const dconn* __restrict__ conns, const int* __restrict__ conn_count, int res_w, int res_h,
+    hp_human* __restrict__ humans, int* __restrict__ n_humans, int human_cap, int* __restrict__ flags)
+{
+    __shared__ int s_parts[MAXH * HP_COCO_N_PARTS];
+    __shared__ float s_score[MAXH];
+    __shared__ int s_n[MAXH];
+    __shared__ int s_start[HP_COCO_N_PARTS + 1];
+    __shared__ int s_keep[MAXH];
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x;
+    const dpeak* sorted_f = sorted + (size_t)f * HP_COCO_N_PARTS * peak_cap;
+
+    if (lane == 0) {
+        int acc = 0;
+        for (int c = 0; c < HP_COCO_N_PARTS; ++c) {
+            s_start[c] = acc;
+            const int raw = pcount[f * HP_COCO_N_PARTS + c];
+            if (raw > peak_cap)
+                atomicOr(flags, 1);
+            acc += min(raw, peak_cap);
+        }
+        s_start[HP_COCO_N_PARTS] = acc;
+    }
+    __syncthreads();
+
+    int nh = 0;
+    bool overflow = false;
+    for (int pair_id = 0; pair_id < HP_COCO_N_PAIRS; ++pair_id) {
+        const int p1 = c_pairs[pair_id][0], p2 = c_pairs[pair_id][1];
+        const int nc = conn_count[f * HP_COCO_N_PAIRS + pair_id];
+        const dconn* cl = conns + ((size_t)f * HP_COCO_N_PAIRS + pair_id) * peak_cap;
+        for (int ci = 0; ci < nc; ++ci) {
+            const dconn conn = cl[ci];
+            // which humans touch this connection (paf.cpp:164-168), lowest index first
+            int total = 0, first = -1, second = -1;
+#pragma unroll
+            for (int s = 0; s < MAXH / 64; ++s) {
+                const int h = s * 64 + lane;
+                const bool t = h < nh && (s_parts[h * HP_COCO_N_PARTS + p1] == conn.cid1 || s_parts[h * HP_COCO_N_PARTS + p2] == conn.cid2);
+                unsigned long long m = __ballot(t);
+                total += __popcll(m);
+                if (m && first < 0) {
+                    first = s * 64 + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                }
+                if (m && second < 0)
+                    second = s * 64 + __ffsll((long long)m) - 1;
+            }
+            const float sc2 = sorted_f[(size_t)p2 * peak_cap + (conn.cid2 - s_start[p2])].score; // all_peaks[cid2].score
+            if (total == 1) {
+                if (lane == 0 && s_parts[first * HP_COCO_N_PARTS + p2] != conn.cid2) {
+                    s_parts[first * HP_COCO_N_PARTS + p2] = conn.cid2;
+                    ++s_n[first];
+                    s_score[first] += sc2 + conn.score;
+                }
+            } else if (total >= 2) {
+                bool both = false;
+                if (lane < HP_COCO_N_PARTS)
+                    both = s_parts[first * HP_COCO_N_PARTS + lane] > 0 && s_parts[second * HP_COCO_N_PARTS + lane] > 0; // paf.cpp:185
+                const bool membership = __ballot(both) != 0ull;
+                if (!membership) {
+                    if (lane < HP_COCO_N_PARTS) {
+                        s_parts[first * HP_COCO_N_PARTS + lane] += s_parts[second * HP_COCO_N_PARTS + lane] + 1; // paf.cpp:193
+                        s_parts[second * HP_COCO_N_PARTS + lane] = -1; // erased (paf.cpp:202): never touches again
+                    }
+                    if (lane == 0) {
+                        s_n[first] += s_n[second];
+                        s_score[first] += s_score[second];
+                        s_score[first] += conn.score;
+                        s_n[second] = -(1 << 20); // erased: fails the n_parts filter
+                    }
+                } else if (lane == 0) {
+                    s_parts[first * HP_COCO_N_PARTS + p2] = conn.cid2;
+                    s_n[first] += 1;
+                    s_score[first] += sc2 + conn.score;
+                }
+            } else if (pair_id <= 16) { // !is_virtual_pair, coco.hpp:6
+                if (nh < MAXH) {
+                    if (lane < HP_COCO_N_PARTS)
+                        s_parts[nh * HP_COCO_N_PARTS + lane] = lane == p1 ? conn.cid1 : (lane == p2 ? conn.cid2 : -1);
+                    if (lane == 0) {
+                        const float sc1 = sorted_f[(size_t)p1 * peak_cap + (conn.cid1 - s_start[p1])].score;
+                        s_n[nh] = 2;
+                        s_score[nh] = sc1 + sc2 + conn.score;
+                    }
+                    ++nh;
+                } else
+                    overflow = true;
+            }
+            __syncthreads();
+        }
+    }
+    if (overflow && lane == 0)
+        atomicOr(flags, 4);
+
+    // remove_if (paf.cpp:226-230), survivors keep their relative order
+    int kept = 0;
+#pragma unroll
+    for (int s = 0; s < MAXH / 64; ++s) {
+        const int h = s * 64 + lane;
+        bool keep = false;
+        if (h < nh) {
+            const int np = s_n[h];
+            keep = !(np < THRESH_PART_CNT || s_score[h] / np < THRESH_HUMAN_SCORE);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep)
+            s_keep[kept + __popcll(m & ((1ull << lane) - 1ull))] = h;
+        kept += __popcll(m);
+    }
+    __syncthreads();
+    if (lane == 0)
+        n_humans[f] = kept;
+    hp_human* out = humans + (size_t)f * human_cap;
+    for (int i = 0; i < kept && i < human_cap; ++i) {
+        const int h = s_keep[i];
+        if (lane < HP_COCO_N_PARTS) {
+            hp_body_part bp;
+            bp.has_value = 0;
+            bp.x = 0.f, bp.y = 0.f, bp.score = 0.f;
+            const int id = s_parts[h * HP_COCO_N_PARTS + lane];
+            if (id != -1) {
+                const dpeak p = peak_by_id(sorted_f, s_start, peak_cap, id);
+                bp.has_value = 1;
+                bp.score = p.score;
+                bp.x = static_cast<float>(p.x) / res_w; // paf.cpp:367-368
+                bp.y = static_cast<float>(p.y) / res_h;
+            }
+            out[i].parts[lane] = bp;
+        }
+        if (lane == 0)
+            out[i].score = s_score[h];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// resize tables on the host: identical arithmetic to oracle/paf_oracle.cpp::make_tab (OpenCV 4.4.0 resize.cpp).
+struct host_tab {
+    std::vector<int> ofs, ofs1;
+    std::vector<float> c0, c1;
+    int vmax;
+};
+
+host_tab make_tab(int ssize, int dsize)
+{
+    host_tab t;
+    t.ofs.resize(dsize), t.ofs1.resize(dsize), t.c0.resize(dsize), t.c1.resize(dsize);
+    t.vmax = dsize;
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; ++d) {
+        int s = (int)std::floor(d * scale);
+        float f = (float)((d + 1) - (s + 1) * inv_scale);
+        f = f <= 0 ? 0.f : f - (float)std::floor(f);
+        if (s < 0)
+            f = 0, s = 0;
+        if (s + 1 >= ssize) {
+            t.vmax = std::min(t.vmax, d);
+            if (s >= ssize - 1)
+                f = 0, s = ssize - 1;
+        }
+        t.ofs[d] = s;
+        t.ofs1[d] = std::min(s + 1, ssize - 1);
+        t.c0[d] = 1.f - f;
+        t.c1[d] = f;
+    }
+    return t;
+}
+
+gauss_t make_gauss(double sigma)
+{
+    // OpenCV 4.4.0 getGaussianKernel(17, 3.0, CV_32F): double exp, normalised, narrowed to float
+    gauss_t gk;
+    double v[KSIZE];
+    const int n2 = (KSIZE - 1) / 2;
+    const double scale2x = -0.125 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0, x = 1 - KSIZE; i < n2; ++i, x += 2) {
+        v[i] = std::exp((double)(x * x) * scale2x);
+        sum += v[i];
+    }
+    sum = sum * 2 + 1.0;
+    const double mul1 = 1.0 / sum;
+    for (int i = 0; i < n2; ++i)
+        gk.k[i] = gk.k[KSIZE - 1 - i] = (float)(v[i] * mul1);
+    gk.k[n2] = (float)(1.0 * mul1);
+    return gk;
+}
+
+} // namespace
+
+// =====================================================================================================
+struct hp_paf {
+    float conf_thresh, paf_thresh;
+    int res_w, res_h;
+    int max_batch;
+    int peak_cap = 512;   // peaks per part per frame
+    int cand_cap = 2048;  // candidates per limb per frame that survive the two criteria
+    int human_cap = 128;  // humans per frame copied back
+
+    bool shaped = false;
+    geom_t g{};
+    gauss_t gk{};
+    int TH = 24, TW = 0, tiles_x = 0, tiles_y = 0, src_rows_cap = 0, Uw_cap = 0, Rw_cap = 0;
+    size_t peaks_lds = 0, limbs_lds = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    hp::dev_buf tables, plist, sorted, pcount, conns, conn_count, flags, humans, n_humans, in_conf, in_paf;
+    hp::host_buf h_humans, h_counts; // h_counts: [n_humans(max_batch) | flags(1)]
+    int pending = 0; // frames of the enqueued, not yet collected batch
+    int last_n = 0;  // frames of the last completed batch (debug taps)
+
+    int shape(const int conf_shape[3], const int paf_shape[3]);
+};
+
+int hp_paf::shape(const int cs[3], const int ps[3])
+{
+    HP_REQUIRE(cs && ps, HP_ERR_INVALID, "paf: null shape");
+    HP_REQUIRE(cs[0] > 0 && cs[1] > 0 && cs[2] > 0 && ps[0] > 0, HP_ERR_INVALID, "paf: bad shape");
+    HP_REQUIRE(cs[1] == ps[1] && cs[2] == ps[2], HP_ERR_INVALID,
+        "paf: conf [%d,%d,%d] and paf [%d,%d,%d] disagree (reference asserts, src/paf.cpp:318-319)", cs[0], cs[1], cs[2], ps[0], ps[1], ps[2]);
+    if (shaped) {
+        HP_REQUIRE(cs[0] == g.J && cs[1] == g.R && cs[2] == g.Cc && ps[0] == g.L2, HP_ERR_STATE,
+            "paf: feature-map shape changed after the first call (the reference allocates once, src/paf.cpp:321-332)");
+        return HP_OK;
+    }
+    HP_REQUIRE(cs[0] >= HP_COCO_N_PARTS && ps[0] >= 2 * HP_COCO_N_PAIRS, HP_ERR_INVALID,
+        "paf: need >= 18 conf and >= 38 paf channels, got %d / %d", cs[0], ps[0]);
+    g.J = cs[0], g.L2 = ps[0], g.R = cs[1], g.Cc = cs[2];
+    // src/paf.cpp:311-315: `auto [n, fw, fh] = dims()` => fw = rows, fh = cols; default Size(fw*4, fh*4)
+    const int fw = g.R, fh = g.Cc;
+    if (res_w == -1 || res_h == -1)
+        res_w = fw * 4, res_h = fh * 4;
+    HP_REQUIRE(res_w > 0 && res_h > 0, HP_ERR_INVALID, "paf: bad resolution %dx%d", res_w, res_h);
+    HP_REQUIRE(!(res_h == g.R && res_w == g.Cc), HP_ERR_INVALID,
+        "paf: resolution == feature size: the reference's resize_area returns without writing (post_process.hpp:31-32)");
+    HP_REQUIRE(res_w < 65536 / 2 && res_h < 65536 / 2, HP_ERR_INVALID, "paf: resolution too large");
+    g.UH = res_h, g.UW = res_w;
+    g.feat_height = fh; // m_feature_size = Size(fw, fh) -> .height (paf.cpp:329, :354)
+
+    const host_tab tx = make_tab(g.Cc, g.UW), ty = make_tab(g.R, g.UH);
+    g.vmax_x = tx.vmax;
+    gk = make_gauss(3.0);
+    // one table buffer: ofs_x | c0_x | c1_x | ofs_y0 | ofs_y1 | c0_y | c1_y
+    std::vector<int> blob((size_t)3 * g.UW + 4 * g.UH);
+    int* b = blob.data();
+    memcpy(b, tx.ofs.data(), g.UW * 4), memcpy(b + g.UW, tx.c0.data(), g.UW * 4), memcpy(b + 2 * g.UW, tx.c1.data(), g.UW * 4);
+    int* by = b + 3 * g.UW;
+    memcpy(by, ty.ofs.data(), g.UH * 4), memcpy(by + g.UH, ty.ofs1.data(), g.UH * 4);
+    memcpy(by + 2 * g.UH, ty.c0.data(), g.UH * 4), memcpy(by + 3 * g.UH, ty.c1.data(), g.UH * 4);
+    HP_TRY(tables.alloc(blob.size() * 4));
+    HP_HIP_TRY(hipMemcpy(tables.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+    const int* d = tables.as<int>();
+    g.ofs_x = d, g.c0_x = (const float*)(d + g.UW), g.c1_x = (const float*)(d + 2 * g.UW);
+    const int* dy = d + 3 * g.UW;
+    g.ofs_y0 = dy, g.ofs_y1 = dy + g.UH, g.c0_y = (const float*)(dy + 2 * g.UH), g.c1_y = (const float*)(dy + 3 * g.UH);
+
+    // tiling of the up-sampled map: bands of TH rows, full width unless the LDS budget says otherwise
+    TH = std::min(24, g.UH);
+    TW = g.UW;
+    auto lds_for = [&](int tw) {
+        const int uw = std::min(g.UW, tw + 2 + 2 * KR), rw = std::min(g.UW, tw + 2);
+        // source rows a band can touch: (TH + 2 + 2*KR) up-sampled rows span at most this many source rows
+        const int rows = std::min(g.R, (int)std::ceil((TH + 2 + 2 * KR) * (double)g.R / g.UH) + 3);
+        return (size_t)4 * ((size_t)rows * g.Cc + (size_t)(TH + 2 + 2 * KR) * uw + (size_t)(TH + 2 + 2 * KR) * rw);
+    };
+    while (lds_for(TW) > 64 * 1024 && TW > 32)
+        TW = (TW + 1) / 2;
+    tiles_x = hp::ceil_div(g.UW, TW), tiles_y = hp::ceil_div(g.UH, TH);
+    Uw_cap = std::min(g.UW, TW + 2 + 2 * KR), Rw_cap = std::min(g.UW, TW + 2);
+    src_rows_cap = std::min(g.R, (int)std::ceil((TH + 2 + 2 * KR) * (double)g.R / g.UH) + 3);
+    peaks_lds = lds_for(TW);
+    limbs_lds = (size_t)4 * 2 * g.R * g.Cc + (size_t)cand_cap * (sizeof(cand_t) + sizeof(int));
+    HP_REQUIRE(peaks_lds <= 160 * 1024 && limbs_lds <= 160 * 1024, HP_ERR_INVALID, "paf: feature map too large for LDS tiling");
+    HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_peaks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)peaks_lds));
+    HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limbs_lds));
+
+    const size_t B = max_batch;
+    HP_TRY(plist.alloc(B * HP_COCO_N_PARTS * peak_cap * sizeof(dpeak)));
+    HP_TRY(sorted.alloc(B * HP_COCO_N_PARTS * peak_cap * sizeof(dpeak)));
+    HP_TRY(pcount.alloc(B * HP_COCO_N_PARTS * sizeof(int)));
+    HP_TRY(conns.alloc(B * HP_COCO_N_PAIRS * peak_cap * sizeof(dconn)));
+    HP_TRY(conn_count.alloc(B * HP_COCO_N_PAIRS * sizeof(int)));
+    HP_TRY(flags.alloc(sizeof(int)));
+    HP_TRY(humans.alloc(B * human_cap * sizeof(hp_human)));
+    HP_TRY(n_humans.alloc(B * sizeof(int)));
+    HP_TRY(h_humans.alloc(B * human_cap * sizeof(hp_human)));
+    HP_TRY(h_counts.alloc((B + 1) * sizeof(int)));
+    shaped = true;
+    return HP_OK;
+}
+
+extern "C" {
+
+int hp_paf_create(hp_paf** out, float conf_thresh, float paf_thresh, int res_w, int res_h, int max_batch)
+{
+    HP_REQUIRE(out, HP_ERR_INVALID, "hp_paf_create: null out");
+    HP_REQUIRE(max_batch >= 1 && max_batch <= 65535, HP_ERR_INVALID, "hp_paf_create: max_batch %d", max_batch);
+    hp_paf* p = new hp_paf();
+    p->conf_thresh = conf_thresh, p->paf_thresh = paf_thresh, p->res_w = res_w, p->res_h = res_h, p->max_batch = max_batch;
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        hp::set_error("hp_paf_create: %s", hipGetErrorString(e));
+        delete p;
+        return HP_ERR_HIP;
+    }
+    *out = p;
+    return HP_OK;
+}
+
+void hp_paf_destroy(hp_paf* p)
+{
+    if (!p)
+        return;
+    if (p->stream)
+        (void)hipStreamSynchronize(p->stream);
+    if (p->done)
+        (void)hipEventDestroy(p->done);
+    if (p->stream)
+        (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int hp_paf_set_conf_thresh(hp_paf* p, float thresh)
+{
+    HP_REQUIRE(p, HP_ERR_INVALID, "null parser");
+    p->conf_thresh = thresh;
+    return HP_OK;
+}
+
+int hp_paf_set_paf_thresh(hp_paf* p, float thresh)
+{
+    HP_REQUIRE(p, HP_ERR_INVALID, "null parser");
+    p->paf_thresh = thresh;
+    return HP_OK;
+}
+
+static int launch_peaks(hp_paf* p, int n, const float* dev_conf, hipStream_t s, float* dump_up, float* dump_smooth, int channels)
+{
+    dim3 grid(p->tiles_x * p->tiles_y, channels, n);
+    hipLaunchKernelGGL(paf_peaks_kernel, grid, dim3(PEAK_THREADS), p->peaks_lds, s, dev_conf, p->g, p->gk, p->conf_thresh,
+        p->TH, p->TW, p->tiles_x, p->src_rows_cap, p->Uw_cap, p->Rw_cap, p->plist.as<dpeak>(), p->pcount.as<int>(), p->peak_cap,
+        dump_up, dump_smooth);
+    HP_HIP_TRY(hipGetLastError());
+    return HP_OK;
+}
+
+int hp_paf_enqueue(hp_paf* p, int n, const float* dev_conf, const int conf_shape[3], const float* dev_paf,
+    const int paf_shape[3], void* stream)
+{
+    HP_REQUIRE(p && dev_conf && dev_paf, HP_ERR_INVALID, "hp_paf_enqueue: null argument");
+    HP_REQUIRE(n >= 1 && n <= p->max_batch, HP_ERR_CAPACITY, "hp_paf_enqueue: batch %d > max_batch %d", n, p->max_batch);
+    HP_REQUIRE(p->pending == 0, HP_ERR_STATE, "hp_paf_enqueue: previous batch not collected");
+    HP_TRY(p->shape(conf_shape, paf_shape));
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+
+    HP_HIP_TRY(hipMemsetAsync(p->pcount.p, 0, (size_t)n * HP_COCO_N_PARTS * sizeof(int), s));
+    HP_HIP_TRY(hipMemsetAsync(p->flags.p, 0, sizeof(int), s));
+    HP_TRY(launch_peaks(p, n, dev_conf, s, nullptr, nullptr, HP_COCO_N_PARTS));
+    hipLaunchKernelGGL(paf_sort_kernel, dim3(HP_COCO_N_PARTS, n), dim3(256), p->peak_cap * sizeof(int), s,
+        p->plist.as<dpeak>(), p->pcount.as<int>(), p->peak_cap, p->sorted.as<dpeak>());
+    hipLaunchKernelGGL(paf_limbs_kernel, dim3(HP_COCO_N_PAIRS, n), dim3(256), p->limbs_lds, s, dev_paf, p->g, p->paf_thresh,
+        p->sorted.as<dpeak>(), p->pcount.as<int>(), p->peak_cap, p->cand_cap, p->conns.as<dconn>(), p->conn_count.as<int>(),
+        p->flags.as<int>());
+    hipLaunchKernelGGL(paf_assemble_kernel, dim3(n), dim3(64), 0, s, p->sorted.as<dpeak>(), p->pcount.as<int>(), p->peak_cap,
+        p->conns.as<dconn>(), p->conn_count.as<int>(), p->res_w, p->res_h, p->humans.as<hp_human>(), p->n_humans.as<int>(),
+        p->human_cap, p->flags.as<int>());
+    HP_HIP_TRY(hipGetLastError());
+    HP_HIP_TRY(hipMemcpyAsync(p->h_humans.p, p->humans.p, (size_t)n * p->human_cap * sizeof(hp_human), hipMemcpyDeviceToHost, s));
+    HP_HIP_TRY(hipMemcpyAsync(p->h_counts.p, p->n_humans.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HP_HIP_TRY(hipMemcpyAsync(p->h_counts.as<int>() + p->max_batch, p->flags.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HP_HIP_TRY(hipEventRecord(p->done, s));
+    p->pending = n;
+    return HP_OK;
+}
+
+int hp_paf_collect(hp_paf* p, hp_human* out, int cap_per_frame, int* n_out)
+{
+    HP_REQUIRE(p && n_out, HP_ERR_INVALID, "hp_paf_collect: null argument");
+    HP_REQUIRE(p->pending > 0, HP_ERR_STATE, "hp_paf_collect: nothing enqueued");
+    HP_HIP_TRY(hipEventSynchronize(p->done));
+    const int n = p->pending;
+    p->pending = 0;
+    p->last_n = n;
+    const int fl = p->h_counts.as<int>()[p->max_batch];
+    HP_REQUIRE(fl == 0, HP_ERR_CAPACITY, "paf: device list overflow (flags=%d: 1=peaks/part>%d, 2=candidates/limb>%d, 4=humans>%d)",
+        fl, p->peak_cap, p->cand_cap, MAXH);
+    int rc = HP_OK;
+    for (int f = 0; f < n; ++f) {
+        const int nh = p->h_counts.as<int>()[f];
+        n_out[f] = nh;
+        if (nh > cap_per_frame || nh > p->human_cap) {
+            hp::set_error("paf: frame %d has %d humans, capacity %d", f, nh, std::min(cap_per_frame, p->human_cap));
+            rc = HP_ERR_CAPACITY;
+        }
+        if (out)
+            memcpy(out + (size_t)f * cap_per_frame, p->h_humans.as<hp_human>() + (size_t)f * p->human_cap,
+                sizeof(hp_human) * std::min(std::min(nh, cap_per_frame), p->human_cap));
+    }
+    return rc;
+}
+
+int hp_paf_process_batch(hp_paf* p, int n, const float* conf, const int conf_shape[3], const float* paf,
+    const int paf_shape[3], int on_device, hp_human* out, int cap_per_frame, int* n_out)
+{
+    HP_REQUIRE(p && conf && paf && conf_shape && paf_shape, HP_ERR_INVALID, "hp_paf_process_batch: null argument");
+    HP_REQUIRE(n >= 1 && n <= p->max_batch, HP_ERR_CAPACITY, "hp_paf_process_batch: batch %d > max_batch %d", n, p->max_batch);
+    const float *dc = conf, *dp = paf;
+    if (!on_device) {
+        const size_t cb = (size_t)n * conf_shape[0] * conf_shape[1] * conf_shape[2] * sizeof(float);
+        const size_t pb = (size_t)n * paf_shape[0] * paf_shape[1] * paf_shape[2] * sizeof(float);
+        if (p->in_conf.bytes < cb)
+            HP_TRY(p->in_conf.alloc((size_t)p->max_batch * conf_shape[0] * conf_shape[1] * conf_shape[2] * sizeof(float)));
+        if (p->in_paf.bytes < pb)
+            HP_TRY(p->in_paf.alloc((size_t)p->max_batch * paf_shape[0] * paf_shape[1] * paf_shape[2] * sizeof(float)));
+        HP_HIP_TRY(hipMemcpyAsync(p->in_conf.p, conf, cb, hipMemcpyHostToDevice, p->stream));
+        HP_HIP_TRY(hipMemcpyAsync(p->in_paf.p, paf, pb, hipMemcpyHostToDevice, p->stream));
+        dc = p->in_conf.as<float>(), dp = p->in_paf.as<float>();
+    }
+    HP_TRY(hp_paf_enqueue(p, n, dc, conf_shape, dp, paf_shape, nullptr));
+    return hp_paf_collect(p, out, cap_per_frame, n_out);
+}
+
+int hp_paf_debug_peaks(hp_paf* p, int frame, hp_peak* out, int cap, int* n)
+{
+    HP_REQUIRE(p && n && p->shaped, HP_ERR_INVALID, "hp_paf_debug_peaks: bad argument");
+    HP_REQUIRE(frame >= 0 && frame < p->last_n && p->pending == 0, HP_ERR_STATE, "hp_paf_debug_peaks: no completed batch holds frame %d", frame);
+    std::vector<int> cnt(HP_COCO_N_PARTS);
+    HP_HIP_TRY(hipMemcpy(cnt.data(), p->pcount.as<int>() + frame * HP_COCO_N_PARTS, cnt.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<dpeak> buf(p->peak_cap);
+    int id = 0;
+    for (int k = 0; k < HP_COCO_N_PARTS; ++k) {
+        const int nk = std::min(cnt[k], p->peak_cap);
+        HP_HIP_TRY(hipMemcpy(buf.data(), p->sorted.as<dpeak>() + ((size_t)frame * HP_COCO_N_PARTS + k) * p->peak_cap, nk * sizeof(dpeak), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nk; ++i, ++id)
+            if (out && id < cap)
+                out[id] = hp_peak{ k, buf[i].x, buf[i].y, buf[i].score, id };
+    }
+    *n = id;
+    return HP_OK;
+}
+
+int hp_paf_debug_conns(hp_paf* p, int frame, hp_conn* out, int cap, int* n)
+{
+    HP_REQUIRE(p && n && p->shaped, HP_ERR_INVALID, "hp_paf_debug_conns: bad argument");
+    HP_REQUIRE(frame >= 0 && frame < p->last_n && p->pending == 0, HP_ERR_STATE, "hp_paf_debug_conns: no completed batch holds frame %d", frame);
+    std::vector<int> cnt(HP_COCO_N_PAIRS);
+    HP_HIP_TRY(hipMemcpy(cnt.data(), p->conn_count.as<int>() + frame * HP_COCO_N_PAIRS, cnt.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<dconn> buf(p->peak_cap);
+    int id = 0;
+    for (int l = 0; l < HP_COCO_N_PAIRS; ++l) {
+        HP_HIP_TRY(hipMemcpy(buf.data(), p->conns.as<dconn>() + ((size_t)frame * HP_COCO_N_PAIRS + l) * p->peak_cap, cnt[l] * sizeof(dconn), hipMemcpyDeviceToHost));
+        for (int i = 0; i < cnt[l]; ++i, ++id)
+            if (out && id < cap)
+                out[id] = hp_conn{ l, buf[i].cid1, buf[i].cid2, buf[i].score };
+    }
+    *n = id;
+    return HP_OK;
+}
+
+int hp_paf_debug_maps(hp_paf* p, const float* host_conf, const int conf_shape[3], float* host_up, float* host_smoothed)
+{
+    HP_REQUIRE(p && host_conf && conf_shape, HP_ERR_INVALID, "hp_paf_debug_maps: null argument");
+    HP_REQUIRE(p->pending == 0, HP_ERR_STATE, "hp_paf_debug_maps: a batch is in flight");
+    int ps[3] = { 2 * HP_COCO_N_PAIRS, conf_shape[1], conf_shape[2] };
+    if (p->shaped)
+        ps[0] = p->g.L2;
+    HP_TRY(p->shape(conf_shape, ps));
+    const size_t in_b = (size_t)p->g.J * p->g.R * p->g.Cc * 4, out_b = (size_t)p->g.J * p->g.UH * p->g.UW * 4;
+    hp::dev_buf din, dup, dsm;
+    HP_TRY(din.alloc(in_b));
+    HP_TRY(dup.alloc(out_b));
+    HP_TRY(dsm.alloc(out_b));
+    HP_HIP_TRY(hipMemcpy(din.p, host_conf, in_b, hipMemcpyHostToDevice));
+    HP_HIP_TRY(hipMemsetAsync(p->pcount.p, 0, (size_t)HP_COCO_N_PARTS * sizeof(int), p->stream));
+    HP_TRY(launch_peaks(p, 1, din.as<float>(), p->stream, dup.as<float>(), dsm.as<float>(), p->g.J));
+    HP_HIP_TRY(hipStreamSynchronize(p->stream));
+    if (host_up)
+        HP_HIP_TRY(hipMemcpy(host_up, dup.p, out_b, hipMemcpyDeviceToHost));
+    if (host_smoothed)
+        HP_HIP_TRY(hipMemcpy(host_smoothed, dsm.p, out_b, hipMemcpyDeviceToHost));
+    return HP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,121 @@
+"""Host-side mirror of ``hyperpose::parser`` (reference include/hyperpose/operator/parser/*.hpp) over the C ABI.
+
+``Paf`` has the constructor arguments, setters and ``process`` meaning of ``hyperpose::parser::paf``
+(paf.hpp:17-93); the batched / asynchronous forms are the MI355X additions.  All arithmetic happens in
+libhp_hip.so on the GPU — this file only marshals pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CONN_DTYPE, HUMAN_DTYPE, PEAK_DTYPE, Conn, Human, Peak, as_ptr, check, lib
+
+_FP = C.POINTER(C.c_float)
+
+
+class Paf:
+    """``hyperpose::parser::paf`` (conf_thresh=0.05, paf_thresh=0.05, resolution_size=(-1,-1))."""
+
+    def __init__(self, conf_thresh: float = 0.05, paf_thresh: float = 0.05, resolution_size=(-1, -1),
+                 max_batch: int = 8, cap_per_frame: int = 128):
+        self._h = C.c_void_p()
+        self.max_batch = int(max_batch)
+        self.cap = int(cap_per_frame)
+        w, h = resolution_size  # cv::Size(width, height)
+        check(lib().hp_paf_create(C.byref(self._h), C.c_float(conf_thresh), C.c_float(paf_thresh), int(w), int(h),
+                                  self.max_batch))
+        self._out = (Human * (self.max_batch * self.cap))()
+        self._n = (C.c_int * self.max_batch)()
+        self._pending = 0
+
+    def close(self):
+        if self._h:
+            lib().hp_paf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_paf_thresh(self, thresh: float):
+        check(lib().hp_paf_set_paf_thresh(self._h, C.c_float(thresh)))
+
+    def set_conf_thresh(self, thresh: float):
+        check(lib().hp_paf_set_conf_thresh(self._h, C.c_float(thresh)))
+
+    def _humans(self, n: int):
+        arr = np.frombuffer(self._out, dtype=HUMAN_DTYPE)
+        return [arr[f * self.cap: f * self.cap + self._n[f]].copy() for f in range(n)]
+
+    def process(self, conf: np.ndarray, paf: np.ndarray):
+        """One frame, host arrays conf [J,rows,cols], paf [2L,rows,cols] -> structured array of humans."""
+        return self.process_batch(conf[None], paf[None])[0]
+
+    def process_batch(self, conf, paf):
+        """n frames at once from host numpy arrays ([n,J,rows,cols] / [n,2L,rows,cols])."""
+        conf = np.ascontiguousarray(conf, np.float32)
+        paf = np.ascontiguousarray(paf, np.float32)
+        n = conf.shape[0]
+        cs = (C.c_int * 3)(*conf.shape[1:])
+        ps = (C.c_int * 3)(*paf.shape[1:])
+        check(lib().hp_paf_process_batch(self._h, n, conf.ctypes.data_as(_FP), cs, paf.ctypes.data_as(_FP), ps, 0,
+                                         self._out, self.cap, self._n))
+        return self._humans(n)
+
+    def process_batch_device(self, conf_dev, paf_dev, n: int, conf_shape, paf_shape):
+        cs = (C.c_int * 3)(*conf_shape)
+        ps = (C.c_int * 3)(*paf_shape)
+        check(lib().hp_paf_process_batch(self._h, n, as_ptr(conf_dev), cs, as_ptr(paf_dev), ps, 1, self._out, self.cap,
+                                         self._n))
+        return self._humans(n)
+
+    def enqueue(self, conf_dev, paf_dev, n: int, conf_shape, paf_shape, stream=None):
+        cs = (C.c_int * 3)(*conf_shape)
+        ps = (C.c_int * 3)(*paf_shape)
+        check(lib().hp_paf_enqueue(self._h, n, as_ptr(conf_dev), cs, as_ptr(paf_dev), ps,
+                                   C.c_void_p(stream) if stream else None))
+        self._pending = n
+
+    def collect(self):
+        n = self._pending
+        check(lib().hp_paf_collect(self._h, self._out, self.cap, self._n))
+        self._pending = 0
+        return self._humans(n)
+
+    # ---- stage-wise parity taps -------------------------------------------------------------------
+    def debug_peaks(self, frame: int = 0, cap: int = 16384) -> np.ndarray:
+        buf = (Peak * cap)()
+        n = C.c_int(0)
+        check(lib().hp_paf_debug_peaks(self._h, frame, buf, cap, C.byref(n)))
+        return np.frombuffer(buf, dtype=PEAK_DTYPE, count=min(n.value, cap)).copy()
+
+    def debug_conns(self, frame: int = 0, cap: int = 16384) -> np.ndarray:
+        buf = (Conn * cap)()
+        n = C.c_int(0)
+        check(lib().hp_paf_debug_conns(self._h, frame, buf, cap, C.byref(n)))
+        return np.frombuffer(buf, dtype=CONN_DTYPE, count=min(n.value, cap)).copy()
+
+    def debug_maps(self, conf: np.ndarray, res_h: int, res_w: int):
+        conf = np.ascontiguousarray(conf, np.float32)
+        cs = (C.c_int * 3)(*conf.shape)
+        up = np.zeros((conf.shape[0], res_h, res_w), np.float32)
+        sm = np.zeros_like(up)
+        check(lib().hp_paf_debug_maps(self._h, conf.ctypes.data_as(_FP), cs, up.ctypes.data_as(_FP), sm.ctypes.data_as(_FP)))
+        return up, sm
+
+
+def preproc_u8hwc_to_f32nchw(images: np.ndarray, factor: float = 1.0 / 255, flip_rb: bool = True) -> np.ndarray:
+    """``hyperpose::nhwc_images_append_nchw_batch`` (src/data.cpp:21-51) on the GPU, host arrays in/out."""
+    images = np.ascontiguousarray(images, np.uint8)
+    n, h, w, c = images.shape
+    assert c == 3
+    din = _lib.DevBuf.from_numpy(images)
+    dout = _lib.DevBuf(n * 3 * h * w * 4)
+    check(lib().hp_preproc_u8hwc_to_f32nchw(din.ptr, n, h, w, C.c_double(factor), int(flip_rb), dout.ptr, None))
+    check(lib().hp_device_synchronize())
+    return dout.to_numpy(np.float32, (n, 3, h, w))

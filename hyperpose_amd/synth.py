@@ -53,7 +53,8 @@ def skeletons(rng: np.random.Generator, n_people: int, rows: int, cols: int,
 
 
 def paf_maps(rng: np.random.Generator, batch: int, rows: int = 46, cols: int = 54, people=(1, 2, 4, 8),
-             sigma: float = 1.0, band: float = 1.0, noise: float = 0.01, drop_joint_prob: float = 0.05):
+             sigma: float = 1.0, band: float = 1.0, noise: float = 0.01, drop_joint_prob: float = 0.05,
+             scale_range=(14.0, 34.0)):
     """Synthetic (conf ``[B,19,rows,cols]``, paf ``[B,38,rows,cols]``) float32 + the joint list per frame."""
     yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float64)
     conf = np.zeros((batch, 19, rows, cols))
@@ -61,7 +62,7 @@ def paf_maps(rng: np.random.Generator, batch: int, rows: int = 46, cols: int = 5
     truth = []
     for b in range(batch):
         n = int(people[b % len(people)])
-        sk = skeletons(rng, n, rows, cols)
+        sk = skeletons(rng, n, rows, cols, scale_range=scale_range)
         visible = rng.uniform(size=(n, 18)) >= drop_joint_prob
         truth.append((sk, visible))
         for p in range(n):
