@@ -1,0 +1,546 @@
+// engine.cpp — hyperpose::dnn engine on gfx950 (replaces reference src/tensorrt.cpp).
+//
+// The reference hands an exported graph to TensorRT (create_{uff,onnx,serialized}_engine, src/tensorrt.cpp:121-252),
+// allocates one device buffer per binding for max_batch (:255-316) and, per call, does H2D of an f32 NCHW
+// batch, executeV2, and one D2H per (output x image) (:364-434).  Here the graph is a static layer list
+// (include/hp_hip.h: hp_layer) executed as a fixed schedule of hand-written HIP kernels (conv_kernels.hip)
+// on one stream, optionally replayed from a captured hipGraph:
+//   * input stays u8 HWC in HBM; the u8->f32 / BGR->RGB / mean-std step of src/data.cpp:21-51 is folded into the
+//     first convolution's load;
+//   * activations are NHWC fp16 with fp32 MFMA accumulation, concat is a channel offset into a shared buffer;
+//   * heads write fp32 NCHW straight from the conv epilogue into the buffers the parser kernels read —
+//     feature maps never cross PCIe.
+#include "conv_kernels.hpp"
+#include "hp_common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+struct tensor_info {
+    bool defined = false;
+    int H = 0, W = 0, C = 0; // C = total channels written
+    int cs = 0;              // channel stride of the buffer
+    hp::dev_buf buf;
+};
+
+struct out_info {
+    std::string name;
+    int tensor, coff, channels, act;
+    int H, W;
+    int fused_layer = -1; // layer whose epilogue writes it, or -1 -> conversion kernel
+    std::unique_ptr<hp::dev_buf> buf;
+};
+
+struct step {
+    int layer;
+    int op;
+    bool first = false; // direct 3-channel conv
+    hp::conv_params cp{};
+    hp::first_conv_params fp{};
+    hp::dw_params dp{};
+    hp::pool_params pp{};
+    double flops = 0, bytes = 0; // per frame
+};
+
+void same_pad(int in, int k, int stride, int dil, int& out, int& pad_before)
+{
+    // TF "SAME": out = ceil(in / stride); pad_total = max((out-1)*stride + (k-1)*dil + 1 - in, 0); extra at the end
+    out = (in + stride - 1) / stride;
+    const int total = std::max((out - 1) * stride + (k - 1) * dil + 1 - in, 0);
+    pad_before = total / 2;
+}
+
+} // namespace
+
+struct hp_engine {
+    int in_w = 0, in_h = 0, max_batch = 0;
+    double factor = 1.0 / 255;
+    int flip_rb = 1;
+    float mean[3] = { 0, 0, 0 }, inv_std[3] = { 1, 1, 1 };
+    std::vector<hp_layer> layers;
+    std::vector<std::unique_ptr<tensor_info>> tensors;
+    std::vector<out_info> outputs; // sorted by name
+    std::vector<step> steps;
+    std::vector<std::unique_ptr<hp::dev_buf>> weight_bufs;
+    hp::dev_buf in_stage; // staging for host inputs
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // captured graphs keyed by (n, input pointer, kind)
+    struct graph_key {
+        int n;
+        const void* ptr;
+        int kind;
+        bool operator<(const graph_key& o) const { return std::tie(n, ptr, kind) < std::tie(o.n, o.ptr, o.kind); }
+    };
+    std::map<graph_key, hipGraphExec_t> graphs;
+    bool use_graph = true;
+
+    ~hp_engine()
+    {
+        for (auto& g : graphs)
+            (void)hipGraphExecDestroy(g.second);
+        if (ev0)
+            (void)hipEventDestroy(ev0);
+        if (ev1)
+            (void)hipEventDestroy(ev1);
+        if (stream)
+            (void)hipStreamDestroy(stream);
+    }
+
+    int build(const hp_engine_desc* d);
+    int enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s);
+    int run_step(step& st, const uint8_t* u8, const float* f32, int n, hipStream_t s);
+};
+
+int hp_engine::build(const hp_engine_desc* d)
+{
+    HP_REQUIRE(d->in_w > 0 && d->in_h > 0 && d->max_batch >= 1, HP_ERR_INVALID, "engine: bad input size / batch");
+    HP_REQUIRE(d->layers && d->n_layers > 0 && d->weights, HP_ERR_INVALID, "engine: no layers / weights");
+    in_w = d->in_w, in_h = d->in_h, max_batch = d->max_batch, factor = d->factor, flip_rb = d->flip_rb;
+    for (int c = 0; c < 3; ++c)
+        mean[c] = d->mean[c], inv_std[c] = d->inv_std[c];
+    layers.assign(d->layers, d->layers + d->n_layers);
+
+    // ---- pass 1: tensor shapes
+    int max_id = 0;
+    for (const auto& L : layers)
+        max_id = std::max({ max_id, L.in, L.out, L.res });
+    tensors.resize(max_id + 1);
+    for (auto& t : tensors)
+        t = std::make_unique<tensor_info>();
+    tensors[0]->defined = true, tensors[0]->H = in_h, tensors[0]->W = in_w, tensors[0]->C = 3;
+    struct geo {
+        int OH, OW, pt, pl;
+    };
+    std::vector<geo> geos(layers.size());
+    for (size_t i = 0; i < layers.size(); ++i) {
+        const hp_layer& L = layers[i];
+        HP_REQUIRE(L.in >= 0 && L.in <= max_id && tensors[L.in]->defined, HP_ERR_INVALID, "layer %zu reads undefined tensor %d", i, L.in);
+        HP_REQUIRE(L.out > 0, HP_ERR_INVALID, "layer %zu: bad output tensor %d", i, L.out);
+        HP_REQUIRE(L.op == HP_OP_CONV || L.op == HP_OP_DWCONV || L.op == HP_OP_MAXPOOL, HP_ERR_INVALID, "layer %zu: unknown op %d", i, L.op);
+        HP_REQUIRE(L.stride >= 1 && L.kh >= 1 && L.kw >= 1 && L.dil >= 1, HP_ERR_INVALID, "layer %zu: bad geometry", i);
+        const tensor_info& ti = *tensors[L.in];
+        HP_REQUIRE(L.in_coff >= 0 && L.in_coff + L.cin <= ti.C, HP_ERR_INVALID, "layer %zu reads channels [%d,%d) of a %d-channel tensor", i, L.in_coff, L.in_coff + L.cin, ti.C);
+        geo g;
+        same_pad(ti.H, L.kh, L.stride, L.dil, g.OH, g.pt);
+        same_pad(ti.W, L.kw, L.stride, L.dil, g.OW, g.pl);
+        geos[i] = g;
+        tensor_info& to = *tensors[L.out];
+        if (!to.defined)
+            to.defined = true, to.H = g.OH, to.W = g.OW;
+        HP_REQUIRE(to.H == g.OH && to.W == g.OW, HP_ERR_INVALID, "layer %zu: writers of tensor %d disagree on its size", i, L.out);
+        to.C = std::max(to.C, L.out_coff + L.cout);
+        if (L.res >= 0) {
+            HP_REQUIRE(tensors[L.res]->defined && tensors[L.res]->H == g.OH && tensors[L.res]->W == g.OW && tensors[L.res]->C >= L.cout,
+                HP_ERR_INVALID, "layer %zu: residual tensor %d does not match the output", i, L.res);
+        }
+        if (L.op != HP_OP_CONV)
+            HP_REQUIRE(L.cin == L.cout, HP_ERR_INVALID, "layer %zu: depthwise/pool need cin == cout", i);
+    }
+    for (size_t t = 1; t < tensors.size(); ++t) {
+        tensor_info& ti = *tensors[t];
+        if (!ti.defined)
+            continue;
+        ti.cs = round_up(ti.C, 32);
+        const size_t bytes = (size_t)max_batch * ti.H * ti.W * ti.cs * sizeof(__half);
+        HP_TRY(ti.buf.alloc(bytes));
+        HP_HIP_TRY(hipMemset(ti.buf.p, 0, bytes)); // pad channels must read as zero
+    }
+
+    // ---- outputs
+    HP_REQUIRE(d->n_outputs >= 1 && d->outputs, HP_ERR_INVALID, "engine: no outputs");
+    for (int i = 0; i < d->n_outputs; ++i) {
+        const hp_output_desc& o = d->outputs[i];
+        HP_REQUIRE(o.tensor > 0 && o.tensor <= max_id && tensors[o.tensor]->defined, HP_ERR_INVALID, "output %d: bad tensor", i);
+        const tensor_info& ti = *tensors[o.tensor];
+        HP_REQUIRE(o.coff >= 0 && o.channels > 0 && o.coff + o.channels <= ti.C, HP_ERR_INVALID, "output %d: bad channel range", i);
+        out_info oi;
+        oi.name.assign(o.name, strnlen(o.name, sizeof(o.name)));
+        oi.tensor = o.tensor, oi.coff = o.coff, oi.channels = o.channels, oi.act = o.act, oi.H = ti.H, oi.W = ti.W;
+        outputs.push_back(std::move(oi));
+    }
+    std::stable_sort(outputs.begin(), outputs.end(), [](const out_info& a, const out_info& b) { return a.name < b.name; }); // tensorrt.cpp:405
+    for (auto& o : outputs) {
+        o.buf = std::make_unique<hp::dev_buf>();
+        HP_TRY(o.buf->alloc((size_t)max_batch * o.channels * o.H * o.W * sizeof(float)));
+        // fuse into the producing conv when one MFMA conv writes exactly this channel range and no post-op is needed
+        int writers = 0, last = -1;
+        for (size_t i = 0; i < layers.size(); ++i)
+            if (layers[i].out == o.tensor && layers[i].out_coff < o.coff + o.channels && layers[i].out_coff + layers[i].cout > o.coff)
+                ++writers, last = (int)i;
+        if (writers == 1 && layers[last].op == HP_OP_CONV && layers[last].in != 0 && layers[last].out_coff == o.coff
+            && layers[last].cout == o.channels && o.act == HP_ACT_NONE)
+            o.fused_layer = last;
+    }
+
+    // ---- pass 2: pack weights, build the schedule
+    auto blob = [&](int64_t off, size_t n, const char* what, size_t layer) -> const float* {
+        if (off < 0 || (size_t)off + n > d->n_weights) {
+            hp::set_error("layer %zu: %s range [%lld,+%zu) outside the %zu-float weight blob", layer, what, (long long)off, n, d->n_weights);
+            return nullptr;
+        }
+        return d->weights + off;
+    };
+    auto upload = [&](const void* src, size_t bytes, void** dst) -> int {
+        weight_bufs.push_back(std::make_unique<hp::dev_buf>());
+        HP_TRY(weight_bufs.back()->alloc(bytes));
+        HP_HIP_TRY(hipMemcpy(weight_bufs.back()->p, src, bytes, hipMemcpyHostToDevice));
+        *dst = weight_bufs.back()->p;
+        return HP_OK;
+    };
+
+    for (size_t i = 0; i < layers.size(); ++i) {
+        const hp_layer& L = layers[i];
+        const tensor_info& ti = *tensors[L.in];
+        tensor_info& to = *tensors[L.out];
+        const geo& g = geos[i];
+        step st;
+        st.layer = (int)i, st.op = L.op;
+        const double opix = (double)g.OH * g.OW;
+        if (L.op == HP_OP_CONV && L.in == 0) {
+            HP_REQUIRE(L.cin == 3 && L.in_coff == 0, HP_ERR_INVALID, "layer %zu: the network input has 3 channels", i);
+            HP_REQUIRE(L.dil == 1 && L.res < 0 && L.act != HP_ACT_PRELU, HP_ERR_INVALID, "layer %zu: unsupported first-layer options", i);
+            const size_t nw = (size_t)L.cout * L.kh * L.kw * 3;
+            const float* w = blob(L.w_off, nw, "weights", i);
+            if (!w)
+                return HP_ERR_INVALID;
+            std::vector<float> bias(round_up(L.cout, 8), 0.f);
+            if (L.b_off >= 0) {
+                const float* b = blob(L.b_off, L.cout, "bias", i);
+                if (!b)
+                    return HP_ERR_INVALID;
+                std::copy(b, b + L.cout, bias.begin());
+            }
+            st.first = true;
+            auto& p = st.fp;
+            p.factor = factor, p.flip_rb = flip_rb;
+            for (int c = 0; c < 3; ++c)
+                p.mean[c] = mean[c], p.inv_std[c] = inv_std[c];
+            p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.Cout = L.cout, p.KH = L.kh, p.KW = L.kw, p.stride = L.stride;
+            p.pad_t = g.pt, p.pad_l = g.pl, p.act = L.act, p.act_param = L.act_param;
+            void* dw = nullptr;
+            void* db = nullptr;
+            HP_TRY(upload(w, nw * sizeof(float), &dw));
+            HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
+            p.w = (const float*)dw, p.bias = (const float*)db;
+            p.out = to.buf.as<__half>(), p.out_cs = to.cs, p.out_coff = L.out_coff;
+            st.flops = 2.0 * opix * L.cout * L.kh * L.kw * 3;
+            st.bytes = (double)ti.H * ti.W * 3 + opix * L.cout * 2 + nw * 4;
+        } else if (L.op == HP_OP_CONV) {
+            const int cin_pad = round_up(L.cin, 32);
+            HP_REQUIRE(L.in_coff % 8 == 0 && L.in_coff + cin_pad <= ti.cs, HP_ERR_INVALID,
+                "layer %zu: channel slice [%d,+%d) not 8-aligned / exceeds the padded stride %d", i, L.in_coff, cin_pad, ti.cs);
+            const int cout_pad = L.cout > 64 ? round_up(L.cout, 128) : 64;
+            const int taps = L.kh * L.kw;
+            const size_t nw = (size_t)L.cout * taps * L.cin;
+            const float* w = blob(L.w_off, nw, "weights", i);
+            if (!w)
+                return HP_ERR_INVALID;
+            std::vector<__half> packed((size_t)taps * cout_pad * cin_pad, __float2half(0.f));
+            for (int co = 0; co < L.cout; ++co)
+                for (int t = 0; t < taps; ++t)
+                    for (int ci = 0; ci < L.cin; ++ci)
+                        packed[((size_t)t * cout_pad + co) * cin_pad + ci] = __float2half(w[((size_t)co * taps + t) * L.cin + ci]);
+            std::vector<float> bias(cout_pad, 0.f), alpha;
+            if (L.b_off >= 0) {
+                const float* b = blob(L.b_off, L.cout, "bias", i);
+                if (!b)
+                    return HP_ERR_INVALID;
+                std::copy(b, b + L.cout, bias.begin());
+            }
+            auto& p = st.cp;
+            void* dw = nullptr;
+            void* db = nullptr;
+            HP_TRY(upload(packed.data(), packed.size() * sizeof(__half), &dw));
+            HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
+            p.w = (const __half*)dw, p.bias = (const float*)db, p.alpha = nullptr;
+            if (L.act == HP_ACT_PRELU) {
+                alpha.assign(cout_pad, 0.f);
+                const float* a = blob(L.alpha_off, L.cout, "prelu slopes", i);
+                if (!a)
+                    return HP_ERR_INVALID;
+                std::copy(a, a + L.cout, alpha.begin());
+                void* da = nullptr;
+                HP_TRY(upload(alpha.data(), alpha.size() * sizeof(float), &da));
+                p.alpha = (const float*)da;
+            }
+            p.in = ti.buf.as<__half>(), p.in_cs = ti.cs, p.in_coff = L.in_coff;
+            p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.Cin = cin_pad, p.Cout = L.cout, p.Cout_pad = cout_pad;
+            p.KH = L.kh, p.KW = L.kw, p.stride = L.stride, p.dil = L.dil, p.pad_t = g.pt, p.pad_l = g.pl;
+            p.act = L.act, p.act_param = L.act_param;
+            p.res = nullptr, p.res_cs = 0, p.res_coff = 0, p.res_before_act = L.res_before_act;
+            if (L.res >= 0)
+                p.res = tensors[L.res]->buf.as<__half>(), p.res_cs = tensors[L.res]->cs;
+            p.out = to.buf.as<__half>(), p.out_cs = to.cs, p.out_coff = L.out_coff;
+            p.out_f32 = nullptr;
+            for (auto& o : outputs)
+                if (o.fused_layer == (int)i)
+                    p.out_f32 = o.buf->as<float>();
+            st.flops = 2.0 * opix * L.cout * taps * L.cin;
+            st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cout * 2 + (double)nw * 2;
+        } else if (L.op == HP_OP_DWCONV) {
+            HP_REQUIRE(L.kh == 3 && L.kw == 3, HP_ERR_INVALID, "layer %zu: depthwise kernels are 3x3", i);
+            HP_REQUIRE(L.cin % 8 == 0 && L.in_coff % 8 == 0 && L.out_coff % 8 == 0, HP_ERR_INVALID, "layer %zu: depthwise needs 8-aligned channels", i);
+            const float* w = blob(L.w_off, (size_t)L.cin * 9, "weights", i);
+            if (!w)
+                return HP_ERR_INVALID;
+            std::vector<__half> packed((size_t)9 * L.cin);
+            for (int c = 0; c < L.cin; ++c)
+                for (int t = 0; t < 9; ++t)
+                    packed[(size_t)t * L.cin + c] = __float2half(w[(size_t)c * 9 + t]);
+            std::vector<float> bias(L.cin, 0.f);
+            if (L.b_off >= 0) {
+                const float* b = blob(L.b_off, L.cin, "bias", i);
+                if (!b)
+                    return HP_ERR_INVALID;
+                std::copy(b, b + L.cin, bias.begin());
+            }
+            auto& p = st.dp;
+            void* dw = nullptr;
+            void* db = nullptr;
+            HP_TRY(upload(packed.data(), packed.size() * sizeof(__half), &dw));
+            HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
+            p.w = (const __half*)dw, p.bias = (const float*)db;
+            p.in = ti.buf.as<__half>(), p.in_cs = ti.cs, p.in_coff = L.in_coff;
+            p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.C = L.cin, p.stride = L.stride, p.dil = L.dil;
+            p.pad_t = g.pt, p.pad_l = g.pl, p.act = L.act, p.act_param = L.act_param;
+            p.out = to.buf.as<__half>(), p.out_cs = to.cs, p.out_coff = L.out_coff;
+            st.flops = 2.0 * opix * L.cin * 9;
+            st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cin * 2;
+        } else { // max-pool
+            HP_REQUIRE(L.cin % 8 == 0 && L.in_coff % 8 == 0 && L.out_coff % 8 == 0 && L.kh == L.kw, HP_ERR_INVALID, "layer %zu: bad pool", i);
+            auto& p = st.pp;
+            p.in = ti.buf.as<__half>(), p.in_cs = ti.cs, p.in_coff = L.in_coff;
+            p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.C = L.cin, p.k = L.kh, p.stride = L.stride;
+            p.pad_t = g.pt, p.pad_l = g.pl;
+            p.out = to.buf.as<__half>(), p.out_cs = to.cs, p.out_coff = L.out_coff;
+            st.flops = 0;
+            st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cin * 2;
+        }
+        steps.push_back(st);
+    }
+    HP_REQUIRE(!steps.empty() && steps[0].first, HP_ERR_INVALID, "engine: the first layer must be a CONV reading tensor 0");
+
+    HP_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HP_HIP_TRY(hipEventCreate(&ev0));
+    HP_HIP_TRY(hipEventCreate(&ev1));
+    return HP_OK;
+}
+
+int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hipStream_t s)
+{
+    if (st.first) {
+        st.fp.in_u8 = u8, st.fp.in_f32 = f32, st.fp.B = n;
+        HP_HIP_TRY(hp::launch_first_conv(st.fp, s));
+    } else if (st.op == HP_OP_CONV) {
+        st.cp.B = n, st.cp.npix = n * st.cp.OH * st.cp.OW;
+        HP_HIP_TRY(hp::launch_conv_mfma(st.cp, s));
+    } else if (st.op == HP_OP_DWCONV) {
+        st.dp.B = n;
+        HP_HIP_TRY(hp::launch_dwconv3x3(st.dp, s));
+    } else {
+        st.pp.B = n;
+        HP_HIP_TRY(hp::launch_maxpool(st.pp, s));
+    }
+    return HP_OK;
+}
+
+int hp_engine::enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s)
+{
+    for (auto& st : steps)
+        HP_TRY(run_step(st, u8, f32, n, s));
+    for (auto& o : outputs)
+        if (o.fused_layer < 0) {
+            const tensor_info& ti = *tensors[o.tensor];
+            HP_HIP_TRY(hp::launch_nhwc_to_nchw_f32(ti.buf.as<__half>(), ti.cs, o.coff, n, o.H, o.W, o.channels, o.act, o.buf->as<float>(), s));
+        }
+    return HP_OK;
+}
+
+extern "C" {
+
+int hp_engine_create(hp_engine** out, const hp_engine_desc* desc)
+{
+    HP_REQUIRE(out && desc, HP_ERR_INVALID, "hp_engine_create: null argument");
+    std::unique_ptr<hp_engine> e(new hp_engine());
+    HP_TRY(e->build(desc));
+    *out = e.release();
+    return HP_OK;
+}
+
+void hp_engine_destroy(hp_engine* e)
+{
+    if (!e)
+        return;
+    if (e->stream)
+        (void)hipStreamSynchronize(e->stream);
+    delete e;
+}
+
+int hp_engine_max_batch(const hp_engine* e) { return e ? e->max_batch : HP_ERR_INVALID; }
+
+int hp_engine_input_size(const hp_engine* e, int* w, int* h)
+{
+    HP_REQUIRE(e && w && h, HP_ERR_INVALID, "hp_engine_input_size: null argument");
+    *w = e->in_w, *h = e->in_h;
+    return HP_OK;
+}
+
+static int infer_common(hp_engine* e, const void* input, size_t frame_bytes, int n, int on_device, void* stream, int kind)
+{
+    HP_REQUIRE(e && input, HP_ERR_INVALID, "hp_engine_infer: null argument");
+    HP_REQUIRE(n >= 1, HP_ERR_INVALID, "hp_engine_infer: empty batch");
+    // src/tensorrt.cpp:439-443 throws std::logic_error here
+    HP_REQUIRE(n <= e->max_batch, HP_ERR_CAPACITY, "Input batch size overflow: Yours@%d Max@%d", n, e->max_batch);
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    const void* dev_in = input;
+    if (!on_device) {
+        const size_t need = (size_t)e->max_batch * e->in_h * e->in_w * 3 * sizeof(float);
+        if (e->in_stage.bytes < need)
+            HP_TRY(e->in_stage.alloc(need));
+        HP_HIP_TRY(hipMemcpyAsync(e->in_stage.p, input, frame_bytes * n, hipMemcpyHostToDevice, s));
+        dev_in = e->in_stage.p;
+    }
+    const uint8_t* u8 = kind == 0 ? (const uint8_t*)dev_in : nullptr;
+    const float* f32 = kind == 1 ? (const float*)dev_in : nullptr;
+    if (!e->use_graph)
+        return e->enqueue(u8, f32, n, s);
+
+    const hp_engine::graph_key key{ n, dev_in, kind };
+    auto it = e->graphs.find(key);
+    if (it == e->graphs.end()) {
+        // capture the whole schedule once per (batch, input buffer); replays cost one launch
+        hipGraph_t graph = nullptr;
+        HP_HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc = e->enqueue(u8, f32, n, s);
+        const hipError_t ee = hipStreamEndCapture(s, &graph);
+        if (rc != HP_OK) {
+            if (graph)
+                (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        HP_HIP_TRY(ee);
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HP_HIP_TRY(ie);
+        if (e->graphs.size() > 64) { // bound the cache for callers that pass a fresh pointer every time
+            for (auto& g : e->graphs)
+                (void)hipGraphExecDestroy(g.second);
+            e->graphs.clear();
+        }
+        it = e->graphs.emplace(key, exec).first;
+    }
+    HP_HIP_TRY(hipGraphLaunch(it->second, s));
+    return HP_OK;
+}
+
+int hp_engine_infer_u8(hp_engine* e, const uint8_t* hwc_bgr, int n, int on_device, void* stream)
+{
+    HP_REQUIRE(e, HP_ERR_INVALID, "hp_engine_infer_u8: null engine");
+    return infer_common(e, hwc_bgr, (size_t)e->in_h * e->in_w * 3, n, on_device, stream, 0);
+}
+
+int hp_engine_infer_f32(hp_engine* e, const float* nchw, int n, int on_device, void* stream)
+{
+    HP_REQUIRE(e, HP_ERR_INVALID, "hp_engine_infer_f32: null engine");
+    return infer_common(e, nchw, (size_t)e->in_h * e->in_w * 3 * sizeof(float), n, on_device, stream, 1);
+}
+
+int hp_engine_synchronize(hp_engine* e)
+{
+    HP_REQUIRE(e, HP_ERR_INVALID, "null engine");
+    HP_HIP_TRY(hipStreamSynchronize(e->stream));
+    return HP_OK;
+}
+
+void* hp_engine_stream(hp_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int hp_engine_set_graph(hp_engine* e, int enable)
+{
+    HP_REQUIRE(e, HP_ERR_INVALID, "null engine");
+    e->use_graph = enable != 0;
+    return HP_OK;
+}
+
+int hp_engine_num_outputs(const hp_engine* e) { return e ? (int)e->outputs.size() : HP_ERR_INVALID; }
+
+int hp_engine_output(const hp_engine* e, int i, const char** name, int shape[3], const float** dev)
+{
+    HP_REQUIRE(e && i >= 0 && i < (int)e->outputs.size(), HP_ERR_INVALID, "hp_engine_output: index %d", i);
+    const out_info& o = e->outputs[i];
+    if (name)
+        *name = o.name.c_str();
+    if (shape)
+        shape[0] = o.channels, shape[1] = o.H, shape[2] = o.W;
+    if (dev)
+        *dev = o.buf->as<float>();
+    return HP_OK;
+}
+
+int hp_engine_output_to_host(hp_engine* e, int i, int n, float* host)
+{
+    HP_REQUIRE(e && host && i >= 0 && i < (int)e->outputs.size() && n >= 1 && n <= e->max_batch, HP_ERR_INVALID, "hp_engine_output_to_host: bad argument");
+    const out_info& o = e->outputs[i];
+    HP_HIP_TRY(hipStreamSynchronize(e->stream));
+    HP_HIP_TRY(hipMemcpy(host, o.buf->p, (size_t)n * o.channels * o.H * o.W * sizeof(float), hipMemcpyDeviceToHost));
+    return HP_OK;
+}
+
+int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int shape[3])
+{
+    HP_REQUIRE(e && tensor > 0 && tensor < (int)e->tensors.size() && e->tensors[tensor]->defined, HP_ERR_INVALID, "hp_engine_debug_tensor: bad tensor %d", tensor);
+    const tensor_info& ti = *e->tensors[tensor];
+    if (shape)
+        shape[0] = ti.C, shape[1] = ti.H, shape[2] = ti.W;
+    if (!host)
+        return HP_OK;
+    HP_REQUIRE(n >= 1 && n <= e->max_batch, HP_ERR_INVALID, "hp_engine_debug_tensor: bad batch");
+    hp::dev_buf tmp;
+    HP_TRY(tmp.alloc((size_t)n * ti.C * ti.H * ti.W * sizeof(float)));
+    HP_HIP_TRY(hp::launch_nhwc_to_nchw_f32(ti.buf.as<__half>(), ti.cs, 0, n, ti.H, ti.W, ti.C, 0, tmp.as<float>(), e->stream));
+    HP_HIP_TRY(hipStreamSynchronize(e->stream));
+    HP_HIP_TRY(hipMemcpy(host, tmp.p, tmp.bytes, hipMemcpyDeviceToHost));
+    return HP_OK;
+}
+
+int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int cap, int* n_out)
+{
+    HP_REQUIRE(e && n >= 1 && n <= e->max_batch && iters >= 1 && n_out, HP_ERR_INVALID, "hp_engine_profile: bad argument");
+    // a zero-filled synthetic input: only timing matters here
+    const size_t need = (size_t)e->max_batch * e->in_h * e->in_w * 3 * sizeof(float);
+    if (e->in_stage.bytes < need)
+        HP_TRY(e->in_stage.alloc(need));
+    const uint8_t* u8 = e->in_stage.as<uint8_t>();
+    int k = 0;
+    for (auto& st : e->steps) {
+        HP_TRY(e->run_step(st, u8, nullptr, n, e->stream)); // warm
+        HP_HIP_TRY(hipEventRecord(e->ev0, e->stream));
+        for (int it = 0; it < iters; ++it)
+            HP_TRY(e->run_step(st, u8, nullptr, n, e->stream));
+        HP_HIP_TRY(hipEventRecord(e->ev1, e->stream));
+        HP_HIP_TRY(hipEventSynchronize(e->ev1));
+        float ms = 0;
+        HP_HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        if (out && k < cap) {
+            out[k].layer = st.layer, out[k].op = st.op;
+            out[k].tile = (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp) : 0;
+            out[k].ms = ms / iters;
+            out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
+        }
+        ++k;
+    }
+    *n_out = k;
+    return HP_OK;
+}
+
+} // extern "C"

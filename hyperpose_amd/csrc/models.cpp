@@ -1,0 +1,356 @@
+// models.cpp — built-in network topologies as hp_layer lists (include/hp_hip.h) + deterministic synthetic
+// weights.  Each builder restates one exported model of the reference's training library; BatchNorm layers
+// are inference-folded into the preceding convolution (so every conv_block = conv + bias + activation):
+//   MobilenetDilated backbone   hyperpose/Model/backbones.py:177-229 (dw_conv_block :190-197)
+//   vggtiny backbone            hyperpose/Model/backbones.py:343-391
+//   vgg19 backbone              hyperpose/Model/backbones.py:447-509 (subtracts vgg_mean/255, :455,501)
+//   LightWeightOpenPose head    hyperpose/Model/openpose/model/lw_openpose.py:12-191
+//   OpenPose (CMU) head         hyperpose/Model/openpose/model/openpose.py:13-198
+// The released weights are Google-Drive downloads (scripts/downloader.py:12-21) and there is no network, so
+// weights are synthetic: He-normal kernels from a counter-based generator (same numbers from C++ and Python).
+#include "hp_common.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+struct hp_model {
+    std::string arch;
+    int in_w = 0, in_h = 0;
+    std::vector<hp_layer> layers;
+    std::vector<float> init_scale; // per layer multiplier on the He std (final linear heads are kept small)
+    std::vector<hp_output_desc> outputs;
+    int64_t n_weights = 0;
+    int next_tensor = 1;
+    float mean[3] = { 0, 0, 0 }, inv_std[3] = { 1, 1, 1 };
+
+    int new_tensor() { return next_tensor++; }
+
+    // generic layer append; returns the output tensor id
+    int add(int op, int in, int in_coff, int cin, int cout, int k, int stride, int dil, int act, bool bias,
+        int out = -1, int out_coff = 0, int res = -1, int res_before_act = 0, float scale = 1.f, float act_param = 0.f)
+    {
+        hp_layer L;
+        memset(&L, 0, sizeof(L));
+        L.op = op, L.in = in, L.in_coff = in_coff, L.res = res, L.res_before_act = res_before_act;
+        L.out = out < 0 ? new_tensor() : out, L.out_coff = out_coff;
+        L.cin = cin, L.cout = cout, L.kh = k, L.kw = k, L.stride = stride, L.dil = dil, L.act = act, L.act_param = act_param;
+        L.w_off = -1, L.b_off = -1, L.alpha_off = -1;
+        if (op == HP_OP_CONV) {
+            L.w_off = n_weights;
+            n_weights += (int64_t)cout * k * k * cin;
+        } else if (op == HP_OP_DWCONV) {
+            L.w_off = n_weights;
+            n_weights += (int64_t)cin * k * k;
+        }
+        if (bias && op != HP_OP_MAXPOOL) {
+            L.b_off = n_weights;
+            n_weights += cout;
+        }
+        if (act == HP_ACT_PRELU) {
+            L.alpha_off = n_weights;
+            n_weights += cout;
+        }
+        layers.push_back(L);
+        init_scale.push_back(scale);
+        return L.out;
+    }
+    int conv(int in, int cin, int cout, int k, int act, int stride = 1, int dil = 1, int in_coff = 0)
+    {
+        return add(HP_OP_CONV, in, in_coff, cin, cout, k, stride, dil, act, true);
+    }
+    int dw_block(int in, int cin, int cout, int stride = 1, int dil = 1)
+    {
+        // dw_conv_block: DepthwiseConv2d(b=None)+BN+ReLU, Conv2d 1x1 (b=None)+BN+ReLU  (backbones.py:190-197)
+        const int t = add(HP_OP_DWCONV, in, 0, cin, cin, 3, stride, dil, HP_ACT_RELU, true);
+        return add(HP_OP_CONV, t, 0, cin, cout, 1, 1, 1, HP_ACT_RELU, true);
+    }
+    int pool(int in, int c, int k, int stride) { return add(HP_OP_MAXPOOL, in, 0, c, c, k, stride, 1, HP_ACT_NONE, false); }
+    void output(const char* name, int tensor, int coff, int channels, int act = HP_ACT_NONE)
+    {
+        hp_output_desc o;
+        memset(&o, 0, sizeof(o));
+        strncpy(o.name, name, sizeof(o.name) - 1);
+        o.tensor = tensor, o.coff = coff, o.channels = channels, o.act = act;
+        outputs.push_back(o);
+    }
+};
+
+namespace {
+
+int backbone_mobilenet_dilated(hp_model& m, int& out_c)
+{
+    int t = m.conv(0, 3, 32, 3, HP_ACT_RELU, 2); // conv_block(32, strides 2)
+    t = m.dw_block(t, 32, 64);
+    t = m.dw_block(t, 64, 128, 2);
+    t = m.dw_block(t, 128, 128);
+    t = m.dw_block(t, 128, 256, 2);
+    t = m.dw_block(t, 256, 256);
+    t = m.dw_block(t, 256, 512);
+    t = m.dw_block(t, 512, 512, 1, 2); // dilation 2, scale_size == 8 -> strides (1,1)
+    t = m.dw_block(t, 512, 512);
+    t = m.dw_block(t, 512, 512);
+    t = m.dw_block(t, 512, 512);
+    t = m.dw_block(t, 512, 512);
+    out_c = 512;
+    return t;
+}
+
+int backbone_vggtiny(hp_model& m, int& out_c)
+{
+    int t = m.conv(0, 3, 32, 3, HP_ACT_RELU);
+    t = m.conv(t, 32, 64, 3, HP_ACT_RELU);
+    t = m.pool(t, 64, 2, 2);
+    t = m.conv(t, 64, 128, 3, HP_ACT_RELU);
+    t = m.conv(t, 128, 128, 3, HP_ACT_RELU);
+    t = m.pool(t, 128, 2, 2);
+    t = m.conv(t, 128, 200, 3, HP_ACT_RELU);
+    t = m.conv(t, 200, 200, 3, HP_ACT_RELU);
+    t = m.conv(t, 200, 200, 3, HP_ACT_RELU);
+    t = m.pool(t, 200, 2, 2);
+    t = m.conv(t, 200, 384, 3, HP_ACT_RELU);
+    t = m.conv(t, 384, 384, 3, HP_ACT_RELU);
+    out_c = 384;
+    return t;
+}
+
+int backbone_vgg19(hp_model& m, int& out_c)
+{
+    // forward: x = x - vgg_mean (/255), backbones.py:455,501
+    m.mean[0] = 103.939f / 255, m.mean[1] = 116.779f / 255, m.mean[2] = 123.68f / 255;
+    int t = m.conv(0, 3, 64, 3, HP_ACT_RELU);
+    t = m.conv(t, 64, 64, 3, HP_ACT_RELU);
+    t = m.pool(t, 64, 2, 2);
+    t = m.conv(t, 64, 128, 3, HP_ACT_RELU);
+    t = m.conv(t, 128, 128, 3, HP_ACT_RELU);
+    t = m.pool(t, 128, 2, 2);
+    t = m.conv(t, 128, 256, 3, HP_ACT_RELU);
+    for (int i = 0; i < 3; ++i)
+        t = m.conv(t, 256, 256, 3, HP_ACT_RELU);
+    t = m.pool(t, 256, 2, 2);
+    t = m.conv(t, 256, 512, 3, HP_ACT_RELU);
+    t = m.conv(t, 512, 512, 3, HP_ACT_RELU);
+    out_c = 512;
+    return t;
+}
+
+// LightWeightOpenPose head (lw_openpose.py:38-75): cpm -> init stage -> concat(185) -> one refinement stage.
+void head_lw_openpose(hp_model& m, int feat, int feat_c)
+{
+    const int NC = 128, NCONF = 19, NPAF = 38;
+    // Cpm_stage (:106-121): 1x1 relu; x + 3 x conv_block(3x3 +BN+relu); 3x3 relu
+    const int x = m.conv(feat, feat_c, NC, 1, HP_ACT_RELU);
+    int y = m.conv(x, NC, NC, 3, HP_ACT_RELU);
+    y = m.conv(y, NC, NC, 3, HP_ACT_RELU);
+    y = m.add(HP_OP_CONV, y, 0, NC, NC, 3, 1, 1, HP_ACT_RELU, true, -1, 0, x, 0);
+    const int cat = m.new_tensor(); // [cpm 128 | init conf 19 | init paf 38]  (tf.concat, :58)
+    m.add(HP_OP_CONV, y, 0, NC, NC, 3, 1, 1, HP_ACT_RELU, true, cat, 0);
+    // Init_stage (:123-148)
+    int a = m.conv(cat, NC, NC, 3, HP_ACT_RELU, 1, 1, 0);
+    a = m.conv(a, NC, NC, 3, HP_ACT_RELU);
+    a = m.conv(a, NC, NC, 3, HP_ACT_RELU);
+    const int hc = m.conv(a, NC, 512, 1, HP_ACT_RELU);
+    m.add(HP_OP_CONV, hc, 0, 512, NCONF, 1, 1, 1, HP_ACT_NONE, true, cat, NC, -1, 0, 0.02f);
+    const int hp_ = m.conv(a, NC, 512, 1, HP_ACT_RELU);
+    m.add(HP_OP_CONV, hp_, 0, 512, NPAF, 1, 1, 1, HP_ACT_NONE, true, cat, NC + NCONF, -1, 0, 0.02f);
+    // Refinement_stage (:150-191): 5 blocks {1x1 relu; 2 x conv_block; residual}
+    int r = cat, rc = NC + NCONF + NPAF;
+    for (int b = 0; b < 5; ++b) {
+        const int u = m.conv(r, rc, NC, 1, HP_ACT_RELU);
+        const int v = m.conv(u, NC, NC, 3, HP_ACT_RELU);
+        r = m.add(HP_OP_CONV, v, 0, NC, NC, 3, 1, 1, HP_ACT_RELU, true, -1, 0, u, 0);
+        rc = NC;
+    }
+    const int rcf = m.conv(r, NC, 512, 1, HP_ACT_RELU);
+    const int conf = m.add(HP_OP_CONV, rcf, 0, 512, NCONF, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 0.02f);
+    const int rpf = m.conv(r, NC, 512, 1, HP_ACT_RELU);
+    const int paf = m.add(HP_OP_CONV, rpf, 0, 512, NPAF, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 0.02f);
+    m.output("conf", conf, 0, NCONF); // infer() returns (conf_map, paf_map), :71-75
+    m.output("paf", paf, 0, NPAF);
+}
+
+// OpenPose (CMU) head (openpose.py): CPM 3x3 512->256, 256->128 (ReLU); init stage per branch 3 x (3x3 128 + PReLU),
+// 1x1 128->512 PReLU, 1x1 512->{19,38} PReLU; 5 refinement stages on concat(128+19+38): 7x7 185->128, 4 x 7x7 128->128,
+// 1x1 128->128, 1x1 128->{19,38}, every conv followed by PReLU.
+void head_openpose(hp_model& m, int feat, int feat_c)
+{
+    const int NC = 128, NCONF = 19, NPAF = 38, NCAT = NC + NCONF + NPAF;
+    const int t = m.conv(feat, feat_c, 256, 3, HP_ACT_RELU);
+    // Stage k reads concat([cpm, conf_{k-1}, paf_{k-1}]) (openpose.py:62) and both of its branches read that SAME
+    // concat, so the two branches' outputs must not overwrite their own input: two concat buffers are used
+    // alternately; the (cheap) last CPM conv is issued twice with shared weights to put the cpm slice in both.
+    int cat[2] = { m.new_tensor(), m.new_tensor() };
+    m.add(HP_OP_CONV, t, 0, 256, NC, 3, 1, 1, HP_ACT_RELU, true, cat[0], 0);
+    {
+        hp_layer dup = m.layers.back(); // same w_off / b_off
+        dup.out = cat[1];
+        m.layers.push_back(dup);
+        m.init_scale.push_back(1.f);
+    }
+    auto branch_init = [&](int n_out, int dst, int dst_off) {
+        int a = m.conv(cat[0], NC, NC, 3, HP_ACT_PRELU, 1, 1, 0);
+        a = m.conv(a, NC, NC, 3, HP_ACT_PRELU);
+        a = m.conv(a, NC, NC, 3, HP_ACT_PRELU);
+        a = m.conv(a, NC, 512, 1, HP_ACT_PRELU);
+        m.add(HP_OP_CONV, a, 0, 512, n_out, 1, 1, 1, HP_ACT_PRELU, true, dst, dst_off, -1, 0, 0.05f);
+    };
+    // the init stage reads only the cpm slice of cat[0] and writes conf/paf into cat[1]
+    branch_init(NCONF, cat[1], NC);
+    branch_init(NPAF, cat[1], NC + NCONF);
+    int conf_t = -1, paf_t = -1;
+    for (int s = 0; s < 5; ++s) {
+        const bool last = (s == 4);
+        const int src = cat[(s + 1) & 1], dst = cat[s & 1];
+        auto branch = [&](int n_out, int out_t, int out_off) {
+            int a = m.conv(src, NCAT, NC, 7, HP_ACT_PRELU, 1, 1, 0);
+            for (int i = 0; i < 4; ++i)
+                a = m.conv(a, NC, NC, 7, HP_ACT_PRELU);
+            a = m.conv(a, NC, NC, 1, HP_ACT_PRELU);
+            return m.add(HP_OP_CONV, a, 0, NC, n_out, 1, 1, 1, HP_ACT_PRELU, true, out_t, out_off, -1, 0, 0.05f);
+        };
+        if (last) {
+            conf_t = branch(NCONF, -1, 0);
+            paf_t = branch(NPAF, -1, 0);
+        } else {
+            branch(NCONF, dst, NC);
+            branch(NPAF, dst, NC + NCONF);
+        }
+    }
+    m.output("conf", conf_t, 0, NCONF);
+    m.output("paf", paf_t, 0, NPAF);
+}
+
+// counter-based generator: splitmix64 hash -> two uniforms -> Box-Muller
+inline uint64_t mix(uint64_t z)
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+inline float normal_at(uint64_t seed, uint64_t layer, uint64_t idx)
+{
+    const uint64_t h = mix(mix(seed ^ (layer * 0x100000001b3ull)) + idx);
+    const uint64_t h2 = mix(h);
+    const double u1 = ((h >> 11) + 1.0) / 9007199254740993.0; // (0,1]
+    const double u2 = (h2 >> 11) / 9007199254740992.0;
+    return (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
+}
+
+} // namespace
+
+extern "C" {
+
+const char* hp_model_archs(void) { return "lw_openpose_mobilenet,lw_openpose_vggtiny,openpose_vgg19"; }
+
+int hp_model_build(hp_model** out, const char* arch, int in_w, int in_h)
+{
+    HP_REQUIRE(out && arch, HP_ERR_INVALID, "hp_model_build: null argument");
+    HP_REQUIRE(in_w >= 32 && in_h >= 32, HP_ERR_INVALID, "hp_model_build: input %dx%d too small", in_w, in_h);
+    std::unique_ptr<hp_model> m(new hp_model());
+    m->arch = arch, m->in_w = in_w, m->in_h = in_h;
+    int c = 0;
+    const std::string a = arch;
+    if (a == "lw_openpose_mobilenet") {
+        const int f = backbone_mobilenet_dilated(*m, c);
+        head_lw_openpose(*m, f, c);
+    } else if (a == "lw_openpose_vggtiny") {
+        const int f = backbone_vggtiny(*m, c);
+        head_lw_openpose(*m, f, c);
+    } else if (a == "openpose_vgg19") {
+        const int f = backbone_vgg19(*m, c);
+        head_openpose(*m, f, c);
+    } else {
+        hp::set_error("hp_model_build: unknown arch '%s' (have: %s)", arch, hp_model_archs());
+        return HP_ERR_INVALID;
+    }
+    *out = m.release();
+    return HP_OK;
+}
+
+void hp_model_destroy(hp_model* m) { delete m; }
+
+int hp_model_layers(const hp_model* m, const hp_layer** layers, int* n)
+{
+    HP_REQUIRE(m && layers && n, HP_ERR_INVALID, "hp_model_layers: null argument");
+    *layers = m->layers.data(), *n = (int)m->layers.size();
+    return HP_OK;
+}
+
+int hp_model_outputs(const hp_model* m, const hp_output_desc** outs, int* n)
+{
+    HP_REQUIRE(m && outs && n, HP_ERR_INVALID, "hp_model_outputs: null argument");
+    *outs = m->outputs.data(), *n = (int)m->outputs.size();
+    return HP_OK;
+}
+
+size_t hp_model_num_weights(const hp_model* m) { return m ? (size_t)m->n_weights : 0; }
+
+int hp_model_preproc(const hp_model* m, float mean[3], float inv_std[3])
+{
+    HP_REQUIRE(m && mean && inv_std, HP_ERR_INVALID, "hp_model_preproc: null argument");
+    for (int c = 0; c < 3; ++c)
+        mean[c] = m->mean[c], inv_std[c] = m->inv_std[c];
+    return HP_OK;
+}
+
+double hp_model_flops_per_frame(const hp_model* m)
+{
+    if (!m)
+        return 0;
+    // replay the SAME-padding shape propagation of engine.cpp
+    std::vector<int> H(m->next_tensor, 0), W(m->next_tensor, 0);
+    H[0] = m->in_h, W[0] = m->in_w;
+    double flops = 0;
+    for (const hp_layer& L : m->layers) {
+        const int oh = (H[L.in] + L.stride - 1) / L.stride, ow = (W[L.in] + L.stride - 1) / L.stride;
+        H[L.out] = oh, W[L.out] = ow;
+        if (L.op == HP_OP_CONV)
+            flops += 2.0 * oh * ow * L.cout * L.kh * L.kw * L.cin;
+        else if (L.op == HP_OP_DWCONV)
+            flops += 2.0 * oh * ow * L.cin * L.kh * L.kw;
+    }
+    return flops;
+}
+
+int hp_model_init_weights(const hp_model* m, uint64_t seed, float* blob, size_t n)
+{
+    HP_REQUIRE(m && blob, HP_ERR_INVALID, "hp_model_init_weights: null argument");
+    HP_REQUIRE(n >= (size_t)m->n_weights, HP_ERR_INVALID, "hp_model_init_weights: blob too small (%zu < %lld)", n, (long long)m->n_weights);
+    for (size_t li = 0; li < m->layers.size(); ++li) {
+        const hp_layer& L = m->layers[li];
+        if (L.op == HP_OP_MAXPOOL)
+            continue;
+        const int fan_in = L.op == HP_OP_CONV ? L.kh * L.kw * L.cin : L.kh * L.kw;
+        const size_t nw = L.op == HP_OP_CONV ? (size_t)L.cout * L.kh * L.kw * L.cin : (size_t)L.cin * L.kh * L.kw;
+        const float stdv = m->init_scale[li] * std::sqrt(2.0f / fan_in);
+        for (size_t i = 0; i < nw; ++i)
+            blob[L.w_off + i] = stdv * normal_at(seed, li, i);
+        if (L.b_off >= 0)
+            for (int i = 0; i < L.cout; ++i)
+                blob[L.b_off + i] = 0.02f * m->init_scale[li] * normal_at(seed, li, nw + i);
+        if (L.alpha_off >= 0)
+            for (int i = 0; i < L.cout; ++i)
+                blob[L.alpha_off + i] = 0.25f;
+    }
+    return HP_OK;
+}
+
+int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
+    const float* weights, size_t n_weights)
+{
+    HP_REQUIRE(out && m && weights, HP_ERR_INVALID, "hp_engine_create_from_model: null argument");
+    hp_engine_desc d;
+    memset(&d, 0, sizeof(d));
+    d.in_w = m->in_w, d.in_h = m->in_h, d.max_batch = max_batch, d.factor = factor, d.flip_rb = flip_rb;
+    for (int c = 0; c < 3; ++c)
+        d.mean[c] = m->mean[c], d.inv_std[c] = m->inv_std[c];
+    d.layers = m->layers.data(), d.n_layers = (int)m->layers.size();
+    d.outputs = m->outputs.data(), d.n_outputs = (int)m->outputs.size();
+    d.weights = weights, d.n_weights = n_weights;
+    return hp_engine_create(out, &d);
+}
+
+} // extern "C"

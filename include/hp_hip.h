@@ -115,6 +115,104 @@ int hp_paf_debug_conns(hp_paf* p, int frame, hp_conn* out, int cap, int* n);
  * host pointers, either output may be NULL (tests only; the production kernels never materialise them). */
 int hp_paf_debug_maps(hp_paf* p, const float* host_conf, const int conf_shape[3], float* host_up, float* host_smoothed);
 
+/* ---- hyperpose::dnn engine: replaces dnn::tensorrt (include/hyperpose/operator/dnn/tensorrt.hpp:33-141,
+ * src/tensorrt.cpp).  The network is a static list of layers over numbered tensors (tensor 0 = the input
+ * image); weights are one fp32 blob in the layouts below.  TensorRT's UFF/ONNX parsing is replaced by the
+ * built-in topology builders (hp_model_*) that restate hyperpose/Model/<arch>.py; ONNX import is a later row
+ * (SURVEY.md 8f).  Activations live in HBM as NHWC fp16 (fp32 accumulate on MFMA); network outputs are
+ * fp32 NCHW, the layout of feature_map_t. */
+enum { HP_OP_CONV = 1, HP_OP_DWCONV = 2, HP_OP_MAXPOOL = 3 };
+enum { HP_ACT_NONE = 0, HP_ACT_RELU = 1, HP_ACT_RELU6 = 2, HP_ACT_LEAKY = 3, HP_ACT_PRELU = 4, HP_ACT_SIGMOID = 5, HP_ACT_SOFTPLUS = 6 };
+
+typedef struct hp_layer {
+    int32_t op;              /* HP_OP_* */
+    int32_t in, in_coff;     /* tensor read (0 = network input) and its first channel */
+    int32_t res;             /* residual tensor added in the epilogue, or -1 */
+    int32_t res_before_act;  /* 1: act(conv + res) (ResNet); 0: act(conv) + res (LW-OpenPose blocks) */
+    int32_t out, out_coff;   /* tensor written and its first channel (concat by offset) */
+    int32_t cin, cout;
+    int32_t kh, kw, stride, dil; /* padding is TF "SAME": out = ceil(in/stride), extra pad bottom/right */
+    int32_t act;             /* HP_ACT_* applied after bias (BatchNorm is folded into w/bias by the caller) */
+    float act_param;         /* LeakyReLU slope */
+    int64_t w_off;           /* float offset in the blob: CONV [cout][kh][kw][cin]; DWCONV [c][kh][kw] */
+    int64_t b_off;           /* bias [cout], or -1 for zeros */
+    int64_t alpha_off;       /* PReLU slopes [cout], or -1 */
+} hp_layer;
+
+typedef struct hp_output_desc {
+    char name[48];           /* outputs are returned sorted by name (src/tensorrt.cpp:405) */
+    int32_t tensor, coff, channels;
+    int32_t act;             /* element-wise op applied while converting to fp32 NCHW (HP_ACT_NONE / SIGMOID / SOFTPLUS) */
+} hp_output_desc;
+
+typedef struct hp_engine_desc {
+    int32_t in_w, in_h, max_batch;   /* tensorrt(..., cv::Size input_size, int max_batch_size = 8, ...) */
+    double factor;                   /* tensorrt.hpp:49: every input element is multiplied by factor (default 1/255) */
+    int32_t flip_rb;                 /* BGR -> RGB (default true) */
+    float mean[3], inv_std[3];       /* in-graph input normalisation of VGG19 / PifPaf, applied after factor */
+    const hp_layer* layers;
+    int32_t n_layers;
+    const hp_output_desc* outputs;
+    int32_t n_outputs;
+    const float* weights;            /* host fp32 blob */
+    size_t n_weights;
+} hp_engine_desc;
+
+typedef struct hp_engine hp_engine;
+int hp_engine_create(hp_engine** out, const hp_engine_desc* desc);
+void hp_engine_destroy(hp_engine* e);
+int hp_engine_max_batch(const hp_engine* e);                  /* tensorrt::max_batch_size() */
+int hp_engine_input_size(const hp_engine* e, int* w, int* h); /* tensorrt::input_size() */
+
+/* tensorrt::inference(std::vector<cv::Mat>) with network-sized frames (src/tensorrt.cpp:436-461): n u8 HWC BGR
+ * frames [n,in_h,in_w,3]; the u8->f32 conversion of src/data.cpp:21-51 is fused into the first layer.
+ * n > max_batch returns HP_ERR_CAPACITY (the reference throws std::logic_error, :439-443).  The call only
+ * ENQUEUES on `stream` (NULL = the engine's own stream); outputs stay in device memory. */
+int hp_engine_infer_u8(hp_engine* e, const uint8_t* hwc_bgr, int n, int on_device, void* stream);
+/* tensorrt::inference(const std::vector<float>&, size_t) (src/tensorrt.cpp:364-434): n f32 NCHW frames, no
+ * scaling / channel swap. */
+int hp_engine_infer_f32(hp_engine* e, const float* nchw, int n, int on_device, void* stream);
+int hp_engine_synchronize(hp_engine* e);
+void* hp_engine_stream(hp_engine* e); /* hipStream_t of the engine */
+int hp_engine_set_graph(hp_engine* e, int enable); /* replay the schedule from a captured hipGraph (default on) */
+
+/* Outputs, sorted by name.  shape[] receives the non-batch dims (C,H,W), dev the fp32 NCHW device buffer
+ * [max_batch][C][H][W] of which the first n frames are valid after the last inference completed. */
+int hp_engine_num_outputs(const hp_engine* e);
+int hp_engine_output(const hp_engine* e, int i, const char** name, int shape[3], const float** dev);
+int hp_engine_output_to_host(hp_engine* e, int i, int n, float* host); /* synchronises, then D2H */
+/* Read back an internal fp16 NHWC tensor as fp32 NCHW [n][C][H][W] (layer-wise parity tests only). */
+int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int shape[3]);
+
+/* Per-layer device time (ms, averaged over iters) measured with HIP events on the engine stream for batch n:
+ * the numbers the roofline report is built from.  flops = 2*MACs of the layer for that batch. */
+typedef struct hp_layer_time {
+    int32_t layer, op, tile; /* tile = BM*1000+BN for MFMA convs, 0 otherwise */
+    float ms;
+    double flops, bytes;     /* algorithmic FLOPs and compulsory HBM bytes (inputs + weights + outputs once) */
+} hp_layer_time;
+int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int cap, int* n_out);
+
+/* ---- built-in topologies (restating hyperpose/Model/<arch>.py) --------------------- */
+typedef struct hp_model hp_model;
+/* arch: "lw_openpose_mobilenet" (MobilenetDilated + LightWeightOpenPose, backbones.py:177-229,
+ * openpose/model/lw_openpose.py), "lw_openpose_vggtiny" (backbones.py:343-391), "openpose_vgg19"
+ * (backbones.py:447-509, openpose/model/openpose.py), ... see hp_model_archs(). */
+int hp_model_build(hp_model** out, const char* arch, int in_w, int in_h);
+void hp_model_destroy(hp_model* m);
+const char* hp_model_archs(void);                       /* comma-separated list */
+int hp_model_layers(const hp_model* m, const hp_layer** layers, int* n);
+int hp_model_outputs(const hp_model* m, const hp_output_desc** outs, int* n);
+size_t hp_model_num_weights(const hp_model* m);
+int hp_model_preproc(const hp_model* m, float mean[3], float inv_std[3]);
+double hp_model_flops_per_frame(const hp_model* m);     /* 2*MACs of all CONV/DWCONV layers */
+/* Deterministic synthetic weights (there is no network to fetch the released models): He-normal conv
+ * kernels from a counter-based generator keyed by (seed, layer, index), small biases, PReLU slopes 0.25. */
+int hp_model_init_weights(const hp_model* m, uint64_t seed, float* blob, size_t n);
+/* Convenience: build an engine for a built-in topology with blob weights. */
+int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
+                                const float* weights, size_t n_weights);
+
 #ifdef __cplusplus
 }
 #endif

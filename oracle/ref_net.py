@@ -1,0 +1,110 @@
+"""oracle/ref_net.py — TEST INFRASTRUCTURE ONLY.
+
+Plain PyTorch fp32 (CPU) evaluation of an ``hp_layer`` list: the conv-stack oracle for the engine.  The
+reference's engine is TensorRT running an exported TensorFlow graph (src/tensorrt.cpp:393); neither is
+available here and no reference activations exist ("parity unpinned"), so the oracle is the
+textbook definition of every layer with TensorFlow's "SAME" padding (pad_total = max((ceil(i/s)-1)*s +
+(k-1)*d + 1 - i, 0), the extra pixel at the bottom/right), cross-checked op by op against
+``torch.nn.functional.conv2d``.  Pre-processing follows src/data.cpp:21-51 (oracle/paf_oracle.cpp).
+
+``match_fp16=True`` rounds weights and every stored activation to fp16 exactly where the engine does (HBM
+storage), keeping fp32 accumulation: the comparison then isolates kernel bugs from quantisation noise.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import loader
+
+OP_CONV, OP_DWCONV, OP_MAXPOOL = 1, 2, 3
+
+
+def _same_pad(size, k, s, d):
+    out = -(-size // s)
+    total = max((out - 1) * s + (k - 1) * d + 1 - size, 0)
+    return out, total // 2, total - total // 2
+
+
+def _act(x, act, param, alpha):
+    if act == 1:
+        return F.relu(x)
+    if act == 2:
+        return torch.clamp(x, 0, 6)
+    if act == 3:
+        return torch.where(x > 0, x, x * param)
+    if act == 4:
+        return torch.where(x > 0, x, x * alpha.view(1, -1, 1, 1))
+    if act == 5:
+        return torch.sigmoid(x)
+    if act == 6:
+        return F.softplus(x)
+    return x
+
+
+def _q(x, on):
+    return x.half().float() if on else x
+
+
+def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, frames_f32: np.ndarray = None,
+        factor=1.0 / 255, flip_rb=True, mean=(0, 0, 0), inv_std=(1, 1, 1), match_fp16=True, return_tensors=False):
+    """Returns {name: [n,C,H,W] float32} (and the dict of internal tensors when return_tensors)."""
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    w = torch.from_numpy(np.ascontiguousarray(weights, np.float32))
+    if frames_u8 is not None:
+        x0 = torch.from_numpy(loader.nhwc_u8_to_nchw_f32(frames_u8, factor, flip_rb))
+    else:
+        x0 = torch.from_numpy(np.ascontiguousarray(frames_f32, np.float32))
+    x0 = (x0 - torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)) * torch.tensor(inv_std, dtype=torch.float32).view(1, 3, 1, 1)
+    tensors = {0: x0}
+    for L in layers:
+        x = tensors[L.in_][:, L.in_coff:L.in_coff + L.cin]
+        oh, pt, pb = _same_pad(x.shape[2], L.kh, L.stride, L.dil)
+        ow, pl, pr = _same_pad(x.shape[3], L.kw, L.stride, L.dil)
+        first = (L.in_ == 0)
+        if L.op == OP_MAXPOOL:
+            xp = F.pad(x, (pl, pr, pt, pb), value=float("-inf"))
+            y = F.max_pool2d(xp, L.kh, L.stride)
+        else:
+            xp = F.pad(x, (pl, pr, pt, pb))
+            if L.op == OP_CONV:
+                wt = w[L.w_off:L.w_off + L.cout * L.kh * L.kw * L.cin].view(L.cout, L.kh, L.kw, L.cin).permute(0, 3, 1, 2)
+                groups = 1
+            else:
+                wt = w[L.w_off:L.w_off + L.cin * L.kh * L.kw].view(L.cin, 1, L.kh, L.kw)
+                groups = L.cin
+            wt = _q(wt, match_fp16 and not first)  # the first layer keeps fp32 weights in the engine
+            b = w[L.b_off:L.b_off + L.cout] if L.b_off >= 0 else None
+            y = F.conv2d(xp, wt.contiguous(), b, stride=L.stride, dilation=L.dil, groups=groups)
+            alpha = w[L.alpha_off:L.alpha_off + L.cout] if L.alpha_off >= 0 else None
+            if L.res >= 0:
+                r = tensors[L.res][:, :L.cout]
+                y = _act(y + r, L.act, L.act_param, alpha) if L.res_before_act else _act(y, L.act, L.act_param, alpha) + r
+            else:
+                y = _act(y, L.act, L.act_param, alpha)
+        assert y.shape[2] == oh and y.shape[3] == ow
+        full = tensors.get(L.out)
+        need = L.out_coff + L.cout
+        if full is None:
+            full = torch.zeros(y.shape[0], need, oh, ow)
+        elif full.shape[1] < need:
+            full = torch.cat([full, torch.zeros(y.shape[0], need - full.shape[1], oh, ow)], 1)
+        full = full.clone()
+        full[:, L.out_coff:need] = y  # un-rounded copy kept for fused fp32 outputs
+        tensors[L.out] = full
+        tensors[("raw", L.out, L.out_coff)] = y
+        # what later layers read back from HBM is the fp16-rounded value
+        tensors[L.out][:, L.out_coff:need] = _q(y, match_fp16)
+    result = {}
+    for o in outputs:
+        name = o.name.decode() if isinstance(o.name, bytes) else o.name
+        raw = tensors.get(("raw", o.tensor, o.coff))
+        if raw is not None and raw.shape[1] == o.channels and o.act == 0:
+            v = raw  # conv epilogue writes the fp32 accumulator result directly
+        else:
+            v = _act(tensors[o.tensor][:, o.coff:o.coff + o.channels], o.act, 0.0, None)
+        result[name] = v.numpy()
+    if return_tensors:
+        return result, {k: v.numpy() for k, v in tensors.items() if isinstance(k, int)}
+    return result

@@ -1,0 +1,221 @@
+"""GPU: the HIP conv stack (libhp_hip.so through the C ABI) vs the plain PyTorch fp32 oracle (oracle/ref_net.py).
+
+Tolerance: activations/weights are fp16 in HBM with fp32 MFMA accumulation.  Against the oracle evaluated with
+the SAME fp16 storage points (match_fp16=True) the only differences are fp32 summation order and rare fp16
+rounding flips: |err| <= 2e-3 * max|ref| + 1e-3.  Against the pure fp32 oracle the bound is the fp16 one (1e-2).
+"""
+import numpy as np
+import pytest
+
+from hyperpose_amd import engine as E
+from oracle import ref_net
+
+pytestmark = pytest.mark.gpu
+
+
+class Out:
+    def __init__(self, name, tensor, coff, channels, act=0):
+        self.name, self.tensor, self.coff, self.channels, self.act = name.encode(), tensor, coff, channels, act
+
+    def c(self):
+        o = E.OutputDesc()
+        o.name, o.tensor, o.coff, o.channels, o.act = self.name, self.tensor, self.coff, self.channels, self.act
+        return o
+
+
+class Net:
+    """Tiny graph builder for kernel-level tests (weights appended to one blob, He-scaled)."""
+
+    def __init__(self, seed=0):
+        self.layers, self.w, self.rng, self.nt = [], [], np.random.default_rng(seed), 1
+
+    def _alloc(self, n, std):
+        off = sum(len(x) for x in self.w)
+        self.w.append((self.rng.normal(0, std, n)).astype(np.float32))
+        return off
+
+    def conv(self, in_, cin, cout, k=1, stride=1, dil=1, act=E.ACT_RELU, out=None, out_coff=0, in_coff=0, res=-1,
+             res_before_act=0, op=E.OP_CONV, act_param=0.0):
+        if out is None:
+            out = self.nt
+            self.nt += 1
+        if op == E.OP_CONV:
+            w_off = self._alloc(cout * k * k * cin, np.sqrt(2.0 / (k * k * cin)))
+        elif op == E.OP_DWCONV:
+            w_off = self._alloc(cin * k * k, np.sqrt(2.0 / (k * k)))
+        else:
+            w_off = -1
+        b_off = self._alloc(cout, 0.1) if op != E.OP_MAXPOOL else -1
+        a_off = -1
+        if act == E.ACT_PRELU:
+            a_off = self._alloc(cout, 0.0)
+            self.w[-1][:] = self.rng.uniform(0.1, 0.4, cout)
+        self.layers.append(E.make_layer(op, in_, out, cin, cout, k, stride, dil, act, in_coff, out_coff, res,
+                                        res_before_act, w_off, b_off, a_off, act_param))
+        return out
+
+    def new_tensor(self):
+        t = self.nt
+        self.nt += 1
+        return t
+
+    def blob(self):
+        return np.concatenate(self.w) if self.w else np.zeros(1, np.float32)
+
+
+def _run_both(net, outs, frames, h, w, max_batch=None, f32=False, **kw):
+    blob = net.blob()
+    eng = E.Engine(net.layers, [o.c() for o in outs], blob, w, h, max_batch or len(frames), **kw)
+    if f32:
+        got = eng.inference_f32(frames)
+        ref = ref_net.run(net.layers, outs, blob, frames_f32=frames, match_fp16=True)
+    else:
+        got = eng.inference(frames)
+        ref = ref_net.run(net.layers, outs, blob, frames_u8=frames, match_fp16=True,
+                          factor=kw.get("factor", 1 / 255), flip_rb=kw.get("flip_rgb", True),
+                          mean=kw.get("mean", (0, 0, 0)), inv_std=kw.get("inv_std", (1, 1, 1)))
+    return eng, got, ref
+
+
+def _close(got, ref, rel=2e-3, abs_=1e-3):
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    assert err <= rel * scale + abs_, f"max err {err:.4g} vs scale {scale:.4g}"
+
+
+def _check(got, ref, n, **tol):
+    names = sorted(ref)
+    for b in range(n):
+        assert [nm for nm, _ in got[b]] == names  # ordered by tensor name, src/tensorrt.cpp:405
+        for nm, arr in got[b]:
+            _close(arr, ref[nm][b], **tol)
+
+
+def _frames(n, h, w, seed=0):
+    return np.random.default_rng(seed).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+
+
+def test_first_conv_u8_and_f32(hp):
+    for stride, k, cout in ((2, 3, 32), (1, 3, 64), (2, 7, 64)):
+        net = Net(1)
+        t = net.conv(0, 3, cout, k, stride)
+        fr = _frames(2, 37, 45)
+        _, got, ref = _run_both(net, [Out("y", t, 0, cout)], fr, 37, 45, flip_rgb=True, mean=(0.4, 0.45, 0.5), inv_std=(2., 3., 4.))
+        _check(got, ref, 2)
+    net = Net(2)
+    t = net.conv(0, 3, 32, 3, 2)
+    x = np.random.default_rng(3).normal(size=(2, 3, 20, 28)).astype(np.float32)
+    _, got, ref = _run_both(net, [Out("y", t, 0, 32)], x, 20, 28, f32=True)
+    _check(got, ref, 2)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,dil", [
+    (32, 64, 1, 1, 1), (64, 128, 1, 1, 1), (128, 128, 3, 1, 1), (128, 512, 1, 1, 1), (512, 19, 1, 1, 1),
+    (512, 38, 1, 1, 1), (64, 64, 3, 2, 1), (96, 128, 3, 1, 2), (128, 128, 7, 1, 1), (256, 200, 3, 1, 1),
+    (64, 256, 1, 2, 1),
+])
+def test_mfma_conv_shapes(hp, cin, cout, k, stride, dil):
+    net = Net(cin * 7 + cout)
+    t0 = net.conv(0, 3, cin, 3, 1)
+    t = net.conv(t0, cin, cout, k, stride, dil, act=E.ACT_RELU)
+    fr = _frames(3, 23, 29, seed=cout)
+    _, got, ref = _run_both(net, [Out("y", t, 0, cout)], fr, 23, 29)
+    _check(got, ref, 3)
+
+
+def test_mfma_conv_is_not_transposed(hp):
+    """Asymmetric, structured weights (not random): catches row/col or channel-order mix-ups exactly."""
+    net = Net(0)
+    t0 = net.conv(0, 3, 32, 1, 1, act=E.ACT_NONE)
+    t = net.conv(t0, 32, 64, 3, 1, act=E.ACT_NONE)
+    w = net.blob()
+    L0, L1 = net.layers
+    w[:] = 0
+    for c in range(32):  # t0[c] = B channel (u8 index 0 after flip: R<-B) * (c+1)/32
+        w[L0.w_off + c * 3 + (c % 3)] = (c + 1) / 32.0
+    for co in range(64):  # y[co] = tap(ky=co%3, kx=(co//3)%3) of channel co%32 times (1 + co/64)
+        w[L1.w_off + ((co * 3 + co % 3) * 3 + (co // 3) % 3) * 32 + co % 32] = 1.0 + co / 64.0
+    net.w = [w]
+    fr = _frames(2, 17, 21, seed=5)
+    _, got, ref = _run_both(net, [Out("y", t, 0, 64)], fr, 17, 21)
+    _check(got, ref, 2, rel=1e-3, abs_=1e-4)
+
+
+def test_depthwise_pool_residual_concat_prelu(hp):
+    net = Net(4)
+    a = net.conv(0, 3, 32, 3, 2)
+    d = net.conv(a, 32, 32, 3, 1, op=E.OP_DWCONV)
+    d2 = net.conv(d, 32, 32, 3, 2, op=E.OP_DWCONV)
+    d3 = net.conv(d2, 32, 32, 3, 1, dil=2, op=E.OP_DWCONV, act=E.ACT_RELU6)
+    p = net.conv(d3, 32, 32, 2, 2, op=E.OP_MAXPOOL, act=E.ACT_NONE)
+    p3 = net.conv(d3, 32, 32, 3, 2, op=E.OP_MAXPOOL, act=E.ACT_NONE)
+    cat = net.new_tensor()
+    x = net.conv(p, 32, 128, 1, out=cat, out_coff=0)
+    net.conv(p3, 32, 19, 1, act=E.ACT_NONE, out=cat, out_coff=128)
+    net.conv(p3, 32, 38, 3, act=E.ACT_LEAKY, out=cat, out_coff=147, act_param=0.1)
+    u = net.conv(cat, 185, 128, 1)
+    v = net.conv(u, 128, 128, 3, act=E.ACT_PRELU)
+    r = net.conv(v, 128, 128, 3, res=u, res_before_act=0)
+    r2 = net.conv(r, 128, 128, 1, res=u, res_before_act=1)
+    s = net.conv(cat, 128, 64, 3, in_coff=0, act=E.ACT_SIGMOID)
+    fr = _frames(2, 64, 80, seed=9)
+    outs = [Out("a_r2", r2, 0, 128), Out("b_cat", cat, 0, 185), Out("c_sig", s, 0, 64), Out("d_slice", cat, 128, 57)]
+    _, got, ref = _run_both(net, outs, fr, 64, 80)
+    _check(got, ref, 2)
+
+
+def test_lw_openpose_small_end_to_end(hp):
+    m = E.Model("lw_openpose_mobilenet", 96, 80)
+    w = m.init_weights(3)
+    eng = E.Engine.from_model(m, w, max_batch=4)
+    fr = _frames(3, 80, 96, seed=1)
+    got = eng.inference(fr)
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True)
+    assert got[0][0][0] == "conf" and got[0][1][0] == "paf"
+    _check(got, ref, 3, rel=5e-3, abs_=2e-3)
+    ref32 = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=False)
+    _check(got, ref32, 3, rel=3e-2, abs_=5e-3)
+    # replay from the captured graph and without it give identical bits
+    again = eng.inference(fr)
+    eng.set_graph(False)
+    plain = eng.inference(fr)
+    for b in range(3):
+        for i in range(2):
+            assert np.array_equal(got[b][i][1], again[b][i][1]) and np.array_equal(got[b][i][1], plain[b][i][1])
+
+
+def test_lw_openpose_full_size_config1(hp):
+    """BASELINE config 1 geometry: 368x432, conf [19,46,54] + paf [38,46,54]."""
+    m = E.Model("lw_openpose_mobilenet", 432, 368)
+    w = m.init_weights(20241)
+    eng = E.Engine.from_model(m, w, max_batch=8)
+    fr = _frames(2, 368, 432, seed=2)
+    got = eng.inference(fr)
+    assert got[0][0][1].shape == (19, 46, 54) and got[0][1][1].shape == (38, 46, 54)
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True)
+    _check(got, ref, 2, rel=5e-3, abs_=2e-3)
+
+
+def test_vggtiny_and_batch_overflow(hp):
+    m = E.Model("lw_openpose_vggtiny", 64, 48)
+    w = m.init_weights(5)
+    eng = E.Engine.from_model(m, w, max_batch=2)
+    fr = _frames(2, 48, 64, seed=4)
+    got = eng.inference(fr)
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True)
+    _check(got, ref, 2, rel=5e-3, abs_=2e-3)
+    with pytest.raises(ValueError):  # reference: std::logic_error, src/tensorrt.cpp:439-443
+        eng.inference(_frames(3, 48, 64))
+    import ctypes as C
+    rc = hp.lib().hp_engine_infer_u8(eng._h, fr.ctypes.data_as(C.POINTER(C.c_uint8)), 3, 0, None)
+    assert rc == hp.HP_ERR_CAPACITY
+
+
+def test_openpose_vgg19_small(hp):
+    m = E.Model("openpose_vgg19", 64, 48)
+    w = m.init_weights(6)
+    eng = E.Engine.from_model(m, w, max_batch=1)
+    fr = _frames(1, 48, 64, seed=6)
+    got = eng.inference(fr)
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True, mean=m.mean, inv_std=m.inv_std)
+    _check(got, ref, 1, rel=1e-2, abs_=2e-3)
