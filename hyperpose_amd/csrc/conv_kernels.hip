@@ -22,6 +22,7 @@ namespace hp {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4))); // native 16-byte vector (HIP's uint4 struct defeats SROA here)
 
 __device__ __forceinline__ float apply_act(float v, int act, float param, float alpha)
 {
@@ -55,7 +56,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk)
         return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int EPI>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
 {
     constexpr int CH = BK / 8;            // 16-byte chunks per tile row
@@ -87,45 +88,42 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
             ix0[i] = ox * p.stride - p.pad_l;
         } else {
             pb[i] = 0;
-            iy0[i] = -(1 << 28);
+            iy0[i] = -(1 << 20); // clamps to row 0 and is flagged invalid for every tap
             ix0[i] = 0;
         }
     }
 
-    uint4 ra[A_LD], rb[B_LD];
+    // Global loads of the NEXT K-step are issued before the MFMA phase of the current one and consumed after
+    // it; every load is unconditional (clamped address, zeroed at the LDS store when the tap falls in the
+    // padding) so that nothing forces an early s_waitcnt.  (Written without lambdas: hipcc keeps lambda-captured
+    // register arrays in scratch.)
+    u32x4 ra[A_LD], rb[B_LD];
+    unsigned bvalid = 0;
     int l_ky = 0, l_kx = 0, l_kc = 0;
-    auto gload = [&]() {
-        const int tap = l_ky * p.KW + l_kx;
-        const __half* wbase = p.w + ((size_t)tap * p.Cout_pad + m0) * p.Cin + l_kc * BK + ld_chunk * 8;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            ra[i] = *reinterpret_cast<const uint4*>(wbase + (size_t)(ld_row + i * RPP) * p.Cin);
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int iy = iy0[i] + l_ky * p.dil, ix = ix0[i] + l_kx * p.dil;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = *reinterpret_cast<const uint4*>(p.in + ((size_t)(pb[i] + iy) * p.W + ix) * p.in_cs + p.in_coff + l_kc * BK + ld_chunk * 8);
-            rb[i] = v;
-        }
-        if (++l_kc == KC) {
-            l_kc = 0;
-            if (++l_kx == p.KW) {
-                l_kx = 0;
-                ++l_ky;
-            }
-        }
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* a = lds + buf * TILE_BYTES;
-        unsigned char* b = a + BM * BK * 2;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<uint4*>(a + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i)
-            *reinterpret_cast<uint4*>(b + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = rb[i];
-    };
+#define HP_GLOAD()                                                                                               \
+    {                                                                                                            \
+        const int tap_ = l_ky * p.KW + l_kx;                                                                     \
+        const __half* wbase_ = p.w + ((size_t)tap_ * p.Cout_pad + m0) * p.Cin + l_kc * BK + ld_chunk * 8;        \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                         \
+            ra[i] = *reinterpret_cast<const u32x4*>(wbase_ + (size_t)(ld_row + i * RPP) * p.Cin);                \
+        bvalid = 0;                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                                         \
+        {                                                                                                        \
+            const int iy_ = iy0[i] + l_ky * p.dil, ix_ = ix0[i] + l_kx * p.dil;                                  \
+            const bool ok_ = iy_ >= 0 && iy_ < p.H && ix_ >= 0 && ix_ < p.W;                                     \
+            bvalid |= (ok_ ? 1u : 0u) << i;                                                                      \
+            const int cy_ = min(max(iy_, 0), p.H - 1), cx_ = min(max(ix_, 0), p.W - 1);                          \
+            rb[i] = *reinterpret_cast<const u32x4*>(                                                             \
+                p.in + ((size_t)(pb[i] + cy_) * p.W + cx_) * p.in_cs + p.in_coff + l_kc * BK + ld_chunk * 8);    \
+        }                                                                                                        \
+        if (++l_kc == KC) {                                                                                      \
+            l_kc = 0;                                                                                            \
+            if (++l_kx == p.KW) {                                                                                \
+                l_kx = 0;                                                                                        \
+                ++l_ky;                                                                                          \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -138,14 +136,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
 
     const int steps = p.KH * p.KW * KC;
     const int frow = lane & 31, fk = lane >> 5;
-    gload();
+    HP_GLOAD();
     for (int s = 0; s < steps; ++s) {
-        lstore(s & 1);
+        unsigned char* a = lds + (s & 1) * TILE_BYTES;
+        unsigned char* b = a + BM * BK * 2;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            *reinterpret_cast<u32x4*>(a + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const unsigned keep = ((bvalid >> i) & 1u) ? 0xffffffffu : 0u;
+            *reinterpret_cast<u32x4*>(b + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = rb[i] & keep;
+        }
         __syncthreads();
         if (s + 1 < steps)
-            gload();
-        const unsigned char* a = lds + (s & 1) * TILE_BYTES;
-        const unsigned char* b = a + BM * BK * 2;
+            HP_GLOAD();
+        __builtin_amdgcn_sched_barrier(0); // keep the prefetch ABOVE the MFMA phase (hipcc otherwise sinks it to its use)
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             half8 fa[TM], fb[TN];
@@ -161,76 +167,126 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+#undef HP_GLOAD
 
-    // epilogue: lane holds pixel n = (lane & 31) of each 32-wide tile and channels 8g + 4*(lane>>5) + {0..3}
+    // epilogue: lane holds pixel n = (lane & 31) of each 32-wide tile and channels 8g + 4*(lane>>5) + {0..3}.
+    // Activations are piecewise linear: y = v > 0 ? min(v, hi) : v * slope  (none/relu/relu6/leaky/prelu).
+    const float hi = p.act_hi;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-        if (n >= p.npix)
-            continue;
-        const int b = n / OHW, rem = n - b * OHW;
+        const bool nvalid = n < p.npix;
+        int b = 0, rem = 0;
+        if (EPI == 1) {
+            b = n / OHW;
+            rem = n - b * OHW;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int m = m0 + wm * (BM / 2) + i * 32 + 8 * g + 4 * (lane >> 5);
-                if (m >= p.Cout)
-                    continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = acc[i][j][4 * g + r] + p.bias[m + r];
-                float rs[4] = { 0.f, 0.f, 0.f, 0.f };
-                const bool full = (m + 3 < p.Cout);
-                if (p.res) {
-                    const __half* rp = p.res + (size_t)n * p.res_cs + p.res_coff + m;
-                    if (full && (((p.res_coff + m) & 3) == 0) && ((p.res_cs & 3) == 0)) {
-                        const half4 h = *reinterpret_cast<const half4*>(rp);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            rs[r] = (float)h[r];
-                    } else {
-                        for (int r = 0; r < 4 && m + r < p.Cout; ++r)
-                            rs[r] = __half2float(rp[r]);
+                if (nvalid && m < p.Cout) {
+                    const float4 bs = *reinterpret_cast<const float4*>(p.bias + m);
+                    float4 sl = make_float4(p.act_slope, p.act_slope, p.act_slope, p.act_slope);
+                    if (p.alpha)
+                        sl = *reinterpret_cast<const float4*>(p.alpha + m);
+                    float v0 = acc[i][j][4 * g + 0] + bs.x, v1 = acc[i][j][4 * g + 1] + bs.y;
+                    float v2 = acc[i][j][4 * g + 2] + bs.z, v3 = acc[i][j][4 * g + 3] + bs.w;
+                    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+                    if (p.res) {
+                        const __half* rp = p.res + (size_t)n * p.res_cs + p.res_coff + m;
+                        if (EPI == 0) {
+                            const half4 h = *reinterpret_cast<const half4*>(rp);
+                            r0 = (float)h[0], r1 = (float)h[1], r2 = (float)h[2], r3 = (float)h[3];
+                        } else {
+                            r0 = __half2float(rp[0]);
+                            r1 = m + 1 < p.Cout ? __half2float(rp[1]) : 0.f;
+                            r2 = m + 2 < p.Cout ? __half2float(rp[2]) : 0.f;
+                            r3 = m + 3 < p.Cout ? __half2float(rp[3]) : 0.f;
+                        }
+                        if (p.res_before_act)
+                            v0 += r0, v1 += r1, v2 += r2, v3 += r3, r0 = r1 = r2 = r3 = 0.f;
                     }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float al = p.alpha ? p.alpha[m + r] : 0.f;
-                    if (p.res && p.res_before_act)
-                        v[r] = apply_act(v[r] + rs[r], p.act, p.act_param, al);
-                    else
-                        v[r] = apply_act(v[r], p.act, p.act_param, al) + rs[r];
-                }
-                if (p.out) {
-                    __half* op = p.out + (size_t)n * p.out_cs + p.out_coff + m;
-                    if (full && (((p.out_coff + m) & 3) == 0) && ((p.out_cs & 3) == 0)) {
+                    v0 = (v0 > 0.f ? fminf(v0, hi) : v0 * sl.x) + r0;
+                    v1 = (v1 > 0.f ? fminf(v1, hi) : v1 * sl.y) + r1;
+                    v2 = (v2 > 0.f ? fminf(v2, hi) : v2 * sl.z) + r2;
+                    v3 = (v3 > 0.f ? fminf(v3, hi) : v3 * sl.w) + r3;
+                    if (EPI == 0) {
                         half4 h;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            h[r] = (_Float16)v[r];
-                        *reinterpret_cast<half4*>(op) = h;
+                        h[0] = (_Float16)v0, h[1] = (_Float16)v1, h[2] = (_Float16)v2, h[3] = (_Float16)v3;
+                        *reinterpret_cast<half4*>(p.out + (size_t)n * p.out_cs + p.out_coff + m) = h;
                     } else {
-                        for (int r = 0; r < 4 && m + r < p.Cout; ++r)
-                            op[r] = __float2half(v[r]);
+                        const bool c1 = m + 1 < p.Cout, c2 = m + 2 < p.Cout, c3 = m + 3 < p.Cout;
+                        if (p.out) {
+                            __half* op = p.out + (size_t)n * p.out_cs + p.out_coff + m;
+                            op[0] = __float2half(v0);
+                            if (c1)
+                                op[1] = __float2half(v1);
+                            if (c2)
+                                op[2] = __float2half(v2);
+                            if (c3)
+                                op[3] = __float2half(v3);
+                        }
+                        if (p.out_f32) {
+                            float* fp = p.out_f32 + ((size_t)b * p.Cout + m) * OHW + rem;
+                            fp[0] = v0;
+                            if (c1)
+                                fp[OHW] = v1;
+                            if (c2)
+                                fp[2 * (size_t)OHW] = v2;
+                            if (c3)
+                                fp[3 * (size_t)OHW] = v3;
+                        }
                     }
-                }
-                if (p.out_f32) {
-                    for (int r = 0; r < 4 && m + r < p.Cout; ++r)
-                        p.out_f32[((size_t)b * p.Cout + m + r) * OHW + rem] = v[r];
                 }
             }
         }
     }
 }
 
+// fast epilogue (aligned fp16 NHWC vectors) when every 4-channel group is whole and 8-byte aligned
+static bool fast_epilogue(const conv_params& p)
+{
+    return p.out && !p.out_f32 && p.Cout % 4 == 0 && p.out_coff % 4 == 0 && p.out_cs % 4 == 0
+        && (!p.res || (p.res_coff % 4 == 0 && p.res_cs % 4 == 0));
+}
+
 template <int BM, int BN, int BK>
 static hipError_t launch_tile(const conv_params& p, hipStream_t s)
 {
     dim3 grid((p.npix + BN - 1) / BN, p.Cout_pad / BM);
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK>), grid, dim3(256), 0, s, p);
+    if (fast_epilogue(p))
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, 0>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, 1>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
+}
+
+bool set_act(conv_params& p)
+{
+    const float inf = __builtin_huge_valf();
+    switch (p.act) {
+    case ACT_NONE:
+        p.act_slope = 1.f, p.act_hi = inf;
+        return true;
+    case ACT_RELU:
+        p.act_slope = 0.f, p.act_hi = inf;
+        return true;
+    case ACT_RELU6:
+        p.act_slope = 0.f, p.act_hi = 6.f;
+        return true;
+    case ACT_LEAKY:
+        p.act_slope = p.act_param, p.act_hi = inf;
+        return true;
+    case ACT_PRELU:
+        p.act_slope = 0.f, p.act_hi = inf;
+        return p.alpha != nullptr;
+    default:
+        return false;
+    }
 }
 
 int conv_mfma_tile(const conv_params& p)
@@ -322,8 +378,10 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const first_conv_params
         if (g * 8 + 7 < p.Cout && ((p.out_coff & 7) == 0) && ((p.out_cs & 7) == 0))
             *reinterpret_cast<half8*>(op) = h;
         else
-            for (int r = 0; r < 8 && g * 8 + r < p.Cout; ++r)
-                reinterpret_cast<_Float16*>(op)[r] = h[r];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (g * 8 + r < p.Cout)
+                    reinterpret_cast<_Float16*>(op)[r] = h[r];
     }
 }
 

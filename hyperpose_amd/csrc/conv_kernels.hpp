@@ -29,8 +29,9 @@ struct conv_params {
     const __half* w;    // packed [KH*KW][Cout_pad][Cin]
     const float* bias;  // [Cout_pad]
     const float* alpha; // PReLU slopes [Cout_pad] or nullptr
-    int act;
+    int act;          // ACT_NONE / RELU / RELU6 / LEAKY / PRELU (the piecewise-linear ones)
     float act_param;
+    float act_slope, act_hi; // y = v > 0 ? min(v, act_hi) : v * act_slope, filled by set_act()
     // optional residual (same shape as the output), added after (res_before_act = 0) or before the activation
     const __half* res;
     int res_cs, res_coff, res_before_act;
@@ -41,6 +42,8 @@ struct conv_params {
     int npix;       // B*OH*OW
 };
 
+// fills act_slope / act_hi from act / act_param; false for activations the MFMA epilogue does not fuse
+bool set_act(conv_params& p);
 // Dense k x k convolution as an implicit GEMM on MFMA (v_mfma_f32_32x32x16_f16).  Returns hipError_t.
 hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s);
 // which tile the launcher picks (for reporting): returns BM*1000+BN

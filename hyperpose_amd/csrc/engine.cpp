@@ -285,6 +285,7 @@ int hp_engine::build(const hp_engine_desc* d)
             for (auto& o : outputs)
                 if (o.fused_layer == (int)i)
                     p.out_f32 = o.buf->as<float>();
+            HP_REQUIRE(hp::set_act(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
             st.flops = 2.0 * opix * L.cout * taps * L.cin;
             st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cout * 2 + (double)nw * 2;
         } else if (L.op == HP_OP_DWCONV) {

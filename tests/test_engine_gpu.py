@@ -157,9 +157,10 @@ def test_depthwise_pool_residual_concat_prelu(hp):
     v = net.conv(u, 128, 128, 3, act=E.ACT_PRELU)
     r = net.conv(v, 128, 128, 3, res=u, res_before_act=0)
     r2 = net.conv(r, 128, 128, 1, res=u, res_before_act=1)
-    s = net.conv(cat, 128, 64, 3, in_coff=0, act=E.ACT_SIGMOID)
+    s = net.conv(cat, 128, 64, 3, in_coff=0, act=E.ACT_NONE)  # sigmoid/softplus are output post-ops
     fr = _frames(2, 64, 80, seed=9)
-    outs = [Out("a_r2", r2, 0, 128), Out("b_cat", cat, 0, 185), Out("c_sig", s, 0, 64), Out("d_slice", cat, 128, 57)]
+    outs = [Out("a_r2", r2, 0, 128), Out("b_cat", cat, 0, 185), Out("c_sig", s, 0, 64, act=E.ACT_SIGMOID), Out("d_slice", cat, 128, 57),
+            Out("e_softplus", s, 8, 40, act=E.ACT_SOFTPLUS)]
     _, got, ref = _run_both(net, outs, fr, 64, 80)
     _check(got, ref, 2)
 
