@@ -159,23 +159,17 @@ def main():
     from hyperpose_amd import _lib, synth
     from hyperpose_amd.engine import Model
 
+    from hyperpose_amd import dist as hd
+
     torch.cuda.set_device(local_rank)
     _lib.init(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        hd.init("nccl", device=dev)
 
     model = Model(ARCH, IN_W, IN_H)
     # one-time weight broadcast from rank 0 over RCCL/xGMI (the only collective of the whole job)
-    if rank == 0:
-        w_host = model.init_weights(20241)
-    else:
-        w_host = np.empty(model.n_weights, np.float32)
-    if world > 1:
-        w_dev = torch.from_numpy(w_host).cuda() if rank == 0 else torch.empty(model.n_weights, dtype=torch.float32, device="cuda")
-        dist.broadcast(w_dev, src=0)
-        w_host = w_dev.cpu().numpy()
-        del w_dev
+    w_host = hd.broadcast_weights(model.init_weights(20241) if rank == 0 else None, model.n_weights, rank, world, device=dev)
 
     # per-rank synthetic inputs, resident in HBM before the timed region
     rng = synth.rng_for(1, salt=rank)
@@ -197,10 +191,7 @@ def main():
         nh = run_loop(pipes, frames_dev, args.steps, injected)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = hd.max_over_ranks(dt, world, device=dev)
         barrier()
         return dt, nh
 

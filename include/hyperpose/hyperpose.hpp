@@ -1,0 +1,6 @@
+// Umbrella header, mirroring the reference's include/hyperpose/hyperpose.hpp.
+#pragma once
+#include "operator/dnn/hip_engine.hpp"
+#include "operator/parser/paf.hpp"
+#include "utility/data.hpp"
+#include "utility/human.hpp"

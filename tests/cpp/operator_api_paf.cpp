@@ -1,0 +1,41 @@
+// The reference's operator-API example (examples/operator_api_batched_images_paf.example.cpp:58-74) written
+// against the mirror headers: engine.inference(batch) -> for each packet parser.process(packet[0], packet[1]).
+// Prints "OK <n_outputs> <humans>"; run by tests/test_cpp_mirror.py on the GPU box.
+#define HYPERPOSE_TENSORRT_COMPAT
+#include <hyperpose/hyperpose.hpp>
+
+#include <cstdio>
+
+int main()
+{
+    if (hp_init(0) != HP_OK) {
+        std::printf("NO_DEVICE %s\n", hp_last_error());
+        return 2;
+    }
+    namespace hp = hyperpose;
+    hp::dnn::tensorrt engine(hp::dnn::builtin_model{ "lw_openpose_mobilenet", {}, 7 }, cv::Size(96, 80), 4);
+    hp::parser::paf parser{};
+    std::vector<cv::Mat> batch;
+    for (int i = 0; i < 3; ++i) {
+        cv::Mat m(80, 96);
+        for (size_t k = 0; k < m.total() * 3; ++k)
+            m.data()[k] = (uint8_t)((k * 31 + i * 7) & 255);
+        batch.push_back(m);
+    }
+    auto packets = engine.inference(batch);
+    size_t humans = 0;
+    for (auto& packet : packets) {
+        if (packet.size() != 2 || packet[0].name() != "conf" || packet[1].name() != "paf")
+            return 3;
+        hp::parser::paf p(parser); // copy-construct like the stream API does (stream.hpp:139)
+        humans += p.process(packet[0], packet[1]).size();
+    }
+    bool threw = false;
+    try {
+        engine.inference(std::vector<cv::Mat>(5, batch[0]));
+    } catch (const std::logic_error&) {
+        threw = true;
+    }
+    std::printf("OK %zu %zu %d\n", packets.size(), humans, (int)threw);
+    return threw ? 0 : 4;
+}
