@@ -119,3 +119,50 @@ def preproc_u8hwc_to_f32nchw(images: np.ndarray, factor: float = 1.0 / 255, flip
     check(lib().hp_preproc_u8hwc_to_f32nchw(din.ptr, n, h, w, C.c_double(factor), int(flip_rb), dout.ptr, None))
     check(lib().hp_device_synchronize())
     return dout.to_numpy(np.float32, (n, 3, h, w))
+
+
+class PoseProposal:
+    """``hyperpose::parser::pose_proposal`` (net_resolution, point_thresh=0.10, limb_thresh=0.05, mns_thresh=0.3),
+    reference include/hyperpose/operator/parser/proposal_network.hpp:17-81."""
+
+    def __init__(self, net_resolution, point_thresh: float = 0.10, limb_thresh: float = 0.05, mns_thresh: float = 0.3,
+                 max_batch: int = 32, cap_per_frame: int = 128):
+        self._h = C.c_void_p()
+        self.max_batch, self.cap = int(max_batch), int(cap_per_frame)
+        w, h = net_resolution  # cv::Size(width, height)
+        check(lib().hp_ppn_create(C.byref(self._h), int(w), int(h), C.c_float(point_thresh), C.c_float(limb_thresh),
+                                  C.c_float(mns_thresh), self.max_batch))
+        self._out = (Human * (self.max_batch * self.cap))()
+        self._n = (C.c_int * self.max_batch)()
+
+    def close(self):
+        if self._h:
+            lib().hp_ppn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_thresholds(self, point_thresh, limb_thresh, nms_thresh):
+        check(lib().hp_ppn_set_thresholds(self._h, C.c_float(point_thresh), C.c_float(limb_thresh), C.c_float(nms_thresh)))
+
+    def process_batch(self, tensors, on_device: bool = False, n: int = None, conf_shape=None, edge_shape=None):
+        """tensors = [conf_point, conf_iou, x, y, w, h, edge]; host numpy arrays with a leading batch dim, or device
+        pointers (DevBuf / torch tensors / ints) with n, conf_shape (K,gh,gw) and edge_shape (E,nh,nw,gh,gw) given."""
+        if not on_device:
+            tensors = [np.ascontiguousarray(t, np.float32) for t in tensors]
+            n = tensors[0].shape[0]
+            conf_shape, edge_shape = tensors[0].shape[1:], tensors[6].shape[1:]
+            ptrs = (C.c_void_p * 7)(*[t.ctypes.data for t in tensors])
+        else:
+            ptrs = (C.c_void_p * 7)(*[as_ptr(t).value for t in tensors])
+        cs, es = (C.c_int * 3)(*conf_shape), (C.c_int * 5)(*edge_shape)
+        check(lib().hp_ppn_process_batch(self._h, n, ptrs, cs, es, int(on_device), self._out, self.cap, self._n))
+        arr = np.frombuffer(self._out, dtype=HUMAN_DTYPE)
+        return [arr[f * self.cap: f * self.cap + self._n[f]].copy() for f in range(n)]
+
+    def process(self, tensors):
+        return self.process_batch([np.asarray(t)[None] for t in tensors])[0]

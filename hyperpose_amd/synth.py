@@ -101,3 +101,43 @@ def paf_maps(rng: np.random.Generator, batch: int, rows: int = 46, cols: int = 5
 def images_u8(rng: np.random.Generator, batch: int, h: int, w: int) -> np.ndarray:
     """Uniform[0,255] u8 ``[B,h,w,3]`` HWC BGR frames (already network-sized: cv::resize is then a copy)."""
     return rng.integers(0, 256, size=(batch, h, w, 3), dtype=np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PoseProposal synthetic tensors (SURVEY.md 8d "PPN synthetic"): reference src/pose_proposal.cpp:12-41.
+COCOPAIR_STD = [(1, 8), (8, 9), (9, 10), (1, 11), (11, 12), (12, 13), (1, 2), (2, 3), (3, 4), (1, 5), (5, 6), (6, 7),
+                (1, 0), (0, 14), (0, 15), (14, 16), (15, 17)]
+
+
+def ppn_maps(rng: np.random.Generator, batch: int, net: int = 384, grid: int = 12, people=(1, 2, 3, 4), nbr: int = 9,
+             spurious: float = 0.01):
+    """7 tensors per frame in parser order (conf_point, conf_iou, x, y, w, h, edge): 6 x [B,18,grid,grid] and
+    edge [B,17,nbr,nbr,grid,grid]; x/y/w/h in input pixels as the network's restore_coor emits them
+    (hyperpose/Model/pose_proposal/model.py:111-119).  True edges are U(0.8,1) (no exact ties), the rest U(0,0.04)."""
+    cell = net / grid
+    conf = rng.uniform(0.0, 0.08, (batch, 18, grid, grid))
+    iou = rng.uniform(0.0, 1.0, (batch, 18, grid, grid))
+    gy, gx = np.mgrid[0:grid, 0:grid]
+    x = np.broadcast_to((gx + 0.5) * cell, (batch, 18, grid, grid)) + rng.normal(0, 4, (batch, 18, grid, grid))
+    y = np.broadcast_to((gy + 0.5) * cell, (batch, 18, grid, grid)) + rng.normal(0, 4, (batch, 18, grid, grid))
+    w = rng.uniform(20, 90, (batch, 18, grid, grid))
+    h = rng.uniform(20, 90, (batch, 18, grid, grid))
+    edge = rng.uniform(0.0, 0.04, (batch, 17, nbr, nbr, grid, grid))
+    spur = rng.uniform(size=conf.shape) < spurious
+    conf[spur] = rng.uniform(0.1, 0.5, int(spur.sum()))
+    for b in range(batch):
+        n = int(people[b % len(people)])
+        sk = skeletons(rng, n, net, net, scale_range=(110.0, 260.0))
+        for p in range(n):
+            cells = np.clip(np.floor(sk[p] / cell).astype(int), 0, grid - 1)  # [18,(cx,cy)]
+            for k in range(18):
+                cx, cy = cells[k]
+                conf[b, k, cy, cx] = rng.uniform(0.6, 1.0)
+                x[b, k, cy, cx], y[b, k, cy, cx] = np.clip(sk[p, k], 0, net - 1)
+                w[b, k, cy, cx], h[b, k, cy, cx] = rng.uniform(30, 80, 2)
+            for l, (p1, p2) in enumerate(COCOPAIR_STD):
+                dx, dy = cells[p2] - cells[p1]
+                if abs(dx) <= nbr // 2 and abs(dy) <= nbr // 2:
+                    edge[b, l, dy + nbr // 2, dx + nbr // 2, cells[p1][1], cells[p1][0]] = rng.uniform(0.8, 1.0)
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    return [f(conf), f(iou), f(x), f(y), f(w), f(h), f(edge)]

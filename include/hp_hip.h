@@ -115,6 +115,20 @@ int hp_paf_debug_conns(hp_paf* p, int frame, hp_conn* out, int cap, int* n);
  * host pointers, either output may be NULL (tests only; the production kernels never materialise them). */
 int hp_paf_debug_maps(hp_paf* p, const float* host_conf, const int conf_shape[3], float* host_up, float* host_smoothed);
 
+/* ---- hyperpose::parser::pose_proposal (include/hyperpose/operator/parser/proposal_network.hpp:17-81,
+ * src/pose_proposal.cpp).  GPU: threshold + box decode + per-class NMS + limb-candidate gather; host: the
+ * order-dependent tail (limb selection, hash merge, filter) on the compacted lists. */
+typedef struct hp_ppn hp_ppn;
+/* pose_proposal(net_resolution, point_thresh = 0.10, limb_thresh = 0.05, mns_thresh = 0.3), proposal_network.hpp:26 */
+int hp_ppn_create(hp_ppn** out, int net_w, int net_h, float point_thresh, float limb_thresh, float nms_thresh, int max_batch);
+void hp_ppn_destroy(hp_ppn* p);
+int hp_ppn_set_thresholds(hp_ppn* p, float point_thresh, float limb_thresh, float nms_thresh); /* set_{point,limb,nms}_thresh */
+/* pose_proposal::process (src/pose_proposal.cpp:68-337) for n frames: tensors[7] = {conf_point, conf_iou, x, y, w, h,
+ * edge}, each batch-major contiguous ([n,K,gh,gw] x6, [n,E,nh,nw,gh,gw]); conf_shape = {K,gh,gw}, edge_shape =
+ * {E,nh,nw,gh,gw}; on_device != 0: device pointers.  out: host [n*cap_per_frame]; n_out: host [n]. */
+int hp_ppn_process_batch(hp_ppn* p, int n, const float* const tensors[7], const int conf_shape[3], const int edge_shape[5],
+                         int on_device, hp_human* out, int cap_per_frame, int* n_out);
+
 /* ---- hyperpose::dnn engine: replaces dnn::tensorrt (include/hyperpose/operator/dnn/tensorrt.hpp:33-141,
  * src/tensorrt.cpp).  The network is a static list of layers over numbered tensors (tensor 0 = the input
  * image); weights are one fp32 blob in the layouts below.  TensorRT's UFF/ONNX parsing is replaced by the

@@ -1,0 +1,50 @@
+"""Generate the committed known-answer vectors for the PoseProposal and PifPaf parsers FROM THE REFERENCE'S OWN
+CODE (oracle/_ref/libhp_ref.so = src/pose_proposal.cpp, src/pifpaf.cpp, src/pifpaf_decoder/*.cpp compiled where
+they lie; only possible in a container that mounts /root/reference).
+
+    python tests/golden/make_golden_ref.py
+
+Inputs are the seeded synthetic tensors of hyperpose_amd/synth.py stored as fp16-representable fp32 (small
+files); outputs are the reference's human_t lists.  The GPU parity tests compare libhp_hip.so with these files
+bit for bit, so they also run on the GPU box where /root/reference does not exist.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from hyperpose_amd import synth  # noqa: E402
+from oracle import loader  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def q16(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def ppn():
+    out, meta = {}, []
+    cases = [(1, 31), (3, 32), (5, 33), (0, 34), (8, 35)]
+    for i, (people, salt) in enumerate(cases):
+        t = synth.ppn_maps(synth.rng_for(3, salt=salt), 1, people=(people,), spurious=0.02 if i % 2 else 0.005)
+        t = [q16(a[0]) for a in t]
+        humans = loader.ref_ppn_process(t)
+        for k, a in enumerate(t):
+            out[f"t{k}_{i}"] = a.astype(np.float16)  # exactly representable: tests widen back to fp32
+        out[f"humans_{i}"] = humans
+        meta.append({"people": people, "n_humans": int(len(humans))})
+        print("ppn", meta[-1])
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "ppn_golden.npz"), **out)
+
+
+if __name__ == "__main__":
+    assert loader.ref_lib() is not None, "oracle/_ref not built (needs /root/reference)"
+    ppn()
+    if hasattr(synth, "pifpaf_maps"):
+        from make_golden_pifpaf import pifpaf  # noqa: E402
+        pifpaf()
