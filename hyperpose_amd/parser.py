@@ -166,3 +166,41 @@ class PoseProposal:
 
     def process(self, tensors):
         return self.process_batch([np.asarray(t)[None] for t in tensors])[0]
+
+
+class PifPaf:
+    """``hyperpose::parser::pifpaf(h, w, thresh=0.1)`` (reference include/hyperpose/operator/parser/pifpaf.hpp:8-26).
+    ``process(paf, pif)`` takes the tensors in the order of the reference's .cpp (src/pifpaf.cpp:7)."""
+
+    def __init__(self, h: int, w: int, thresh: float = 0.1, max_batch: int = 8, cap_per_frame: int = 128):
+        self._h = C.c_void_p()
+        self.max_batch, self.cap = int(max_batch), int(cap_per_frame)
+        check(lib().hp_pifpaf_create(C.byref(self._h), int(h), int(w), C.c_float(thresh), self.max_batch))
+        self._out = (Human * (self.max_batch * self.cap))()
+        self._n = (C.c_int * self.max_batch)()
+
+    def close(self):
+        if self._h:
+            lib().hp_pifpaf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_batch(self, paf, pif, on_device: bool = False, n: int = None, fh: int = None, fw: int = None):
+        if not on_device:
+            paf = np.ascontiguousarray(paf, np.float32)
+            pif = np.ascontiguousarray(pif, np.float32)
+            n, fh, fw = pif.shape[0], pif.shape[-2], pif.shape[-1]
+            a, b = paf.ctypes.data_as(_FP), pif.ctypes.data_as(_FP)
+        else:
+            a, b = as_ptr(paf), as_ptr(pif)
+        check(lib().hp_pifpaf_process_batch(self._h, n, a, b, fh, fw, int(on_device), self._out, self.cap, self._n))
+        arr = np.frombuffer(self._out, dtype=HUMAN_DTYPE)
+        return [arr[f * self.cap: f * self.cap + self._n[f]].copy() for f in range(n)]
+
+    def process(self, paf, pif):
+        return self.process_batch(np.asarray(paf)[None], np.asarray(pif)[None])[0]

@@ -141,3 +141,71 @@ def ppn_maps(rng: np.random.Generator, batch: int, net: int = 384, grid: int = 1
                     edge[b, l, dy + nbr // 2, dx + nbr // 2, cells[p1][1], cells[p1][0]] = rng.uniform(0.8, 1.0)
     f = lambda a: np.ascontiguousarray(a, np.float32)
     return [f(conf), f(iou), f(x), f(y), f(w), f(h), f(edge)]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PifPaf synthetic fields (SURVEY.md 8d "PifPaf synthetic"): OpenPifPaf 17-keypoint topology, bones as in
+# reference src/pifpaf_decoder/openpifpaf_postprocessor.cpp:64-84 (1-based joint indices).
+PIFPAF_BONES = [(16, 14), (14, 12), (17, 15), (15, 13), (12, 13), (6, 12), (7, 13), (6, 7), (6, 8), (7, 9), (8, 10),
+                (9, 11), (2, 3), (1, 2), (1, 3), (2, 4), (3, 5), (4, 6), (5, 7)]
+# 17 OpenPifPaf joints picked from the 18-joint template above (nose, l/r eye, l/r ear, l/r shoulder, ...)
+_PIFPAF_FROM_18 = [0, 15, 14, 17, 16, 5, 2, 6, 3, 7, 4, 11, 8, 12, 9, 13, 10]
+
+
+def pifpaf_maps(rng: np.random.Generator, batch: int, fh: int = 49, fw: int = 49, people=(1, 2, 3, 4), noise: float = 0.02):
+    """(paf ``[B,19,9,fh,fw]``, pif ``[B,17,5,fh,fw]``) in the argument order of ``parser::pifpaf::process``
+    (reference src/pifpaf.cpp:7).  pif = [conf, x, y, b, scale], paf = [conf, x1, y1, x2, y2, b1, b2, s1, s2], all
+    positions/scales in field units (stride 8), as the decoder multiplies them by 8."""
+    yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float64)
+    pif = np.zeros((batch, 17, 5, fh, fw))
+    paf = np.zeros((batch, 19, 9, fh, fw))
+    pif[:, :, 0] = rng.uniform(0, noise, (batch, 17, fh, fw))
+    paf[:, :, 0] = rng.uniform(0, noise, (batch, 19, fh, fw))
+    pif[:, :, 1], pif[:, :, 2] = xx, yy
+    pif[:, :, 4] = 1.0
+    for c in (1, 3):
+        paf[:, :, c], paf[:, :, c + 1] = xx, yy
+    paf[:, :, 7:9] = 1.0
+    for b in range(batch):
+        n = int(people[b % len(people)])
+        sk18 = skeletons(rng, n, fh, fw, scale_range=(16.0, 34.0))
+        for p in range(n):
+            sk = sk18[p][_PIFPAF_FROM_18]
+            size = float(np.ptp(sk[:, 1]))
+            scale = max(0.6, size / 14.0)
+            for k in range(17):
+                d2 = (xx - sk[k, 0]) ** 2 + (yy - sk[k, 1]) ** 2
+                m = d2 <= 2.6 ** 2  # ~21 voting cells: the decoder divides every vote by PIF_NN = 16
+                c = 0.95 * np.exp(-d2 / (2 * 2.5 ** 2))
+                upd = m & (c > pif[b, k, 0])
+                pif[b, k, 0][upd] = c[upd]
+                pif[b, k, 1][upd] = sk[k, 0] + rng.normal(0, 0.03, int(upd.sum()))
+                pif[b, k, 2][upd] = sk[k, 1] + rng.normal(0, 0.03, int(upd.sum()))
+                pif[b, k, 4][upd] = scale * rng.uniform(0.9, 1.1, int(upd.sum()))
+            for l, (j1, j2) in enumerate(PIFPAF_BONES):
+                a, c2 = sk[j1 - 1], sk[j2 - 1]
+                v = c2 - a
+                ln = np.hypot(*v)
+                u = v / max(ln, 1e-6)
+                rx, ry = xx - a[0], yy - a[1]
+                along = rx * u[0] + ry * u[1]
+                perp = np.abs(rx * u[1] - ry * u[0])
+                m = (along >= -1.0) & (along <= ln + 1.0) & (perp <= 1.0)
+                conf = 0.9 * np.exp(-perp ** 2 / 2.0) * rng.uniform(0.85, 1.0, perp.shape)
+                upd = m & (conf > paf[b, l, 0])
+                k = int(upd.sum())
+                paf[b, l, 0][upd] = conf[upd]
+                paf[b, l, 1][upd] = a[0] + rng.normal(0, 0.03, k)
+                paf[b, l, 2][upd] = a[1] + rng.normal(0, 0.03, k)
+                paf[b, l, 3][upd] = c2[0] + rng.normal(0, 0.03, k)
+                paf[b, l, 4][upd] = c2[1] + rng.normal(0, 0.03, k)
+                paf[b, l, 7][upd] = scale
+                paf[b, l, 8][upd] = scale
+    # keep every regressed position inside the field so that the reference's unchecked index arithmetic
+    # (openpifpaf_postprocessor.cpp:693,745) stays in bounds
+    pif[:, :, 1] = np.clip(pif[:, :, 1], 0, fw - 1.01)
+    pif[:, :, 2] = np.clip(pif[:, :, 2], 0, fh - 1.01)
+    for c in (1, 3):
+        paf[:, :, c] = np.clip(paf[:, :, c], 0, fw - 1.01)
+        paf[:, :, c + 1] = np.clip(paf[:, :, c + 1], 0, fh - 1.01)
+    return np.ascontiguousarray(paf, np.float32), np.ascontiguousarray(pif, np.float32)

@@ -129,6 +129,17 @@ int hp_ppn_set_thresholds(hp_ppn* p, float point_thresh, float limb_thresh, floa
 int hp_ppn_process_batch(hp_ppn* p, int n, const float* const tensors[7], const int conf_shape[3], const int edge_shape[5],
                          int on_device, hp_human* out, int cap_per_frame, int* n_out);
 
+/* ---- hyperpose::parser::pifpaf (include/hyperpose/operator/parser/pifpaf.hpp:8-26, src/pifpaf.cpp,
+ * src/pifpaf_decoder/openpifpaf_postprocessor.cpp).  GPU: PIF cell compaction, seed and CAF scoring with the
+ * hi-res confidence map evaluated on demand (never materialised), list packing; host: seed-ordered greedy grow,
+ * occupancy, soft-NMS and the 17 -> 18 key-point remap on the compacted lists. */
+typedef struct hp_pifpaf hp_pifpaf;
+int hp_pifpaf_create(hp_pifpaf** out, int net_h, int net_w, float thresh, int max_batch); /* pifpaf(int h, int w, float thresh = 0.1) */
+void hp_pifpaf_destroy(hp_pifpaf* p);
+/* pifpaf::process(paf, pif) (src/pifpaf.cpp:7 — the .cpp argument order): paf [n,19,9,fh,fw], pif [n,17,5,fh,fw]. */
+int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* pif, int fh, int fw, int on_device,
+                            hp_human* out, int cap_per_frame, int* n_out);
+
 /* ---- hyperpose::dnn engine: replaces dnn::tensorrt (include/hyperpose/operator/dnn/tensorrt.hpp:33-141,
  * src/tensorrt.cpp).  The network is a static list of layers over numbered tensors (tensor 0 = the input
  * image); weights are one fp32 blob in the layouts below.  TensorRT's UFF/ONNX parsing is replaced by the

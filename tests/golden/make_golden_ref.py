@@ -42,9 +42,23 @@ def ppn():
     np.savez_compressed(os.path.join(HERE, "ppn_golden.npz"), **out)
 
 
+def pifpaf():
+    out, meta = {}, []
+    cases = [(1, 49, 49, 41), (3, 49, 49, 42), (6, 49, 49, 43), (0, 49, 49, 44), (2, 33, 41, 45)]
+    for i, (people, fh, fw, salt) in enumerate(cases):
+        paf, pif = synth.pifpaf_maps(synth.rng_for(4, salt=salt), 1, fh, fw, people=(people,))
+        paf, pif = q16(paf[0]), q16(pif[0])
+        net_h, net_w = (fh - 1) * 8 + 1, (fw - 1) * 8 + 1
+        humans = loader.ref_pifpaf_process(paf, pif, net_h, net_w)
+        out[f"paf_{i}"], out[f"pif_{i}"] = paf.astype(np.float16), pif.astype(np.float16)
+        out[f"humans_{i}"] = humans
+        meta.append({"people": people, "fh": fh, "fw": fw, "net_h": net_h, "net_w": net_w, "n_humans": int(len(humans))})
+        print("pifpaf", meta[-1])
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "pifpaf_golden.npz"), **out)
+
+
 if __name__ == "__main__":
     assert loader.ref_lib() is not None, "oracle/_ref not built (needs /root/reference)"
     ppn()
-    if hasattr(synth, "pifpaf_maps"):
-        from make_golden_pifpaf import pifpaf  # noqa: E402
-        pifpaf()
+    pifpaf()
