@@ -138,7 +138,8 @@ def roofline(pipe):
     return {
         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
-        "kernel": f"conv_mfma_kernel<BM={dom_tile // 1000},BN={dom_tile % 1000}>",
+        "kernel": (f"conv3x3_halo_kernel<CIN=128> (128 cout x 8x16 px tile)" if dom_tile >= 3000000
+                   else f"conv_mfma_kernel<BM={dom_tile // 1000},BN={dom_tile % 1000}>"),
         "launches_per_step": dom["n"], "avg_launch_us": round(dom["ms"] / dom["n"] * 1e3, 2),
         "flops_per_launch": round(dom["flops"] / dom["n"]),
         "all_mfma_convs": {"achieved": round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2), "ms_per_step": round(mfma_ms, 4),

@@ -4,17 +4,21 @@
 // semantics (TF "SAME" padding, folded BatchNorm, activation placement) follow the Python model
 // definitions the reference exports from (hyperpose/Model/backbones.py, openpose/model/lw_openpose.py, ...).
 //
-//   conv_mfma_kernel   dense k x k conv as implicit GEMM:  D[cout][pixel] = sum_{tap,cin} W[tap][cout][cin] * X[pixel@tap][cin]
-//                      v_mfma_f32_32x32x16_f16, A = weights, B = activations (both K-contiguous in HBM: packed
-//                      weights [tap][cout][cin], activations NHWC), fp32 accumulate.  256 threads = 2x2 wavefronts,
-//                      block tile BM x BN x BK, global->register->LDS double buffering with ONE barrier per
-//                      K-step, XOR-swizzled LDS rows so that ds_read_b128 fragment reads are bank-conflict free.
-//                      The accumulator layout gives every lane 4 consecutive output channels of one pixel, so
-//                      the NHWC fp16 store is an 8-byte vector; bias / activation / residual / the fp32 NCHW
-//                      copy for the parsers are fused into the epilogue.
-//   first_conv_kernel  3-channel network input (u8 HWC or f32 NCHW): pre-processing (x factor, BGR->RGB, mean/std)
-//                      fused into the load, fp32 math, HBM-bound.
-//   dwconv3x3_kernel   depthwise 3x3, one thread = one pixel x 8 channels (16-byte loads/stores), HBM/L2-bound.
+//   conv_mfma_kernel    dense k x k conv as implicit GEMM:  D[cout][pixel] = sum_{tap,cin} W[tap][cout][cin] * X[pixel@tap][cin]
+//                       v_mfma_f32_32x32x16_f16, A = weights, B = activations (both K-contiguous in HBM: packed
+//                       weights [tap][cout][cin], activations NHWC), fp32 accumulate.  256 threads = 2x2 wavefronts,
+//                       block tile BM x BN x BK, global->register->LDS staging with the loads of K-step s+2 in
+//                       flight while step s computes, ONE barrier per K-step, XOR-swizzled LDS rows so that
+//                       ds_read_b128 fragment reads are bank-conflict free, XCD-aware block->tile mapping.
+//   conv3x3_halo_kernel the 3x3 / stride 1 case (44 % of LW-OpenPose's conv time): an 8x16-pixel output tile and its
+//                       1-pixel halo are staged in LDS ONCE and re-used by all 9 taps (L2 traffic per block drops
+//                       from 9 activation tiles to 1.4), only the weights stream through a prefetched LDS ring.
+//   Both share one epilogue: each lane owns 4 consecutive output channels of a pixel -> 8-byte NHWC stores; bias,
+//   piecewise-linear activation, residual add and the fp32 NCHW copy for the parsers are fused.
+//   first_conv_kernel   3-channel network input (u8 HWC or f32 NCHW): pre-processing (x factor, BGR->RGB, mean/std)
+//                       fused into the load, fp32 math, HBM-bound.
+//   dwconv3x3_kernel    depthwise 3x3, one thread = one pixel x 8 channels (16-byte loads/stores), HBM/L2-bound.
+// Activations carry a zero halo in HBM (conv_kernels.hpp), so taps in the padding are ordinary loads.
 #include "conv_kernels.hpp"
 
 namespace hp {
@@ -23,6 +27,18 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4))); // native 16-byte vector (HIP's uint4 struct defeats SROA here)
+
+// One MFMA, then one LDS read, four times: a single wavefront per SIMD issues in order, so the next fragments' reads
+// must sit INSIDE the 32-cycle shadows of the current MFMAs (cdna_hip_programming.md T19) instead of after them.
+#define HP_INTERLEAVE4()                                                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 
 __device__ __forceinline__ float apply_act(float v, int act, float param, float alpha)
 {
@@ -44,6 +60,11 @@ __device__ __forceinline__ float apply_act(float v, int act, float param, float 
     }
 }
 
+__device__ __forceinline__ long tv_off(const tview& t, int b, int y, int x)
+{
+    return ((long)b * t.img + (long)y * t.wp + x) * t.cs + t.coff;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // LDS tile: ROWS x BK halves, row = BK*2 bytes, 16-byte chunks XOR-swizzled by the row index so that the
 // 16-lane service groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table) hit 16 distinct 16-byte slots.
@@ -56,138 +77,31 @@ __device__ __forceinline__ int lds_off(int row, int chunk)
         return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int BM, int BN, int BK, int EPI>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
+// Shared epilogue.  Lane holds, for MFMA tile (i, j), pixel j-th "column" (given by pb/py/px/pv) and channels
+// m_wave + i*32 + 8g + 4*(lane>>5) + {0..3}, g = 0..3.  Activations are piecewise linear:
+// y = v > 0 ? min(v, hi) : v * slope  (none / relu / relu6 / leaky / prelu).
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void conv_epilogue(const conv_params& p, const floatx16 (&acc)[TM][TN], int m_wave, int lane,
+    const int (&pb)[TN], const int (&py)[TN], const int (&px)[TN], const bool (&pv)[TN])
 {
-    constexpr int CH = BK / 8;            // 16-byte chunks per tile row
-    constexpr int RPP = 256 / CH;         // tile rows covered by one pass of the 256 threads
-    constexpr int A_LD = BM / RPP;        // 16-byte global loads per thread for the weight tile
-    constexpr int B_LD = BN / RPP;        // ... for the activation tile
-    constexpr int TM = BM / 64, TN = BN / 64; // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
-    constexpr int TILE_BYTES = (BM + BN) * BK * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-    const int ld_row = tid / CH, ld_chunk = tid % CH;
-    const int KC = p.Cin / BK;
-    const int OHW = p.OH * p.OW;
-
-    // activation rows (pixels) this thread stages
-    int pb[B_LD], iy0[B_LD], ix0[B_LD];
-#pragma unroll
-    for (int i = 0; i < B_LD; ++i) {
-        const int n = n0 + ld_row + i * RPP;
-        if (n < p.npix) {
-            const int b = n / OHW, rem = n - b * OHW;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            pb[i] = b * p.H;
-            iy0[i] = oy * p.stride - p.pad_t;
-            ix0[i] = ox * p.stride - p.pad_l;
-        } else {
-            pb[i] = 0;
-            iy0[i] = -(1 << 20); // clamps to row 0 and is flagged invalid for every tap
-            ix0[i] = 0;
-        }
-    }
-
-    // Global loads of the NEXT K-step are issued before the MFMA phase of the current one and consumed after
-    // it; every load is unconditional (clamped address, zeroed at the LDS store when the tap falls in the
-    // padding) so that nothing forces an early s_waitcnt.  (Written without lambdas: hipcc keeps lambda-captured
-    // register arrays in scratch.)
-    u32x4 ra[A_LD], rb[B_LD];
-    unsigned bvalid = 0;
-    int l_ky = 0, l_kx = 0, l_kc = 0;
-#define HP_GLOAD()                                                                                               \
-    {                                                                                                            \
-        const int tap_ = l_ky * p.KW + l_kx;                                                                     \
-        const __half* wbase_ = p.w + ((size_t)tap_ * p.Cout_pad + m0) * p.Cin + l_kc * BK + ld_chunk * 8;        \
-        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                         \
-            ra[i] = *reinterpret_cast<const u32x4*>(wbase_ + (size_t)(ld_row + i * RPP) * p.Cin);                \
-        bvalid = 0;                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                                         \
-        {                                                                                                        \
-            const int iy_ = iy0[i] + l_ky * p.dil, ix_ = ix0[i] + l_kx * p.dil;                                  \
-            const bool ok_ = iy_ >= 0 && iy_ < p.H && ix_ >= 0 && ix_ < p.W;                                     \
-            bvalid |= (ok_ ? 1u : 0u) << i;                                                                      \
-            const int cy_ = min(max(iy_, 0), p.H - 1), cx_ = min(max(ix_, 0), p.W - 1);                          \
-            rb[i] = *reinterpret_cast<const u32x4*>(                                                             \
-                p.in + ((size_t)(pb[i] + cy_) * p.W + cx_) * p.in_cs + p.in_coff + l_kc * BK + ld_chunk * 8);    \
-        }                                                                                                        \
-        if (++l_kc == KC) {                                                                                      \
-            l_kc = 0;                                                                                            \
-            if (++l_kx == p.KW) {                                                                                \
-                l_kx = 0;                                                                                        \
-                ++l_ky;                                                                                          \
-            }                                                                                                    \
-        }                                                                                                        \
-    }
-
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[i][j][r] = 0.f;
-
-    const int steps = p.KH * p.KW * KC;
-    const int frow = lane & 31, fk = lane >> 5;
-    HP_GLOAD();
-    for (int s = 0; s < steps; ++s) {
-        unsigned char* a = lds + (s & 1) * TILE_BYTES;
-        unsigned char* b = a + BM * BK * 2;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<u32x4*>(a + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const unsigned keep = ((bvalid >> i) & 1u) ? 0xffffffffu : 0u;
-            *reinterpret_cast<u32x4*>(b + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = rb[i] & keep;
-        }
-        __syncthreads();
-        if (s + 1 < steps)
-            HP_GLOAD();
-        __builtin_amdgcn_sched_barrier(0); // keep the prefetch ABOVE the MFMA phase (hipcc otherwise sinks it to its use)
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            half8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const half8*>(a + lds_off<BK>(wm * (BM / 2) + i * 32 + frow, ks * 2 + fk));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const half8*>(b + lds_off<BK>(wn * (BN / 2) + j * 32 + frow, ks * 2 + fk));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#undef HP_GLOAD
-
-    // epilogue: lane holds pixel n = (lane & 31) of each 32-wide tile and channels 8g + 4*(lane>>5) + {0..3}.
-    // Activations are piecewise linear: y = v > 0 ? min(v, hi) : v * slope  (none/relu/relu6/leaky/prelu).
     const float hi = p.act_hi;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-        const bool nvalid = n < p.npix;
-        int b = 0, rem = 0;
-        if (EPI == 1) {
-            b = n / OHW;
-            rem = n - b * OHW;
+        const bool nvalid = pv[j];
+        long o_off = 0, r_off = 0, f_off = 0;
+        if (nvalid) {
+            if (p.out.p)
+                o_off = tv_off(p.out, pb[j], py[j], px[j]);
+            if (p.res.p)
+                r_off = tv_off(p.res, pb[j], py[j], px[j]);
+            if (EPI == 1)
+                f_off = ((long)pb[j] * p.Cout * p.OH + py[j]) * p.OW + px[j];
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + 8 * g + 4 * (lane >> 5);
+                const int m = m_wave + i * 32 + 8 * g + 4 * (lane >> 5);
                 if (nvalid && m < p.Cout) {
                     const float4 bs = *reinterpret_cast<const float4*>(p.bias + m);
                     float4 sl = make_float4(p.act_slope, p.act_slope, p.act_slope, p.act_slope);
@@ -196,8 +110,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
                     float v0 = acc[i][j][4 * g + 0] + bs.x, v1 = acc[i][j][4 * g + 1] + bs.y;
                     float v2 = acc[i][j][4 * g + 2] + bs.z, v3 = acc[i][j][4 * g + 3] + bs.w;
                     float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-                    if (p.res) {
-                        const __half* rp = p.res + (size_t)n * p.res_cs + p.res_coff + m;
+                    if (p.res.p) {
+                        const __half* rp = p.res.p + r_off + m;
                         if (EPI == 0) {
                             const half4 h = *reinterpret_cast<const half4*>(rp);
                             r0 = (float)h[0], r1 = (float)h[1], r2 = (float)h[2], r3 = (float)h[3];
@@ -217,11 +131,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
                     if (EPI == 0) {
                         half4 h;
                         h[0] = (_Float16)v0, h[1] = (_Float16)v1, h[2] = (_Float16)v2, h[3] = (_Float16)v3;
-                        *reinterpret_cast<half4*>(p.out + (size_t)n * p.out_cs + p.out_coff + m) = h;
+                        *reinterpret_cast<half4*>(p.out.p + o_off + m) = h;
                     } else {
                         const bool c1 = m + 1 < p.Cout, c2 = m + 2 < p.Cout, c3 = m + 3 < p.Cout;
-                        if (p.out) {
-                            __half* op = p.out + (size_t)n * p.out_cs + p.out_coff + m;
+                        if (p.out.p) {
+                            __half* op = p.out.p + o_off + m;
                             op[0] = __float2half(v0);
                             if (c1)
                                 op[1] = __float2half(v1);
@@ -231,14 +145,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
                                 op[3] = __float2half(v3);
                         }
                         if (p.out_f32) {
-                            float* fp = p.out_f32 + ((size_t)b * p.Cout + m) * OHW + rem;
+                            const long plane = (long)p.OH * p.OW;
+                            float* fp = p.out_f32 + f_off + (long)m * plane;
                             fp[0] = v0;
                             if (c1)
-                                fp[OHW] = v1;
+                                fp[plane] = v1;
                             if (c2)
-                                fp[2 * (size_t)OHW] = v2;
+                                fp[2 * plane] = v2;
                             if (c3)
-                                fp[3 * (size_t)OHW] = v3;
+                                fp[3 * plane] = v3;
                         }
                     }
                 }
@@ -247,21 +162,489 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
     }
 }
 
-// fast epilogue (aligned fp16 NHWC vectors) when every 4-channel group is whole and 8-byte aligned
+// Fast epilogue (EPI == 0: aligned fp16 NHWC output, whole 4-channel groups): every wavefront transposes its
+// accumulator tile through a private LDS slab ([32 pixels][32*TM channels] fp32 per pass, rows padded by 16 B so that
+// both the ds_write_b128 of the MFMA layout and the ds_read_b128 of the store layout are conflict-free) and then
+// stores 16 bytes per lane with 4*TM consecutive lanes covering one pixel's contiguous channel run — 8 cache lines
+// per store instruction instead of 64 with the raw MFMA layout (cdna_hip_programming.md T21).  Bias, activation and
+// the residual add happen on the store side in fp32, i.e. the same arithmetic as the direct epilogue.
+template <int TM>
+struct stage_geom {
+    static constexpr int ROW = TM * 128 + 16;          // bytes per staged pixel row
+    static constexpr int SLAB = 32 * ROW + 32 * 8 * 2; // + per-pixel output / residual offsets (long)
+    static constexpr int CPP = TM * 4;                 // 8-channel chunks per pixel
+    static constexpr int PPP = 64 / CPP;               // pixels per store pass
+    static constexpr int PASSES = 32 / PPP;
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const floatx16 (&acc)[TM][TN], int m_wave, int lane,
+    unsigned char* slab, const int (&pb)[TN], const int (&py)[TN], const int (&px)[TN], const bool (&pv)[TN])
+{
+    using G = stage_geom<TM>;
+    long* s_ooff = reinterpret_cast<long*>(slab + 32 * G::ROW);
+    long* s_roff = s_ooff + 32;
+    const int chunk = lane % G::CPP, prow = lane / G::CPP;
+    const int mc = m_wave + chunk * 8; // first of this lane's 8 output channels on the store side (Cout % 8 == 0 here)
+    const bool mvalid = mc < p.Cout;
+    float bs[8], sl[8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + mc), b1 = *reinterpret_cast<const float4*>(p.bias + mc + 4);
+        bs[0] = b0.x, bs[1] = b0.y, bs[2] = b0.z, bs[3] = b0.w, bs[4] = b1.x, bs[5] = b1.y, bs[6] = b1.z, bs[7] = b1.w;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            sl[r] = p.act_slope;
+        if (p.alpha) { // uniform
+            const float4 a0 = *reinterpret_cast<const float4*>(p.alpha + mc), a1 = *reinterpret_cast<const float4*>(p.alpha + mc + 4);
+            sl[0] = a0.x, sl[1] = a0.y, sl[2] = a0.z, sl[3] = a0.w, sl[4] = a1.x, sl[5] = a1.y, sl[6] = a1.z, sl[7] = a1.w;
+        }
+    }
+    const float hi = p.act_hi;
+    const bool has_res = p.res.p != nullptr; // uniform
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        // MFMA layout -> LDS: lane owns pixel (lane & 31), channels i*32 + 8g + 4*(lane>>5) + {0..3}
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = acc[i][j][4 * g + 0], v.y = acc[i][j][4 * g + 1], v.z = acc[i][j][4 * g + 2], v.w = acc[i][j][4 * g + 3];
+                *reinterpret_cast<float4*>(slab + (lane & 31) * G::ROW + (i * 32 + 8 * g + 4 * (lane >> 5)) * 4) = v;
+            }
+        if (lane < 32) {
+            s_ooff[lane] = pv[j] ? tv_off(p.out, pb[j], py[j], px[j]) : -1;
+            s_roff[lane] = (pv[j] && has_res) ? tv_off(p.res, pb[j], py[j], px[j]) : 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's LDS writes have landed (DS ops retire in order)
+        __builtin_amdgcn_wave_barrier();
+        // store side: offsets, then ALL residual loads (unconditional, straight-line), then math + 16-byte stores
+        long oo[G::PASSES];
+        half8 rs[G::PASSES];
+#pragma unroll
+        for (int ps = 0; ps < G::PASSES; ++ps)
+            oo[ps] = s_ooff[ps * G::PPP + prow];
+        if (has_res) {
+#pragma unroll
+            for (int ps = 0; ps < G::PASSES; ++ps) // invalid pixels read offset 0: in bounds, result unused
+                rs[ps] = *reinterpret_cast<const half8*>(p.res.p + s_roff[ps * G::PPP + prow] + (mvalid ? mc : 0));
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < G::PASSES; ++ps)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    rs[ps][r] = (_Float16)0.f;
+        }
+#pragma unroll
+        for (int ps = 0; ps < G::PASSES; ++ps) {
+            const int pix = ps * G::PPP + prow;
+            const float4 a0 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32);
+            const float4 a1 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32 + 16);
+            const float v[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+            half8 h;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float x = v[r] + bs[r];
+                const float rr = (float)rs[ps][r];
+                if (p.res_before_act)
+                    x += rr;
+                x = x > 0.f ? fminf(x, hi) : x * sl[r];
+                if (!p.res_before_act)
+                    x += rr;
+                h[r] = (_Float16)x;
+            }
+            if (oo[ps] >= 0 && mvalid)
+                *reinterpret_cast<half8*>(p.out.p + oo[ps] + mc) = h;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // slab reads done before the next pass overwrites it
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generic implicit GEMM.  1-D grid; block id -> (pixel tile, cout tile) with the cout tiles of one pixel tile
+// adjacent and consecutive logical ids on the same XCD (blocks are dispatched round-robin over the 8 XCDs).
+template <int BM, int BN, int BK, int EPI>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
+{
+    constexpr int CH = BK / 8;            // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CH;         // tile rows covered by one pass of the 256 threads
+    constexpr int A_LD = BM / RPP;        // 16-byte global loads per thread for the weight tile
+    constexpr int B_LD = BN / RPP;        // ... for the activation tile
+    constexpr int TM = BM / 64, TN = BN / 64; // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
+    constexpr int TILE_BYTES = (BM + BN) * BK * 2;
+    constexpr int EPI_BYTES = EPI == 0 ? 4 * stage_geom<TM>::SLAB : 0;
+    constexpr int LDS_BYTES = 2 * TILE_BYTES > EPI_BYTES ? 2 * TILE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int MB = p.Cout_pad / BM;
+    int m0, n0;
+    {
+        const int total = gridDim.x, P = blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = P & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (P >> 3);
+        m0 = (L % MB) * BM;
+        n0 = (L / MB) * BN;
+    }
+
+    const int ld_row = tid / CH, ld_chunk = tid % CH;
+    const int KC = p.Cin / BK;
+    const int OHW = p.OH * p.OW;
+
+    // per-thread element offsets of the activation rows (pixels) it stages; rows past the end alias the last pixel
+    long rowoff[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+        const int n = min(n0 + ld_row + i * RPP, p.npix - 1);
+        const int b = n / OHW, rem = n - b * OHW;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        rowoff[i] = tv_off(p.in, b, oy * p.stride - p.pad_t, ox * p.stride - p.pad_l) + ld_chunk * 8;
+    }
+    const __half* wrow = p.w + (size_t)(m0 + ld_row) * p.Cin + ld_chunk * 8;
+    const long w_tap_stride = (long)p.Cout_pad * p.Cin;
+
+    // two register sets: the loads of K-step s+2 are in flight while step s computes
+    u32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
+    int l_ky = 0, l_kx = 0, l_kc = 0;
+#define HP_GLOAD(RA, RB)                                                                                          \
+    {                                                                                                             \
+        const long toff_ = ((long)(l_ky * p.dil) * p.in.wp + l_kx * p.dil) * p.in.cs + l_kc * BK;                 \
+        const __half* wb_ = wrow + (long)(l_ky * p.KW + l_kx) * w_tap_stride + l_kc * BK;                         \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                          \
+            RA[i] = *reinterpret_cast<const u32x4*>(wb_ + (size_t)(i * RPP) * p.Cin);                             \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                                          \
+            RB[i] = *reinterpret_cast<const u32x4*>(p.in.p + rowoff[i] + toff_);                                  \
+        if (++l_kc == KC) {                                                                                       \
+            l_kc = 0;                                                                                             \
+            if (++l_kx == p.KW) {                                                                                 \
+                l_kx = 0;                                                                                         \
+                ++l_ky;                                                                                           \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+#define HP_LSTORE(RA, RB, BUF)                                                                                    \
+    {                                                                                                             \
+        unsigned char* a_ = lds + (BUF) * TILE_BYTES;                                                             \
+        unsigned char* b_ = a_ + BM * BK * 2;                                                                     \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                          \
+            *reinterpret_cast<u32x4*>(a_ + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = RA[i];                      \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                                          \
+            *reinterpret_cast<u32x4*>(b_ + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = RB[i];                      \
+    }
+#define HP_FRAGS(FA, FB, KS)                                                                                      \
+    {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                            \
+            FA[i] = *reinterpret_cast<const half8*>(a_ + lds_off<BK>(wm * (BM / 2) + i * 32 + frow, (KS) * 2 + fk)); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                            \
+            FB[j] = *reinterpret_cast<const half8*>(b_ + lds_off<BK>(wn * (BN / 2) + j * 32 + frow, (KS) * 2 + fk)); \
+    }
+#define HP_MMA(FA, FB)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                            \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[i], FB[j], acc[i][j], 0, 0, 0);
+// fragments of k-substep ks+1 are read from LDS while the MFMAs of substep ks execute
+#define HP_COMPUTE(BUF)                                                                                           \
+    {                                                                                                             \
+        const unsigned char* a_ = lds + (BUF) * TILE_BYTES;                                                       \
+        const unsigned char* b_ = a_ + BM * BK * 2;                                                               \
+        half8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];                                                                 \
+        HP_FRAGS(fa0, fb0, 0);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < BK / 16; ks += 2)                                                 \
+        {                                                                                                         \
+            HP_FRAGS(fa1, fb1, ks + 1);                                                                           \
+            HP_MMA(fa0, fb0);                                                                                     \
+            HP_INTERLEAVE4();                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if (ks + 2 < BK / 16) {                                                                               \
+                HP_FRAGS(fa0, fb0, ks + 2);                                                                       \
+                HP_MMA(fa1, fb1);                                                                                 \
+                HP_INTERLEAVE4();                                                                                 \
+            } else {                                                                                              \
+                HP_MMA(fa1, fb1);                                                                                 \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+
+    const int steps = p.KH * p.KW * KC;
+    const int frow = lane & 31, fk = lane >> 5;
+    HP_GLOAD(ra0, rb0);
+    if (steps > 1)
+        HP_GLOAD(ra1, rb1);
+    for (int s = 0; s < steps; s += 2) {
+        HP_LSTORE(ra0, rb0, 0);
+        __syncthreads();
+        if (s + 2 < steps)
+            HP_GLOAD(ra0, rb0);
+        __builtin_amdgcn_sched_barrier(0); // keep the prefetch ABOVE the MFMA phase (hipcc otherwise sinks it to its use)
+        HP_COMPUTE(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < steps) {
+            HP_LSTORE(ra1, rb1, 1);
+            __syncthreads();
+            if (s + 3 < steps)
+                HP_GLOAD(ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            HP_COMPUTE(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef HP_GLOAD
+#undef HP_LSTORE
+#undef HP_COMPUTE
+#undef HP_FRAGS
+#undef HP_MMA
+
+    int pb[TN], py[TN], px[TN];
+    bool pv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        pv[j] = n < p.npix;
+        const int nn = min(n, p.npix - 1);
+        pb[j] = nn / OHW;
+        const int rem = nn - pb[j] * OHW;
+        py[j] = rem / p.OW;
+        px[j] = rem - py[j] * p.OW;
+    }
+    if (EPI == 0) {
+        __syncthreads(); // every wave is done with the main-loop tiles before the slabs overwrite them
+        conv_epilogue_staged<TM, TN>(p, acc, m0 + wm * (BM / 2), lane, lds + wave * stage_geom<TM>::SLAB, pb, py, px, pv);
+    } else
+        conv_epilogue<TM, TN, EPI>(p, acc, m0 + wm * (BM / 2), lane, pb, py, px, pv);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / dilation 1 with the input tile + halo resident in LDS.  Block = 128 output channels x (8 x 16)
+// output pixels; 4 wavefronts as 2 (channels) x 2 (pixel rows 0-3 / 4-7), each 64 ch x 64 px = 2x2 MFMA tiles.
+// Halo tile: 10 x 18 pixels x CIN halves, per-pixel 16-byte chunks XOR-swizzled by the pixel index.
+// Weights: [tap][cout][cin] streamed in K-steps of 64 through a double-buffered LDS tile, register-prefetched two
+// steps ahead.
+constexpr int HT_H = 8, HT_W = 16, HP_H = HT_H + 2, HP_W = HT_W + 2;
+
+template <int CIN, int EPI>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_params p, int tiles_x, int tiles_y)
+{
+    constexpr int BM = 128, BK = 64;
+    constexpr int CHP = CIN / 8;              // 16-byte chunks per halo pixel
+    constexpr int KC = CIN / BK;
+    constexpr int HALO_BYTES = HP_H * HP_W * CIN * 2;
+    constexpr int A_BYTES = BM * BK * 2;
+    constexpr int A_LD = BM / 32;             // 4 x 16-byte loads per thread per K-step
+    static_assert(HALO_BYTES + 2 * A_BYTES >= 4 * stage_geom<2>::SLAB, "epilogue slabs must fit in the main-loop LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_BYTES + 2 * A_BYTES];
+    unsigned char* const s_halo = lds;
+    unsigned char* const s_a = lds + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * HT_H, x0 = tx * HT_W;
+
+    // ---- weights prefetch (two register sets), then the halo tile
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+    const __half* wrow = p.w + (size_t)(m0 + ld_row) * CIN + ld_chunk * 8;
+    const long w_tap_stride = (long)p.Cout_pad * CIN;
+    u32x4 ra0[A_LD], ra1[A_LD];
+    int l_tap = 0, l_kc = 0;
+#define HP_WLOAD(RA)                                                                                              \
+    {                                                                                                             \
+        const __half* wb_ = wrow + (long)l_tap * w_tap_stride + l_kc * BK;                                        \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                          \
+            RA[i] = *reinterpret_cast<const u32x4*>(wb_ + (size_t)(i * 32) * CIN);                                \
+        if (++l_kc == KC) {                                                                                       \
+            l_kc = 0;                                                                                             \
+            ++l_tap;                                                                                              \
+        }                                                                                                         \
+    }
+#define HP_WSTORE(RA, BUF)                                                                                        \
+    {                                                                                                             \
+        unsigned char* a_ = s_a + (BUF) * A_BYTES;                                                                \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                          \
+            *reinterpret_cast<u32x4*>(a_ + lds_off<BK>(ld_row + i * 32, ld_chunk)) = RA[i];                       \
+    }
+    int dbg_i = 0;
+#define HP_STAMP()                                                                                                \
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)                                                  \
+        p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
+    HP_WLOAD(ra0);
+    HP_WLOAD(ra1);
+
+    // halo tile: issue ALL loads first (one L2 round trip), then the LDS stores
+    {
+        constexpr int NIT = (HP_H * HP_W * CHP + 255) / 256;
+        u32x4 hv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int hp = min(i, HP_H * HP_W * CHP - 1) / CHP, c = i % CHP;
+            const int hy = hp / HP_W, hx = hp - hy * HP_W;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            const bool ok = y <= p.H && x <= p.W; // y, x >= -1 always: inside the zero halo of the HBM tensor
+            const u32x4 v = *reinterpret_cast<const u32x4*>(p.in.p + tv_off(p.in, b, min(y, p.H), min(x, p.W)) + c * 8);
+            hv[it] = v & (ok ? 0xffffffffu : 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < HP_H * HP_W * CHP) {
+                const int hp = i / CHP, c = i - hp * CHP;
+                *reinterpret_cast<u32x4*>(s_halo + hp * (CIN * 2) + ((c ^ (hp & (CHP - 1))) << 4)) = hv[it];
+            }
+        }
+    }
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fk = lane >> 5;
+    // this lane's two B-fragment pixels (tile coordinates): N-tile j covers tile rows wn*4 + 2j, +1
+    const int bcol = lane & 15, brow = wn * 4 + ((lane & 31) >> 4);
+    int c_tap = 0, c_kc = 0;
+#define HP_HFRAGS(FA, FB, KS)                                                                                     \
+    {                                                                                                             \
+        const int ch_ = c_kc * 8 + (KS) * 2 + fk;                                                                 \
+        FA[0] = *reinterpret_cast<const half8*>(a_ + lds_off<BK>(wm * 64 + frow, (KS) * 2 + fk));                 \
+        FA[1] = *reinterpret_cast<const half8*>(a_ + lds_off<BK>(wm * 64 + 32 + frow, (KS) * 2 + fk));            \
+        FB[0] = *reinterpret_cast<const half8*>(s_halo + hp0_ * (CIN * 2) + ((ch_ ^ (hp0_ & (CHP - 1))) << 4));   \
+        FB[1] = *reinterpret_cast<const half8*>(s_halo + hp1_ * (CIN * 2) + ((ch_ ^ (hp1_ & (CHP - 1))) << 4));   \
+    }
+#define HP_HMMA(FA, FB)                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[i], FB[j], acc[i][j], 0, 0, 0);
+#define HP_HCOMPUTE(BUF)                                                                                          \
+    {                                                                                                             \
+        const unsigned char* a_ = s_a + (BUF) * A_BYTES;                                                          \
+        const int ky_ = c_tap / 3, kx_ = c_tap - ky_ * 3;                                                         \
+        const int hp0_ = (brow + ky_) * HP_W + bcol + kx_, hp1_ = hp0_ + 2 * HP_W;                                \
+        half8 fa0[2], fb0[2], fa1[2], fb1[2];                                                                     \
+        HP_HFRAGS(fa0, fb0, 0);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        HP_HFRAGS(fa1, fb1, 1);                                                                                   \
+        HP_HMMA(fa0, fb0);                                                                                        \
+        HP_INTERLEAVE4();                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        HP_HFRAGS(fa0, fb0, 2);                                                                                   \
+        HP_HMMA(fa1, fb1);                                                                                        \
+        HP_INTERLEAVE4();                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        HP_HFRAGS(fa1, fb1, 3);                                                                                   \
+        HP_HMMA(fa0, fb0);                                                                                        \
+        HP_INTERLEAVE4();                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        HP_HMMA(fa1, fb1);                                                                                        \
+        if (++c_kc == KC) {                                                                                       \
+            c_kc = 0;                                                                                             \
+            ++c_tap;                                                                                              \
+        }                                                                                                         \
+    }
+
+    constexpr int steps = 9 * KC;
+    HP_STAMP();
+    for (int s = 0; s < steps; s += 2) {
+        HP_WSTORE(ra0, 0);
+        __syncthreads(); // also publishes the halo tile on the first iteration
+        HP_STAMP();
+        if (s + 2 < steps)
+            HP_WLOAD(ra0);
+        __builtin_amdgcn_sched_barrier(0);
+        HP_HCOMPUTE(0);
+        __builtin_amdgcn_sched_barrier(0);
+        HP_STAMP();
+        if (s + 1 < steps) {
+            HP_WSTORE(ra1, 1);
+            __syncthreads();
+            HP_STAMP();
+            if (s + 3 < steps)
+                HP_WLOAD(ra1);
+            __builtin_amdgcn_sched_barrier(0);
+            HP_HCOMPUTE(1);
+            __builtin_amdgcn_sched_barrier(0);
+            HP_STAMP();
+        }
+    }
+#undef HP_WLOAD
+#undef HP_WSTORE
+#undef HP_HCOMPUTE
+#undef HP_HFRAGS
+#undef HP_HMMA
+
+    int pb[2], py[2], px[2];
+    bool pv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        pb[j] = b;
+        py[j] = y0 + brow + 2 * j;
+        px[j] = x0 + bcol;
+        pv[j] = py[j] < p.OH && px[j] < p.OW;
+    }
+    HP_STAMP();
+    if (EPI == 0) {
+        __syncthreads();
+        conv_epilogue_staged<2, 2>(p, acc, m0 + wm * 64, lane, lds + wave * stage_geom<2>::SLAB, pb, py, px, pv);
+    } else
+        conv_epilogue<2, 2, EPI>(p, acc, m0 + wm * 64, lane, pb, py, px, pv);
+    HP_STAMP();
+#undef HP_STAMP
+}
+
+// fast epilogue (aligned fp16 NHWC vectors) when every 8-channel chunk is whole and 16-byte aligned
 static bool fast_epilogue(const conv_params& p)
 {
-    return p.out && !p.out_f32 && p.Cout % 4 == 0 && p.out_coff % 4 == 0 && p.out_cs % 4 == 0
-        && (!p.res || (p.res_coff % 4 == 0 && p.res_cs % 4 == 0));
+    return p.out.p && !p.out_f32 && p.Cout % 8 == 0 && p.out.coff % 8 == 0 && p.out.cs % 8 == 0
+        && (!p.res.p || (p.res.coff % 8 == 0 && p.res.cs % 8 == 0));
+}
+
+static bool use_halo(const conv_params& p)
+{
+    return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil == 1 && p.pad_t == 1 && p.pad_l == 1 && (p.Cin == 128 || p.Cin == 64)
+        && p.Cout_pad % 128 == 0 && p.in.coff % 8 == 0;
 }
 
 template <int BM, int BN, int BK>
 static hipError_t launch_tile(const conv_params& p, hipStream_t s)
 {
-    dim3 grid((p.npix + BN - 1) / BN, p.Cout_pad / BM);
+    dim3 grid(((p.npix + BN - 1) / BN) * (p.Cout_pad / BM));
     if (fast_epilogue(p))
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, 0>), grid, dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, 1>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+template <int CIN>
+static hipError_t launch_halo(const conv_params& p, hipStream_t s)
+{
+    const int tiles_x = (p.OW + HT_W - 1) / HT_W, tiles_y = (p.OH + HT_H - 1) / HT_H;
+    dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / 128);
+    if (fast_epilogue(p))
+        hipLaunchKernelGGL((conv3x3_halo_kernel<CIN, 0>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<CIN, 1>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
     return hipGetLastError();
 }
 
@@ -291,6 +674,8 @@ bool set_act(conv_params& p)
 
 int conv_mfma_tile(const conv_params& p)
 {
+    if (use_halo(p))
+        return 3000000 + 128 * 1000 + 128;
     const int BM = (p.Cout_pad % 128 == 0) ? 128 : 64;
     // prefer the 128-pixel tile only when it still fills the 256 CUs at least once
     const long blocks128 = (long)((p.npix + 127) / 128) * (p.Cout_pad / BM);
@@ -300,6 +685,8 @@ int conv_mfma_tile(const conv_params& p)
 
 hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
 {
+    if (use_halo(p))
+        return p.Cin == 128 ? launch_halo<128>(p, s) : launch_halo<64>(p, s);
     const int t = conv_mfma_tile(p);
     const int BM = t / 1000, BN = t % 1000;
     const bool k64 = (p.Cin % 64 == 0);
@@ -374,14 +761,15 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const first_conv_params
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             h[r] = (_Float16)apply_act(acc[r], p.act, p.act_param, 0.f);
-        __half* op = p.out + (size_t)n * p.out_cs + p.out_coff + g * 8;
-        if (g * 8 + 7 < p.Cout && ((p.out_coff & 7) == 0) && ((p.out_cs & 7) == 0))
+        __half* op = p.out.p + tv_off(p.out, b, oy, ox) + g * 8;
+        if (g * 8 + 7 < p.Cout && ((p.out.coff & 7) == 0))
             *reinterpret_cast<half8*>(op) = h;
-        else
+        else {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 if (g * 8 + r < p.Cout)
                     reinterpret_cast<_Float16*>(op)[r] = h[r];
+        }
     }
 }
 
@@ -415,28 +803,26 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const dw_params p)
             const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cg * 8 + 4);
             acc[0] = b0.x, acc[1] = b0.y, acc[2] = b0.z, acc[3] = b0.w, acc[4] = b1.x, acc[5] = b1.y, acc[6] = b1.z, acc[7] = b1.w;
         }
+        // taps in the padding read the zero halo: no bounds checks, all 9 loads issue back to back
+        const __half* base = p.in.p + tv_off(p.in, b, oy * p.stride - p.pad_t, ox * p.stride - p.pad_l) + cg * 8;
+        half8 x[9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * p.stride - p.pad_t + ky * p.dil;
-            if (iy < 0 || iy >= p.H)
-                continue;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * p.stride - p.pad_l + kx * p.dil;
-                if (ix < 0 || ix >= p.W)
-                    continue;
-                const half8 x = *reinterpret_cast<const half8*>(p.in + (((size_t)b * p.H + iy) * p.W + ix) * p.in_cs + p.in_coff + cg * 8);
-                const half8 w = *reinterpret_cast<const half8*>(p.w + (size_t)(ky * 3 + kx) * p.C + cg * 8);
+            for (int kx = 0; kx < 3; ++kx)
+                x[ky * 3 + kx] = *reinterpret_cast<const half8*>(base + ((long)(ky * p.dil) * p.in.wp + kx * p.dil) * p.in.cs);
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    acc[r] += (float)x[r] * (float)w[r];
-            }
+        for (int tpp = 0; tpp < 9; ++tpp) {
+            const half8 w = *reinterpret_cast<const half8*>(p.w + (size_t)tpp * p.C + cg * 8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                acc[r] += (float)x[tpp][r] * (float)w[r];
         }
         half8 h;
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             h[r] = (_Float16)apply_act(acc[r], p.act, p.act_param, 0.f);
-        *reinterpret_cast<half8*>(p.out + (size_t)n * p.out_cs + p.out_coff + cg * 8) = h;
+        *reinterpret_cast<half8*>(p.out.p + tv_off(p.out, b, oy, ox) + cg * 8) = h;
     }
 }
 
@@ -465,13 +851,13 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const pool_params p)
             m[r] = -65504.f;
         for (int ky = 0; ky < p.k; ++ky) {
             const int iy = oy * p.stride - p.pad_t + ky;
-            if (iy < 0 || iy >= p.H)
+            if (iy < 0 || iy >= p.H) // SAME max-pool pads with -inf, not with the zero halo
                 continue;
             for (int kx = 0; kx < p.k; ++kx) {
                 const int ix = ox * p.stride - p.pad_l + kx;
                 if (ix < 0 || ix >= p.W)
                     continue;
-                const half8 x = *reinterpret_cast<const half8*>(p.in + (((size_t)b * p.H + iy) * p.W + ix) * p.in_cs + p.in_coff + cg * 8);
+                const half8 x = *reinterpret_cast<const half8*>(p.in.p + tv_off(p.in, b, iy, ix) + cg * 8);
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
                     m[r] = fmaxf(m[r], (float)x[r]);
@@ -481,7 +867,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const pool_params p)
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             h[r] = (_Float16)m[r];
-        *reinterpret_cast<half8*>(p.out + (size_t)n * p.out_cs + p.out_coff + cg * 8) = h;
+        *reinterpret_cast<half8*>(p.out.p + tv_off(p.out, b, oy, ox) + cg * 8) = h;
     }
 }
 
@@ -494,25 +880,25 @@ hipError_t launch_maxpool(const pool_params& p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const __half* __restrict__ in, int in_cs, int in_coff, int B, int HW,
-    int C, int act, float* __restrict__ out)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(tview in, int B, int H, int W, int C, int act, float* __restrict__ out)
 {
+    const int HW = H * W;
     const long total = (long)B * C * HW;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int pix = (int)(i % HW);
         const long t = i / HW;
         const int c = (int)(t % C), b = (int)(t / C);
-        const float v = __half2float(in[((size_t)b * HW + pix) * in_cs + in_coff + c]);
+        const int y = pix / W, x = pix - y * W;
+        const float v = __half2float(in.p[tv_off(in, b, y, x) + c]);
         out[i] = apply_act(v, act, 0.f, 0.f);
     }
 }
 
-hipError_t launch_nhwc_to_nchw_f32(const __half* in, int in_cs, int in_coff, int B, int H, int W, int C, int act, float* out,
-    hipStream_t s)
+hipError_t launch_nhwc_to_nchw_f32(tview in, int B, int H, int W, int C, int act, float* out, hipStream_t s)
 {
     const long total = (long)B * C * H * W;
     const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, in, in_cs, in_coff, B, H * W, C, act, out);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, C, act, out);
     return hipGetLastError();
 }
 

@@ -3,8 +3,11 @@
 // (src/tensorrt.cpp:393 `executeV2`): every layer of the exported graphs (hyperpose/Model/backbones.py,
 // openpose/model/*.py, pose_proposal/model.py, pifpaf/model.py) maps onto one of the launches below.
 //
-// Activation layout in HBM: NHWC fp16, channel count padded to a multiple of 8 (16-byte vectors), a tensor
-// may be a channel slice [coff, coff+C) of a wider buffer with pixel stride `cs` (concat by offset).
+// Activation layout in HBM: NHWC fp16 with a ZERO HALO: a tensor [B][H][W][C] lives in a buffer
+// [B][H+2P][W+2P][cs] (cs = channel stride, multiple of 32; P = the largest padding any consumer needs) whose
+// border and pad channels are zeroed once and never written, so convolution taps that fall into the padding are
+// plain in-bounds loads of zeros — no per-tap bounds checks, no clamping, uniform per-tap address offsets.
+// A tensor may be a channel slice [coff, coff+C) of a wider buffer (concat by offset).
 // Network outputs are written fp32 NCHW [B][C][H][W], the layout feature_map_t / the parsers consume.
 #pragma once
 #include <hip/hip_fp16.h>
@@ -16,37 +19,47 @@ namespace hp {
 
 enum act_t : int { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2, ACT_LEAKY = 3, ACT_PRELU = 4, ACT_SIGMOID = 5, ACT_SOFTPLUS = 6 };
 
+// fp16 NHWC view with halo: element (b, y, x, c) is p[((long)b * img + (long)y * wp + x) * cs + coff + c],
+// valid for y in [-P, H+P), x in [-P, W+P).
+struct tview {
+    __half* p;   // interior origin: image 0, pixel (0,0), channel 0 of the underlying buffer
+    int cs;      // channel stride (elements per pixel)
+    int coff;    // first channel of this tensor inside the buffer
+    int wp;      // padded row length in pixels (W + 2P)
+    int img;     // padded pixels per image ((H + 2P) * (W + 2P))
+};
+
 struct conv_params {
-    // input: fp16 NHWC view
-    const __half* in;
-    int in_cs, in_coff;
+    tview in;
     int B, H, W;
     int OH, OW;
-    int Cin;      // channels read per tap; multiple of 32 for the MFMA kernel
+    int Cin;      // channels read per tap; multiple of 32 for the MFMA kernels
     int Cout;     // real output channels
     int Cout_pad; // rows of the packed weight matrix (multiple of the M tile)
     int KH, KW, stride, dil, pad_t, pad_l;
     const __half* w;    // packed [KH*KW][Cout_pad][Cin]
     const float* bias;  // [Cout_pad]
     const float* alpha; // PReLU slopes [Cout_pad] or nullptr
-    int act;          // ACT_NONE / RELU / RELU6 / LEAKY / PRELU (the piecewise-linear ones)
+    int act;            // ACT_NONE / RELU / RELU6 / LEAKY / PRELU (the piecewise-linear ones)
     float act_param;
     float act_slope, act_hi; // y = v > 0 ? min(v, act_hi) : v * act_slope, filled by set_act()
     // optional residual (same shape as the output), added after (res_before_act = 0) or before the activation
-    const __half* res;
-    int res_cs, res_coff, res_before_act;
+    tview res; // res.p == nullptr: none
+    int res_before_act;
     // outputs (either may be null)
-    __half* out;
-    int out_cs, out_coff;
+    tview out;      // out.p may be null
     float* out_f32; // fp32 NCHW [B][Cout][OH][OW]
     int npix;       // B*OH*OW
+    unsigned long long* dbg; // optional s_memtime timeline of block 0 / wave 0 (tools/microbench), nullptr in production
 };
 
 // fills act_slope / act_hi from act / act_param; false for activations the MFMA epilogue does not fuse
 bool set_act(conv_params& p);
-// Dense k x k convolution as an implicit GEMM on MFMA (v_mfma_f32_32x32x16_f16).  Returns hipError_t.
+// Dense k x k convolution as an implicit GEMM on MFMA (v_mfma_f32_32x32x16_f16).  Picks between the generic
+// implicit-GEMM kernel and the LDS-halo 3x3 kernel.  Returns hipError_t.
 hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s);
-// which tile the launcher picks (for reporting): returns BM*1000+BN
+// which kernel/tile the launcher picks (for reporting): BM*1000+BN for the generic kernel, 3000000+BM*1000+BN for
+// the 3x3 halo kernel
 int conv_mfma_tile(const conv_params& p);
 
 struct first_conv_params {
@@ -62,39 +75,33 @@ struct first_conv_params {
     const float* bias;
     int act;
     float act_param;
-    __half* out;
-    int out_cs, out_coff;
+    tview out;
 };
 // Direct convolution for the 3-channel network input (u8 HWC or f32 NCHW), pre-processing fused into the load.
 hipError_t launch_first_conv(const first_conv_params& p, hipStream_t s);
 
 struct dw_params {
-    const __half* in;
-    int in_cs, in_coff;
+    tview in;
     int B, H, W, OH, OW, C; // C multiple of 8
     int stride, dil, pad_t, pad_l;
     const __half* w;   // packed [9][C]
     const float* bias; // [C]
     int act;
     float act_param;
-    __half* out;
-    int out_cs, out_coff;
+    tview out;
 };
 // Depthwise 3x3 (VALU, HBM/L2-bound): one thread = one output pixel x 8 channels.
 hipError_t launch_dwconv3x3(const dw_params& p, hipStream_t s);
 
 struct pool_params {
-    const __half* in;
-    int in_cs, in_coff;
+    tview in;
     int B, H, W, OH, OW, C;
     int k, stride, pad_t, pad_l;
-    __half* out;
-    int out_cs, out_coff;
+    tview out;
 };
 hipError_t launch_maxpool(const pool_params& p, hipStream_t s);
 
 // fp16 NHWC view -> fp32 NCHW (for outputs not produced by a conv epilogue) with an optional element-wise op.
-hipError_t launch_nhwc_to_nchw_f32(const __half* in, int in_cs, int in_coff, int B, int H, int W, int C, int act, float* out,
-    hipStream_t s);
+hipError_t launch_nhwc_to_nchw_f32(tview in, int B, int H, int W, int C, int act, float* out, hipStream_t s);
 
 } // namespace hp

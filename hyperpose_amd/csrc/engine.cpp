@@ -28,7 +28,16 @@ struct tensor_info {
     bool defined = false;
     int H = 0, W = 0, C = 0; // C = total channels written
     int cs = 0;              // channel stride of the buffer
+    int P = 0;               // zero halo (pixels) around every image: the largest padding any consumer needs
     hp::dev_buf buf;
+    hp::tview view(int coff) const
+    {
+        hp::tview v;
+        const int wp = W + 2 * P;
+        v.p = buf.as<__half>() + ((size_t)P * wp + P) * cs;
+        v.cs = cs, v.coff = coff, v.wp = wp, v.img = (H + 2 * P) * wp;
+        return v;
+    }
 };
 
 struct out_info {
@@ -145,15 +154,21 @@ int hp_engine::build(const hp_engine_desc* d)
         }
         if (L.op != HP_OP_CONV)
             HP_REQUIRE(L.cin == L.cout, HP_ERR_INVALID, "layer %zu: depthwise/pool need cin == cout", i);
+        if (L.op != HP_OP_MAXPOOL && L.in != 0) {
+            // halo this consumer needs on its input: SAME padding before / after in both dimensions
+            const int pb_y = std::max((g.OH - 1) * L.stride + (L.kh - 1) * L.dil + 1 - ti.H - g.pt, 0);
+            const int pb_x = std::max((g.OW - 1) * L.stride + (L.kw - 1) * L.dil + 1 - ti.W - g.pl, 0);
+            tensors[L.in]->P = std::max({ tensors[L.in]->P, g.pt, g.pl, pb_y, pb_x });
+        }
     }
     for (size_t t = 1; t < tensors.size(); ++t) {
         tensor_info& ti = *tensors[t];
         if (!ti.defined)
             continue;
         ti.cs = round_up(ti.C, 32);
-        const size_t bytes = (size_t)max_batch * ti.H * ti.W * ti.cs * sizeof(__half);
+        const size_t bytes = (size_t)max_batch * (ti.H + 2 * ti.P) * (ti.W + 2 * ti.P) * ti.cs * sizeof(__half);
         HP_TRY(ti.buf.alloc(bytes));
-        HP_HIP_TRY(hipMemset(ti.buf.p, 0, bytes)); // pad channels must read as zero
+        HP_HIP_TRY(hipMemset(ti.buf.p, 0, bytes)); // the halo and the pad channels must read as zero, forever
     }
 
     // ---- outputs
@@ -232,7 +247,7 @@ int hp_engine::build(const hp_engine_desc* d)
             HP_TRY(upload(w, nw * sizeof(float), &dw));
             HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
             p.w = (const float*)dw, p.bias = (const float*)db;
-            p.out = to.buf.as<__half>(), p.out_cs = to.cs, p.out_coff = L.out_coff;
+            p.out = to.view(L.out_coff);
             st.flops = 2.0 * opix * L.cout * L.kh * L.kw * 3;
             st.bytes = (double)ti.H * ti.W * 3 + opix * L.cout * 2 + nw * 4;
         } else if (L.op == HP_OP_CONV) {
@@ -273,15 +288,16 @@ int hp_engine::build(const hp_engine_desc* d)
                 HP_TRY(upload(alpha.data(), alpha.size() * sizeof(float), &da));
                 p.alpha = (const float*)da;
             }
-            p.in = ti.buf.as<__half>(), p.in_cs = ti.cs, p.in_coff = L.in_coff;
+            p.in = ti.view(L.in_coff);
             p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.Cin = cin_pad, p.Cout = L.cout, p.Cout_pad = cout_pad;
             p.KH = L.kh, p.KW = L.kw, p.stride = L.stride, p.dil = L.dil, p.pad_t = g.pt, p.pad_l = g.pl;
             p.act = L.act, p.act_param = L.act_param;
-            p.res = nullptr, p.res_cs = 0, p.res_coff = 0, p.res_before_act = L.res_before_act;
+            p.res = hp::tview{ nullptr, 0, 0, 0, 0 }, p.res_before_act = L.res_before_act;
             if (L.res >= 0)
-                p.res = tensors[L.res]->buf.as<__half>(), p.res_cs = tensors[L.res]->cs;
-            p.out = to.buf.as<__half>(), p.out_cs = to.cs, p.out_coff = L.out_coff;
+                p.res = tensors[L.res]->view(0);
+            p.out = to.view(L.out_coff);
             p.out_f32 = nullptr;
+            p.dbg = nullptr;
             for (auto& o : outputs)
                 if (o.fused_layer == (int)i)
                     p.out_f32 = o.buf->as<float>();
@@ -311,19 +327,19 @@ int hp_engine::build(const hp_engine_desc* d)
             HP_TRY(upload(packed.data(), packed.size() * sizeof(__half), &dw));
             HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
             p.w = (const __half*)dw, p.bias = (const float*)db;
-            p.in = ti.buf.as<__half>(), p.in_cs = ti.cs, p.in_coff = L.in_coff;
+            p.in = ti.view(L.in_coff);
             p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.C = L.cin, p.stride = L.stride, p.dil = L.dil;
             p.pad_t = g.pt, p.pad_l = g.pl, p.act = L.act, p.act_param = L.act_param;
-            p.out = to.buf.as<__half>(), p.out_cs = to.cs, p.out_coff = L.out_coff;
+            p.out = to.view(L.out_coff);
             st.flops = 2.0 * opix * L.cin * 9;
             st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cin * 2;
         } else { // max-pool
             HP_REQUIRE(L.cin % 8 == 0 && L.in_coff % 8 == 0 && L.out_coff % 8 == 0 && L.kh == L.kw, HP_ERR_INVALID, "layer %zu: bad pool", i);
             auto& p = st.pp;
-            p.in = ti.buf.as<__half>(), p.in_cs = ti.cs, p.in_coff = L.in_coff;
+            p.in = ti.view(L.in_coff);
             p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.C = L.cin, p.k = L.kh, p.stride = L.stride;
             p.pad_t = g.pt, p.pad_l = g.pl;
-            p.out = to.buf.as<__half>(), p.out_cs = to.cs, p.out_coff = L.out_coff;
+            p.out = to.view(L.out_coff);
             st.flops = 0;
             st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cin * 2;
         }
@@ -362,7 +378,7 @@ int hp_engine::enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s
     for (auto& o : outputs)
         if (o.fused_layer < 0) {
             const tensor_info& ti = *tensors[o.tensor];
-            HP_HIP_TRY(hp::launch_nhwc_to_nchw_f32(ti.buf.as<__half>(), ti.cs, o.coff, n, o.H, o.W, o.channels, o.act, o.buf->as<float>(), s));
+            HP_HIP_TRY(hp::launch_nhwc_to_nchw_f32(ti.view(o.coff), n, o.H, o.W, o.channels, o.act, o.buf->as<float>(), s));
         }
     return HP_OK;
 }
@@ -508,7 +524,7 @@ int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int sha
     HP_REQUIRE(n >= 1 && n <= e->max_batch, HP_ERR_INVALID, "hp_engine_debug_tensor: bad batch");
     hp::dev_buf tmp;
     HP_TRY(tmp.alloc((size_t)n * ti.C * ti.H * ti.W * sizeof(float)));
-    HP_HIP_TRY(hp::launch_nhwc_to_nchw_f32(ti.buf.as<__half>(), ti.cs, 0, n, ti.H, ti.W, ti.C, 0, tmp.as<float>(), e->stream));
+    HP_HIP_TRY(hp::launch_nhwc_to_nchw_f32(ti.view(0), n, ti.H, ti.W, ti.C, 0, tmp.as<float>(), e->stream));
     HP_HIP_TRY(hipStreamSynchronize(e->stream));
     HP_HIP_TRY(hipMemcpy(host, tmp.p, tmp.bytes, hipMemcpyDeviceToHost));
     return HP_OK;

@@ -54,6 +54,11 @@ int main(int argc, char** argv)
         float ms = time_ms(s, 20, [&] { hipLaunchKernelGGL(mfma_only, dim3(blocks), dim3(256), 0, s, dout, iters); });
         double fl = (double)blocks * 4 /*waves*/ * iters * 4.0 * 32 * 32 * 16 * 2;
         printf("mfma_only: %.3f ms  %.0f TFLOP/s\n", ms, fl / ms / 1e9);
+        for (int bl : {256, 512, 768}) {
+            float ms1 = time_ms(s, 20, [&] { hipLaunchKernelGGL(mfma_only, dim3(bl), dim3(256), 0, s, dout, iters); });
+            double fl1 = (double)bl * 4 * iters * 4.0 * 32 * 32 * 16 * 2;
+            printf("mfma_only %d blocks (%d wave/SIMD): %.3f ms  %.0f TFLOP/s\n", bl, bl / 256, ms1, fl1 / ms1 / 1e9);
+        }
     }
     {
         size_t n = 512ull << 20; float4 *a, *b; CK(hipMalloc(&a, n)); CK(hipMalloc(&b, n));
@@ -71,15 +76,27 @@ int main(int argc, char** argv)
     for (auto c : cfgs) {
         hp::conv_params p{};
         const int cout_pad = c.cout > 64 ? (c.cout + 127) / 128 * 128 : 64;
+        const int P = c.k / 2, Hp = c.H + 2 * P, Wp = c.W + 2 * P;
         __half *in, *out, *w; float* bias;
-        size_t in_n = (size_t)c.B * c.H * c.W * c.cin, out_n = (size_t)c.B * c.H * c.W * c.cout, w_n = (size_t)c.k * c.k * cout_pad * c.cin;
+        size_t in_n = (size_t)c.B * Hp * Wp * c.cin, out_n = (size_t)c.B * c.H * c.W * c.cout, w_n = (size_t)c.k * c.k * cout_pad * c.cin;
         CK(hipMalloc(&in, in_n * 2)); CK(hipMalloc(&out, out_n * 2)); CK(hipMalloc(&w, w_n * 2)); CK(hipMalloc(&bias, cout_pad * 4));
         CK(hipMemset(in, 0x11, in_n * 2)); CK(hipMemset(w, 0x11, w_n * 2)); CK(hipMemset(bias, 0, cout_pad * 4));
-        p.in = in, p.in_cs = c.cin, p.in_coff = 0, p.B = c.B, p.H = c.H, p.W = c.W, p.OH = c.H, p.OW = c.W;
+        p.in = hp::tview{ in + ((size_t)P * Wp + P) * c.cin, c.cin, 0, Wp, Hp * Wp };
+        p.B = c.B, p.H = c.H, p.W = c.W, p.OH = c.H, p.OW = c.W;
         p.Cin = c.cin, p.Cout = c.cout, p.Cout_pad = cout_pad, p.KH = p.KW = c.k, p.stride = 1, p.dil = 1, p.pad_t = p.pad_l = c.k / 2;
         p.w = w, p.bias = bias, p.alpha = nullptr, p.act = hp::ACT_RELU; hp::set_act(p);
-        p.res = nullptr, p.out = out, p.out_cs = c.cout, p.out_coff = 0, p.out_f32 = nullptr, p.npix = c.B * c.H * c.W;
+        p.res = hp::tview{ nullptr, 0, 0, 0, 0 }, p.out = hp::tview{ out, c.cout, 0, c.W, c.H * c.W }, p.out_f32 = nullptr, p.npix = c.B * c.H * c.W;
+        p.dbg = nullptr;
         float ms = time_ms(s, 300, [&] { CK(hp::launch_conv_mfma(p, s)); });
+        if (c.k == 3 && c.B == 8) {
+            unsigned long long* dbg; CK(hipMalloc(&dbg, 64 * 8)); CK(hipMemset(dbg, 0, 64 * 8));
+            p.dbg = dbg; CK(hp::launch_conv_mfma(p, s)); CK(hipStreamSynchronize(s));
+            unsigned long long h[64]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            printf("  timeline (s_memtime deltas):");
+            for (int i = 1; i < 64 && h[i]; ++i) printf(" %llu", h[i] - h[i - 1]);
+            printf("  total %llu\n", h[0] ? 0ull : 0ull);
+            p.dbg = nullptr; CK(hipFree(dbg));
+        }
         double fl = 2.0 * p.npix * c.cout * c.k * c.k * c.cin;
         printf("conv %dx%d %d->%d B=%d tile=%d: %.1f us  %.1f TFLOP/s\n", c.k, c.k, c.cin, c.cout, c.B, hp::conv_mfma_tile(p), ms * 1e3, fl / ms / 1e9);
         CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(w)); CK(hipFree(bias));
