@@ -177,11 +177,16 @@ struct stage_geom {
     static constexpr int PASSES = 32 / PPP;
 };
 
+#define HP_ESTAMP()                                                                                               \
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                                           \
+        p.dbg[40 + (edbg++)] = __builtin_amdgcn_s_memtime();
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const floatx16 (&acc)[TM][TN], int m_wave, int lane,
     unsigned char* slab, const int (&pb)[TN], const int (&py)[TN], const int (&px)[TN], const bool (&pv)[TN])
 {
     using G = stage_geom<TM>;
+    int edbg = 0;
+    HP_ESTAMP();
     long* s_ooff = reinterpret_cast<long*>(slab + 32 * G::ROW);
     long* s_roff = s_ooff + 32;
     const int chunk = lane % G::CPP, prow = lane / G::CPP;
@@ -201,6 +206,8 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
     }
     const float hi = p.act_hi;
     const bool has_res = p.res.p != nullptr; // uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HP_ESTAMP();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         // MFMA layout -> LDS: lane owns pixel (lane & 31), channels i*32 + 8g + 4*(lane>>5) + {0..3}
@@ -218,6 +225,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's LDS writes have landed (DS ops retire in order)
         __builtin_amdgcn_wave_barrier();
+        HP_ESTAMP();
         // store side: offsets, then ALL residual loads (unconditional, straight-line), then math + 16-byte stores
         long oo[G::PASSES];
         half8 rs[G::PASSES];
@@ -258,8 +266,10 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // slab reads done before the next pass overwrites it
         __builtin_amdgcn_wave_barrier();
+        HP_ESTAMP();
     }
 }
+#undef HP_ESTAMP
 
 // ---------------------------------------------------------------------------------------------------
 // Generic implicit GEMM.  1-D grid; block id -> (pixel tile, cout tile) with the cout tiles of one pixel tile
@@ -787,50 +797,148 @@ hipError_t launch_first_conv(const first_conv_params& p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(const dw_params p)
+// Depthwise 3x3.  The vector-memory path of a CU delivers ~16 B/clk whether a request hits L1 or not, so re-reading
+// every input pixel for each of its 9 taps (the naive gather) runs at 1/9 of that.  Here a block stages the
+// (TH*stride + 2*dil) x (TW*stride + 2*dil) input tile of 64 channels in LDS with ONE coalesced 16-byte load per element
+// (128 contiguous bytes per pixel), then every thread produces pixels x 8 channels from LDS: global traffic is
+// one read + one write of the tensor.  The zero halo of the HBM layout makes every load unconditional except at the
+// ragged right/bottom tile edges.
+// acc[r] += (float)x.h[r] * (float)w.h[r] for 8 packed halves: one v_fma_mix_f32 per MAC (fp16 operands, fp32
+// accumulate).  Written as inline asm because hipcc otherwise converts BOTH operands to fp32 first (2 v_cvt + half a
+// v_pk_fma_f32 per MAC and ~70 extra VGPRs, which halves the occupancy of this latency-bound kernel).
+__device__ __forceinline__ void mac8_f16(float (&acc)[8], const u32x4 x, const u32x4 w)
 {
-    const int CG = p.C / 8;
-    const long total = (long)p.B * p.OH * p.OW * CG;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int cg = (int)(i % CG);
-        const long n = i / CG;
-        const int ox = (int)(n % p.OW);
-        const long t = n / p.OW;
-        const int oy = (int)(t % p.OH), b = (int)(t / p.OH);
-        float acc[8];
-        {
-            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cg * 8);
-            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cg * 8 + 4);
-            acc[0] = b0.x, acc[1] = b0.y, acc[2] = b0.z, acc[3] = b0.w, acc[4] = b1.x, acc[5] = b1.y, acc[6] = b1.z, acc[7] = b1.w;
-        }
-        // taps in the padding read the zero halo: no bounds checks, all 9 loads issue back to back
-        const __half* base = p.in.p + tv_off(p.in, b, oy * p.stride - p.pad_t, ox * p.stride - p.pad_l) + cg * 8;
-        half8 x[9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-                x[ky * 3 + kx] = *reinterpret_cast<const half8*>(base + ((long)(ky * p.dil) * p.in.wp + kx * p.dil) * p.in.cs);
-#pragma unroll
-        for (int tpp = 0; tpp < 9; ++tpp) {
-            const half8 w = *reinterpret_cast<const half8*>(p.w + (size_t)tpp * p.C + cg * 8);
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                acc[r] += (float)x[tpp][r] * (float)w[r];
-        }
-        half8 h;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-            h[r] = (_Float16)apply_act(acc[r], p.act, p.act_param, 0.f);
-        *reinterpret_cast<half8*>(p.out.p + tv_off(p.out, b, oy, ox) + cg * 8) = h;
+    for (int q = 0; q < 4; ++q) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * q]) : "v"(x[q]), "v"(w[q]));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * q + 1]) : "v"(x[q]), "v"(w[q]));
     }
 }
 
-hipError_t launch_dwconv3x3(const dw_params& p, hipStream_t s)
+constexpr int DW_TH = 8, DW_TW = 8, DW_CG = 8; // output tile 8x8 pixels, 8 chunks of 8 channels = 64 channels
+
+template <int NLD> // 16-byte loads per thread per tile = ceil(IH*IW*8 / 256)
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const dw_params p, int tiles_x, int tiles_y, int cgroups, int total_tiles)
 {
-    const long total = (long)p.B * p.OH * p.OW * (p.C / 8);
-    const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks), dim3(256), 0, s, p);
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_lds[];
+    const int tid = threadIdx.x;
+    const int IH = (DW_TH - 1) * p.stride + 2 * p.dil + 1, IW = (DW_TW - 1) * p.stride + 2 * p.dil + 1;
+    const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1; // extent of the zero halo in HBM
+    const int chunk = tid & 7;
+    const int nelem = IH * IW * DW_CG;
+
+    // persistent block: the loads of tile t+1 are in flight (in registers) while tile t is computed from LDS
+    half8 nxt[NLD];
+    auto decode = [&](int t, int& cgi, int& tx, int& ty, int& b) {
+        cgi = t % cgroups;
+        t /= cgroups;
+        tx = t % tiles_x;
+        t /= tiles_x;
+        ty = t % tiles_y;
+        b = t / tiles_y;
+    };
+#define HP_DW_LOAD(T)                                                                                             \
+    {                                                                                                             \
+        int cgi_, tx_, ty_, b_;                                                                                   \
+        decode(T, cgi_, tx_, ty_, b_);                                                                            \
+        const int c0_ = cgi_ * DW_CG * 8;                                                                         \
+        const int iy0_ = ty_ * DW_TH * p.stride - p.pad_t, ix0_ = tx_ * DW_TW * p.stride - p.pad_l;               \
+        const bool cv_ = c0_ + chunk * 8 < p.C;                                                                   \
+        _Pragma("unroll") for (int k = 0; k < NLD; ++k)                                                           \
+        {                                                                                                         \
+            const int i = tid + k * 256;                                                                          \
+            const int hp = min(i, nelem - 1) >> 3;                                                                \
+            const int hy = hp / IW, hx = hp - hy * IW;                                                            \
+            const int y = iy0_ + hy, x = ix0_ + hx;                                                               \
+            const bool ok = cv_ && y <= ymax && x <= xmax;                                                        \
+            half8 v = *reinterpret_cast<const half8*>(p.in.p + tv_off(p.in, b_, min(y, ymax), min(x, xmax)) + (cv_ ? c0_ + chunk * 8 : 0)); \
+            if (!ok)                                                                                              \
+                _Pragma("unroll") for (int r = 0; r < 8; ++r) v[r] = (_Float16)0.f;                               \
+            nxt[k] = v;                                                                                           \
+        }                                                                                                         \
+    }
+    int t = blockIdx.x;
+    if (t < total_tiles)
+        HP_DW_LOAD(t);
+    for (; t < total_tiles; t += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * 256;
+            if (i < nelem)
+                *reinterpret_cast<half8*>(dw_lds + (size_t)i * 16) = nxt[k];
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < total_tiles)
+            HP_DW_LOAD(t + (int)gridDim.x);
+        int cgi, tx, ty, b;
+        decode(t, cgi, tx, ty, b);
+        const int c0 = cgi * DW_CG * 8;
+        // this tile's 9 x 64 weights go through LDS too: kept as fp16 and read right before use, otherwise hipcc
+        // hoists 72 fp32 conversions into registers and the kernel drops to 2 waves/SIMD
+        half8* s_w = reinterpret_cast<half8*>(dw_lds + (size_t)nelem * 16);
+        if (tid < 72)
+            s_w[tid] = (c0 + (tid & 7) * 8 < p.C) ? *reinterpret_cast<const half8*>(p.w + (size_t)(tid >> 3) * p.C + c0 + (tid & 7) * 8) : half8{};
+        __syncthreads();
+        if (c0 + chunk * 8 < p.C) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + c0 + chunk * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + c0 + chunk * 8 + 4);
+#pragma unroll 1 // keep the live set small (occupancy hides the LDS / store latency here, not ILP)
+            for (int pass = 0; pass < DW_TH * DW_TW * DW_CG / 256; ++pass) {
+                const int pix = (tid >> 3) + pass * 32;
+                const int py = pix / DW_TW, px = pix - py * DW_TW;
+                const int oy = ty * DW_TH + py, ox = tx * DW_TW + px;
+                float acc[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    u32x4 x[3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int hp = (py * p.stride + ky * p.dil) * IW + px * p.stride + kx * p.dil;
+                        x[kx] = *reinterpret_cast<const u32x4*>(dw_lds + ((size_t)hp * DW_CG + chunk) * 16);
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        mac8_f16(acc, x[kx], *reinterpret_cast<const u32x4*>(&s_w[(ky * 3 + kx) * 8 + chunk]));
+                }
+                if (oy < p.OH && ox < p.OW) {
+                    half8 h;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        h[r] = (_Float16)(acc[r] > 0.f ? fminf(acc[r], p.act_hi) : acc[r] * p.act_slope);
+                    *reinterpret_cast<half8*>(p.out.p + tv_off(p.out, b, oy, ox) + c0 + chunk * 8) = h;
+                }
+            }
+        }
+        __syncthreads(); // the tile in LDS is consumed before the next one overwrites it
+    }
+#undef HP_DW_LOAD
+}
+
+hipError_t launch_dwconv3x3(const dw_params& p_in, hipStream_t s)
+{
+    dw_params p = p_in;
+    {   // piecewise-linear activations only (none / relu / relu6 / leaky), as y = v > 0 ? min(v, hi) : v * slope
+        conv_params tmp{};
+        tmp.act = p.act, tmp.act_param = p.act_param, tmp.alpha = nullptr;
+        if (p.act == ACT_PRELU || !set_act(tmp))
+            return hipErrorInvalidValue;
+        p.act_slope = tmp.act_slope, p.act_hi = tmp.act_hi;
+    }
+    const int tiles_x = (p.OW + DW_TW - 1) / DW_TW, tiles_y = (p.OH + DW_TH - 1) / DW_TH;
+    const int cgroups = (p.C + DW_CG * 8 - 1) / (DW_CG * 8);
+    const int IH = (DW_TH - 1) * p.stride + 2 * p.dil + 1, IW = (DW_TW - 1) * p.stride + 2 * p.dil + 1;
+    const size_t lds = (size_t)IH * IW * DW_CG * 16 + 72 * 16;
+    const int total = tiles_x * tiles_y * cgroups * p.B;
+    const int nld = (IH * IW * DW_CG + 255) / 256;
+    const dim3 grid(std::min(total, 256 * 12));
+    if (nld <= 4)
+        hipLaunchKernelGGL((dwconv3x3_kernel<4>), grid, dim3(256), lds, s, p, tiles_x, tiles_y, cgroups, total);
+    else if (nld <= 5)
+        hipLaunchKernelGGL((dwconv3x3_kernel<5>), grid, dim3(256), lds, s, p, tiles_x, tiles_y, cgroups, total);
+    else if (nld <= 10)
+        hipLaunchKernelGGL((dwconv3x3_kernel<10>), grid, dim3(256), lds, s, p, tiles_x, tiles_y, cgroups, total);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -84,6 +84,8 @@ struct dw_params {
     tview in;
     int B, H, W, OH, OW, C; // C multiple of 8
     int stride, dil, pad_t, pad_l;
+    int halo; // zero-halo width of the input tensor in HBM (pixels)
+    float act_slope, act_hi; // filled by launch_dwconv3x3
     const __half* w;   // packed [9][C]
     const float* bias; // [C]
     int act;

@@ -329,7 +329,7 @@ int hp_engine::build(const hp_engine_desc* d)
             p.w = (const __half*)dw, p.bias = (const float*)db;
             p.in = ti.view(L.in_coff);
             p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.C = L.cin, p.stride = L.stride, p.dil = L.dil;
-            p.pad_t = g.pt, p.pad_l = g.pl, p.act = L.act, p.act_param = L.act_param;
+            p.pad_t = g.pt, p.pad_l = g.pl, p.act = L.act, p.act_param = L.act_param, p.halo = ti.P;
             p.out = to.view(L.out_coff);
             st.flops = 2.0 * opix * L.cin * 9;
             st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cin * 2;

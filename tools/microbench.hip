@@ -33,6 +33,32 @@ __global__ __launch_bounds__(256) void copy4(const float4* in, float4* out, size
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) out[i] = in[i];
 }
 
+// every block streams the same `bytes` region `reps` times with 16-byte loads (L2 / MALL resident read bandwidth)
+__global__ __launch_bounds__(256) void read_loop(const float4* in, size_t n16, int reps, float* out)
+{
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int r = 0; r < reps; ++r)
+        for (size_t i = (size_t)blockIdx.x % 7 * 256 + threadIdx.x; i < n16; i += 256 * 8) {
+            const float4 v0 = in[i], v1 = in[(i + 256 * 2) % n16], v2 = in[(i + 256 * 4) % n16], v3 = in[(i + 256 * 6) % n16];
+            acc.x += v0.x + v1.x + v2.x + v3.x, acc.y += v0.y + v1.y + v2.y + v3.y, acc.z += v0.z + v1.z, acc.w += v2.w + v3.w;
+        }
+    if (acc.x == 12345.f) out[0] = acc.y + acc.z + acc.w;
+}
+
+// dw-like access pattern without compute: block = 8x8 pixel tile x 64 channels (128 B per pixel at C*2-byte stride)
+__global__ __launch_bounds__(256) void tile_copy(const __half* in, __half* out, int B, int H, int W, int C, int tiles_x, int tiles_y, int cgroups)
+{
+    int t = blockIdx.x; const int cgi = t % cgroups; t /= cgroups; const int tx = t % tiles_x; t /= tiles_x; const int ty = t % tiles_y, b = t / tiles_y;
+    const int chunk = threadIdx.x & 7;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int pix = (threadIdx.x >> 3) + pass * 32, y = ty * 8 + pix / 8, x = tx * 8 + pix % 8;
+        if (y < H && x < W) {
+            const size_t off = (((size_t)b * H + y) * W + x) * C + cgi * 64 + chunk * 8;
+            *reinterpret_cast<float4*>(out + off) = *reinterpret_cast<const float4*>(in + off);
+        }
+    }
+}
+
 static float time_ms(hipStream_t s, int iters, const std::function<void()>& f)
 {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -70,6 +96,39 @@ int main(int argc, char** argv)
         printf("copy 32MB (cache resident): %.3f ms  %.0f GB/s (r+w)\n", ms, 2.0 * m / ms / 1e6);
         CK(hipFree(a)); CK(hipFree(b));
     }
+    for (size_t mb : {1, 2, 16, 128}) {
+        const size_t bytes = mb << 20; float4* buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 0, bytes));
+        const int reps = mb >= 16 ? 2 : 16, blocks = 256 * 4;
+        float ms = time_ms(s, 20, [&] { hipLaunchKernelGGL(read_loop, dim3(blocks), dim3(256), 0, s, buf, bytes / 16, reps, dout); });
+        const double rd = (double)blocks * reps * (bytes / 2.0); // each block reads 4 of every 8 256-vector groups
+        printf("read_loop %zu MB region: %.3f ms  %.1f TB/s  = %.1f B/clk/CU @2.1GHz\n", mb, ms, rd / ms / 1e9, rd / ms / 1e3 / 256 / 2.1e9 * 1e3);
+        CK(hipFree(buf));
+    }
+    {   // depthwise 3x3 at LW-OpenPose shapes vs a plain 16-byte copy of the same tensor
+        for (int C : {512, 128}) {
+            const int B = 8, H = 46, W = 54, P = 1, Hp = H + 2, Wp = W + 2;
+            __half *in, *out, *w; float* bias;
+            size_t n_in = (size_t)B * Hp * Wp * C;
+            CK(hipMalloc(&in, n_in * 2)); CK(hipMalloc(&out, n_in * 2)); CK(hipMalloc(&w, 9 * C * 2)); CK(hipMalloc(&bias, C * 4));
+            CK(hipMemset(in, 0x11, n_in * 2)); CK(hipMemset(w, 0x11, 9 * C * 2)); CK(hipMemset(bias, 0, C * 4));
+            hp::dw_params p{};
+            p.in = hp::tview{ in + ((size_t)P * Wp + P) * C, C, 0, Wp, Hp * Wp };
+            p.out = hp::tview{ out + ((size_t)P * Wp + P) * C, C, 0, Wp, Hp * Wp };
+            p.B = B, p.H = H, p.W = W, p.OH = H, p.OW = W, p.C = C, p.stride = 1, p.dil = 1, p.pad_t = p.pad_l = 1, p.halo = 1;
+            p.w = w, p.bias = bias, p.act = hp::ACT_RELU, p.act_param = 0;
+            float ms = time_ms(s, 300, [&] { CK(hp::launch_dwconv3x3(p, s)); });
+            double bytes = 2.0 * B * H * W * C * 2;
+            printf("dwconv3x3 C=%d B=8 46x54: %.1f us  %.0f GB/s (r+w once)\n", C, ms * 1e3, bytes / ms / 1e6);
+            {
+                const int tx_ = (W + 7) / 8, ty_ = (H + 7) / 8, cg_ = C / 64;
+                float ms3 = time_ms(s, 300, [&] { hipLaunchKernelGGL(tile_copy, dim3(tx_ * ty_ * cg_ * B), dim3(256), 0, s, in, out, B, H, W, C, tx_, ty_, cg_); });
+                printf("  tile-pattern copy (8x8 px x 64 ch blocks): %.1f us  %.0f GB/s\n", ms3 * 1e3, bytes / ms3 / 1e6);
+            }
+            float ms2 = time_ms(s, 300, [&] { hipLaunchKernelGGL(copy4, dim3(256 * 8), dim3(256), 0, s, (const float4*)in, (float4*)out, n_in * 2 / 16); });
+            printf("  plain copy of the same %.1f MB tensor: %.1f us  %.0f GB/s\n", n_in * 2 / 1e6, ms2 * 1e3, 2.0 * n_in * 2 / ms2 / 1e6);
+            CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(w)); CK(hipFree(bias));
+        }
+    }
     struct cfg { int cin, cout, k, H, W, B; };
     std::vector<cfg> cfgs = { {128, 128, 3, 46, 54, 8}, {512, 512, 1, 46, 54, 8}, {128, 512, 1, 46, 54, 8}, {128, 128, 1, 46, 54, 8},
                               {128, 128, 3, 46, 54, 32}, {512, 512, 1, 46, 54, 32}, {128, 128, 3, 46, 54, 1} };
@@ -93,7 +152,9 @@ int main(int argc, char** argv)
             p.dbg = dbg; CK(hp::launch_conv_mfma(p, s)); CK(hipStreamSynchronize(s));
             unsigned long long h[64]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
             printf("  timeline (s_memtime deltas):");
-            for (int i = 1; i < 64 && h[i]; ++i) printf(" %llu", h[i] - h[i - 1]);
+            for (int i = 1; i < 40 && h[i]; ++i) printf(" %llu", h[i] - h[i - 1]);
+            printf("\n  epilogue stamps:");
+            for (int i = 41; i < 64 && h[i]; ++i) printf(" %llu", h[i] - h[i - 1]);
             printf("  total %llu\n", h[0] ? 0ull : 0ull);
             p.dbg = nullptr; CK(hipFree(dbg));
         }
