@@ -988,25 +988,39 @@ hipError_t launch_maxpool(const pool_params& p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(tview in, int B, int H, int W, int C, int act, float* __restrict__ out)
+__global__ __launch_bounds__(256) void output_transform_kernel(tview in, int B, int H, int W, out_xform x, float* __restrict__ out)
 {
-    const int HW = H * W;
-    const long total = (long)B * C * HW;
+    const int sc = x.shuffle, CO = x.C / (sc * sc), OH = x.out_h, OW = x.out_w;
+    const long total = (long)B * CO * OH * OW;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int pix = (int)(i % HW);
-        const long t = i / HW;
-        const int c = (int)(t % C), b = (int)(t / C);
-        const int y = pix / W, x = pix - y * W;
-        const float v = __half2float(in.p[tv_off(in, b, y, x) + c]);
-        out[i] = apply_act(v, act, 0.f, 0.f);
+        const int ox = (int)(i % OW);
+        long t = i / OW;
+        const int oy = (int)(t % OH);
+        t /= OH;
+        const int c = (int)(t % CO), b = (int)(t / CO);
+        // pixel_shuffle: [b, c, sy, sx, h, w] -> [b, c, h, sy, w, sx]  (hyperpose/Model/pifpaf/utils.py:371-379)
+        const int y = oy / sc, sy = oy - y * sc, xx = ox / sc, sx = ox - xx * sc;
+        const int cin = c * sc * sc + sy * sc + sx;
+        float v = __half2float(in.p[tv_off(in, b, y, xx) + cin]);
+        int act = x.act;
+        if (x.group > 0) {
+            const int comp = c % x.group;
+            act = ((x.sigmoid_mask >> comp) & 1u) ? ACT_SIGMOID : (((x.softplus_mask >> comp) & 1u) ? ACT_SOFTPLUS : ACT_NONE);
+        }
+        v = apply_act(v, act, 0.f, 0.f);
+        if (x.grid == 1)
+            v += (float)ox;
+        else if (x.grid == 2)
+            v += (float)oy;
+        out[i] = v * x.scale;
     }
 }
 
-hipError_t launch_nhwc_to_nchw_f32(tview in, int B, int H, int W, int C, int act, float* out, hipStream_t s)
+hipError_t launch_output_transform(tview in, int B, int H, int W, const out_xform& x, float* out, hipStream_t s)
 {
-    const long total = (long)B * C * H * W;
+    const long total = (long)B * (x.C / (x.shuffle * x.shuffle)) * x.out_h * x.out_w;
     const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, C, act, out);
+    hipLaunchKernelGGL(output_transform_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, x, out);
     return hipGetLastError();
 }
 

@@ -103,7 +103,18 @@ struct pool_params {
 };
 hipError_t launch_maxpool(const pool_params& p, hipStream_t s);
 
-// fp16 NHWC view -> fp32 NCHW (for outputs not produced by a conv epilogue) with an optional element-wise op.
-hipError_t launch_nhwc_to_nchw_f32(tview in, int B, int H, int W, int C, int act, float* out, hipStream_t s);
+// fp16 NHWC view -> fp32 NCHW network output (for outputs not produced by a conv epilogue): optional pixel shuffle x2,
+// crop, element-wise / per-component sigmoid / softplus, and the PoseProposal restore_coor affine map.
+struct out_xform {
+    int C;        // channels read from the view
+    int act;      // applied to every channel when group == 0
+    int shuffle;  // 1 or 2
+    int group;    // 0 or components per group
+    unsigned sigmoid_mask, softplus_mask;
+    int out_h, out_w; // output spatial size (after shuffle / crop)
+    float scale;
+    int grid;
+};
+hipError_t launch_output_transform(tview in, int B, int H, int W, const out_xform& x, float* out, hipStream_t s);
 
 } // namespace hp

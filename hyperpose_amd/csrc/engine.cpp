@@ -43,7 +43,10 @@ struct tensor_info {
 struct out_info {
     std::string name;
     int tensor, coff, channels, act;
-    int H, W;
+    int H, W;       // source tensor size
+    hp::out_xform x{}; // conversion parameters; x.out_h / x.out_w / (C / shuffle^2) is the reported shape
+    int out_c() const { return x.C / (x.shuffle * x.shuffle); }
+    bool plain() const { return x.shuffle == 1 && x.group == 0 && x.out_h == H && x.out_w == W && x.scale == 1.f && x.grid == 0; }
     int fused_layer = -1; // layer whose epilogue writes it, or -1 -> conversion kernel
     std::unique_ptr<hp::dev_buf> buf;
 };
@@ -181,19 +184,26 @@ int hp_engine::build(const hp_engine_desc* d)
         out_info oi;
         oi.name.assign(o.name, strnlen(o.name, sizeof(o.name)));
         oi.tensor = o.tensor, oi.coff = o.coff, oi.channels = o.channels, oi.act = o.act, oi.H = ti.H, oi.W = ti.W;
+        oi.x.C = o.channels, oi.x.act = o.act, oi.x.shuffle = o.shuffle == 2 ? 2 : 1, oi.x.group = o.group;
+        oi.x.sigmoid_mask = o.sigmoid_mask, oi.x.softplus_mask = o.softplus_mask;
+        HP_REQUIRE(o.shuffle == 0 || o.shuffle == 1 || o.shuffle == 2, HP_ERR_INVALID, "output %d: shuffle must be 0, 1 or 2", i);
+        HP_REQUIRE(oi.x.C % (oi.x.shuffle * oi.x.shuffle) == 0, HP_ERR_INVALID, "output %d: channels not divisible by shuffle^2", i);
+        oi.x.out_h = o.out_h > 0 ? o.out_h : ti.H * oi.x.shuffle, oi.x.out_w = o.out_w > 0 ? o.out_w : ti.W * oi.x.shuffle;
+        HP_REQUIRE(oi.x.out_h <= ti.H * oi.x.shuffle && oi.x.out_w <= ti.W * oi.x.shuffle, HP_ERR_INVALID, "output %d: crop larger than the map", i);
+        oi.x.scale = o.scale == 0.f ? 1.f : o.scale, oi.x.grid = o.grid;
         outputs.push_back(std::move(oi));
     }
     std::stable_sort(outputs.begin(), outputs.end(), [](const out_info& a, const out_info& b) { return a.name < b.name; }); // tensorrt.cpp:405
     for (auto& o : outputs) {
         o.buf = std::make_unique<hp::dev_buf>();
-        HP_TRY(o.buf->alloc((size_t)max_batch * o.channels * o.H * o.W * sizeof(float)));
+        HP_TRY(o.buf->alloc((size_t)max_batch * o.out_c() * o.x.out_h * o.x.out_w * sizeof(float)));
         // fuse into the producing conv when one MFMA conv writes exactly this channel range and no post-op is needed
         int writers = 0, last = -1;
         for (size_t i = 0; i < layers.size(); ++i)
             if (layers[i].out == o.tensor && layers[i].out_coff < o.coff + o.channels && layers[i].out_coff + layers[i].cout > o.coff)
                 ++writers, last = (int)i;
         if (writers == 1 && layers[last].op == HP_OP_CONV && layers[last].in != 0 && layers[last].out_coff == o.coff
-            && layers[last].cout == o.channels && o.act == HP_ACT_NONE)
+            && layers[last].cout == o.channels && o.act == HP_ACT_NONE && o.plain())
             o.fused_layer = last;
     }
 
@@ -378,7 +388,7 @@ int hp_engine::enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s
     for (auto& o : outputs)
         if (o.fused_layer < 0) {
             const tensor_info& ti = *tensors[o.tensor];
-            HP_HIP_TRY(hp::launch_nhwc_to_nchw_f32(ti.view(o.coff), n, o.H, o.W, o.channels, o.act, o.buf->as<float>(), s));
+            HP_HIP_TRY(hp::launch_output_transform(ti.view(o.coff), n, o.H, o.W, o.x, o.buf->as<float>(), s));
         }
     return HP_OK;
 }
@@ -498,7 +508,7 @@ int hp_engine_output(const hp_engine* e, int i, const char** name, int shape[3],
     if (name)
         *name = o.name.c_str();
     if (shape)
-        shape[0] = o.channels, shape[1] = o.H, shape[2] = o.W;
+        shape[0] = o.out_c(), shape[1] = o.x.out_h, shape[2] = o.x.out_w;
     if (dev)
         *dev = o.buf->as<float>();
     return HP_OK;
@@ -509,7 +519,7 @@ int hp_engine_output_to_host(hp_engine* e, int i, int n, float* host)
     HP_REQUIRE(e && host && i >= 0 && i < (int)e->outputs.size() && n >= 1 && n <= e->max_batch, HP_ERR_INVALID, "hp_engine_output_to_host: bad argument");
     const out_info& o = e->outputs[i];
     HP_HIP_TRY(hipStreamSynchronize(e->stream));
-    HP_HIP_TRY(hipMemcpy(host, o.buf->p, (size_t)n * o.channels * o.H * o.W * sizeof(float), hipMemcpyDeviceToHost));
+    HP_HIP_TRY(hipMemcpy(host, o.buf->p, (size_t)n * o.out_c() * o.x.out_h * o.x.out_w * sizeof(float), hipMemcpyDeviceToHost));
     return HP_OK;
 }
 
@@ -524,7 +534,9 @@ int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int sha
     HP_REQUIRE(n >= 1 && n <= e->max_batch, HP_ERR_INVALID, "hp_engine_debug_tensor: bad batch");
     hp::dev_buf tmp;
     HP_TRY(tmp.alloc((size_t)n * ti.C * ti.H * ti.W * sizeof(float)));
-    HP_HIP_TRY(hp::launch_nhwc_to_nchw_f32(ti.view(0), n, ti.H, ti.W, ti.C, 0, tmp.as<float>(), e->stream));
+    hp::out_xform px{};
+    px.C = ti.C, px.act = 0, px.shuffle = 1, px.group = 0, px.out_h = ti.H, px.out_w = ti.W, px.scale = 1.f, px.grid = 0;
+    HP_HIP_TRY(hp::launch_output_transform(ti.view(0), n, ti.H, ti.W, px, tmp.as<float>(), e->stream));
     HP_HIP_TRY(hipStreamSynchronize(e->stream));
     HP_HIP_TRY(hipMemcpy(host, tmp.p, tmp.bytes, hipMemcpyDeviceToHost));
     return HP_OK;

@@ -222,6 +222,77 @@ void head_openpose(hp_model& m, int feat, int feat_c)
     m.output("paf", paf_t, 0, NPAF);
 }
 
+// Resnet50_backbone (backbones.py:587-697): conv 7x7 s2 (+BN+ReLU), optional max-pool 3x3 s2, bottlenecks [3,4,6,3]
+// = {1x1, 3x3 (stride), 1x1 x4} + BN, projection shortcut when the shape changes, relu(x + res) (:697);
+// scale_size == 32 -> stride 2 in stages 3 and 4 (:598-601).
+int backbone_resnet50(hp_model& m, int& out_c, bool use_pool, bool stride32)
+{
+    int t = m.conv(0, 3, 64, 7, HP_ACT_RELU, 2);
+    if (use_pool)
+        t = m.pool(t, 64, 3, 2);
+    int cin = 64;
+    auto block = [&](int nf, int stride) {
+        int res = t;
+        if (stride != 1 || cin != 4 * nf)
+            res = m.add(HP_OP_CONV, t, 0, cin, 4 * nf, 1, stride, 1, HP_ACT_NONE, true); // downsample conv + BN
+        int x = m.conv(t, cin, nf, 1, HP_ACT_RELU);
+        x = m.conv(x, nf, nf, 3, HP_ACT_RELU, stride);
+        t = m.add(HP_OP_CONV, x, 0, nf, 4 * nf, 1, 1, 1, HP_ACT_RELU, true, -1, 0, res, 1, 0.5f); // relu(bn3(conv3) + res)
+        cin = 4 * nf;
+    };
+    const int s34 = stride32 ? 2 : 1;
+    for (int i = 0; i < 3; ++i)
+        block(64, 1);
+    for (int i = 0; i < 4; ++i)
+        block(128, i == 0 ? 2 : 1);
+    for (int i = 0; i < 6; ++i)
+        block(256, i == 0 ? s34 : 1);
+    for (int i = 0; i < 3; ++i)
+        block(512, i == 0 ? s34 : 1);
+    out_c = 2048;
+    return t;
+}
+
+// PoseProposal head (pose_proposal/model.py:13-119): 3x3 C->512 +BN+LeakyReLU(0.1), 3x3 512->512 (same), 1x1 512 ->
+// 6K + 9*9*L, sigmoid, split into pc, pi, px, py, pw, ph [K,h,w] and pe [L,9,9,h,w], restore_coor on x/y/w/h (:111-119).
+// Outputs are named so that their name order is the parser's argument order (src/pose_proposal.cpp:12-20).
+void head_pose_proposal(hp_model& m, int feat, int feat_c, int in_w, int in_h)
+{
+    const int K = 18, L = 17, NB = 9;
+    int t = m.add(HP_OP_CONV, feat, 0, feat_c, 512, 3, 1, 1, HP_ACT_LEAKY, true, -1, 0, -1, 0, 1.f, 0.1f);
+    t = m.add(HP_OP_CONV, t, 0, 512, 512, 3, 1, 1, HP_ACT_LEAKY, true, -1, 0, -1, 0, 1.f, 0.1f);
+    const int o = m.add(HP_OP_CONV, t, 0, 512, 6 * K + NB * NB * L, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 1.f);
+    const int gh = (in_h + 31) / 32, gw = (in_w + 31) / 32;
+    auto out = [&](const char* name, int coff, int ch, float scale, int grid) {
+        m.output(name, o, coff, ch, HP_ACT_SIGMOID);
+        m.outputs.back().scale = scale, m.outputs.back().grid = grid;
+    };
+    out("0_conf_point", 0, K, 1.f, 0);
+    out("1_conf_iou", K, K, 1.f, 0);
+    out("2_x", 2 * K, K, (float)in_w / gw, 1); // rx = (x + grid_x) * grid_size_x
+    out("3_y", 3 * K, K, (float)in_h / gh, 2);
+    out("4_w", 4 * K, K, (float)in_w, 0);      // rw = w * win
+    out("5_h", 5 * K, K, (float)in_h, 0);
+    out("6_edge", 6 * K, NB * NB * L, 1.f, 0);  // [L*9*9, h, w] == [L, 9, 9, h, w] in memory
+}
+
+// Pifpaf heads (pifpaf/model.py:215-281): 1x1 C -> 17*5*4 and 1x1 C -> 19*9*4, pixel_shuffle(2), sigmoid on the
+// confidences, softplus on the scales; the last row/column is cropped so that an (8k+1)-pixel input yields the
+// (k+1)-cell fields the decoder's H_hr = (H-1)*8+1 convention assumes.  Outputs in the argument
+// order of parser::pifpaf::process(paf, pif) (src/pifpaf.cpp:7).
+void head_pifpaf(hp_model& m, int feat, int feat_c, int in_w, int in_h)
+{
+    const int pif = m.add(HP_OP_CONV, feat, 0, feat_c, 17 * 5 * 4, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 0.3f);
+    const int paf = m.add(HP_OP_CONV, feat, 0, feat_c, 19 * 9 * 4, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 0.3f);
+    const int fh = (in_h - 1) / 8 + 1, fw = (in_w - 1) / 8 + 1;
+    m.output("0_paf", paf, 0, 19 * 9 * 4);
+    hp_output_desc& a = m.outputs.back();
+    a.shuffle = 2, a.group = 9, a.sigmoid_mask = 1u, a.softplus_mask = (1u << 7) | (1u << 8), a.out_h = fh, a.out_w = fw;
+    m.output("1_pif", pif, 0, 17 * 5 * 4);
+    hp_output_desc& b = m.outputs.back();
+    b.shuffle = 2, b.group = 5, b.sigmoid_mask = 1u, b.softplus_mask = 1u << 4, b.out_h = fh, b.out_w = fw;
+}
+
 // counter-based generator: splitmix64 hash -> two uniforms -> Box-Muller
 inline uint64_t mix(uint64_t z)
 {
@@ -243,7 +314,7 @@ inline float normal_at(uint64_t seed, uint64_t layer, uint64_t idx)
 
 extern "C" {
 
-const char* hp_model_archs(void) { return "lw_openpose_mobilenet,lw_openpose_vggtiny,openpose_vgg19"; }
+const char* hp_model_archs(void) { return "lw_openpose_mobilenet,lw_openpose_vggtiny,openpose_vgg19,pose_proposal_resnet50,pifpaf_resnet50"; }
 
 int hp_model_build(hp_model** out, const char* arch, int in_w, int in_h)
 {
@@ -262,6 +333,16 @@ int hp_model_build(hp_model** out, const char* arch, int in_w, int in_h)
     } else if (a == "openpose_vgg19") {
         const int f = backbone_vgg19(*m, c);
         head_openpose(*m, f, c);
+    } else if (a == "pose_proposal_resnet50") {
+        const int f = backbone_resnet50(*m, c, true, true);
+        head_pose_proposal(*m, f, c, in_w, in_h);
+    } else if (a == "pifpaf_resnet50") {
+        // x = (x - mean) / std with the ImageNet statistics (pifpaf/model.py:38-39,56)
+        const float mean[3] = { 0.485f, 0.456f, 0.406f }, stdv[3] = { 0.229f, 0.224f, 0.225f };
+        for (int k = 0; k < 3; ++k)
+            m->mean[k] = mean[k], m->inv_std[k] = 1.f / stdv[k];
+        const int f = backbone_resnet50(*m, c, false, true);
+        head_pifpaf(*m, f, c, in_w, in_h);
     } else {
         hp::set_error("hp_model_build: unknown arch '%s' (have: %s)", arch, hp_model_archs());
         return HP_ERR_INVALID;

@@ -26,7 +26,9 @@ class Layer(C.Structure):
 
 class OutputDesc(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("tensor", C.c_int32), ("coff", C.c_int32), ("channels", C.c_int32),
-                ("act", C.c_int32)]
+                ("act", C.c_int32), ("shuffle", C.c_int32), ("group", C.c_int32), ("sigmoid_mask", C.c_uint32),
+                ("softplus_mask", C.c_uint32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("scale", C.c_float),
+                ("grid", C.c_int32)]
 
 
 class EngineDesc(C.Structure):

@@ -166,8 +166,16 @@ typedef struct hp_layer {
 
 typedef struct hp_output_desc {
     char name[48];           /* outputs are returned sorted by name (src/tensorrt.cpp:405) */
-    int32_t tensor, coff, channels;
-    int32_t act;             /* element-wise op applied while converting to fp32 NCHW (HP_ACT_NONE / SIGMOID / SOFTPLUS) */
+    int32_t tensor, coff, channels; /* channel range of the fp16 tensor that feeds this output */
+    int32_t act;             /* element-wise op while converting to fp32 NCHW (HP_ACT_NONE / SIGMOID / SOFTPLUS), all channels */
+    /* optional transforms used by the PoseProposal / PifPaf heads (all zero = plain conversion): */
+    int32_t shuffle;         /* 2: pixel_shuffle(x, 2) (hyperpose/Model/pifpaf/utils.py:371-379): C/4 channels, 2H x 2W */
+    int32_t group;           /* > 0: output channels come in groups of `group` components with per-component ops: */
+    uint32_t sigmoid_mask;   /*      bit k set -> sigmoid on component k   (pif conf, paf conf) */
+    uint32_t softplus_mask;  /*      bit k set -> softplus on component k  (pif / paf scales)   */
+    int32_t out_h, out_w;    /* crop of the (shuffled) map, 0 = keep (PifPaf: 2*25 = 50 -> 49) */
+    float scale;             /* y = (op(v) + grid term) * scale; 0 means 1 (PoseProposal restore_coor, model.py:111-119) */
+    int32_t grid;            /* 1: add the column index, 2: add the row index before scaling */
 } hp_output_desc;
 
 typedef struct hp_engine_desc {

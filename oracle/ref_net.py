@@ -99,11 +99,35 @@ def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, fram
     result = {}
     for o in outputs:
         name = o.name.decode() if isinstance(o.name, bytes) else o.name
+        shuffle = getattr(o, "shuffle", 0) or 1
+        group = getattr(o, "group", 0)
+        scale = getattr(o, "scale", 0.0) or 1.0
+        grid = getattr(o, "grid", 0)
+        out_h, out_w = getattr(o, "out_h", 0), getattr(o, "out_w", 0)
+        plain = shuffle == 1 and group == 0 and scale == 1.0 and grid == 0 and not out_h and not out_w
         raw = tensors.get(("raw", o.tensor, o.coff))
-        if raw is not None and raw.shape[1] == o.channels and o.act == 0:
+        if plain and raw is not None and raw.shape[1] == o.channels and o.act == 0:
             v = raw  # conv epilogue writes the fp32 accumulator result directly
         else:
-            v = _act(tensors[o.tensor][:, o.coff:o.coff + o.channels], o.act, 0.0, None)
+            v = tensors[o.tensor][:, o.coff:o.coff + o.channels]
+            if shuffle == 2:  # hyperpose/Model/pifpaf/utils.py:371-379
+                v = F.pixel_shuffle(v, 2)
+            if out_h or out_w:
+                v = v[:, :, :out_h or None, :out_w or None]
+            if group:
+                v = v.clone()
+                for comp in range(group):
+                    if (getattr(o, "sigmoid_mask", 0) >> comp) & 1:
+                        v[:, comp::group] = torch.sigmoid(v[:, comp::group])
+                    elif (getattr(o, "softplus_mask", 0) >> comp) & 1:
+                        v[:, comp::group] = F.softplus(v[:, comp::group])
+            else:
+                v = _act(v, o.act, 0.0, None)
+            if grid == 1:
+                v = v + torch.arange(v.shape[3], dtype=torch.float32).view(1, 1, 1, -1)
+            elif grid == 2:
+                v = v + torch.arange(v.shape[2], dtype=torch.float32).view(1, 1, -1, 1)
+            v = v * scale
         result[name] = v.numpy()
     if return_tensors:
         return result, {k: v.numpy() for k, v in tensors.items() if isinstance(k, int)}

@@ -14,12 +14,17 @@ pytestmark = pytest.mark.gpu
 
 
 class Out:
-    def __init__(self, name, tensor, coff, channels, act=0):
+    def __init__(self, name, tensor, coff, channels, act=0, **kw):
         self.name, self.tensor, self.coff, self.channels, self.act = name.encode(), tensor, coff, channels, act
+        self.shuffle, self.group, self.sigmoid_mask, self.softplus_mask = 0, 0, 0, 0
+        self.out_h, self.out_w, self.scale, self.grid = 0, 0, 0.0, 0
+        for k, v in kw.items():
+            setattr(self, k, v)
 
     def c(self):
         o = E.OutputDesc()
-        o.name, o.tensor, o.coff, o.channels, o.act = self.name, self.tensor, self.coff, self.channels, self.act
+        for f, _ in E.OutputDesc._fields_:
+            setattr(o, f, getattr(self, f))
         return o
 
 
@@ -220,3 +225,64 @@ def test_openpose_vgg19_small(hp):
     got = eng.inference(fr)
     ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True, mean=m.mean, inv_std=m.inv_std)
     _check(got, ref, 1, rel=1e-2, abs_=2e-3)
+
+
+def test_output_transforms(hp):
+    """pixel shuffle x2 + crop + per-component sigmoid/softplus (PifPaf heads) and sigmoid + grid affine (PPN)."""
+    net = Net(11)
+    a = net.conv(0, 3, 32, 3, 2)
+    t = net.conv(a, 32, 40, 1, act=E.ACT_NONE)  # 40 = 2 groups x 5 comps x 4 sub-pixels
+    fr = _frames(2, 22, 30, seed=3)
+    outs = [Out("a_shuf", t, 0, 40, shuffle=2, group=5, sigmoid_mask=1, softplus_mask=1 << 4, out_h=21, out_w=29),
+            Out("b_gridx", t, 0, 16, act=E.ACT_SIGMOID, scale=32.0, grid=1),
+            Out("c_gridy", t, 16, 8, act=E.ACT_SIGMOID, scale=8.0, grid=2),
+            Out("d_scaled", t, 24, 16, act=E.ACT_SIGMOID, scale=384.0)]
+    eng, got, ref = _run_both(net, outs, fr, 22, 30)
+    assert [s for _, s, _ in eng.outputs] == [(10, 21, 29), (16, 11, 15), (8, 11, 15), (16, 11, 15)]
+    _check(got, ref, 2, rel=2e-3, abs_=2e-3)
+
+
+def test_pose_proposal_resnet50_end_to_end(hp):
+    """BASELINE config 3 topology at reduced size: engine outputs (device-resident) -> PPN parser, against the torch
+    oracle for the conv stack and the reference's own parser (oracle/_ref) on the same feature maps."""
+    from hyperpose_amd.parser import PoseProposal
+    from oracle import loader
+    m = E.Model("pose_proposal_resnet50", 160, 128)
+    w = m.init_weights(12)
+    eng = E.Engine.from_model(m, w, max_batch=2)
+    fr = _frames(2, 128, 160, seed=8)
+    got = eng.inference(fr)
+    assert [n for n, _ in got[0]] == ["0_conf_point", "1_conf_iou", "2_x", "3_y", "4_w", "5_h", "6_edge"]
+    assert got[0][0][1].shape == (18, 4, 5) and got[0][6][1].shape == (17 * 81, 4, 5)
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True)
+    _check(got, ref, 2, rel=2e-2, abs_=5e-3)
+    parser = PoseProposal((160, 128), max_batch=2)
+    shapes = [s for _, s, _ in eng.outputs]
+    humans = parser.process_batch([p for _, _, p in eng.outputs], on_device=True, n=2, conf_shape=shapes[0],
+                                  edge_shape=(17, 9, 9) + shapes[0][1:])
+    if loader.ref_lib() is not None:
+        for b in range(2):
+            t = [got[b][i][1] for i in range(6)] + [got[b][6][1].reshape(17, 9, 9, 4, 5)]
+            refh = loader.ref_ppn_process(t, 160, 128)
+            assert humans[b].tobytes() == refh.tobytes()
+
+
+def test_pifpaf_resnet50_end_to_end(hp):
+    """BASELINE config 4 topology at reduced size (97x97 -> 13x13 fields)."""
+    from hyperpose_amd.parser import PifPaf
+    from oracle import loader
+    m = E.Model("pifpaf_resnet50", 97, 97)
+    w = m.init_weights(13)
+    eng = E.Engine.from_model(m, w, max_batch=2)
+    fr = _frames(2, 97, 97, seed=9)
+    got = eng.inference(fr)
+    assert [n for n, _ in got[0]] == ["0_paf", "1_pif"]
+    assert got[0][0][1].shape == (19 * 9, 13, 13) and got[0][1][1].shape == (17 * 5, 13, 13)
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True, mean=m.mean, inv_std=m.inv_std)
+    _check(got, ref, 2, rel=2e-2, abs_=5e-3)
+    parser = PifPaf(97, 97, max_batch=2)
+    humans = parser.process_batch(eng.outputs[0][2], eng.outputs[1][2], on_device=True, n=2, fh=13, fw=13)
+    if loader.ref_lib() is not None:
+        for b in range(2):
+            refh = loader.ref_pifpaf_process(got[b][0][1].reshape(19, 9, 13, 13), got[b][1][1].reshape(17, 5, 13, 13), 97, 97)
+            assert humans[b].tobytes() == refh.tobytes()
