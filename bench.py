@@ -38,7 +38,7 @@ BATCH = 8
 IN_H, IN_W = 368, 432
 ARCH = "lw_openpose_mobilenet"
 PEAK_F16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
-PIPES = 3  # independent engine+parser instances per GPU, one HIP stream each, batches round-robin over them
+PIPES = 4  # independent engine+parser instances per GPU, one HIP stream each, batches round-robin over them
 
 
 def parse_args():
@@ -135,9 +135,19 @@ def roofline(pipe):
     mfma_ms = sum(p["ms"] for p in mfma)
     mfma_fl = sum(p["flops"] for p in mfma)
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        key = "conv3x3_halo_kernel<128, 0>" if dom_tile >= 3000000 else f"conv_mfma_kernel<{dom_tile // 1000}, {dom_tile % 1000}, 64, 0>"
+        for name, d in pmc.items():
+            if key in name and "hbm_bytes_per_launch" in d:
+                traffic = round(d["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+        "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
         "kernel": (f"conv3x3_halo_kernel<CIN=128> (128 cout x 8x16 px tile)" if dom_tile >= 3000000
                    else f"conv_mfma_kernel<BM={dom_tile // 1000},BN={dom_tile % 1000}>"),
         "launches_per_step": dom["n"], "avg_launch_us": round(dom["ms"] / dom["n"] * 1e3, 2),

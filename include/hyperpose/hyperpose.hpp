@@ -2,5 +2,7 @@
 #pragma once
 #include "operator/dnn/hip_engine.hpp"
 #include "operator/parser/paf.hpp"
+#include "operator/parser/pifpaf.hpp"
+#include "operator/parser/proposal_network.hpp"
 #include "utility/data.hpp"
 #include "utility/human.hpp"

@@ -30,6 +30,24 @@ int main()
         hp::parser::paf p(parser); // copy-construct like the stream API does (stream.hpp:139)
         humans += p.process(packet[0], packet[1]).size();
     }
+    {   // the other two parsers through their mirrors, fed by their engines (reduced sizes)
+        hp::dnn::tensorrt ppn_engine(hp::dnn::builtin_model{ "pose_proposal_resnet50", {}, 3 }, cv::Size(160, 128), 2);
+        hp::parser::pose_proposal ppn(cv::Size(160, 128));
+        cv::Mat m(128, 160);
+        for (size_t k = 0; k < m.total() * 3; ++k)
+            m.data()[k] = (uint8_t)((k * 13) & 255);
+        auto out = ppn_engine.inference({ m });
+        if (out[0].size() != 7)
+            return 5;
+        humans += ppn.process(out[0]).size();
+        hp::dnn::tensorrt pp_engine(hp::dnn::builtin_model{ "pifpaf_resnet50", {}, 4 }, cv::Size(97, 97), 2);
+        hp::parser::pifpaf pp(97, 97);
+        cv::Mat m2(97, 97);
+        auto out2 = pp_engine.inference({ m2 });
+        if (out2[0].size() != 2)
+            return 6;
+        humans += pp.process(out2[0]).size();
+    }
     bool threw = false;
     try {
         engine.inference(std::vector<cv::Mat>(5, batch[0]));
