@@ -21,6 +21,7 @@ struct hp_model {
     int in_w = 0, in_h = 0;
     std::vector<hp_layer> layers;
     std::vector<float> init_scale; // per layer multiplier on the He std (final linear heads are kept small)
+    std::vector<float> init_bias;  // per layer constant added to every bias (keeps sigmoid heads sparse with synthetic weights)
     std::vector<hp_output_desc> outputs;
     int64_t n_weights = 0;
     int next_tensor = 1;
@@ -55,6 +56,7 @@ struct hp_model {
         }
         layers.push_back(L);
         init_scale.push_back(scale);
+        init_bias.push_back(0.f);
         return L.out;
     }
     int conv(int in, int cin, int cout, int k, int act, int stride = 1, int dil = 1, int in_coff = 0)
@@ -188,6 +190,7 @@ void head_openpose(hp_model& m, int feat, int feat_c)
         dup.out = cat[1];
         m.layers.push_back(dup);
         m.init_scale.push_back(1.f);
+        m.init_bias.push_back(0.f);
     }
     auto branch_init = [&](int n_out, int dst, int dst_off) {
         int a = m.conv(cat[0], NC, NC, 3, HP_ACT_PRELU, 1, 1, 0);
@@ -261,7 +264,8 @@ void head_pose_proposal(hp_model& m, int feat, int feat_c, int in_w, int in_h)
     const int K = 18, L = 17, NB = 9;
     int t = m.add(HP_OP_CONV, feat, 0, feat_c, 512, 3, 1, 1, HP_ACT_LEAKY, true, -1, 0, -1, 0, 1.f, 0.1f);
     t = m.add(HP_OP_CONV, t, 0, 512, 512, 3, 1, 1, HP_ACT_LEAKY, true, -1, 0, -1, 0, 1.f, 0.1f);
-    const int o = m.add(HP_OP_CONV, t, 0, 512, 6 * K + NB * NB * L, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 1.f);
+    const int o = m.add(HP_OP_CONV, t, 0, 512, 6 * K + NB * NB * L, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 0.08f);
+    m.init_bias.back() = -4.f; // synthetic weights: sigmoid(-4 + N(0,~1)) keeps a few % of the cells above the thresholds
     const int gh = (in_h + 31) / 32, gw = (in_w + 31) / 32;
     auto out = [&](const char* name, int coff, int ch, float scale, int grid) {
         m.output(name, o, coff, ch, HP_ACT_SIGMOID);
@@ -282,8 +286,11 @@ void head_pose_proposal(hp_model& m, int feat, int feat_c, int in_w, int in_h)
 // order of parser::pifpaf::process(paf, pif) (src/pifpaf.cpp:7).
 void head_pifpaf(hp_model& m, int feat, int feat_c, int in_w, int in_h)
 {
-    const int pif = m.add(HP_OP_CONV, feat, 0, feat_c, 17 * 5 * 4, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 0.3f);
-    const int paf = m.add(HP_OP_CONV, feat, 0, feat_c, 19 * 9 * 4, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 0.3f);
+    // synthetic weights: small logits around -3 keep the random-weight fields sparse (the backbone output has std ~8)
+    const int pif = m.add(HP_OP_CONV, feat, 0, feat_c, 17 * 5 * 4, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 0.05f);
+    m.init_bias.back() = -3.f;
+    const int paf = m.add(HP_OP_CONV, feat, 0, feat_c, 19 * 9 * 4, 1, 1, 1, HP_ACT_NONE, true, -1, 0, -1, 0, 0.05f);
+    m.init_bias.back() = -3.f;
     const int fh = (in_h - 1) / 8 + 1, fw = (in_w - 1) / 8 + 1;
     m.output("0_paf", paf, 0, 19 * 9 * 4);
     hp_output_desc& a = m.outputs.back();
@@ -411,7 +418,7 @@ int hp_model_init_weights(const hp_model* m, uint64_t seed, float* blob, size_t 
             blob[L.w_off + i] = stdv * normal_at(seed, li, i);
         if (L.b_off >= 0)
             for (int i = 0; i < L.cout; ++i)
-                blob[L.b_off + i] = 0.02f * m->init_scale[li] * normal_at(seed, li, nw + i);
+                blob[L.b_off + i] = m->init_bias[li] + 0.02f * m->init_scale[li] * normal_at(seed, li, nw + i);
         if (L.alpha_off >= 0)
             for (int i = 0; i < L.cout; ++i)
                 blob[L.alpha_off + i] = 0.25f;

@@ -26,8 +26,8 @@ namespace {
 constexpr int PPN_K = 18;       // key-point classes the tail indexes (human_t has 18 parts)
 constexpr int PPN_LIMBS = 17;   // COCOPAIR_STD.size(), pose_proposal.cpp:23-41
 constexpr int PPN_MAXG = 256;   // grid cells per map supported (12x12 = 144 in the reference model)
-constexpr int PPN_MAXB = 64;    // NMS survivors kept per class
-constexpr int PPN_MAXC = 512;   // limb candidates kept per limb
+constexpr int PPN_MAXB = 144;   // NMS survivors kept per class (a 12x12 grid cannot yield more)
+constexpr int PPN_MAXC = 2048;  // limb candidates kept per limb
 constexpr int HDR = 64;         // ints per frame: [0,18) survivors, [18,35) candidates, [35] flags
 
 // pose_proposal.cpp:23-41
@@ -396,8 +396,22 @@ int hp_ppn_process_batch(hp_ppn* p, int n, const float* const tensors[7], const 
         p->boxes.as<ppn_box>(), p->cands.as<ppn_cand>());
     HP_HIP_TRY(hipGetLastError());
     HP_HIP_TRY(hipMemcpyAsync(p->h_hdr.p, p->hdr.p, (size_t)n * HDR * sizeof(int), hipMemcpyDeviceToHost, p->stream));
-    HP_HIP_TRY(hipMemcpyAsync(p->h_boxes.p, p->boxes.p, (size_t)n * PPN_K * PPN_MAXB * sizeof(ppn_box), hipMemcpyDeviceToHost, p->stream));
-    HP_HIP_TRY(hipMemcpyAsync(p->h_cands.p, p->cands.p, (size_t)n * PPN_LIMBS * PPN_MAXC * sizeof(ppn_cand), hipMemcpyDeviceToHost, p->stream));
+    HP_HIP_TRY(hipStreamSynchronize(p->stream));
+    // only the used prefix of every fixed-capacity row crosses PCIe (2-D copies: width = longest list of the batch)
+    int max_b = 0, max_c = 0;
+    for (int f = 0; f < n; ++f) {
+        const int* hdr = p->h_hdr.as<int>() + (size_t)f * HDR;
+        for (int c = 0; c < PPN_K; ++c)
+            max_b = std::max(max_b, hdr[c]);
+        for (int l = 0; l < PPN_LIMBS; ++l)
+            max_c = std::max(max_c, hdr[PPN_K + l]);
+    }
+    if (max_b > 0)
+        HP_HIP_TRY(hipMemcpy2DAsync(p->h_boxes.p, PPN_MAXB * sizeof(ppn_box), p->boxes.p, PPN_MAXB * sizeof(ppn_box), (size_t)max_b * sizeof(ppn_box),
+            (size_t)n * PPN_K, hipMemcpyDeviceToHost, p->stream));
+    if (max_c > 0)
+        HP_HIP_TRY(hipMemcpy2DAsync(p->h_cands.p, PPN_MAXC * sizeof(ppn_cand), p->cands.p, PPN_MAXC * sizeof(ppn_cand), (size_t)max_c * sizeof(ppn_cand),
+            (size_t)n * PPN_LIMBS, hipMemcpyDeviceToHost, p->stream));
     HP_HIP_TRY(hipStreamSynchronize(p->stream));
     int rc = HP_OK;
     for (int f = 0; f < n; ++f) {

@@ -1,0 +1,106 @@
+"""GPU: the BASELINE.json configurations at their FULL sizes, through size-independent properties (the torch CPU oracle
+would need minutes per frame at these sizes; small-size parity against it is in test_engine_gpu.py):
+  * batch invariance — frame i of a full batch == the same frame run alone (bit for bit: every output pixel
+    accumulates in the same order wherever its tile falls),
+  * duplicated frames in one batch give identical maps, different frames do not,
+  * the parser consuming the device-resident maps agrees bit for bit with the CPU oracle / the reference's own parser
+    fed with the same maps copied to the host.
+"""
+import numpy as np
+import pytest
+
+from hyperpose_amd import engine as E
+from hyperpose_amd import synth
+from oracle import loader
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps(eng, frames):
+    got = eng.inference(frames)
+    return [[a for _, a in g] for g in got]
+
+
+def _check_invariance(eng, frames, probe=(0, 5)):
+    full = _maps(eng, frames)
+    for i in probe:
+        alone = _maps(eng, frames[i:i + 1])[0]
+        for a, b in zip(alone, full[i]):
+            assert np.array_equal(a, b), f"frame {i} differs between batch and single run"
+    assert all(np.isfinite(a).all() for m in full for a in m)
+    return full
+
+
+def test_config1_lw_openpose_b8_368x432(hp):
+    from hyperpose_amd.parser import Paf
+    m = E.Model("lw_openpose_mobilenet", 432, 368)
+    eng = E.Engine.from_model(m, m.init_weights(20241), max_batch=8)
+    fr = synth.images_u8(synth.rng_for(1), 8, 368, 432)
+    fr[3] = fr[1]
+    full = _check_invariance(eng, fr)
+    assert np.array_equal(full[3][0], full[1][0]) and not np.array_equal(full[2][0], full[1][0])
+    # parser on the device-resident DNN output == oracle on the same maps
+    eng.inference(fr)
+    p = Paf(max_batch=8)
+    (_, cs, cp), (_, ps, pp) = eng.outputs
+    humans = p.process_batch_device(cp, pp, 8, cs, ps)
+    for b in range(8):
+        oh, _, _ = loader.paf_process(full[b][0], full[b][1])
+        assert humans[b].tobytes() == oh.tobytes()
+
+
+def test_config2_openpose_vgg19_b16_432x768(hp):
+    from hyperpose_amd.parser import Paf
+    m = E.Model("openpose_vgg19", 768, 432)
+    eng = E.Engine.from_model(m, m.init_weights(20242), max_batch=16)
+    fr = synth.images_u8(synth.rng_for(2), 16, 432, 768)
+    full = _check_invariance(eng, fr, probe=(0, 9))
+    assert full[0][0].shape == (19, 54, 96) and full[0][1].shape == (38, 54, 96)
+    eng.inference(fr)
+    p = Paf(max_batch=16)
+    (_, cs, cp), (_, ps, pp) = eng.outputs
+    humans = p.process_batch_device(cp, pp, 16, cs, ps)
+    for b in (0, 7, 15):
+        oh, _, _ = loader.paf_process(full[b][0], full[b][1])
+        assert humans[b].tobytes() == oh.tobytes()
+    # injected realistic maps at this geometry (54x96 -> 384 rows x 216 cols up-sampled)
+    conf, paf, _ = synth.paf_maps(synth.rng_for(2, salt=1), 16, 54, 96, people=(2, 4, 8, 16))
+    hs = p.process_batch(conf, paf)
+    total = 0
+    for b in (0, 3, 11):
+        oh, _, _ = loader.paf_process(conf[b], paf[b])
+        assert hs[b].tobytes() == oh.tobytes()
+        total += len(oh)
+    assert total >= 10
+
+
+def test_config3_pose_proposal_resnet50_b32_384(hp):
+    from hyperpose_amd.parser import PoseProposal
+    m = E.Model("pose_proposal_resnet50", 384, 384)
+    eng = E.Engine.from_model(m, m.init_weights(20243), max_batch=32)
+    fr = synth.images_u8(synth.rng_for(3), 32, 384, 384)
+    full = _check_invariance(eng, fr, probe=(0, 20))
+    assert [a.shape for a in full[0]] == [(18, 12, 12)] * 6 + [(17 * 81, 12, 12)]
+    eng.inference(fr)
+    parser = PoseProposal((384, 384), max_batch=32)
+    humans = parser.process_batch([p for _, _, p in eng.outputs], on_device=True, n=32, conf_shape=(18, 12, 12), edge_shape=(17, 9, 9, 12, 12))
+    if loader.ref_lib() is not None:
+        for b in (0, 13, 31):
+            refh = loader.ref_ppn_process(full[b][:6] + [full[b][6].reshape(17, 9, 9, 12, 12)])
+            assert humans[b].tobytes() == refh.tobytes()
+
+
+def test_config4_pifpaf_resnet50_b64_385(hp):
+    from hyperpose_amd.parser import PifPaf
+    m = E.Model("pifpaf_resnet50", 385, 385)
+    eng = E.Engine.from_model(m, m.init_weights(20244), max_batch=64)
+    fr = synth.images_u8(synth.rng_for(4), 64, 385, 385)
+    full = _check_invariance(eng, fr, probe=(0, 40))
+    assert full[0][0].shape == (171, 49, 49) and full[0][1].shape == (85, 49, 49)
+    eng.inference(fr)
+    parser = PifPaf(385, 385, max_batch=64)
+    humans = parser.process_batch(eng.outputs[0][2], eng.outputs[1][2], on_device=True, n=64, fh=49, fw=49)
+    if loader.ref_lib() is not None:
+        for b in (0, 33, 63):
+            refh = loader.ref_pifpaf_process(full[b][0].reshape(19, 9, 49, 49), full[b][1].reshape(17, 5, 49, 49))
+            assert humans[b].tobytes() == refh.tobytes()
