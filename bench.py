@@ -38,7 +38,12 @@ BATCH = 8
 IN_H, IN_W = 368, 432
 ARCH = "lw_openpose_mobilenet"
 PEAK_F16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
-PIPES = 4  # independent engine+parser instances per GPU, one HIP stream each, batches round-robin over them
+# Independent engine+parser instances per GPU, one HIP stream each, batches round-robin over them.  Throughput depends
+# on how those streams land on the runtime's 4 hardware queues (measured on MI355X, tools/queue_probe.py, us/batch):
+# 4 pipes on 2 queues (2+2) 606-617 | 3 pipes on 3 queues 657-667 | 6 pipes on 2 queues 668 | 4 pipes on 4 queues 790-820
+# | 4 pipes on 1 queue 1030.  ROCm hands out hardware queues round-robin per created stream; every Pipe below creates an
+# engine stream and then a (spare) parser stream, which puts the four engine streams on queues 0,2,0,2.
+PIPES = 4
 
 
 def parse_args():

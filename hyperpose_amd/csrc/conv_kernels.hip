@@ -21,6 +21,8 @@
 // Activations carry a zero halo in HBM (conv_kernels.hpp), so taps in the padding are ordinary loads.
 #include "conv_kernels.hpp"
 
+#include <cstdlib>
+
 namespace hp {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -73,8 +75,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk)
 {
     if (BK == 32)
         return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
-    else
+    else if (BK == 64)
         return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    else
+        return row * 256 + ((chunk ^ (row & 15)) << 4);
 }
 
 // Shared epilogue.  Lane holds, for MFMA tile (i, j), pixel j-th "column" (given by pb/py/px/pv) and channels
@@ -437,38 +441,66 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / dilation 1 with the input tile + halo resident in LDS.  Block = 128 output channels x (8 x 16)
-// output pixels; 4 wavefronts as 2 (channels) x 2 (pixel rows 0-3 / 4-7), each 64 ch x 64 px = 2x2 MFMA tiles.
-// Halo tile: 10 x 18 pixels x CIN halves, per-pixel 16-byte chunks XOR-swizzled by the pixel index.
+// 3x3 / stride 1 / dilation 1 with the input tile + halo resident in LDS.  Block = BM output channels x (TH x TW)
+// output pixels; 4 wavefronts as 2 (channels) x 2 (pixel halves), each BM/2 ch x TH*TW/2 px = TM x NT MFMA tiles.
+// Halo tile: (TH+2) x (TW+2) pixels x CIN halves, per-pixel 16-byte chunks XOR-swizzled by the pixel's position so
+// that the 16 lanes of a ds_read_b128 service group (consecutive tile pixels, any tap shift) hit 16 distinct slots.
 // Weights: [tap][cout][cin] streamed in K-steps of 64 through a double-buffered LDS tile, register-prefetched two
-// steps ahead.
-constexpr int HT_H = 8, HT_W = 16, HP_H = HT_H + 2, HP_W = HT_W + 2;
-
-template <int CIN, int EPI>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_params p, int tiles_x, int tiles_y)
+// steps ahead.  Two instantiations: 128 ch x 8x16 px and 64 ch x 16x12 px; the second moves 37 % fewer bytes per CU
+// at the 46 x 54 maps of the OpenPose heads (the layers are CU<-L2 bandwidth bound at batch 8).
+template <int TM, int NT>
+__device__ __forceinline__ void halo_interleave()
 {
-    constexpr int BM = 128, BK = 64;
-    constexpr int CHP = CIN / 8;              // 16-byte chunks per halo pixel
-    constexpr int KC = CIN / BK;
-    constexpr int HALO_BYTES = HP_H * HP_W * CIN * 2;
+    if constexpr (TM == 2 && NT == 2) {
+        HP_INTERLEAVE4();
+    } else { // 1 x 3: three MFMAs shadow four LDS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+}
+
+template <int CIN, int BM, int TH, int TW, int KG, int BK, int EPI>
+__global__ __launch_bounds__(256 * KG) void conv3x3_halo_kernel(const conv_params p, int tiles_x, int tiles_y)
+{
+    // 8 wavefronts = 2 K-groups x (2 channel halves x 2 pixel halves): both K-groups own the same BM/2 x TH*TW/2 wave
+    // tile and split every tap's CIN between them, so each SIMD holds two wavefronts that cover each other's LDS
+    // latency and barrier waits; the partial sums meet through LDS before the epilogue.
+    constexpr int NTHR = 256 * KG;
+    constexpr int KC = CIN / BK;  // K-steps per tap
+    constexpr int CHA = BK / 8;   // 16-byte chunks per weight-tile row
+    constexpr int HPH = TH + 2, HPW = TW + 2;
+    constexpr int TM = BM / 64, NT = TH * TW / 64; // MFMA tiles per wave
+    constexpr int CHP = CIN / 8;                   // 16-byte chunks per halo pixel
+    constexpr int NS = BK / 16 / KG;               // k16 substeps per K-group and K-step
+    constexpr int HALO_BYTES = HPH * HPW * CIN * 2;
     constexpr int A_BYTES = BM * BK * 2;
-    constexpr int A_LD = BM / 32;             // 4 x 16-byte loads per thread per K-step
-    static_assert(HALO_BYTES + 2 * A_BYTES >= 4 * stage_geom<2>::SLAB, "epilogue slabs must fit in the main-loop LDS");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_BYTES + 2 * A_BYTES];
+    constexpr int A_LD = BM * CHA / NTHR; // 16-byte loads per thread per K-step
+    constexpr int RED_BYTES = 4 * TM * NT * 16 * 64 * 4;
+    static_assert(TH * TW % 64 == 0 && BM % 64 == 0 && A_LD >= 1 && NS >= 2 && NS % 2 == 0, "wave tiles are whole 32x32 MFMA tiles");
+    constexpr int LDS_BYTES = HALO_BYTES + 2 * A_BYTES > RED_BYTES ? HALO_BYTES + 2 * A_BYTES : RED_BYTES;
+    static_assert(RED_BYTES / 4 >= stage_geom<TM>::SLAB, "a wave's epilogue slab lives in its own reduction region");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const s_halo = lds;
     unsigned char* const s_a = lds + HALO_BYTES;
+    // swizzle key of halo pixel (hy, hx): consecutive tile pixels (row-major over TW columns) get consecutive keys
+    auto hkey = [](int hy, int hx) { return CHP == 16 ? ((hy * TW + hx) & 15) : (((hy * TW + hx) >> 1) & 7); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM;
     int t = blockIdx.x;
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y, b = t / tiles_y;
-    const int y0 = ty * HT_H, x0 = tx * HT_W;
+    const int y0 = ty * TH, x0 = tx * TW;
 
     // ---- weights prefetch (two register sets), then the halo tile
-    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+    constexpr int RPP = NTHR / CHA; // weight rows covered by one pass of the block's threads
+    const int ld_row = tid / CHA, ld_chunk = tid % CHA;
     const __half* wrow = p.w + (size_t)(m0 + ld_row) * CIN + ld_chunk * 8;
     const long w_tap_stride = (long)p.Cout_pad * CIN;
     u32x4 ra0[A_LD], ra1[A_LD];
@@ -477,7 +509,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_params p, 
     {                                                                                                             \
         const __half* wb_ = wrow + (long)l_tap * w_tap_stride + l_kc * BK;                                        \
         _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                          \
-            RA[i] = *reinterpret_cast<const u32x4*>(wb_ + (size_t)(i * 32) * CIN);                                \
+            RA[i] = *reinterpret_cast<const u32x4*>(wb_ + (size_t)(i * RPP) * CIN);                               \
         if (++l_kc == KC) {                                                                                       \
             l_kc = 0;                                                                                             \
             ++l_tap;                                                                                              \
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_params p, 
     {                                                                                                             \
         unsigned char* a_ = s_a + (BUF) * A_BYTES;                                                                \
         _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                          \
-            *reinterpret_cast<u32x4*>(a_ + lds_off<BK>(ld_row + i * 32, ld_chunk)) = RA[i];                       \
+            *reinterpret_cast<u32x4*>(a_ + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = RA[i];                      \
     }
     int dbg_i = 0;
 #define HP_STAMP()                                                                                                \
@@ -499,13 +531,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_params p, 
 
     // halo tile: issue ALL loads first (one L2 round trip), then the LDS stores
     {
-        constexpr int NIT = (HP_H * HP_W * CHP + 255) / 256;
+        constexpr int NIT = (HPH * HPW * CHP + NTHR - 1) / NTHR;
         u32x4 hv[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            const int hp = min(i, HP_H * HP_W * CHP - 1) / CHP, c = i % CHP;
-            const int hy = hp / HP_W, hx = hp - hy * HP_W;
+            const int i = tid + it * NTHR;
+            const int hp = min(i, HPH * HPW * CHP - 1) / CHP, c = i % CHP;
+            const int hy = hp / HPW, hx = hp - hy * HPW;
             const int y = y0 + hy - 1, x = x0 + hx - 1;
             const bool ok = y <= p.H && x <= p.W; // y, x >= -1 always: inside the zero halo of the HBM tensor
             const u32x4 v = *reinterpret_cast<const u32x4*>(p.in.p + tv_off(p.in, b, min(y, p.H), min(x, p.W)) + c * 8);
@@ -513,60 +545,74 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_params p, 
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            if (i < HP_H * HP_W * CHP) {
+            const int i = tid + it * NTHR;
+            if (i < HPH * HPW * CHP) {
                 const int hp = i / CHP, c = i - hp * CHP;
-                *reinterpret_cast<u32x4*>(s_halo + hp * (CIN * 2) + ((c ^ (hp & (CHP - 1))) << 4)) = hv[it];
+                const int hy = hp / HPW, hx = hp - hy * HPW;
+                *reinterpret_cast<u32x4*>(s_halo + hp * (CIN * 2) + ((c ^ hkey(hy, hx)) << 4)) = hv[it];
             }
         }
     }
 
-    floatx16 acc[2][2];
+    floatx16 acc[TM][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[i][j][r] = 0.f;
 
     const int frow = lane & 31, fk = lane >> 5;
-    // this lane's two B-fragment pixels (tile coordinates): N-tile j covers tile rows wn*4 + 2j, +1
-    const int bcol = lane & 15, brow = wn * 4 + ((lane & 31) >> 4);
-    int c_tap = 0, c_kc = 0;
+    // this lane's B-fragment pixels (tile coordinates): N-tile j covers tile pixels wn*TH*TW/2 + 32j .. +31
+    int brow[NT], bcol[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = wn * (TH * TW / 2) + j * 32 + (lane & 31);
+        brow[j] = n / TW;
+        bcol[j] = n - brow[j] * TW;
+    }
+    // 16-byte chunk (of the tap's CIN) this lane reads in substep ks of its K-group
 #define HP_HFRAGS(FA, FB, KS)                                                                                     \
     {                                                                                                             \
-        const int ch_ = c_kc * 8 + (KS) * 2 + fk;                                                                 \
-        FA[0] = *reinterpret_cast<const half8*>(a_ + lds_off<BK>(wm * 64 + frow, (KS) * 2 + fk));                 \
-        FA[1] = *reinterpret_cast<const half8*>(a_ + lds_off<BK>(wm * 64 + 32 + frow, (KS) * 2 + fk));            \
-        FB[0] = *reinterpret_cast<const half8*>(s_halo + hp0_ * (CIN * 2) + ((ch_ ^ (hp0_ & (CHP - 1))) << 4));   \
-        FB[1] = *reinterpret_cast<const half8*>(s_halo + hp1_ * (CIN * 2) + ((ch_ ^ (hp1_ & (CHP - 1))) << 4));   \
+        const int cha_ = (kg * NS + (KS)) * 2 + fk, ch_ = c_kc * CHA + cha_;                                      \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                            \
+            FA[i] = *reinterpret_cast<const half8*>(a_ + lds_off<BK>(wm * (BM / 2) + i * 32 + frow, cha_));       \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
+            FB[j] = *reinterpret_cast<const half8*>(s_halo + hpo_[j] + ((ch_ ^ hk_[j]) << 4));                    \
     }
 #define HP_HMMA(FA, FB)                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[i], FB[j], acc[i][j], 0, 0, 0);
 #define HP_HCOMPUTE(BUF)                                                                                          \
     {                                                                                                             \
         const unsigned char* a_ = s_a + (BUF) * A_BYTES;                                                          \
         const int ky_ = c_tap / 3, kx_ = c_tap - ky_ * 3;                                                         \
-        const int hp0_ = (brow + ky_) * HP_W + bcol + kx_, hp1_ = hp0_ + 2 * HP_W;                                \
-        half8 fa0[2], fb0[2], fa1[2], fb1[2];                                                                     \
+        int hpo_[NT], hk_[NT];                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
+        {                                                                                                         \
+            hpo_[j] = ((brow[j] + ky_) * HPW + bcol[j] + kx_) * (CIN * 2);                                        \
+            hk_[j] = hkey(brow[j] + ky_, bcol[j] + kx_);                                                          \
+        }                                                                                                         \
+        half8 fa0[TM], fb0[NT], fa1[TM], fb1[NT];                                                                 \
         HP_HFRAGS(fa0, fb0, 0);                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        HP_HFRAGS(fa1, fb1, 1);                                                                                   \
-        HP_HMMA(fa0, fb0);                                                                                        \
-        HP_INTERLEAVE4();                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-        HP_HFRAGS(fa0, fb0, 2);                                                                                   \
-        HP_HMMA(fa1, fb1);                                                                                        \
-        HP_INTERLEAVE4();                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-        HP_HFRAGS(fa1, fb1, 3);                                                                                   \
-        HP_HMMA(fa0, fb0);                                                                                        \
-        HP_INTERLEAVE4();                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-        HP_HMMA(fa1, fb1);                                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < NS; ks += 2)                                                      \
+        {                                                                                                         \
+            HP_HFRAGS(fa1, fb1, ks + 1);                                                                          \
+            HP_HMMA(fa0, fb0);                                                                                    \
+            halo_interleave<TM, NT>();                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if (ks + 2 < NS) {                                                                                    \
+                HP_HFRAGS(fa0, fb0, ks + 2);                                                                      \
+                HP_HMMA(fa1, fb1);                                                                                \
+                halo_interleave<TM, NT>();                                                                        \
+            } else {                                                                                              \
+                HP_HMMA(fa1, fb1);                                                                                \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
         if (++c_kc == KC) {                                                                                       \
             c_kc = 0;                                                                                             \
             ++c_tap;                                                                                              \
@@ -574,7 +620,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_params p, 
     }
 
     constexpr int steps = 9 * KC;
+    int c_tap = 0, c_kc = 0;
     HP_STAMP();
+#pragma unroll 1
     for (int s = 0; s < steps; s += 2) {
         HP_WSTORE(ra0, 0);
         __syncthreads(); // also publishes the halo tile on the first iteration
@@ -603,21 +651,50 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_params p, 
 #undef HP_HFRAGS
 #undef HP_HMMA
 
-    int pb[2], py[2], px[2];
-    bool pv[2];
+    // ---- K-group 1 hands its partial sums to K-group 0: [wave tile][float4 index][lane], 16 bytes per lane
+    __syncthreads(); // every wave is done with the main-loop LDS
+    HP_STAMP();
+    if constexpr (KG == 2) {
+        float4* red = reinterpret_cast<float4*>(lds) + (size_t)(wave & 3) * (TM * NT * 4 * 64) + lane;
+        if (kg == 1) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        red[((i * NT + j) * 4 + g) * 64] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+        __syncthreads();
+        if (kg == 1)
+            return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = red[((i * NT + j) * 4 + g) * 64];
+                    acc[i][j][4 * g] += v.x, acc[i][j][4 * g + 1] += v.y, acc[i][j][4 * g + 2] += v.z, acc[i][j][4 * g + 3] += v.w;
+                }
+    }
+    // K-group 0 finishes alone, without further block-wide barriers
+    int pb[NT], py[NT], px[NT];
+    bool pv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
         pb[j] = b;
-        py[j] = y0 + brow + 2 * j;
-        px[j] = x0 + bcol;
+        py[j] = y0 + brow[j];
+        px[j] = x0 + bcol[j];
         pv[j] = py[j] < p.OH && px[j] < p.OW;
     }
     HP_STAMP();
     if (EPI == 0) {
-        __syncthreads();
-        conv_epilogue_staged<2, 2>(p, acc, m0 + wm * 64, lane, lds + wave * stage_geom<2>::SLAB, pb, py, px, pv);
+        // the slab re-uses this wave's own reduction region, which it has finished reading
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        conv_epilogue_staged<TM, NT>(p, acc, m0 + wm * (BM / 2), lane, lds + (wave & 3) * (RED_BYTES / 4), pb, py, px, pv);
     } else
-        conv_epilogue<2, 2, EPI>(p, acc, m0 + wm * 64, lane, pb, py, px, pv);
+        conv_epilogue<TM, NT, EPI>(p, acc, m0 + wm * (BM / 2), lane, pb, py, px, pv);
     HP_STAMP();
 #undef HP_STAMP
 }
@@ -646,15 +723,37 @@ static hipError_t launch_tile(const conv_params& p, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int CIN>
+// Estimated bytes one CU pulls from L2 for the whole launch with tile (BM ch x TH x TW px): blocks beyond the 256 CUs
+// queue behind the first wave of blocks.
+static double halo_cost(const conv_params& p, int BM, int TH, int TW)
+{
+    const long tiles = (long)((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH) * p.B;
+    const long blocks = tiles * (p.Cout_pad / BM);
+    const double per_block = 9.0 * BM * p.Cin * 2 + (double)(TH + 2) * (TW + 2) * p.Cin * 2 + (double)TH * TW * BM * 2;
+    return per_block * (double)((blocks + 255) / 256);
+}
+// 0: 128 ch x 8x16 px, 1: 64 ch x 16x12 px
+static int g_force_halo_variant = -1;
+void debug_force_halo_variant(int v) { g_force_halo_variant = v; }
+static int halo_variant(const conv_params& p)
+{
+    if (g_force_halo_variant >= 0)
+        return g_force_halo_variant;
+    static const int env_v = getenv("HP_HALO_VARIANT") ? atoi(getenv("HP_HALO_VARIANT")) : -1;
+    if (env_v >= 0)
+        return env_v;
+    return halo_cost(p, 64, 16, 12) < halo_cost(p, 128, 8, 16) ? 1 : 0;
+}
+
+template <int CIN, int BM, int TH, int TW, int KG = 1, int BK = 64>
 static hipError_t launch_halo(const conv_params& p, hipStream_t s)
 {
-    const int tiles_x = (p.OW + HT_W - 1) / HT_W, tiles_y = (p.OH + HT_H - 1) / HT_H;
-    dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / 128);
+    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
+    dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / BM);
     if (fast_epilogue(p))
-        hipLaunchKernelGGL((conv3x3_halo_kernel<CIN, 0>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<CIN, BM, TH, TW, KG, BK, 0>), grid, dim3(256 * KG), 0, s, p, tiles_x, tiles_y);
     else
-        hipLaunchKernelGGL((conv3x3_halo_kernel<CIN, 1>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<CIN, BM, TH, TW, KG, BK, 1>), grid, dim3(256 * KG), 0, s, p, tiles_x, tiles_y);
     return hipGetLastError();
 }
 
@@ -685,7 +784,7 @@ bool set_act(conv_params& p)
 int conv_mfma_tile(const conv_params& p)
 {
     if (use_halo(p))
-        return 3000000 + 128 * 1000 + 128;
+        return halo_variant(p) ? 3000000 + 64 * 1000 + 192 : 3000000 + 128 * 1000 + 128;
     const int BM = (p.Cout_pad % 128 == 0) ? 128 : 64;
     // prefer the 128-pixel tile only when it still fills the 256 CUs at least once
     const long blocks128 = (long)((p.npix + 127) / 128) * (p.Cout_pad / BM);
@@ -695,8 +794,22 @@ int conv_mfma_tile(const conv_params& p)
 
 hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
 {
-    if (use_halo(p))
-        return p.Cin == 128 ? launch_halo<128>(p, s) : launch_halo<64>(p, s);
+    if (use_halo(p)) {
+        // tuning knob: HP_HALO_KG=2 selects the 8-wave split-K form, HP_HALO_BK=128 one K-step per tap (CIN=128 only)
+        static const int kg = getenv("HP_HALO_KG") ? atoi(getenv("HP_HALO_KG")) : 1;
+        static const int bk = getenv("HP_HALO_BK") ? atoi(getenv("HP_HALO_BK")) : 64;
+        const int v = halo_variant(p);
+        if (p.Cin == 64) {
+            if (kg == 2)
+                return v ? launch_halo<64, 64, 16, 12, 2, 64>(p, s) : launch_halo<64, 128, 8, 16, 2, 64>(p, s);
+            return v ? launch_halo<64, 64, 16, 12, 1, 64>(p, s) : launch_halo<64, 128, 8, 16, 1, 64>(p, s);
+        }
+        if (kg == 2 && bk == 128)
+            return v ? launch_halo<128, 64, 16, 12, 2, 128>(p, s) : launch_halo<128, 128, 8, 16, 2, 128>(p, s);
+        if (kg == 2)
+            return v ? launch_halo<128, 64, 16, 12, 2, 64>(p, s) : launch_halo<128, 128, 8, 16, 2, 64>(p, s);
+        return v ? launch_halo<128, 64, 16, 12, 1, 64>(p, s) : launch_halo<128, 128, 8, 16, 1, 64>(p, s);
+    }
     const int t = conv_mfma_tile(p);
     const int BM = t / 1000, BN = t % 1000;
     const bool k64 = (p.Cin % 64 == 0);

@@ -61,6 +61,8 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s);
 // which kernel/tile the launcher picks (for reporting): BM*1000+BN for the generic kernel, 3000000+BM*1000+BN for
 // the 3x3 halo kernel
 int conv_mfma_tile(const conv_params& p);
+// tuning aid (tools/microbench): force the 3x3 halo tile variant (0: 128 ch x 8x16 px, 1: 64 ch x 16x12 px, -1: auto)
+void debug_force_halo_variant(int v);
 
 struct first_conv_params {
     const uint8_t* in_u8; // [B][H][W][3] or nullptr

@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 namespace {

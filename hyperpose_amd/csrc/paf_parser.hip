@@ -7,9 +7,10 @@
 // up-sampled / smoothed / pooled temporaries on the way.
 //
 // Here a whole batch of frames is parsed by four launches that never materialise the up-sampled maps:
-//   1. paf_peaks_kernel    grid (tiles, 18 parts, frames): stage the few source rows a tile needs in LDS,
-//                          up-sample (INTER_AREA semantics) -> 17-tap row filter -> symmetric column
-//                          filter -> 3x3 max / threshold, all inside LDS; append peaks with an atomic.
+//   1. paf_peaks_kernel    grid (bands x strips, 18 parts, frames): one thread per column marches down the
+//                          rows: up-sample (INTER_AREA semantics) -> 17-tap row filter through LDS ->
+//                          symmetric column filter out of a register window -> 3x3 max / threshold on a
+//                          4-row LDS ring; append peaks with an atomic.
 //   2. paf_sort_kernel     grid (18 parts, frames): rank-sort each part's peaks into the reference's scan
 //                          order so that peak ids equal the reference's running index.
 //   3. paf_limbs_kernel    grid (19 limbs, frames): the limb's two PAF source channels live in LDS; one
@@ -111,109 +112,162 @@ __device__ __forceinline__ float up_at(const float* __restrict__ src, int row_ba
 
 // ---------------------------------------------------------------------------------------------------
 // 1. peaks: resize_area + smooth + same_max_pool_3x3 + find_peak_coords (post_process.hpp:26-195), fused.
-// LDS carve (floats): src rows | U tile (re-used for S) | row-filtered tile.
+// One block = one (frame, part, band of BH up-sampled rows, strip of CW columns).  One thread = one column; the block
+// marches down the rows, TWO rows per step, keeping per thread the last 18 row-filtered values in registers (the
+// column filter's window), so the 216 x 184 intermediate planes never exist anywhere: per step a thread up-samples its
+// two samples, the row pair is exchanged through LDS for the 17-tap row filter, the column filter runs out of
+// registers and an 8-row ring of smoothed values in LDS feeds the 3x3 maximum test.  The two rows of a step sit in the
+// two halves of packed-fp32 registers (v_pk_mul_f32 / v_pk_add_f32: the same IEEE roundings as the scalar forms, no
+// fusion).  One barrier per step; ~17 KB of LDS per block.
+// BORDER_REFLECT_101 is handled by evaluating the reflected row / column itself (the same value the CPU code reads).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool DUMP>
 __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __restrict__ conf, geom_t g,
-    gauss_t gk, float thresh, int TH, int TW, int tiles_x, int src_rows_cap, int Uw_cap, int Rw_cap,
+    gauss_t gk, float thresh, int BH, int CW, int strips, int src_rows_cap,
     dpeak* __restrict__ plist, int* __restrict__ pcount, int peak_cap,
     float* __restrict__ dump_up, float* __restrict__ dump_smooth)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int band = blockIdx.x / strips, strip = blockIdx.x % strips;
     const int k = blockIdx.y, f = blockIdx.z;
 
-    const int y0 = ty * TH, y1 = min(g.UH, y0 + TH);
-    const int x0 = tx * TW, x1 = min(g.UW, x0 + TW);
-    // smoothed values needed on the tile plus the 1-px pool halo
-    const int sy_lo = max(0, y0 - 1), sy_hi = min(g.UH, y1 + 1);
-    const int sx_lo = max(0, x0 - 1), sx_hi = min(g.UW, x1 + 1);
-    // row-filtered / up-sampled rows needed for those (reflect101 targets stay inside)
-    const int ry_lo = max(0, sy_lo - KR), ry_hi = min(g.UH, sy_hi + KR);
-    const int ux_lo = max(0, sx_lo - KR), ux_hi = min(g.UW, sx_hi + KR);
-    const int Uh = ry_hi - ry_lo, Uw = ux_hi - ux_lo, Rw = sx_hi - sx_lo, Sh = sy_hi - sy_lo;
-
+    const int y0 = band * BH, y1 = min(g.UH, y0 + BH);
+    const int x0 = strip * CW, x1 = min(g.UW, x0 + CW);
+    const int cw = x1 - x0;
+    // rows really touched (reflections of the rows above / below the map fall inside this range)
+    const int ry_lo = max(0, y0 - KR - 1), ry_hi = min(g.UH, y1 + KR + 1);
     const int row_base = g.ofs_y0[ry_lo];
-    const int row_last = g.ofs_y1[ry_hi - 1];
-    const int nrows = row_last - row_base + 1;
+    const int nrows = g.ofs_y1[ry_hi - 1] - row_base + 1;
 
-    float* s_src = smem;                           // [src_rows_cap][Cc]
-    float* s_U = s_src + src_rows_cap * g.Cc;      // [Uh][Uw]   later S [Sh][Rw]
-    float* s_R = s_U + (TH + 2 + 2 * KR) * Uw_cap; // [Uh][Rw]
-
+    // LDS carve.  The hot loop below is branch-free: threads / rows outside the useful range compute on whatever the
+    // (in-bounds) LDS words hold and their results are never looked at, hence the guard words around s_U.
+    float* s_src = smem;                                                                  // [src_rows_cap][Cc]
+    f32x2* s_U = reinterpret_cast<f32x2*>(s_src + ((src_rows_cap * g.Cc + 1) & ~1)) + KR; // [2][PEAK_THREADS] row pair (+ KR guards each side)
+    float* s_S = reinterpret_cast<float*>(s_U + 2 * PEAK_THREADS + KR) + 1;               // [8][PEAK_THREADS] ring of smoothed rows (+1 guard each side)
+    // per logical row m_begin + i (reflected): source row offsets inside s_src and the two vertical coefficients
+    const int tab_n = BH + 2 * (KR + 1) + 6;
+    int* s_r0 = reinterpret_cast<int*>(s_S + 8 * PEAK_THREADS + 1);
+    int* s_r1 = s_r0 + tab_n;
+    float* s_cy0 = reinterpret_cast<float*>(s_r1 + tab_n);
+    float* s_cy1 = s_cy0 + tab_n;
+    for (int i = tid; i < tab_n; i += PEAK_THREADS) {
+        const int ry = reflect101(y0 - KR - 1 + i, g.UH);
+        s_r0[i] = min(max(g.ofs_y0[ry] - row_base, 0), nrows - 1) * g.Cc; // clamped: rows past the band's needs are never used
+        s_r1[i] = min(max(g.ofs_y1[ry] - row_base, 0), nrows - 1) * g.Cc;
+        s_cy0[i] = g.c0_y[ry];
+        s_cy1[i] = g.c1_y[ry];
+    }
     const float* plane = conf + ((size_t)f * g.J + k) * g.R * g.Cc;
     for (int i = tid; i < nrows * g.Cc; i += PEAK_THREADS)
         s_src[i] = plane[row_base * g.Cc + i];
+
+    // thread t owns column x0 - (KR + 1) + t of the strip's halo; columns outside the map read their reflection
+    const int ux = x0 - (KR + 1) + tid;
+    const bool interior = tid >= KR + 1 && tid < cw + KR + 1;
+    const int rc = reflect101(tid < cw + 2 * (KR + 1) ? ux : 0, g.UW);
+    const int sx = g.ofs_x[rc];
+    const bool two_tap = rc < g.vmax_x;
+    // single-tap columns (x >= OpenCV's xmax) multiply by 1.f and add nothing: up_row keeps that form
+    const float a0 = two_tap ? g.c0_x[rc] : 1.f, a1 = two_tap ? g.c1_x[rc] : 0.f;
+    const int sx1 = two_tap ? sx + 1 : sx;
     __syncthreads();
 
-    // up-sample
-    for (int i = tid; i < Uh * Uw; i += PEAK_THREADS) {
-        const int yy = i / Uw, xx = i - yy * Uw;
-        s_U[yy * Uw + xx] = up_at(s_src, row_base, g, ry_lo + yy, ux_lo + xx);
-    }
-    __syncthreads();
-    if (dump_up) {
-        for (int i = tid; i < (y1 - y0) * (x1 - x0); i += PEAK_THREADS) {
-            const int yy = i / (x1 - x0), xx = i - yy * (x1 - x0);
-            dump_up[(((size_t)f * g.J + k) * g.UH + y0 + yy) * g.UW + x0 + xx] = s_U[(y0 + yy - ry_lo) * Uw + (x0 + xx - ux_lo)];
+    // w[j] = (R[m-16+j], R[m-15+j]): overlapping pairs of the row-filtered column, logical rows m-16 .. m+1
+    f32x2 w[KSIZE];
+#pragma unroll
+    for (int i = 0; i < KSIZE; ++i)
+        w[i] = f32x2{ 0.f, 0.f };
+
+    auto up_row = [&](int i) { // row m_begin + i: HResizeLinear on the two source rows, then VResizeLinear
+        const int r0 = s_r0[i], r1 = s_r1[i];
+        float h0, h1;
+        if (two_tap) {
+            h0 = s_src[r0 + sx] * a0 + s_src[r0 + sx1] * a1;
+            h1 = s_src[r1 + sx] * a0 + s_src[r1 + sx1] * a1;
+        } else {
+            h0 = s_src[r0 + sx] * 1.f;
+            h1 = s_src[r1 + sx] * 1.f;
         }
-    }
+        return h0 * s_cy0[i] + h1 * s_cy1[i];
+    };
 
-    // RowFilter<float,float>: s = k0*S[0]; s += kk*S[kk], BORDER_REFLECT_101
-    for (int i = tid; i < Uh * Rw; i += PEAK_THREADS) {
-        const int yy = i / Rw, xx = i - yy * Rw;
-        const int x = sx_lo + xx;
-        const float* row = s_U + yy * Uw;
-        float s = gk.k[0] * row[reflect101(x - KR, g.UW) - ux_lo];
-#pragma unroll
-        for (int t = 1; t < KSIZE; ++t)
-            s += gk.k[t] * row[reflect101(x - KR + t, g.UW) - ux_lo];
-        s_R[yy * Rw + xx] = s;
-    }
-    __syncthreads();
-
-    // SymmColumnFilter<float>: s = k8*C + 0; s += kk*(S[+kk] + S[-kk])
-    float* s_S = s_U;
-    for (int i = tid; i < Sh * Rw; i += PEAK_THREADS) {
-        const int yy = i / Rw, xx = i - yy * Rw;
-        const int y = sy_lo + yy;
-        float s = gk.k[KR] * s_R[(y - ry_lo) * Rw + xx] + 0.f;
-#pragma unroll
-        for (int t = 1; t <= KR; ++t) {
-            const float a = s_R[(reflect101(y + t, g.UH) - ry_lo) * Rw + xx];
-            const float b = s_R[(reflect101(y - t, g.UH) - ry_lo) * Rw + xx];
-            s += gk.k[KR + t] * (a + b);
+    const int m_begin = y0 - KR - 1;
+    const int m_end = y1 + KR + 3; // the step holding m = m_end tests row y1 - 1 at the latest
+    const bool emit = interior && k < HP_COCO_N_PARTS;
+    int it = 0;
+    for (int m = m_begin; m <= m_end; m += 2, ++it) {
+        // ---- a. up-sample this thread's samples of (reflected) rows m, m+1
+        f32x2 u;
+        u[0] = up_row(2 * it);
+        u[1] = up_row(2 * it + 1);
+        if (DUMP && dump_up && interior) {
+            if (m >= y0 && m < y1)
+                dump_up[(((size_t)f * g.J + k) * g.UH + m) * g.UW + ux] = u[0];
+            if (m + 1 >= y0 && m + 1 < y1)
+                dump_up[(((size_t)f * g.J + k) * g.UH + m + 1) * g.UW + ux] = u[1];
         }
-        s_S[yy * Rw + xx] = s;
-    }
-    __syncthreads();
+        s_U[(it & 1) * PEAK_THREADS + tid] = u;
+        __syncthreads();
 
-    const int tw = x1 - x0, th = y1 - y0;
-    for (int i = tid; i < th * tw; i += PEAK_THREADS) {
-        const int yy = i / tw, xx = i - yy * tw;
-        const int y = y0 + yy, x = x0 + xx;
-        const float v = s_S[(y - sy_lo) * Rw + (x - sx_lo)];
-        if (dump_smooth)
-            dump_smooth[(((size_t)f * g.J + k) * g.UH + y) * g.UW + x] = v;
-        if (k < HP_COCO_N_PARTS && v > thresh) {
-            // same_max_pool_3x3_2d: max over in-range taps == v  <=>  no in-range tap exceeds v
-            bool is_max = true;
+        // ---- b. RowFilter<float,float> on both rows: s = k0*S[0]; s += kk*S[kk]
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+        for (int i = 0; i + 2 < KSIZE; ++i)
+            w[i] = w[i + 2];
+        {
+            const f32x2* row = s_U + (it & 1) * PEAK_THREADS + tid - KR;
+            f32x2 s = gk.k[0] * row[0];
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int ny = y + dy, nx = x + dx;
-                    if (ny >= 0 && ny < g.UH && nx >= 0 && nx < g.UW)
-                        is_max = is_max && !(s_S[(ny - sy_lo) * Rw + (nx - sx_lo)] > v);
-                }
-            if (is_max) {
-                const int pos = atomicAdd(&pcount[f * HP_COCO_N_PARTS + k], 1);
-                if (pos < peak_cap) {
-                    dpeak p;
-                    p.x = x;
-                    p.y = y;
-                    p.score = up_at(s_src, row_base, g, y, x); // raw up-sampled value (post_process.hpp:180)
-                    p.lin = y * g.UW + x;
-                    plist[((size_t)f * HP_COCO_N_PARTS + k) * peak_cap + pos] = p;
+            for (int t = 1; t < KSIZE; ++t)
+                s += gk.k[t] * row[t];
+            w[KSIZE - 2] = f32x2{ w[KSIZE - 3][1], s[0] };
+            w[KSIZE - 1] = s;
+        }
+
+        // ---- c. SymmColumnFilter<float> for rows ys = m - KR, ys + 1: s = k8*C + 0; s += kk*(S[+kk] + S[-kk])
+        const int ys = m - KR;
+        {
+            f32x2 s = gk.k[KR] * w[KR] + 0.f;
+#pragma unroll
+            for (int t = 1; t <= KR; ++t)
+                s += gk.k[KR + t] * (w[KR + t] + w[KR - t]);
+            s_S[(ys & 7) * PEAK_THREADS + tid] = s[0];
+            s_S[((ys + 1) & 7) * PEAK_THREADS + tid] = s[1];
+            if (DUMP && dump_smooth && interior) {
+                if (ys >= y0 && ys < y1)
+                    dump_smooth[(((size_t)f * g.J + k) * g.UH + ys) * g.UW + ux] = s[0];
+                if (ys + 1 >= y0 && ys + 1 < y1)
+                    dump_smooth[(((size_t)f * g.J + k) * g.UH + ys + 1) * g.UW + ux] = s[1];
+            }
+        }
+
+        // ---- d. peaks of rows m - KR - 4, m - KR - 3: their 3x3 neighbourhoods were published by earlier barriers
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int yn = m - KR - 4 + q;
+            const float v = s_S[(yn & 7) * PEAK_THREADS + tid];
+            if (emit && v > thresh && yn >= y0 && yn < y1) {
+                // same_max_pool_3x3_2d: max over in-range taps == v  <=>  no in-range tap exceeds v
+                bool is_max = true;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int ny = yn + dy, nx = ux + dx;
+                        if (ny >= 0 && ny < g.UH && nx >= 0 && nx < g.UW)
+                            is_max = is_max && !(s_S[(ny & 7) * PEAK_THREADS + tid + dx] > v);
+                    }
+                if (is_max) {
+                    const int pos = atomicAdd(&pcount[f * HP_COCO_N_PARTS + k], 1);
+                    if (pos < peak_cap) {
+                        dpeak p;
+                        p.x = ux;
+                        p.y = yn;
+                        p.score = up_at(s_src, row_base, g, yn, ux); // raw up-sampled value (post_process.hpp:180)
+                        p.lin = yn * g.UW + ux;
+                        plist[((size_t)f * HP_COCO_N_PARTS + k) * peak_cap + pos] = p;
+                    }
                 }
             }
         }
@@ -612,7 +666,7 @@ struct hp_paf {
     bool shaped = false;
     geom_t g{};
     gauss_t gk{};
-    int TH = 24, TW = 0, tiles_x = 0, tiles_y = 0, src_rows_cap = 0, Uw_cap = 0, Rw_cap = 0;
+    int BH = 0, CW = 0, strips = 0, bands = 0, src_rows_cap = 0; // peaks kernel tiling
     size_t peaks_lds = 0, limbs_lds = 0;
 
     hipStream_t stream = nullptr;
@@ -667,24 +721,19 @@ int hp_paf::shape(const int cs[3], const int ps[3])
     const int* dy = d + 3 * g.UW;
     g.ofs_y0 = dy, g.ofs_y1 = dy + g.UH, g.c0_y = (const float*)(dy + 2 * g.UH), g.c1_y = (const float*)(dy + 3 * g.UH);
 
-    // tiling of the up-sampled map: bands of TH rows, full width unless the LDS budget says otherwise
-    TH = std::min(24, g.UH);
-    TW = g.UW;
-    auto lds_for = [&](int tw) {
-        const int uw = std::min(g.UW, tw + 2 + 2 * KR), rw = std::min(g.UW, tw + 2);
-        // source rows a band can touch: (TH + 2 + 2*KR) up-sampled rows span at most this many source rows
-        const int rows = std::min(g.R, (int)std::ceil((TH + 2 + 2 * KR) * (double)g.R / g.UH) + 3);
-        return (size_t)4 * ((size_t)rows * g.Cc + (size_t)(TH + 2 + 2 * KR) * uw + (size_t)(TH + 2 + 2 * KR) * rw);
-    };
-    while (lds_for(TW) > 64 * 1024 && TW > 32)
-        TW = (TW + 1) / 2;
-    tiles_x = hp::ceil_div(g.UW, TW), tiles_y = hp::ceil_div(g.UH, TH);
-    Uw_cap = std::min(g.UW, TW + 2 + 2 * KR), Rw_cap = std::min(g.UW, TW + 2);
-    src_rows_cap = std::min(g.R, (int)std::ceil((TH + 2 + 2 * KR) * (double)g.R / g.UH) + 3);
-    peaks_lds = lds_for(TW);
+    // tiling of the up-sampled map for the peaks kernel: strips of <= 238 columns (one thread per column plus a
+    // 9-column halo each side), bands of ~54 rows (each band recomputes 18 halo rows)
+    strips = hp::ceil_div(g.UW, PEAK_THREADS - 2 * (KR + 1));
+    CW = hp::ceil_div(g.UW, strips);
+    bands = std::max(1, (g.UH + 27) / 54);
+    BH = hp::ceil_div(g.UH, bands);
+    bands = hp::ceil_div(g.UH, BH);
+    src_rows_cap = std::min(g.R, (int)std::ceil((BH + 2 * (KR + 1)) * (double)g.R / g.UH) + 3);
+    peaks_lds = (size_t)4 * ((size_t)src_rows_cap * g.Cc + 2 + 4 * KR + 2 + (2 * 2 + 8) * PEAK_THREADS + 4 * (BH + 2 * (KR + 1) + 6));
     limbs_lds = (size_t)4 * 2 * g.R * g.Cc + (size_t)cand_cap * (sizeof(cand_t) + sizeof(int));
     HP_REQUIRE(peaks_lds <= 160 * 1024 && limbs_lds <= 160 * 1024, HP_ERR_INVALID, "paf: feature map too large for LDS tiling");
-    HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_peaks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)peaks_lds));
+    HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_peaks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)peaks_lds));
+    HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_peaks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)peaks_lds));
     HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limbs_lds));
 
     const size_t B = max_batch;
@@ -751,10 +800,13 @@ int hp_paf_set_paf_thresh(hp_paf* p, float thresh)
 
 static int launch_peaks(hp_paf* p, int n, const float* dev_conf, hipStream_t s, float* dump_up, float* dump_smooth, int channels)
 {
-    dim3 grid(p->tiles_x * p->tiles_y, channels, n);
-    hipLaunchKernelGGL(paf_peaks_kernel, grid, dim3(PEAK_THREADS), p->peaks_lds, s, dev_conf, p->g, p->gk, p->conf_thresh,
-        p->TH, p->TW, p->tiles_x, p->src_rows_cap, p->Uw_cap, p->Rw_cap, p->plist.as<dpeak>(), p->pcount.as<int>(), p->peak_cap,
-        dump_up, dump_smooth);
+    dim3 grid(p->bands * p->strips, channels, n);
+    if (dump_up || dump_smooth)
+        hipLaunchKernelGGL(paf_peaks_kernel<true>, grid, dim3(PEAK_THREADS), p->peaks_lds, s, dev_conf, p->g, p->gk, p->conf_thresh,
+            p->BH, p->CW, p->strips, p->src_rows_cap, p->plist.as<dpeak>(), p->pcount.as<int>(), p->peak_cap, dump_up, dump_smooth);
+    else
+        hipLaunchKernelGGL(paf_peaks_kernel<false>, grid, dim3(PEAK_THREADS), p->peaks_lds, s, dev_conf, p->g, p->gk, p->conf_thresh,
+            p->BH, p->CW, p->strips, p->src_rows_cap, p->plist.as<dpeak>(), p->pcount.as<int>(), p->peak_cap, dump_up, dump_smooth);
     HP_HIP_TRY(hipGetLastError());
     return HP_OK;
 }

@@ -146,6 +146,13 @@ int main(int argc, char** argv)
         p.w = w, p.bias = bias, p.alpha = nullptr, p.act = hp::ACT_RELU; hp::set_act(p);
         p.res = hp::tview{ nullptr, 0, 0, 0, 0 }, p.out = hp::tview{ out, c.cout, 0, c.W, c.H * c.W }, p.out_f32 = nullptr, p.npix = c.B * c.H * c.W;
         p.dbg = nullptr;
+        if (c.k == 3)
+            for (int v : {0, 1}) {
+                hp::debug_force_halo_variant(v);
+                float msv = time_ms(s, 300, [&] { CK(hp::launch_conv_mfma(p, s)); });
+                printf("  halo variant %d (tile %d): %.1f us\n", v, hp::conv_mfma_tile(p), msv * 1e3);
+            }
+        hp::debug_force_halo_variant(-1);
         float ms = time_ms(s, 300, [&] { CK(hp::launch_conv_mfma(p, s)); });
         if (c.k == 3 && c.B == 8) {
             unsigned long long* dbg; CK(hipMalloc(&dbg, 64 * 8)); CK(hipMemset(dbg, 0, 64 * 8));
