@@ -22,6 +22,7 @@
 #include "conv_kernels.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace hp {
 
@@ -210,6 +211,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
     }
     const float hi = p.act_hi;
     const bool has_res = p.res.p != nullptr; // uniform
+    const bool clamp_only = !has_res && !p.alpha && p.act_slope == 0.f; // uniform: v > 0 ? min(v, hi) : v * 0 == med3(v, 0, hi) up to the sign of zero
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     HP_ESTAMP();
 #pragma unroll
@@ -247,26 +249,42 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
                 for (int r = 0; r < 8; ++r)
                     rs[ps][r] = (_Float16)0.f;
         }
+        if (clamp_only) { // relu / relu6 family without a residual: bias add + one v_med3_f32 per value
 #pragma unroll
-        for (int ps = 0; ps < G::PASSES; ++ps) {
-            const int pix = ps * G::PPP + prow;
-            const float4 a0 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32);
-            const float4 a1 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32 + 16);
-            const float v[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-            half8 h;
+            for (int ps = 0; ps < G::PASSES; ++ps) {
+                const int pix = ps * G::PPP + prow;
+                const float4 a0 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32);
+                const float4 a1 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32 + 16);
+                const float v[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+                half8 h;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float x = v[r] + bs[r];
-                const float rr = (float)rs[ps][r];
-                if (p.res_before_act)
-                    x += rr;
-                x = x > 0.f ? fminf(x, hi) : x * sl[r];
-                if (!p.res_before_act)
-                    x += rr;
-                h[r] = (_Float16)x;
+                for (int r = 0; r < 8; ++r)
+                    h[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r] + bs[r], 0.f, hi);
+                if (oo[ps] >= 0 && mvalid)
+                    *reinterpret_cast<half8*>(p.out.p + oo[ps] + mc) = h;
             }
-            if (oo[ps] >= 0 && mvalid)
-                *reinterpret_cast<half8*>(p.out.p + oo[ps] + mc) = h;
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < G::PASSES; ++ps) {
+                const int pix = ps * G::PPP + prow;
+                const float4 a0 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32);
+                const float4 a1 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32 + 16);
+                const float v[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+                half8 h;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float x = v[r] + bs[r];
+                    const float rr = (float)rs[ps][r];
+                    if (p.res_before_act)
+                        x += rr;
+                    x = x > 0.f ? fminf(x, hi) : x * sl[r];
+                    if (!p.res_before_act)
+                        x += rr;
+                    h[r] = (_Float16)x;
+                }
+                if (oo[ps] >= 0 && mvalid)
+                    *reinterpret_cast<half8*>(p.out.p + oo[ps] + mc) = h;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // slab reads done before the next pass overwrites it
         __builtin_amdgcn_wave_barrier();
@@ -394,27 +412,39 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
 
     const int steps = p.KH * p.KW * KC;
     const int frow = lane & 31, fk = lane >> 5;
+    int dbg_i = 0;
+#define HP_STAMP()                                                                                                \
+    if (p.dbg && blockIdx.x == 0 && tid == 0)                                                                     \
+        p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
     HP_GLOAD(ra0, rb0);
     if (steps > 1)
         HP_GLOAD(ra1, rb1);
     for (int s = 0; s < steps; s += 2) {
         HP_LSTORE(ra0, rb0, 0);
+        HP_STAMP();
         __syncthreads();
+        HP_STAMP();
         if (s + 2 < steps)
             HP_GLOAD(ra0, rb0);
         __builtin_amdgcn_sched_barrier(0); // keep the prefetch ABOVE the MFMA phase (hipcc otherwise sinks it to its use)
         HP_COMPUTE(0);
         __builtin_amdgcn_sched_barrier(0);
+        HP_STAMP();
         if (s + 1 < steps) {
             HP_LSTORE(ra1, rb1, 1);
+            HP_STAMP();
             __syncthreads();
+            HP_STAMP();
             if (s + 3 < steps)
                 HP_GLOAD(ra1, rb1);
             __builtin_amdgcn_sched_barrier(0);
             HP_COMPUTE(1);
             __builtin_amdgcn_sched_barrier(0);
+            HP_STAMP();
         }
     }
+#undef HP_STAMP
 #undef HP_GLOAD
 #undef HP_LSTORE
 #undef HP_COMPUTE
@@ -786,6 +816,14 @@ int conv_mfma_tile(const conv_params& p)
     if (use_halo(p))
         return halo_variant(p) ? 3000000 + 64 * 1000 + 192 : 3000000 + 128 * 1000 + 128;
     const int BM = (p.Cout_pad % 128 == 0) ? 128 : 64;
+    // one 128 x 320 tile per CU when that covers the layer in a single round of <= 256 equal blocks: fewest bytes per
+    // CU and no tail (a 1x1 512->512 layer at 8 x 46 x 54 pixels is 252 such blocks vs 624 blocks of 128 x 128)
+    static const int big = getenv("HP_CONV_BIGTILE") ? atoi(getenv("HP_CONV_BIGTILE")) : 0;
+    if (big && BM == 128 && p.Cin % 32 == 0) {
+        const long blocks320 = (long)((p.npix + 319) / 320) * (p.Cout_pad / 128);
+        if (blocks320 <= 256 && blocks320 >= 192)
+            return 128 * 1000 + 320;
+    }
     // prefer the 128-pixel tile only when it still fills the 256 CUs at least once
     const long blocks128 = (long)((p.npix + 127) / 128) * (p.Cout_pad / BM);
     const int BN = blocks128 >= 256 ? 128 : 64;
@@ -813,6 +851,8 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
     const int t = conv_mfma_tile(p);
     const int BM = t / 1000, BN = t % 1000;
     const bool k64 = (p.Cin % 64 == 0);
+    if (BM == 128 && BN == 320)
+        return launch_tile<128, 320, 32>(p, s);
     if (BM == 128 && BN == 128)
         return k64 ? launch_tile<128, 128, 64>(p, s) : launch_tile<128, 128, 32>(p, s);
     if (BM == 128 && BN == 64)
@@ -928,6 +968,13 @@ __device__ __forceinline__ void mac8_f16(float (&acc)[8], const u32x4 x, const u
     }
 }
 
+// depthwise activation y = v > 0 ? min(v, hi) : v * slope; the relu / relu6 family (slope == 0) is one v_med3_f32
+template <bool CLAMP>
+__device__ __forceinline__ float dw_act(float v, float slope, float hi)
+{
+    return CLAMP ? __builtin_amdgcn_fmed3f(v, 0.f, hi) : (v > 0.f ? fminf(v, hi) : v * slope);
+}
+
 constexpr int DW_TH = 8, DW_TW = 8, DW_CG = 8; // output tile 8x8 pixels, 8 chunks of 8 channels = 64 channels
 
 template <int NLD> // 16-byte loads per thread per tile = ceil(IH*IW*8 / 256)
@@ -939,6 +986,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const dw_params p, int t
     const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1; // extent of the zero halo in HBM
     const int chunk = tid & 7;
     const int nelem = IH * IW * DW_CG;
+    const bool clamp_only = p.act_slope == 0.f; // uniform
 
     // persistent block: the loads of tile t+1 are in flight (in registers) while tile t is computed from LDS
     half8 nxt[NLD];
@@ -995,6 +1043,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const dw_params p, int t
         if (c0 + chunk * 8 < p.C) {
             const float4 b0 = *reinterpret_cast<const float4*>(p.bias + c0 + chunk * 8);
             const float4 b1 = *reinterpret_cast<const float4*>(p.bias + c0 + chunk * 8 + 4);
+            auto passes = [&](auto clamp_tag) {
+            constexpr bool CLAMP = decltype(clamp_tag)::value;
 #pragma unroll 1 // keep the live set small (occupancy hides the LDS / store latency here, not ILP)
             for (int pass = 0; pass < DW_TH * DW_TW * DW_CG / 256; ++pass) {
                 const int pix = (tid >> 3) + pass * 32;
@@ -1017,10 +1067,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const dw_params p, int t
                     half8 h;
 #pragma unroll
                     for (int r = 0; r < 8; ++r)
-                        h[r] = (_Float16)(acc[r] > 0.f ? fminf(acc[r], p.act_hi) : acc[r] * p.act_slope);
+                        h[r] = (_Float16)dw_act<CLAMP>(acc[r], p.act_slope, p.act_hi);
                     *reinterpret_cast<half8*>(p.out.p + tv_off(p.out, b, oy, ox) + c0 + chunk * 8) = h;
                 }
             }
+            };
+            if (clamp_only)
+                passes(std::true_type{});
+            else
+                passes(std::false_type{});
         }
         __syncthreads(); // the tile in LDS is consumed before the next one overwrites it
     }
@@ -1053,6 +1108,324 @@ hipError_t launch_dwconv3x3(const dw_params& p_in, hipStream_t s)
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Depthwise 3x3 + pointwise 1x1 in ONE launch (MobileNet's separable block, backbones.py MobilenetDilated): the
+// depthwise output never exists in HBM.  Every kernel boundary on this chip sends the whole activation through the
+// memory-side fabric (the per-XCD L2s are not coherent with each other), so the unfused pair writes and re-reads
+// B*H*W*C halves for nothing and pays the depthwise kernel's own launch.
+//   block  = one (image, TH x TW output-pixel tile) x ALL output channels; 4 wavefronts split the output channels
+//            (Cout_pad / 4 rows each = TM 32-row MFMA tiles), every wavefront covers all NT = TH*TW/32 pixel tiles.
+//   K loop = chunks of CK input channels: the chunk's input halo tile goes global -> registers -> LDS (prefetched one
+//            chunk ahead), the 256 threads evaluate the depthwise taps from LDS with the same arithmetic as
+//            dwconv3x3_kernel (bias first, fp32 v_fma_mix accumulation tap by tap, activation, RN to fp16) and drop the
+//            result into the swizzled B tile; the pointwise MFMAs read B from LDS and A straight from global memory:
+//            the 1x1 weights are packed in MFMA-fragment order [32-row tile][k16 step][lane][8 halves], so one
+//            wavefront-wide 16-byte load is one fully coalesced 1 KB fragment that only this wavefront needs - no
+//            LDS staging, no barrier for A, re-issued for the next chunk as soon as its MFMAs are done.
+//   epilogue = conv_epilogue_staged (bias, activation, 16-byte NHWC stores, 64 * TM bytes contiguous per pixel).
+// Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also drains vmcnt, i.e. every global
+// prefetch in flight (measured: 1.5k cycles per K-chunk in sepconv_kernel when the weight prefetch crosses a barrier).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int TM, int NT, int TH, int TW, int S, int D, int CK>
+__global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int tiles_x, int tiles_y)
+{
+    constexpr int NPX = TH * TW;
+    static_assert(NPX == NT * 32, "pixel tile = NT MFMA tiles");
+    constexpr int IH = (TH - 1) * S + 2 * D + 1, IW = (TW - 1) * S + 2 * D + 1;
+    constexpr int CG = CK / 8;                       // 16-byte channel groups per pixel and chunk
+    constexpr int PIECES = IH * IW * CG;             // 16-byte pieces of one halo chunk
+    constexpr int NLD = (PIECES + 255) / 256;
+    constexpr int ITEMS = NPX * CG / 256;            // (pixel, channel group) depthwise items per thread and chunk
+    static_assert(NPX * CG % 256 == 0, "whole depthwise items per thread");
+    constexpr int KS = CK / 16;                      // k16 steps per chunk
+    constexpr int HALO_BYTES = PIECES * 16;
+    constexpr int B_BYTES = NPX * CK * 2;
+    constexpr int DWW_BYTES = 9 * SEP_CMAX * 2 + SEP_CMAX * 4;
+    constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * B_BYTES + DWW_BYTES;
+    constexpr int EPI_BYTES = 4 * stage_geom<TM>::SLAB;
+    constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    unsigned char* const s_halo = lds; // two buffers: chunk k lives in buffer k & 1
+    unsigned char* const s_b = lds + 2 * HALO_BYTES;
+    __half* const s_dww = reinterpret_cast<__half*>(lds + 2 * HALO_BYTES + 2 * B_BYTES); // [9][C]
+    float* const s_dwb = reinterpret_cast<float*>(s_dww + 9 * SEP_CMAX);              // [C]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int iy0 = y0 * S - p.pad_t, ix0 = x0 * S - p.pad_l;
+    const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1; // extent of the zero halo in HBM
+    const int C = p.C, KQ = C / 16, NCH = C / CK;
+
+    // ---- pointwise weights of chunk 0: a[ks][i] = fragment (32-row tile wave*TM + i, k16 step ks)
+    const int mt0 = (blockIdx.y * 4 + wave) * TM; // first 32-row tile of this wavefront (blockIdx.y: slab of 128 * TM output channels)
+    const __half* wfrag = p.pw.w + ((size_t)mt0 * KQ * 64 + lane) * 8;
+    u32x4 a[KS][TM];
+#define HP_ALOAD(KSI, CHUNK)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                \
+        a[KSI][i] = *reinterpret_cast<const u32x4*>(wfrag + ((size_t)i * KQ + (CHUNK) * KS + (KSI)) * 512);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        HP_ALOAD(ks, 0);
+
+    // ---- halo chunk loader (registers)
+    u32x4 hv[NLD];
+    const __half* hsrc[NLD]; // this thread's halo pieces: address of chunk 0 and the out-of-tensor mask, fixed for the kernel
+    unsigned hmask[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = min(tid + k * 256, PIECES - 1);
+        const int hp = i / CG, c = i - hp * CG;
+        const int hy = hp / IW, hx = hp - hy * IW;
+        const int y = iy0 + hy, x = ix0 + hx;
+        hmask[k] = (y <= ymax && x <= xmax) ? 0xffffffffu : 0u;
+        hsrc[k] = p.in.p + tv_off(p.in, b, min(y, ymax), min(x, xmax)) + c * 8;
+    }
+#define HP_HLOAD(CHUNK)                                                                                           \
+    _Pragma("unroll") for (int k = 0; k < NLD; ++k)                                                               \
+        hv[k] = *reinterpret_cast<const u32x4*>(hsrc[k] + (CHUNK) * CK);
+    HP_HLOAD(0);
+    int dbg_i = 0;
+#define HP_STAMP()                                                                                                \
+    if (p.pw.dbg && blockIdx.x == 0 && tid == 0)                                                                  \
+        p.pw.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
+
+    // depthwise weights + bias -> LDS (once)
+    for (int i = tid; i < 9 * C / 8; i += 256)
+        reinterpret_cast<u32x4*>(s_dww)[i] = reinterpret_cast<const u32x4*>(p.dw_w)[i];
+    for (int i = tid; i < C / 4; i += 256)
+        reinterpret_cast<float4*>(s_dwb)[i] = reinterpret_cast<const float4*>(p.dw_bias)[i];
+
+    floatx16 acc[TM][NT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+
+    const int g = tid % CG;          // this thread's channel group inside the chunk
+    const int frow = lane & 31, fk = lane >> 5;
+    const float dw_hi = p.dw_hi;
+    // tile-local LDS offsets of this thread's depthwise items (tap (0,0) of the halo tile; B-tile slot)
+    int xoff[ITEMS], boff[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int pix = (tid + r * 256) / CG;
+        const int py = pix / TW, px = pix - py * TW;
+        xoff[r] = ((py * S) * IW + px * S) * CG * 16 + g * 16;
+        boff[r] = lds_off<CK>(pix, g);
+    }
+
+    // One schedule "slot" = one depthwise unit (a tap = 8 v_fma_mix, or an item's activation + B-tile write) followed by
+    // its share of the chunk's MFMAs: the units of chunk kc+1 sit in the shadows of the MFMAs of chunk kc (a wave
+    // issues in order: the VALU work has to be BETWEEN the MFMAs in program order, cdna_hip_programming.md T19).
+    // sched_barrier(0) pins the order.  An item's nine inputs are re-loaded tap by tap for the NEXT item as soon as the
+    // current one has used them, so the LDS latency has a whole item to hide in.
+    constexpr int NM = KS * TM * NT; // MFMAs per chunk and wave
+    constexpr int NU = ITEMS * 10;   // depthwise units per chunk and thread: 9 taps + 1 finish per item
+    u32x4 wv[9], x[9];
+    float v[8];
+    half8 fb[2][NT];
+    // DW: emit the depthwise units of chunk `kd` into B buffer kd & 1;  MM: emit the MFMAs of chunk `km` (B buffer km & 1)
+    // (the depthwise activation is relu / relu6 here, one v_med3_f32: a second code path for the general piecewise-linear
+    // form would duplicate the MFMA schedule and hipcc then spills the accumulators at the join)
+    auto phase = [&](auto dw_tag, auto mm_tag, int kd, int km, int kn) {
+        constexpr bool DW = decltype(dw_tag)::value, MM = decltype(mm_tag)::value;
+        unsigned char* const bt_d = s_b + (kd & 1) * B_BYTES;
+        const unsigned char* const hl = s_halo + (kd & 1) * HALO_BYTES;
+        const unsigned char* const bt_m = s_b + (km & 1) * B_BYTES;
+        const int cg0 = kd * CK + g * 8;
+        float4 b0, b1;
+        if (DW) {
+            b0 = *reinterpret_cast<const float4*>(s_dwb + cg0), b1 = *reinterpret_cast<const float4*>(s_dwb + cg0 + 4);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+                wv[t9] = *reinterpret_cast<const u32x4*>(s_dww + (size_t)t9 * C + cg0);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+                x[t9] = *reinterpret_cast<const u32x4*>(hl + xoff[0] + (((t9 / 3) * D) * IW + (t9 % 3) * D) * CG * 16);
+        }
+        if (MM) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                fb[0][j] = *reinterpret_cast<const half8*>(bt_m + lds_off<CK>(j * 32 + frow, fk));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int SLOTS = DW ? NU : 1;
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            if (DW) {
+                const int r = u / 10, q = u % 10;
+                if (q == 0) {
+                    v[0] = b0.x, v[1] = b0.y, v[2] = b0.z, v[3] = b0.w, v[4] = b1.x, v[5] = b1.y, v[6] = b1.z, v[7] = b1.w;
+                }
+                if (q < 9) {
+                    mac8_f16(v, x[q], wv[q]);
+                    if (r + 1 < ITEMS)
+                        x[q] = *reinterpret_cast<const u32x4*>(hl + xoff[r + 1] + (((q / 3) * D) * IW + (q % 3) * D) * CG * 16);
+                } else {
+                    half8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        h[e] = (_Float16)dw_act<true>(v[e], 0.f, dw_hi);
+                    *reinterpret_cast<half8*>(bt_d + boff[r]) = h;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MM) {
+                // constant trip count + predicate: hipcc unrolls inner loops first, variable bounds would leave a real loop
+                // (and the register arrays in scratch)
+                constexpr int PER = DW ? (NM + NU - 1) / NU : NM;
+                const int m_lo = DW ? u * NM / NU : 0, m_hi = DW ? (u + 1) * NM / NU : NM;
+#pragma unroll
+                for (int mm = 0; mm < PER; ++mm) {
+                    const int m = m_lo + mm;
+                    if (m >= m_hi)
+                        continue;
+                    const int ks = m / (TM * NT), idx = m % (TM * NT), i = idx / NT, j = idx % NT;
+                    if (idx == 0 && ks + 1 < KS) {
+#pragma unroll
+                        for (int jj = 0; jj < NT; ++jj)
+                            fb[(ks + 1) & 1][jj] = *reinterpret_cast<const half8*>(bt_m + lds_off<CK>(jj * 32 + frow, (ks + 1) * 2 + fk));
+                    }
+                    half8 fa;
+                    __builtin_memcpy(&fa, &a[ks][i], 16);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                    if (idx == TM * NT - 1) {
+#pragma unroll
+                        for (int ii = 0; ii < TM; ++ii)
+                            a[ks][ii] = *reinterpret_cast<const u32x4*>(wfrag + ((size_t)ii * KQ + kn * KS + ks) * 512);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto halo_to_lds = [&](int chunk) {
+        unsigned char* const dst = s_halo + (chunk & 1) * HALO_BYTES;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (tid + k * 256 < PIECES)
+                *reinterpret_cast<u32x4*>(dst + (size_t)(tid + k * 256) * 16) = hv[k] & hmask[k]; // mask HERE: the loads stay in flight
+    };
+
+    // ---- chunk 0: halo -> LDS, depthwise -> B[0]; chunk 1's halo lands meanwhile
+    halo_to_lds(0);
+    {
+        const int k1 = min(1, NCH - 1);
+        HP_HLOAD(k1);
+    }
+    lds_barrier(); // halo chunk 0 and the depthwise weights visible
+    HP_STAMP();
+    phase(std::true_type{}, std::false_type{}, 0, 0, 0);
+    halo_to_lds(1);
+    HP_STAMP();
+    // ---- steady state, ONE barrier per chunk: depthwise of chunk kc+1 under the MFMAs of chunk kc, then the halo of
+    // chunk kc+2 (requested at the top of the iteration) goes into the buffer chunk kc vacated
+    for (int kc = 0; kc + 1 < NCH; ++kc) {
+        lds_barrier(); // B[kc&1] and halo[(kc+1)&1] complete; B[(kc+1)&1] and halo[kc&1] free
+        HP_STAMP();
+        const int k2 = min(kc + 2, NCH - 1); // unconditional prefetches (the last is redundant): straight-line code lets hipcc
+        HP_HLOAD(k2);                        // count vmcnt exactly instead of draining at every control-flow join
+        __builtin_amdgcn_sched_barrier(0);
+        phase(std::true_type{}, std::true_type{}, kc + 1, kc, kc + 1);
+        HP_STAMP();
+        halo_to_lds(kc + 2);
+        HP_STAMP();
+    }
+    // ---- last chunk: MFMAs only
+    lds_barrier();
+    phase(std::false_type{}, std::true_type{}, 0, NCH - 1, NCH - 1);
+    HP_STAMP();
+#undef HP_STAMP
+#undef HP_ALOAD
+#undef HP_HLOAD
+
+    int pb[NT], py[NT], px[NT];
+    bool pv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + (lane & 31);
+        pb[j] = b;
+        py[j] = y0 + n / TW;
+        px[j] = x0 + n % TW;
+        pv[j] = py[j] < p.OH && px[j] < p.OW;
+    }
+    __syncthreads(); // every wave is done with the main-loop LDS before the slabs overwrite it
+    conv_epilogue_staged<TM, NT>(p.pw, acc, mt0 * 32, lane, lds + wave * stage_geom<TM>::SLAB, pb, py, px, pv);
+}
+
+template <int TM, int NT, int TH, int TW, int S, int D, int CK>
+static hipError_t launch_sep(const sep_params& p, hipStream_t s)
+{
+    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
+    // blockIdx.y: slabs of 128 * TM output channels; each slab recomputes the depthwise tile (cheap next to a second
+    // pass through the fabric) and two slabs of one CU cover each other's depthwise / MFMA / store phases
+    hipLaunchKernelGGL((sepconv_kernel<TM, NT, TH, TW, S, D, CK>), dim3(tiles_x * tiles_y * p.B, p.pw.Cout_pad / (128 * TM)), dim3(256), 0, s, p, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+// which instantiation serves (Cout_pad, stride, dilation, C); 0 = none (the engine then keeps the two launches)
+int sepconv_variant_for(int C, int cout_pad, int stride, int dil)
+{
+    if (C > SEP_CMAX || C % 32 || cout_pad % 128)
+        return 0;
+    const int tm = cout_pad / 128;
+    if (tm == 1 && stride == 1 && dil == 1)
+        return 1;
+    if (tm == 1 && stride == 2 && dil == 1)
+        return 2;
+    if (C % 64)
+        return 0;
+    if (tm == 2 && stride == 2 && dil == 1)
+        return 3;
+    if (tm == 2 && stride == 1 && dil == 1)
+        return 4;
+    if (tm == 4 && stride == 1 && dil == 1)
+        return 5;
+    if (tm == 4 && stride == 1 && dil == 2)
+        return 6;
+    return 0;
+}
+
+int sepconv_variant(const sep_params& p)
+{
+    const conv_params& q = p.pw;
+    if (q.res.p || q.out_f32 || !fast_epilogue(q) || p.in.coff % 8 || p.halo < p.dil || p.dw_slope != 0.f)
+        return 0;
+    return sepconv_variant_for(p.C, q.Cout_pad, p.stride, p.dil);
+}
+
+hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
+{
+    switch (sepconv_variant(p)) {
+    case 1:
+        return launch_sep<1, 12, 16, 24, 1, 1, 32>(p, s);
+    case 2:
+        return launch_sep<1, 6, 8, 24, 2, 1, 32>(p, s);
+    case 3:
+        return launch_sep<2, 3, 8, 12, 2, 1, 64>(p, s);
+    case 4:
+        return launch_sep<2, 3, 8, 12, 1, 1, 64>(p, s);
+    case 5:
+        return launch_sep<4, 3, 8, 12, 1, 1, 64>(p, s);
+    case 6:
+        return launch_sep<4, 3, 8, 12, 1, 2, 64>(p, s);
+    default:
+        return hipErrorInvalidValue;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

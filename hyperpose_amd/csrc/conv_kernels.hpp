@@ -97,6 +97,25 @@ struct dw_params {
 // Depthwise 3x3 (VALU, HBM/L2-bound): one thread = one output pixel x 8 channels.
 hipError_t launch_dwconv3x3(const dw_params& p, hipStream_t s);
 
+// Depthwise 3x3 + pointwise 1x1 fused (sepconv_kernel).  `pw` describes the pointwise half exactly like a 1x1
+// conv_params (Cin = C, bias, activation, out, OH/OW/npix) except that pw.w holds the weights in MFMA-fragment order:
+// half index (((m / 32) * (C / 16) + k / 16) * 64 + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8 for row m, input channel k.
+constexpr int SEP_CMAX = 1024;
+struct sep_params {
+    tview in;
+    int B, H, W, OH, OW, C;
+    int stride, dil, pad_t, pad_l;
+    int halo;            // zero-halo width of the input tensor in HBM (pixels)
+    const __half* dw_w;  // [9][C]
+    const float* dw_bias; // [C]
+    float dw_slope, dw_hi; // depthwise activation as y = v > 0 ? min(v, hi) : v * slope
+    conv_params pw;
+};
+// 0 when no fused instantiation serves this pair (the caller keeps dwconv3x3 + conv_mfma)
+int sepconv_variant(const sep_params& p);
+int sepconv_variant_for(int C, int cout_pad, int stride, int dil); // the pointer-free part of the same decision
+hipError_t launch_sepconv(const sep_params& p, hipStream_t s);
+
 struct pool_params {
     tview in;
     int B, H, W, OH, OW, C;

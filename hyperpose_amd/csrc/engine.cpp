@@ -27,6 +27,7 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 struct tensor_info {
     bool defined = false;
+    bool elided = false;     // produced and consumed inside one fused launch: never materialised in HBM
     int H = 0, W = 0, C = 0; // C = total channels written
     int cs = 0;              // channel stride of the buffer
     int P = 0;               // zero halo (pixels) around every image: the largest padding any consumer needs
@@ -60,8 +61,10 @@ struct step {
     hp::first_conv_params fp{};
     hp::dw_params dp{};
     hp::pool_params pp{};
+    hp::sep_params sp{}; // op == OP_SEPCONV: depthwise layer `layer` fused with the pointwise layer `layer + 1`
     double flops = 0, bytes = 0; // per frame
 };
+constexpr int OP_SEPCONV = 100; // schedule-only op code (not part of the hp_layer ABI)
 
 void same_pad(int in, int k, int stride, int dil, int& out, int& pad_before)
 {
@@ -165,9 +168,40 @@ int hp_engine::build(const hp_engine_desc* d)
             tensors[L.in]->P = std::max({ tensors[L.in]->P, g.pt, g.pl, pb_y, pb_x });
         }
     }
+    // ---- separable blocks: a depthwise layer whose only consumer is the next layer, a plain 1x1 convolution, runs
+    // as ONE launch (sepconv_kernel) and its output tensor is never materialised.  HP_NO_FUSE=1 keeps the two launches.
+    std::vector<char> fuse_with_next(layers.size(), 0);
+    if (!getenv("HP_NO_FUSE")) {
+        for (size_t i = 0; i + 1 < layers.size(); ++i) {
+            const hp_layer &A = layers[i], &Bn = layers[i + 1];
+            if (A.op != HP_OP_DWCONV || A.kh != 3 || A.kw != 3 || A.in == 0 || A.out_coff != 0 || A.in_coff % 8)
+                continue;
+            if (Bn.op != HP_OP_CONV || Bn.kh != 1 || Bn.kw != 1 || Bn.stride != 1 || Bn.in != A.out || Bn.in_coff != 0 || Bn.cin != A.cout
+                || Bn.res >= 0 || Bn.out == A.out || Bn.cout % 8 || Bn.out_coff % 8)
+                continue;
+            if ((A.act != HP_ACT_RELU && A.act != HP_ACT_RELU6) || Bn.act == HP_ACT_SIGMOID || Bn.act == HP_ACT_SOFTPLUS)
+                continue; // the fused kernel evaluates the depthwise activation as one clamp
+            if (tensors[A.out]->C != A.cout)
+                continue;
+            bool sole = true;
+            for (size_t j = 0; j < layers.size(); ++j)
+                if (j != i + 1 && (layers[j].in == A.out || layers[j].res == A.out || (j != i && layers[j].out == A.out)))
+                    sole = false;
+            for (int o = 0; o < d->n_outputs; ++o)
+                if (d->outputs[o].tensor == A.out || d->outputs[o].tensor == Bn.out)
+                    sole = false; // network outputs keep the generic epilogue (fp32 NCHW copy)
+            if (!sole)
+                continue;
+            const int cout_pad = round_up(Bn.cout, 128);
+            if (Bn.cout <= 64 || !hp::sepconv_variant_for(A.cin, cout_pad, A.stride, A.dil))
+                continue; // (<= 64 output channels would idle half of the fused kernel's wavefronts: measured slower than two launches)
+            fuse_with_next[i] = 1;
+            tensors[A.out]->elided = true;
+        }
+    }
     for (size_t t = 1; t < tensors.size(); ++t) {
         tensor_info& ti = *tensors[t];
-        if (!ti.defined)
+        if (!ti.defined || ti.elided)
             continue;
         ti.cs = round_up(ti.C, 32);
         const size_t bytes = (size_t)max_batch * (ti.H + 2 * ti.P) * (ti.W + 2 * ti.P) * ti.cs * sizeof(__half);
@@ -315,6 +349,81 @@ int hp_engine::build(const hp_engine_desc* d)
             HP_REQUIRE(hp::set_act(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
             st.flops = 2.0 * opix * L.cout * taps * L.cin;
             st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cout * 2 + (double)nw * 2;
+        } else if (L.op == HP_OP_DWCONV && fuse_with_next[i]) {
+            const hp_layer& Pn = layers[i + 1];
+            tensor_info& tp = *tensors[Pn.out];
+            const float* w = blob(L.w_off, (size_t)L.cin * 9, "weights", i);
+            if (!w)
+                return HP_ERR_INVALID;
+            std::vector<__half> dpacked((size_t)9 * L.cin);
+            for (int c = 0; c < L.cin; ++c)
+                for (int t = 0; t < 9; ++t)
+                    dpacked[(size_t)t * L.cin + c] = __float2half(w[(size_t)c * 9 + t]);
+            std::vector<float> dbias(L.cin, 0.f);
+            if (L.b_off >= 0) {
+                const float* b = blob(L.b_off, L.cin, "bias", i);
+                if (!b)
+                    return HP_ERR_INVALID;
+                std::copy(b, b + L.cin, dbias.begin());
+            }
+            const int C = L.cin, KQ = C / 16, cout_pad = round_up(Pn.cout, 128);
+            const float* pwf = blob(Pn.w_off, (size_t)Pn.cout * C, "weights", i + 1);
+            if (!pwf)
+                return HP_ERR_INVALID;
+            // MFMA-fragment order: [32-row tile][k16 step][lane = (k % 16 / 8) * 32 + m % 32][k % 8]
+            std::vector<__half> ppacked((size_t)cout_pad * C, __float2half(0.f));
+            for (int m = 0; m < Pn.cout; ++m)
+                for (int k = 0; k < C; ++k)
+                    ppacked[((((size_t)(m / 32) * KQ + k / 16) * 64) + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8] = __float2half(pwf[(size_t)m * C + k]);
+            std::vector<float> pbias(cout_pad, 0.f), alpha;
+            if (Pn.b_off >= 0) {
+                const float* b = blob(Pn.b_off, Pn.cout, "bias", i + 1);
+                if (!b)
+                    return HP_ERR_INVALID;
+                std::copy(b, b + Pn.cout, pbias.begin());
+            }
+            st.op = OP_SEPCONV;
+            auto& p = st.sp;
+            void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
+            HP_TRY(upload(dpacked.data(), dpacked.size() * sizeof(__half), &d0));
+            HP_TRY(upload(dbias.data(), dbias.size() * sizeof(float), &d1));
+            HP_TRY(upload(ppacked.data(), ppacked.size() * sizeof(__half), &d2));
+            HP_TRY(upload(pbias.data(), pbias.size() * sizeof(float), &d3));
+            p.in = ti.view(L.in_coff);
+            p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.C = C, p.stride = L.stride, p.dil = L.dil;
+            p.pad_t = g.pt, p.pad_l = g.pl, p.halo = ti.P;
+            p.dw_w = (const __half*)d0, p.dw_bias = (const float*)d1;
+            {
+                hp::conv_params tmp{};
+                tmp.act = L.act, tmp.act_param = L.act_param, tmp.alpha = nullptr;
+                HP_REQUIRE(hp::set_act(tmp), HP_ERR_INVALID, "layer %zu: unsupported depthwise activation %d", i, L.act);
+                p.dw_slope = tmp.act_slope, p.dw_hi = tmp.act_hi;
+            }
+            auto& q = p.pw;
+            q.w = (const __half*)d2, q.bias = (const float*)d3, q.alpha = nullptr;
+            if (Pn.act == HP_ACT_PRELU) {
+                alpha.assign(cout_pad, 0.f);
+                const float* a = blob(Pn.alpha_off, Pn.cout, "prelu slopes", i + 1);
+                if (!a)
+                    return HP_ERR_INVALID;
+                std::copy(a, a + Pn.cout, alpha.begin());
+                void* da = nullptr;
+                HP_TRY(upload(alpha.data(), alpha.size() * sizeof(float), &da));
+                q.alpha = (const float*)da;
+            }
+            q.H = g.OH, q.W = g.OW, q.OH = g.OH, q.OW = g.OW, q.Cin = C, q.Cout = Pn.cout, q.Cout_pad = cout_pad;
+            q.KH = q.KW = 1, q.stride = 1, q.dil = 1, q.pad_t = q.pad_l = 0;
+            q.act = Pn.act, q.act_param = Pn.act_param;
+            q.res = hp::tview{ nullptr, 0, 0, 0, 0 }, q.res_before_act = 0;
+            q.out = tp.view(Pn.out_coff);
+            q.out_f32 = nullptr, q.dbg = nullptr;
+            HP_REQUIRE(hp::set_act(q), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv", i + 1, Pn.act);
+            HP_REQUIRE(hp::sepconv_variant(p) != 0, HP_ERR_INVALID, "layer %zu: no fused separable kernel for this block (set HP_NO_FUSE=1)", i);
+            st.flops = 2.0 * opix * L.cin * 9 + 2.0 * opix * Pn.cout * C;
+            st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * Pn.cout * 2 + (double)Pn.cout * C * 2;
+            steps.push_back(st);
+            ++i; // the pointwise layer is part of this step
+            continue;
         } else if (L.op == HP_OP_DWCONV) {
             HP_REQUIRE(L.kh == 3 && L.kw == 3, HP_ERR_INVALID, "layer %zu: depthwise kernels are 3x3", i);
             HP_REQUIRE(L.cin % 8 == 0 && L.in_coff % 8 == 0 && L.out_coff % 8 == 0, HP_ERR_INVALID, "layer %zu: depthwise needs 8-aligned channels", i);
@@ -372,6 +481,9 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     } else if (st.op == HP_OP_CONV) {
         st.cp.B = n, st.cp.npix = n * st.cp.OH * st.cp.OW;
         HP_HIP_TRY(hp::launch_conv_mfma(st.cp, s));
+    } else if (st.op == OP_SEPCONV) {
+        st.sp.B = n, st.sp.pw.B = n, st.sp.pw.npix = n * st.sp.OH * st.sp.OW;
+        HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
     } else if (st.op == HP_OP_DWCONV) {
         st.dp.B = n;
         HP_HIP_TRY(hp::launch_dwconv3x3(st.dp, s));
@@ -527,6 +639,7 @@ int hp_engine_output_to_host(hp_engine* e, int i, int n, float* host)
 int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int shape[3])
 {
     HP_REQUIRE(e && tensor > 0 && tensor < (int)e->tensors.size() && e->tensors[tensor]->defined, HP_ERR_INVALID, "hp_engine_debug_tensor: bad tensor %d", tensor);
+    HP_REQUIRE(!e->tensors[tensor]->elided, HP_ERR_STATE, "hp_engine_debug_tensor: tensor %d lives only inside a fused separable block (HP_NO_FUSE=1 materialises it)", tensor);
     const tensor_info& ti = *e->tensors[tensor];
     if (shape)
         shape[0] = ti.C, shape[1] = ti.H, shape[2] = ti.W;
@@ -563,7 +676,7 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
         HP_HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
         if (out && k < cap) {
             out[k].layer = st.layer, out[k].op = st.op;
-            out[k].tile = (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp) : 0;
+            out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp) : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp) : 0;
             out[k].ms = ms / iters;
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
         }

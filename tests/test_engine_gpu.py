@@ -286,3 +286,52 @@ def test_pifpaf_resnet50_end_to_end(hp):
         for b in range(2):
             refh = loader.ref_pifpaf_process(got[b][0][1].reshape(19, 9, 13, 13), got[b][1][1].reshape(17, 5, 13, 13), 97, 97)
             assert humans[b].tobytes() == refh.tobytes()
+
+
+@pytest.mark.parametrize("c,cout,stride,dil,h,w", [
+    (32, 128, 1, 1, 40, 56),     # variant 1: 128-row tile, 16x24 pixels, 32-channel chunks
+    (64, 128, 2, 1, 45, 61),     # variant 2: stride 2 (odd input: SAME pads 1/1)
+    (128, 256, 2, 1, 46, 60),    # variant 3: stride 2 (even input: SAME pads 0/1)
+    (256, 256, 1, 1, 23, 27),    # variant 4
+    (256, 512, 1, 1, 23, 27),    # variant 5
+    (512, 512, 1, 2, 19, 21),    # variant 6: dilation 2
+    (96, 72, 1, 1, 21, 30),      # ragged channels: Cout not a multiple of 32, C = 3 chunks of 32
+])
+def test_fused_separable_block(hp, monkeypatch, c, cout, stride, dil, h, w):
+    """depthwise 3x3 + pointwise 1x1 as one launch (sepconv_kernel): against the oracle, and bit-for-bit against
+    the two-launch schedule (same fp32 depthwise arithmetic, same fp16 rounding point, same MFMA order)."""
+    net = Net(c + cout)
+    a = net.conv(0, 3, c, 3, 1)
+    d = net.conv(a, c, c, 3, stride, dil, op=E.OP_DWCONV, act=E.ACT_RELU6)
+    y = net.conv(d, c, cout, 1, act=E.ACT_RELU)
+    z = net.conv(y, cout, 32, 1, act=E.ACT_NONE)  # the fused block must not be a network output
+    fr = _frames(3, h, w, seed=c)
+    outs = [Out("z", z, 0, 32)]
+    eng, got, ref = _run_both(net, outs, fr, h, w)
+    _check(got, ref, 3)
+    tiles = [p["tile"] for p in eng.profile(3, 1)]
+    assert any(t >= 4000000 for t in tiles), tiles  # the fused kernel really ran
+    mid = eng.debug_tensor(y, 3)
+    monkeypatch.setenv("HP_NO_FUSE", "1")
+    eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 3)
+    got2 = eng2.inference(fr)
+    assert not any(p["tile"] >= 4000000 for p in eng2.profile(3, 1))
+    assert np.array_equal(mid, eng2.debug_tensor(y, 3))
+    for b in range(3):
+        assert np.array_equal(got[b][0][1], got2[b][0][1])
+    with pytest.raises(Exception):
+        eng.debug_tensor(d, 3)  # never materialised
+
+
+def test_lw_openpose_fused_equals_unfused(hp, monkeypatch):
+    m = E.Model("lw_openpose_mobilenet", 432, 368)
+    w = m.init_weights(7)
+    fr = _frames(2, 368, 432, seed=4)
+    eng = E.Engine.from_model(m, w, max_batch=2)
+    assert sum(p["tile"] >= 4000000 for p in eng.profile(2, 1)) == 10  # every MobileNet separable block with > 64 outputs
+    got = eng.inference(fr)
+    monkeypatch.setenv("HP_NO_FUSE", "1")
+    ref = E.Engine.from_model(m, w, max_batch=2).inference(fr)
+    for b in range(2):
+        for i in range(2):
+            assert np.array_equal(got[b][i][1], ref[b][i][1])

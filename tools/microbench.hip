@@ -129,6 +129,35 @@ int main(int argc, char** argv)
             CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(w)); CK(hipFree(bias));
         }
     }
+    {   // fused depthwise + pointwise block at the LW-OpenPose backbone shape
+        for (int C : {512, 128}) {
+            const int B = 8, H = 46, W = 54, P = 1, Hp = H + 2, Wp = W + 2, cout = C;
+            __half *in, *out, *dww, *pww; float *dwb, *pwb;
+            size_t n_in = (size_t)B * Hp * Wp * C, n_out = (size_t)B * H * W * cout;
+            CK(hipMalloc(&in, n_in * 2)); CK(hipMalloc(&out, n_out * 2)); CK(hipMalloc(&dww, 9 * C * 2)); CK(hipMalloc(&pww, (size_t)cout * C * 2));
+            CK(hipMalloc(&dwb, C * 4)); CK(hipMalloc(&pwb, cout * 4));
+            CK(hipMemset(in, 0x11, n_in * 2)); CK(hipMemset(dww, 0x11, 9 * C * 2)); CK(hipMemset(pww, 0x11, (size_t)cout * C * 2));
+            CK(hipMemset(dwb, 0, C * 4)); CK(hipMemset(pwb, 0, cout * 4));
+            hp::sep_params p{};
+            p.in = hp::tview{ in + ((size_t)P * Wp + P) * C, C, 0, Wp, Hp * Wp };
+            p.B = B, p.H = H, p.W = W, p.OH = H, p.OW = W, p.C = C, p.stride = 1, p.dil = 1, p.pad_t = p.pad_l = 1, p.halo = 1;
+            p.dw_w = dww, p.dw_bias = dwb, p.dw_slope = 0.f, p.dw_hi = 6.f;
+            auto& q = p.pw;
+            q.w = pww, q.bias = pwb, q.alpha = nullptr, q.act = hp::ACT_RELU; hp::set_act(q);
+            q.B = B, q.H = H, q.W = W, q.OH = H, q.OW = W, q.Cin = C, q.Cout = cout, q.Cout_pad = cout, q.KH = q.KW = 1, q.stride = 1, q.dil = 1;
+            q.res = hp::tview{ nullptr, 0, 0, 0, 0 }, q.out = hp::tview{ out, cout, 0, W, H * W }, q.out_f32 = nullptr, q.npix = B * H * W, q.dbg = nullptr;
+            float ms = time_ms(s, 200, [&] { CK(hp::launch_sepconv(p, s)); });
+            unsigned long long* dbg; CK(hipMalloc(&dbg, 128 * 8)); CK(hipMemset(dbg, 0, 128 * 8));
+            q.dbg = dbg; CK(hp::launch_sepconv(p, s)); CK(hipStreamSynchronize(s));
+            unsigned long long h[128]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            printf("sepconv C=%d->%d variant %d: %.1f us\n  timeline:", C, cout, hp::sepconv_variant(p), ms * 1e3);
+            for (int i = 1; i < 40 && h[i]; ++i) printf(" %llu", h[i] - h[i - 1]);
+            printf("\n  epilogue:");
+            for (int i = 41; i < 64 && h[i]; ++i) printf(" %llu", h[i] - h[i - 1]);
+            printf("\n");
+            CK(hipFree(dbg)); CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(dww)); CK(hipFree(pww)); CK(hipFree(dwb)); CK(hipFree(pwb));
+        }
+    }
     struct cfg { int cin, cout, k, H, W, B; };
     std::vector<cfg> cfgs = { {128, 128, 3, 46, 54, 8}, {512, 512, 1, 46, 54, 8}, {128, 512, 1, 46, 54, 8}, {128, 128, 1, 46, 54, 8},
                               {128, 128, 3, 46, 54, 32}, {512, 512, 1, 46, 54, 32}, {128, 128, 3, 46, 54, 1} };
@@ -154,7 +183,7 @@ int main(int argc, char** argv)
             }
         hp::debug_force_halo_variant(-1);
         float ms = time_ms(s, 300, [&] { CK(hp::launch_conv_mfma(p, s)); });
-        if (c.k == 3 && c.B == 8) {
+        if (c.B == 8) {
             unsigned long long* dbg; CK(hipMalloc(&dbg, 64 * 8)); CK(hipMemset(dbg, 0, 64 * 8));
             p.dbg = dbg; CK(hp::launch_conv_mfma(p, s)); CK(hipStreamSynchronize(s));
             unsigned long long h[64]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
