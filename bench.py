@@ -141,10 +141,22 @@ def roofline(pipe):
     mfma_fl = sum(p["flops"] for p in mfma)
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/)
+    halo = {3064192: (64, 16, 12), 3128128: (128, 8, 16)}
+    sep = {1: (1, 12, 16, 24, 1, 1, 32), 2: (1, 6, 8, 24, 2, 1, 32), 3: (2, 3, 8, 12, 2, 1, 64), 4: (2, 3, 8, 12, 1, 1, 64),
+           5: (4, 3, 8, 12, 1, 1, 64), 6: (4, 3, 8, 12, 1, 2, 64)}
+    if dom_tile >= 4000000:
+        key = "sepconv_kernel<%d, %d, %d, %d, %d, %d, %d>" % sep[dom_tile - 4000000]
+        label = key + " (fused depthwise 3x3 + pointwise 1x1)"
+    elif dom_tile >= 3000000:
+        bm, th, tw = halo[dom_tile]
+        key = f"conv3x3_halo_kernel<128, {bm}, {th}, {tw}, 1, 64, 0>"
+        label = f"conv3x3_halo_kernel<CIN=128> ({bm} cout x {th}x{tw} px tile, input halo tile resident in LDS)"
+    else:
+        key = f"conv_mfma_kernel<{dom_tile // 1000}, {dom_tile % 1000}, 64, 0>"
+        label = f"conv_mfma_kernel<BM={dom_tile // 1000},BN={dom_tile % 1000}> (implicit GEMM)"
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        key = "conv3x3_halo_kernel<128, 0>" if dom_tile >= 3000000 else f"conv_mfma_kernel<{dom_tile // 1000}, {dom_tile % 1000}, 64, 0>"
         for name, d in pmc.items():
             if key in name and "hbm_bytes_per_launch" in d:
                 traffic = round(d["hbm_bytes_per_launch"])
@@ -153,8 +165,7 @@ def roofline(pipe):
     return {
         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-        "kernel": (f"conv3x3_halo_kernel<CIN=128> (128 cout x 8x16 px tile)" if dom_tile >= 3000000
-                   else f"conv_mfma_kernel<BM={dom_tile // 1000},BN={dom_tile % 1000}>"),
+        "kernel": label,
         "launches_per_step": dom["n"], "avg_launch_us": round(dom["ms"] / dom["n"] * 1e3, 2),
         "flops_per_launch": round(dom["flops"] / dom["n"]),
         "all_mfma_convs": {"achieved": round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2), "ms_per_step": round(mfma_ms, 4),

@@ -68,6 +68,13 @@ __device__ __forceinline__ long tv_off(const tview& t, int b, int y, int x)
     return ((long)b * t.img + (long)y * t.wp + x) * t.cs + t.coff;
 }
 
+// Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also drains vmcnt, i.e. every global
+// prefetch in flight (measured: 1.5k cycles per K-chunk in sepconv_kernel when the weight prefetch crosses a barrier).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // LDS tile: ROWS x BK halves, row = BK*2 bytes, 16-byte chunks XOR-swizzled by the row index so that the
 // 16-lane service groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table) hit 16 distinct 16-byte slots.
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
 
     const int ld_row = tid / CH, ld_chunk = tid % CH;
     const int KC = p.Cin / BK;
+    const int steps = p.KH * p.KW * KC;
     const int OHW = p.OH * p.OW;
 
     // per-thread element offsets of the activation rows (pixels) it stages; rows past the end alias the last pixel
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
 
     // two register sets: the loads of K-step s+2 are in flight while step s computes
     u32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
-    int l_ky = 0, l_kx = 0, l_kc = 0;
+    int l_ky = 0, l_kx = 0, l_kc = 0, l_step = 0;
 #define HP_GLOAD(RA, RB)                                                                                          \
     {                                                                                                             \
         const long toff_ = ((long)(l_ky * p.dil) * p.in.wp + l_kx * p.dil) * p.in.cs + l_kc * BK;                 \
@@ -348,11 +356,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
             RA[i] = *reinterpret_cast<const u32x4*>(wb_ + (size_t)(i * RPP) * p.Cin);                             \
         _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                                          \
             RB[i] = *reinterpret_cast<const u32x4*>(p.in.p + rowoff[i] + toff_);                                  \
-        if (++l_kc == KC) {                                                                                       \
-            l_kc = 0;                                                                                             \
-            if (++l_kx == p.KW) {                                                                                 \
-                l_kx = 0;                                                                                         \
-                ++l_ky;                                                                                           \
+        if (++l_step < steps) { /* the loads past the last K-step repeat it: issued unconditionally, never used */ \
+            if (++l_kc == KC) {                                                                                   \
+                l_kc = 0;                                                                                         \
+                if (++l_kx == p.KW) {                                                                             \
+                    l_kx = 0;                                                                                     \
+                    ++l_ky;                                                                                       \
+                }                                                                                                 \
             }                                                                                                     \
         }                                                                                                         \
     }
@@ -410,7 +420,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
             for (int r = 0; r < 16; ++r)
                 acc[i][j][r] = 0.f;
 
-    const int steps = p.KH * p.KW * KC;
     const int frow = lane & 31, fk = lane >> 5;
     int dbg_i = 0;
 #define HP_STAMP()                                                                                                \
@@ -418,15 +427,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
         p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
     HP_STAMP();
     HP_GLOAD(ra0, rb0);
-    if (steps > 1)
-        HP_GLOAD(ra1, rb1);
+    HP_GLOAD(ra1, rb1);
     for (int s = 0; s < steps; s += 2) {
         HP_LSTORE(ra0, rb0, 0);
         HP_STAMP();
-        __syncthreads();
+        lds_barrier(); // not __syncthreads(): the prefetch of the other register set stays in flight
         HP_STAMP();
-        if (s + 2 < steps)
-            HP_GLOAD(ra0, rb0);
+        HP_GLOAD(ra0, rb0);
         __builtin_amdgcn_sched_barrier(0); // keep the prefetch ABOVE the MFMA phase (hipcc otherwise sinks it to its use)
         HP_COMPUTE(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -434,10 +441,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
         if (s + 1 < steps) {
             HP_LSTORE(ra1, rb1, 1);
             HP_STAMP();
-            __syncthreads();
+            lds_barrier();
             HP_STAMP();
-            if (s + 3 < steps)
-                HP_GLOAD(ra1, rb1);
+            HP_GLOAD(ra1, rb1);
             __builtin_amdgcn_sched_barrier(0);
             HP_COMPUTE(1);
             __builtin_amdgcn_sched_barrier(0);
@@ -534,15 +540,17 @@ __global__ __launch_bounds__(256 * KG) void conv3x3_halo_kernel(const conv_param
     const __half* wrow = p.w + (size_t)(m0 + ld_row) * CIN + ld_chunk * 8;
     const long w_tap_stride = (long)p.Cout_pad * CIN;
     u32x4 ra0[A_LD], ra1[A_LD];
-    int l_tap = 0, l_kc = 0;
+    int l_tap = 0, l_kc = 0, l_step = 0;
 #define HP_WLOAD(RA)                                                                                              \
     {                                                                                                             \
         const __half* wb_ = wrow + (long)l_tap * w_tap_stride + l_kc * BK;                                        \
         _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                          \
             RA[i] = *reinterpret_cast<const u32x4*>(wb_ + (size_t)(i * RPP) * CIN);                               \
-        if (++l_kc == KC) {                                                                                       \
-            l_kc = 0;                                                                                             \
-            ++l_tap;                                                                                              \
+        if (++l_step < 9 * KC) { /* loads past the last K-step repeat it: unconditional, never used */            \
+            if (++l_kc == KC) {                                                                                   \
+                l_kc = 0;                                                                                         \
+                ++l_tap;                                                                                          \
+            }                                                                                                     \
         }                                                                                                         \
     }
 #define HP_WSTORE(RA, BUF)                                                                                        \
@@ -655,20 +663,18 @@ __global__ __launch_bounds__(256 * KG) void conv3x3_halo_kernel(const conv_param
 #pragma unroll 1
     for (int s = 0; s < steps; s += 2) {
         HP_WSTORE(ra0, 0);
-        __syncthreads(); // also publishes the halo tile on the first iteration
+        lds_barrier(); // also publishes the halo tile on the first iteration; the weight prefetch stays in flight
         HP_STAMP();
-        if (s + 2 < steps)
-            HP_WLOAD(ra0);
+        HP_WLOAD(ra0);
         __builtin_amdgcn_sched_barrier(0);
         HP_HCOMPUTE(0);
         __builtin_amdgcn_sched_barrier(0);
         HP_STAMP();
         if (s + 1 < steps) {
             HP_WSTORE(ra1, 1);
-            __syncthreads();
+            lds_barrier();
             HP_STAMP();
-            if (s + 3 < steps)
-                HP_WLOAD(ra1);
+            HP_WLOAD(ra1);
             __builtin_amdgcn_sched_barrier(0);
             HP_HCOMPUTE(1);
             __builtin_amdgcn_sched_barrier(0);
@@ -1125,13 +1131,6 @@ hipError_t launch_dwconv3x3(const dw_params& p_in, hipStream_t s)
 //            wavefront-wide 16-byte load is one fully coalesced 1 KB fragment that only this wavefront needs - no
 //            LDS staging, no barrier for A, re-issued for the next chunk as soon as its MFMAs are done.
 //   epilogue = conv_epilogue_staged (bias, activation, 16-byte NHWC stores, 64 * TM bytes contiguous per pixel).
-// Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also drains vmcnt, i.e. every global
-// prefetch in flight (measured: 1.5k cycles per K-chunk in sepconv_kernel when the weight prefetch crosses a barrier).
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 template <int TM, int NT, int TH, int TW, int S, int D, int CK>
 __global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int tiles_x, int tiles_y)
 {
