@@ -144,7 +144,10 @@ def roofline(pipe):
     halo = {3064192: (64, 16, 12), 3128128: (128, 8, 16)}
     sep = {1: (1, 12, 16, 24, 1, 1, 32), 2: (1, 6, 8, 24, 2, 1, 32), 3: (2, 3, 8, 12, 2, 1, 64), 4: (2, 3, 8, 12, 1, 1, 64),
            5: (4, 3, 8, 12, 1, 1, 64), 6: (4, 3, 8, 12, 1, 2, 64)}
-    if dom_tile >= 4000000:
+    if dom_tile >= 5000000:
+        key = "conv3x3_direct_kernel<128>"
+        label = "conv3x3_direct_kernel<CIN=128> (64 cout x 16x12 px tile, input halo tile in LDS, weights in MFMA-fragment order straight from L2)"
+    elif dom_tile >= 4000000:
         key = "sepconv_kernel<%d, %d, %d, %d, %d, %d, %d>" % sep[dom_tile - 4000000]
         label = key + " (fused depthwise 3x3 + pointwise 1x1)"
     elif dom_tile >= 3000000:

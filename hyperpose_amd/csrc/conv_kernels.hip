@@ -735,11 +735,193 @@ __global__ __launch_bounds__(256 * KG) void conv3x3_halo_kernel(const conv_param
 #undef HP_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / dilation 1, barrier-free form (p.w_layout == 1).  Same tile as the 64 x 16x12 variant above, but the
+// weights never touch LDS: they are packed in MFMA-fragment order [tap][32-row tile][k16 step][lane][8 halves], so every
+// A fragment is one coalesced 1 KB load that exactly one wavefront needs.  The four wavefronts are 2 (32-row tiles) x
+// 2 (halves of every tap's CIN): no two of them want the same weights, all four read their B fragments from the one
+// static halo tile in LDS, and nothing synchronises them between the prologue and the final exchange of the K-halves
+// (each wavefront keeps the three pixel tiles it will store and hands the other three to its partner).
+// LDS = the halo tile only (64.5 KB at CIN = 128): two blocks, or one block and any other conv kernel, share a CU.
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(const conv_params p, int tiles_x, int tiles_y)
+{
+    constexpr int TH = 16, TW = 12, HPH = TH + 2, HPW = TW + 2, NT = 6;
+    constexpr int CHP = CIN / 8;       // 16-byte chunks per halo pixel
+    constexpr int KQ = CIN / 16;       // k16 steps per tap
+    constexpr int NS = KQ / 2;         // ... per tap and K-half
+    constexpr int HALO_BYTES = HPH * HPW * CIN * 2;
+    constexpr int RED_BYTES = 4 * 3 * 16 * 64 * 4; // each wave parks 3 accumulator tiles
+    constexpr int EPI_BYTES = 4 * stage_geom<1>::SLAB;
+    constexpr int LDS_BYTES = HALO_BYTES > RED_BYTES + EPI_BYTES ? HALO_BYTES : RED_BYTES + EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    auto hkey = [](int hy, int hx) { return CHP == 16 ? ((hy * TW + hx) & 15) : (((hy * TW + hx) >> 1) & 7); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, kg = wave >> 1;
+    const int m0 = blockIdx.y * 64;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    int dbg_i = 0;
+#define HP_STAMP()                                                                                                \
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)                                                  \
+        p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
+    // ---- A fragments of taps 0 and 1 (this wave's 32 rows, its half of CIN): 2 x NS loads in flight from the start
+    const long tap_stride = (long)(p.Cout_pad / 32) * KQ * 512; // halves per tap
+    const __half* wfrag = p.w + ((size_t)((m0 / 32 + wm) * KQ + kg * NS) * 64 + lane) * 8;
+    u32x4 a0[NS], a1[NS];
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+        a0[ks] = *reinterpret_cast<const u32x4*>(wfrag + (size_t)ks * 512);
+        a1[ks] = *reinterpret_cast<const u32x4*>(wfrag + tap_stride + (size_t)ks * 512);
+    }
+
+    // ---- halo tile: all loads first (one L2 round trip), then the LDS stores
+    {
+        constexpr int NIT = (HPH * HPW * CHP + 255) / 256;
+        u32x4 hv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int hp = min(i, HPH * HPW * CHP - 1) / CHP, c = i % CHP;
+            const int hy = hp / HPW, hx = hp - hy * HPW;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            const bool ok = y <= p.H && x <= p.W; // y, x >= -1 always: inside the zero halo of the HBM tensor
+            const u32x4 v = *reinterpret_cast<const u32x4*>(p.in.p + tv_off(p.in, b, min(y, p.H), min(x, p.W)) + c * 8);
+            hv[it] = v & (ok ? 0xffffffffu : 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < HPH * HPW * CHP) {
+                const int hp = i / CHP, c = i - hp * CHP;
+                const int hy = hp / HPW, hx = hp - hy * HPW;
+                *reinterpret_cast<u32x4*>(lds + hp * (CIN * 2) + ((c ^ hkey(hy, hx)) << 4)) = hv[it];
+            }
+        }
+    }
+
+    floatx16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[j][r] = 0.f;
+
+    const int fk = lane >> 5;
+    int brow[NT], bcol[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + (lane & 31);
+        brow[j] = n / TW;
+        bcol[j] = n - brow[j] * TW;
+    }
+    HP_STAMP();
+    lds_barrier(); // the halo tile is complete; the only barrier before the K-halves meet
+    HP_STAMP();
+
+    // one tap: NS k16 steps of 6 MFMAs; the B fragments of step ks+1 are read while step ks multiplies, and the A
+    // fragments of tap + 2 are requested as soon as this tap's are consumed
+    // per-lane constants of the B-fragment addresses: pixel offset and swizzle key at tap (0,0), this lane's chunk
+    int hpo0[NT], key0[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        hpo0[j] = (brow[j] * HPW + bcol[j]) * (CIN * 2);
+        key0[j] = brow[j] * TW + bcol[j];
+    }
+    const int cb16 = ((kg * NS) * 2 + fk) << 4;
+#define HP_TAP(A, TAP)                                                                                            \
+    {                                                                                                             \
+        const int ky_ = (TAP) / 3, kx_ = (TAP) - ky_ * 3;                                                         \
+        const int toff_ = (ky_ * HPW + kx_) * (CIN * 2), tkey_ = ky_ * TW + kx_; /* uniform */                    \
+        int base_[NT], k16_[NT];                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
+        {                                                                                                         \
+            base_[j] = hpo0[j] + toff_;                                                                           \
+            k16_[j] = (CHP == 16 ? ((key0[j] + tkey_) & 15) : (((key0[j] + tkey_) >> 1) & 7)) << 4;               \
+        }                                                                                                         \
+        half8 fb[2][NT];                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
+            fb[0][j] = *reinterpret_cast<const half8*>(lds + base_[j] + (cb16 ^ k16_[j]));                        \
+        _Pragma("unroll") for (int ks = 0; ks < NS; ++ks)                                                         \
+        {                                                                                                         \
+            if (ks + 1 < NS)                                                                                      \
+                _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
+                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(lds + base_[j] + ((cb16 + (ks + 1) * 32) ^ k16_[j])); \
+            half8 fa;                                                                                             \
+            __builtin_memcpy(&fa, &A[ks], 16);                                                                    \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                        \
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[j], 0, 0, 0);              \
+            A[ks] = *reinterpret_cast<const u32x4*>(wfrag + (long)min((TAP) + 2, 8) * tap_stride + (size_t)ks * 512); \
+        }                                                                                                         \
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < 8; tap += 2) {
+        HP_TAP(a0, tap);
+        HP_STAMP();
+        HP_TAP(a1, tap + 1);
+        HP_STAMP();
+    }
+    HP_TAP(a0, 8);
+    HP_STAMP();
+#undef HP_TAP
+
+    // ---- the K-halves meet: wave (wm, kg) keeps pixel tiles 3*kg .. 3*kg+2 and parks the other three for its partner
+    __syncthreads(); // every wave is done with the halo tile
+    HP_STAMP();
+    float4* const park = reinterpret_cast<float4*>(lds) + (size_t)wave * (3 * 4 * 64) + lane;
+    const float4* const take = reinterpret_cast<const float4*>(lds) + (size_t)(wave ^ 2) * (3 * 4 * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const floatx16& give = kg ? acc[j] : acc[3 + j];
+            park[(j * 4 + g4) * 64] = make_float4(give[4 * g4], give[4 * g4 + 1], give[4 * g4 + 2], give[4 * g4 + 3]);
+        }
+    __syncthreads();
+    floatx16 mine[1][3];
+    int pb[3], py[3], px[3];
+    bool pv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 o = take[(j * 4 + g4) * 64];
+            const floatx16& keep = kg ? acc[3 + j] : acc[j];
+            mine[0][j][4 * g4] = keep[4 * g4] + o.x, mine[0][j][4 * g4 + 1] = keep[4 * g4 + 1] + o.y;
+            mine[0][j][4 * g4 + 2] = keep[4 * g4 + 2] + o.z, mine[0][j][4 * g4 + 3] = keep[4 * g4 + 3] + o.w;
+        }
+        pb[j] = b;
+        py[j] = y0 + (kg ? brow[3 + j] : brow[j]);
+        px[j] = x0 + (kg ? bcol[3 + j] : bcol[j]);
+        pv[j] = py[j] < p.OH && px[j] < p.OW;
+    }
+    HP_STAMP();
+#undef HP_STAMP
+    // the slabs live behind the parking area: no wave can still be reading what another overwrites
+    conv_epilogue_staged<1, 3>(p, mine, m0 + wm * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+}
+
 // fast epilogue (aligned fp16 NHWC vectors) when every 8-channel chunk is whole and 16-byte aligned
 static bool fast_epilogue(const conv_params& p)
 {
     return p.out.p && !p.out_f32 && p.Cout % 8 == 0 && p.out.coff % 8 == 0 && p.out.cs % 8 == 0
         && (!p.res.p || (p.res.coff % 8 == 0 && p.res.cs % 8 == 0));
+}
+
+static bool use_halo(const conv_params& p);
+static bool fast_epilogue(const conv_params& p);
+static int halo_variant(const conv_params& p);
+// 1: the weights of this convolution are to be packed in MFMA-fragment order for conv3x3_direct_kernel
+int conv_weight_layout(const conv_params& p)
+{
+    static const int off = getenv("HP_HALO_DIRECT") ? !atoi(getenv("HP_HALO_DIRECT")) : 0;
+    return !off && use_halo(p) && fast_epilogue(p) && halo_variant(p) == 1 ? 1 : 0;
 }
 
 static bool use_halo(const conv_params& p)
@@ -819,6 +1001,8 @@ bool set_act(conv_params& p)
 
 int conv_mfma_tile(const conv_params& p)
 {
+    if (p.w_layout == 1)
+        return 5000000 + 64 * 1000 + 192;
     if (use_halo(p))
         return halo_variant(p) ? 3000000 + 64 * 1000 + 192 : 3000000 + 128 * 1000 + 128;
     const int BM = (p.Cout_pad % 128 == 0) ? 128 : 64;
@@ -838,6 +1022,17 @@ int conv_mfma_tile(const conv_params& p)
 
 hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
 {
+    if (p.w_layout == 1) {
+        if (!(use_halo(p) && fast_epilogue(p)))
+            return hipErrorInvalidValue; // fragment-ordered weights only fit the direct kernel
+        const int tiles_x = (p.OW + 11) / 12, tiles_y = (p.OH + 15) / 16;
+        dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / 64);
+        if (p.Cin == 128)
+            hipLaunchKernelGGL((conv3x3_direct_kernel<128>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL((conv3x3_direct_kernel<64>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        return hipGetLastError();
+    }
     if (use_halo(p)) {
         // tuning knob: HP_HALO_KG=2 selects the 8-wave split-K form, HP_HALO_BK=128 one K-step per tap (CIN=128 only)
         static const int kg = getenv("HP_HALO_KG") ? atoi(getenv("HP_HALO_KG")) : 1;

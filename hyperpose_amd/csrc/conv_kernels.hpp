@@ -37,7 +37,8 @@ struct conv_params {
     int Cout;     // real output channels
     int Cout_pad; // rows of the packed weight matrix (multiple of the M tile)
     int KH, KW, stride, dil, pad_t, pad_l;
-    const __half* w;    // packed [KH*KW][Cout_pad][Cin]
+    const __half* w;    // packed [KH*KW][Cout_pad][Cin] (w_layout 0) or MFMA-fragment order (w_layout 1, see conv_weight_layout)
+    int w_layout;
     const float* bias;  // [Cout_pad]
     const float* alpha; // PReLU slopes [Cout_pad] or nullptr
     int act;            // ACT_NONE / RELU / RELU6 / LEAKY / PRELU (the piecewise-linear ones)
@@ -61,6 +62,10 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s);
 // which kernel/tile the launcher picks (for reporting): BM*1000+BN for the generic kernel, 3000000+BM*1000+BN for
 // the 3x3 halo kernel
 int conv_mfma_tile(const conv_params& p);
+// Weight layout the launcher wants for this convolution (fill every other field of p first):
+//   0: [tap][Cout_pad][Cin] rows;   1: MFMA-fragment order for the barrier-free 3x3 kernel, half index
+//   ((((tap * (Cout_pad / 32) + m / 32) * (Cin / 16) + k / 16) * 64) + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8
+int conv_weight_layout(const conv_params& p);
 // tuning aid (tools/microbench): force the 3x3 halo tile variant (0: 128 ch x 8x16 px, 1: 64 ch x 16x12 px, -1: auto)
 void debug_force_halo_variant(int v);
 

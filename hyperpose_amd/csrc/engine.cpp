@@ -305,11 +305,6 @@ int hp_engine::build(const hp_engine_desc* d)
             const float* w = blob(L.w_off, nw, "weights", i);
             if (!w)
                 return HP_ERR_INVALID;
-            std::vector<__half> packed((size_t)taps * cout_pad * cin_pad, __float2half(0.f));
-            for (int co = 0; co < L.cout; ++co)
-                for (int t = 0; t < taps; ++t)
-                    for (int ci = 0; ci < L.cin; ++ci)
-                        packed[((size_t)t * cout_pad + co) * cin_pad + ci] = __float2half(w[((size_t)co * taps + t) * L.cin + ci]);
             std::vector<float> bias(cout_pad, 0.f), alpha;
             if (L.b_off >= 0) {
                 const float* b = blob(L.b_off, L.cout, "bias", i);
@@ -320,9 +315,8 @@ int hp_engine::build(const hp_engine_desc* d)
             auto& p = st.cp;
             void* dw = nullptr;
             void* db = nullptr;
-            HP_TRY(upload(packed.data(), packed.size() * sizeof(__half), &dw));
             HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
-            p.w = (const __half*)dw, p.bias = (const float*)db, p.alpha = nullptr;
+            p.w = nullptr, p.w_layout = 0, p.bias = (const float*)db, p.alpha = nullptr;
             if (L.act == HP_ACT_PRELU) {
                 alpha.assign(cout_pad, 0.f);
                 const float* a = blob(L.alpha_off, L.cout, "prelu slopes", i);
@@ -347,6 +341,21 @@ int hp_engine::build(const hp_engine_desc* d)
                 if (o.fused_layer == (int)i)
                     p.out_f32 = o.buf->as<float>();
             HP_REQUIRE(hp::set_act(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
+            // weights: the launcher says which packing its kernel for this shape reads
+            p.B = max_batch, p.npix = max_batch * g.OH * g.OW;
+            p.w_layout = hp::conv_weight_layout(p);
+            std::vector<__half> packed((size_t)taps * cout_pad * cin_pad, __float2half(0.f));
+            const int KQ = cin_pad / 16;
+            for (int co = 0; co < L.cout; ++co)
+                for (int t = 0; t < taps; ++t)
+                    for (int ci = 0; ci < L.cin; ++ci) {
+                        const size_t at = p.w_layout == 1
+                            ? ((((size_t)t * (cout_pad / 32) + co / 32) * KQ + ci / 16) * 64 + (ci % 16 / 8) * 32 + co % 32) * 8 + ci % 8
+                            : ((size_t)t * cout_pad + co) * cin_pad + ci;
+                        packed[at] = __float2half(w[((size_t)co * taps + t) * L.cin + ci]);
+                    }
+            HP_TRY(upload(packed.data(), packed.size() * sizeof(__half), &dw));
+            p.w = (const __half*)dw;
             st.flops = 2.0 * opix * L.cout * taps * L.cin;
             st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cout * 2 + (double)nw * 2;
         } else if (L.op == HP_OP_DWCONV && fuse_with_next[i]) {

@@ -99,4 +99,17 @@ int hp_device_synchronize(void)
     return HP_OK;
 }
 
+int hp_stream_wait_stream(void* waiter, void* signaler)
+{
+    // one-shot event: recorded on `signaler`, awaited by `waiter`, released by the runtime once both have passed it
+    hipEvent_t ev = nullptr;
+    HP_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)signaler);
+    if (e == hipSuccess)
+        e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    (void)hipEventDestroy(ev); // deferred by HIP until the event has completed
+    HP_HIP_TRY(e);
+    return HP_OK;
+}
+
 } // extern "C"

@@ -784,6 +784,8 @@ void hp_paf_destroy(hp_paf* p)
     delete p;
 }
 
+void* hp_paf_stream(hp_paf* p) { return p ? (void*)p->stream : nullptr; }
+
 int hp_paf_set_conf_thresh(hp_paf* p, float thresh)
 {
     HP_REQUIRE(p, HP_ERR_INVALID, "null parser");

@@ -30,6 +30,12 @@ class Paf:
         self._out = (Human * (self.max_batch * self.cap))()
         self._n = (C.c_int * self.max_batch)()
         self._pending = 0
+        lib().hp_paf_stream.restype = C.c_void_p
+        self.stream = lib().hp_paf_stream(self._h)
+
+    def after(self, stream) -> None:
+        """Work enqueued on the parser's own stream from now on waits for everything already enqueued on ``stream``."""
+        check(lib().hp_stream_wait_stream(C.c_void_p(self.stream), C.c_void_p(stream)))
 
     def close(self):
         if self._h:

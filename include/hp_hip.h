@@ -74,6 +74,10 @@ int hp_free_host(void* host);
 int hp_memcpy_h2d(void* dev, const void* host, size_t nbytes);
 int hp_memcpy_d2h(void* host, const void* dev, size_t nbytes);
 int hp_device_synchronize(void);
+/* Everything enqueued on `waiter` after this call starts only after everything enqueued on `signaler` before it has
+ * finished (hipEventRecord + hipStreamWaitEvent).  Lets a parser run on its own stream behind its engine, the way the
+ * reference's stream pipeline hands a batch from its inference thread to its parser thread (stream.hpp:139-190). */
+int hp_stream_wait_stream(void* waiter, void* signaler);
 
 /* ---- pre-processing: replaces hyperpose::nhwc_images_append_nchw_batch (src/data.cpp:21-51) -------
  * u8 HWC (BGR) frames [n,h,w,3] -> f32 CHW [n,3,h,w], value = (float)((double)u8 * factor), channel
@@ -101,6 +105,7 @@ int hp_paf_set_paf_thresh(hp_paf* p, float thresh);  /* paf::set_paf_thresh,  sr
 int hp_paf_process_batch(hp_paf* p, int n, const float* conf, const int conf_shape[3], const float* paf,
                          const int paf_shape[3], int on_device, hp_human* out, int cap_per_frame, int* n_out);
 
+void* hp_paf_stream(hp_paf* p); /* hipStream_t the parser owns (used when enqueue is given stream = NULL) */
 /* Asynchronous halves of the same call for pipelines: enqueue launches the kernels and the D2H copy of the
  * humans on `stream` (NULL = the parser's own stream) and returns at once; collect waits for that batch. */
 int hp_paf_enqueue(hp_paf* p, int n, const float* dev_conf, const int conf_shape[3], const float* dev_paf,

@@ -47,6 +47,14 @@ def test_config1_lw_openpose_b8_368x432(hp):
     for b in range(8):
         oh, _, _ = loader.paf_process(full[b][0], full[b][1])
         assert humans[b].tobytes() == oh.tobytes()
+    # asynchronous hand-over: engine on its stream, parser on its OWN stream behind it (hp_stream_wait_stream)
+    dev = __import__("hyperpose_amd")._lib.DevBuf.from_numpy(fr)
+    eng.enqueue_u8(dev, 8)
+    p.after(eng.stream)
+    p.enqueue(cp, pp, 8, cs, ps)
+    again = p.collect()
+    for b in range(8):
+        assert again[b].tobytes() == humans[b].tobytes()
 
 
 def test_config2_openpose_vgg19_b16_432x768(hp):

@@ -182,6 +182,7 @@ int main(int argc, char** argv)
                 printf("  halo variant %d (tile %d): %.1f us\n", v, hp::conv_mfma_tile(p), msv * 1e3);
             }
         hp::debug_force_halo_variant(-1);
+        p.w_layout = hp::conv_weight_layout(p);
         float ms = time_ms(s, 300, [&] { CK(hp::launch_conv_mfma(p, s)); });
         if (c.B == 8) {
             unsigned long long* dbg; CK(hipMalloc(&dbg, 64 * 8)); CK(hipMemset(dbg, 0, 64 * 8));

@@ -7,6 +7,7 @@ ap.add_argument("--engines-first", action="store_true")
 ap.add_argument("--modes", default="injected")
 ap.add_argument("--tag", default="")
 ap.add_argument("--lanes", type=int, default=0)
+ap.add_argument("--paf-own-stream", action="store_true")
 ap.add_argument("--dummy-mb", type=float, default=0)
 ap.add_argument("--dummy-streams", type=int, default=0)
 a = ap.parse_args()
@@ -49,6 +50,14 @@ if a.lanes:
             p.eng.enqueue_u8(frames_dev, bench.BATCH, stream=p.stream),
             p.paf.enqueue(p.conf_dev if injected else p.dnn_conf, p.paf_dev if injected else p.dnn_paf, bench.BATCH, p.conf_shape, p.paf_shape, stream=p.stream),
             setattr(p, "busy", True))))(p)
+if a.paf_own_stream:
+    for p in pipes:
+        def submit(frames_dev, injected, p=p):
+            p.eng.enqueue_u8(frames_dev, bench.BATCH)
+            p.paf.after(p.eng.stream)
+            p.paf.enqueue(p.conf_dev if injected else p.dnn_conf, p.paf_dev if injected else p.dnn_paf, bench.BATCH, p.conf_shape, p.paf_shape)
+            p.busy = True
+        p.submit = submit
 for mode in a.modes.split(","):
     if mode == "engine":
         def loop(n):
@@ -64,4 +73,4 @@ for mode in a.modes.split(","):
     loop(40)
     t0 = time.perf_counter(); loop(300); dt = time.perf_counter() - t0
     env = {k: v for k, v in os.environ.items() if k.startswith(("HP_", "GPU_MAX"))}
-    print(f"pipes={a.pipes} lanes={a.lanes} ef={int(a.engines_first)} {env} {mode}: {bench.BATCH*300/dt:.0f} FPS {dt/300*1e6:.1f} us/batch", flush=True)
+    print(f"pipes={a.pipes} own={int(a.paf_own_stream)} lanes={a.lanes} ef={int(a.engines_first)} {env} {mode}: {bench.BATCH*300/dt:.0f} FPS {dt/300*1e6:.1f} us/batch", flush=True)
