@@ -1623,6 +1623,215 @@ hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Two chained 1x1 convolutions in ONE launch: K1 -> 512 (relu) -> Cout2 <= 64 (the OpenPose-style heads,
+// lw_openpose.py:123-191: "1x1 128->512 relu, 1x1 512->19|38").  The 512-channel hidden tensor (20 MB per head and batch
+// at 46x54x8) never exists in HBM - and not even in LDS: the first GEMM's accumulator layout IS a B-fragment layout of
+// the second GEMM once the second layer's weights are packed in the matching K order.
+//   block = one (image, 8 x 12 pixel tile); the input tile [96 px][K1] goes to LDS once (swizzled B tiles of 64 ch).
+//   GEMM1: wavefront w owns hidden rows 128w .. 128w+127 (4 x 32-row MFMA tiles) x all 96 pixels; its weight fragments
+//          come straight from L2 in fragment order (as in conv3x3_direct_kernel), two k16 steps ahead.
+//   hidden = fp16(clamp(acc + bias1)) in registers.  In the 32x32 MFMA result, lane (n, h) holds rows
+//          (r & 3) + 8 (r >> 2) + 4h of column n: registers 8s .. 8s+7 are 8 of the 16 rows of k16 step s, and the h = 0 /
+//          h = 1 lanes together hold all 16 - exactly what a B fragment is, for a permuted row order.
+//   GEMM2: out[Cout2 x 96] += W2[:, rows of this wavefront] x hidden: W2 is packed host-side with that row order
+//          (head_params), 8 k16 steps per wavefront; the four partial sums meet through LDS.
+//   store: bias2 / activation, fp16 NHWC slice and / or fp32 NCHW network output.
+template <int NCH>
+__global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int tiles_x, int tiles_y)
+{
+    constexpr int TH = 8, TW = 12, NPX = 96, NT = 3, TM = 4;
+    constexpr int K1 = NCH * 64, KQ1 = K1 / 16; // k16 steps of GEMM1
+    constexpr int X_BYTES = NCH * NPX * 128;    // NCH tiles [96 px][64 ch]
+    constexpr int RED_BYTES = 4 * 24 * 64 * 16; // [wave][float4 index][lane]
+    constexpr int LDS_BYTES = X_BYTES > RED_BYTES ? X_BYTES : RED_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const conv_params& q = p.pw;
+
+    // ---- GEMM1 weights: fragments (row tile wave*4 + i, k16 step 0 and 1) in flight first
+    const __half* w1 = p.w1 + ((size_t)(wave * TM) * KQ1 * 64 + lane) * 8;
+    u32x4 a[2][TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        a[0][i] = *reinterpret_cast<const u32x4*>(w1 + ((size_t)i * KQ1 + 0) * 512);
+        a[1][i] = *reinterpret_cast<const u32x4*>(w1 + ((size_t)i * KQ1 + 1) * 512);
+    }
+    // ---- input tile -> LDS (pixels outside the map alias pixel (H-1, W-1): finite values, masked at the store)
+    {
+        constexpr int PIECES = NPX * NCH * 8, NLD = PIECES / 256;
+        static_assert(PIECES % 256 == 0, "whole pieces per thread");
+        u32x4 xv[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * 256;
+            const int pix = i / (NCH * 8), c = i % (NCH * 8);
+            const int y = min(y0 + pix / TW, p.H - 1), x = min(x0 + pix % TW, p.W - 1);
+            xv[k] = *reinterpret_cast<const u32x4*>(p.in.p + tv_off(p.in, b, y, x) + c * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * 256;
+            const int pix = i / (NCH * 8), c = i % (NCH * 8);
+            *reinterpret_cast<u32x4*>(lds + (c >> 3) * (NPX * 128) + lds_off<64>(pix, c & 7)) = xv[k];
+        }
+    }
+    // GEMM2 weights of this wavefront's 8 k16 steps (2 row tiles each): requested now, needed after GEMM1
+    u32x4 a2[8][2];
+    {
+        const __half* w2 = p.w2 + ((size_t)(wave * 8) * 64 + lane) * 8;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+                a2[s8][i2] = *reinterpret_cast<const u32x4*>(w2 + ((size_t)i2 * 32 + s8) * 512);
+    }
+
+    floatx16 acc[TM][NT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
+    lds_barrier(); // the input tile is complete
+
+    // ---- GEMM1
+#pragma unroll
+    for (int qs = 0; qs < KQ1; ++qs) {
+        half8 fb[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            fb[j] = *reinterpret_cast<const half8*>(lds + (qs / 4) * (NPX * 128) + lds_off<64>(j * 32 + frow, (qs % 4) * 2 + fk));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            half8 fa;
+            __builtin_memcpy(&fa, &a[qs & 1][i], 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+            if (qs + 2 < KQ1)
+                a[qs & 1][i] = *reinterpret_cast<const u32x4*>(w1 + ((size_t)i * KQ1 + qs + 2) * 512);
+        }
+    }
+
+    // ---- hidden activations -> fp16 B fragments of GEMM2, then GEMM2 on this wavefront's 128 hidden rows
+    floatx16 acc2[2][NT];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc2[i2][j][r] = 0.f;
+    const float hi1 = p.hi1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float bs[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.b1 + wave * 128 + i * 32 + 8 * g + 4 * fk);
+            bs[4 * g] = bv.x, bs[4 * g + 1] = bv.y, bs[4 * g + 2] = bv.z, bs[4 * g + 3] = bv.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            half8 hb[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    hb[j][e] = (_Float16)__builtin_amdgcn_fmed3f(acc[i][j][8 * s + e] + bs[8 * s + e], 0.f, hi1);
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                half8 fa;
+                __builtin_memcpy(&fa, &a2[i * 2 + s][i2], 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc2[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, hb[j], acc2[i2][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- the four partial sums meet: wave w finishes float4 slots 6w .. 6w+5 of the 24 per lane
+    __syncthreads(); // every wave is done with the input tile
+    float4* const red = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                red[((size_t)wave * 24 + (i2 * NT + j) * 4 + g) * 64 + lane]
+                    = make_float4(acc2[i2][j][4 * g], acc2[i2][j][4 * g + 1], acc2[i2][j][4 * g + 2], acc2[i2][j][4 * g + 3]);
+    __syncthreads();
+    const long plane = (long)q.OH * q.OW;
+#pragma unroll
+    for (int f6 = 0; f6 < 6; ++f6) {
+        const int f = wave * 6 + f6, tile = f >> 2, g = f & 3, i2 = tile / NT, j = tile % NT;
+        float4 v = red[((size_t)0 * 24 + f) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 o = red[((size_t)w * 24 + f) * 64 + lane];
+            v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+        }
+        const int m = i2 * 32 + 8 * g + 4 * fk;
+        const int n = j * 32 + (lane & 31);
+        const int oy = y0 + n / TW, ox = x0 + n % TW;
+        if (m < q.Cout && oy < q.OH && ox < q.OW) {
+            const float vv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (m + e < q.Cout) {
+                    float x = vv[e] + q.bias[m + e];
+                    const float sl = q.alpha ? q.alpha[m + e] : q.act_slope;
+                    x = x > 0.f ? fminf(x, q.act_hi) : x * sl;
+                    if (q.out.p)
+                        q.out.p[tv_off(q.out, b, oy, ox) + m + e] = __float2half(x);
+                    if (q.out_f32)
+                        q.out_f32[((long)b * q.Cout + m + e) * plane + (long)oy * q.OW + ox] = x;
+                }
+            }
+        }
+    }
+}
+
+// 0: no fused head kernel for this pair
+int mlp_head_variant(int k1, int hidden, int cout2)
+{
+    const int off = getenv("HP_NO_FUSE_HEAD") ? atoi(getenv("HP_NO_FUSE_HEAD")) : 0; // read per engine build (tests toggle it)
+    if (off || hidden != 512 || cout2 > 64 || cout2 < 1)
+        return 0;
+    return k1 == 64 ? 1 : k1 == 128 ? 2 : k1 == 256 ? 4 : 0;
+}
+
+hipError_t launch_mlp_head(const head_params& p, hipStream_t s)
+{
+    const int tiles_x = (p.W + 11) / 12, tiles_y = (p.H + 7) / 8;
+    const dim3 grid(tiles_x * tiles_y * p.B);
+    switch (mlp_head_variant(p.K1, 512, p.pw.Cout)) {
+    case 1:
+        hipLaunchKernelGGL((mlp_head_kernel<1>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        break;
+    case 2:
+        hipLaunchKernelGGL((mlp_head_kernel<2>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        break;
+    case 4:
+        hipLaunchKernelGGL((mlp_head_kernel<4>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool_kernel(const pool_params p)
 {
     const int CG = p.C / 8;

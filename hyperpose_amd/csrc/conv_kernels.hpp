@@ -121,6 +121,24 @@ int sepconv_variant(const sep_params& p);
 int sepconv_variant_for(int C, int cout_pad, int stride, int dil); // the pointer-free part of the same decision
 hipError_t launch_sepconv(const sep_params& p, hipStream_t s);
 
+// Two chained 1x1 convolutions K1 -> 512 (relu family) -> Cout2 <= 64 in one launch (mlp_head_kernel).
+//   w1: MFMA-fragment order, half index (((m / 32) * (K1 / 16) + k / 16) * 64 + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8
+//   w2: rows padded to 64; the hidden channel c = 128 w + 32 i + r32 sits at K-step 8 w + 2 i + s, lane half h, element e
+//       with h = (r32 >> 2) & 1, r = (r32 & 3) + 4 (r32 >> 3), s = r >> 3, e = r & 7:
+//       half index (((m / 32) * 32 + 8 w + 2 i + s) * 64 + h * 32 + m % 32) * 8 + e
+//   pw: bias (padded to 64), activation, out / out_f32, Cout, OH, OW of the SECOND convolution.
+struct head_params {
+    tview in;
+    int B, H, W, K1;
+    const __half* w1;
+    const float* b1; // [512]
+    float hi1;       // hidden activation = clamp(x, 0, hi1)
+    const __half* w2;
+    conv_params pw;
+};
+int mlp_head_variant(int k1, int hidden, int cout2);
+hipError_t launch_mlp_head(const head_params& p, hipStream_t s);
+
 struct pool_params {
     tview in;
     int B, H, W, OH, OW, C;

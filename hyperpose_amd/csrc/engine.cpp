@@ -62,9 +62,11 @@ struct step {
     hp::dw_params dp{};
     hp::pool_params pp{};
     hp::sep_params sp{}; // op == OP_SEPCONV: depthwise layer `layer` fused with the pointwise layer `layer + 1`
+    hp::head_params hp_{}; // op == OP_MLPHEAD: 1x1 conv `layer` (-> 512, relu) fused with the 1x1 conv `layer + 1`
     double flops = 0, bytes = 0; // per frame
 };
-constexpr int OP_SEPCONV = 100; // schedule-only op code (not part of the hp_layer ABI)
+constexpr int OP_SEPCONV = 100; // schedule-only op codes (not part of the hp_layer ABI)
+constexpr int OP_MLPHEAD = 101;
 
 void same_pad(int in, int k, int stride, int dil, int& out, int& pad_before)
 {
@@ -199,6 +201,34 @@ int hp_engine::build(const hp_engine_desc* d)
             tensors[A.out]->elided = true;
         }
     }
+    // ---- two-layer heads: 1x1 K1 -> 512 (relu) whose only consumer is the next layer, a 1x1 512 -> <= 64 channels
+    std::vector<char> head_with_next(layers.size(), 0);
+    if (!getenv("HP_NO_FUSE")) {
+        for (size_t i = 0; i + 1 < layers.size(); ++i) {
+            const hp_layer &A = layers[i], &Bn = layers[i + 1];
+            if (A.op != HP_OP_CONV || A.kh != 1 || A.kw != 1 || A.stride != 1 || A.in == 0 || A.res >= 0 || A.out_coff != 0 || A.in_coff % 8
+                || (A.act != HP_ACT_RELU && A.act != HP_ACT_RELU6))
+                continue;
+            if (Bn.op != HP_OP_CONV || Bn.kh != 1 || Bn.kw != 1 || Bn.stride != 1 || Bn.in != A.out || Bn.in_coff != 0 || Bn.cin != A.cout
+                || Bn.res >= 0 || Bn.out == A.out || Bn.act == HP_ACT_SIGMOID || Bn.act == HP_ACT_SOFTPLUS)
+                continue;
+            if (tensors[A.out]->C != A.cout || !hp::mlp_head_variant(A.cin, A.cout, Bn.cout))
+                continue;
+            if (i > 0 && fuse_with_next[i - 1])
+                continue; // already the pointwise half of a separable block
+            bool sole = true;
+            for (size_t j = 0; j < layers.size(); ++j)
+                if (j != i + 1 && (layers[j].in == A.out || layers[j].res == A.out || (j != i && layers[j].out == A.out)))
+                    sole = false;
+            for (int o = 0; o < d->n_outputs; ++o)
+                if (d->outputs[o].tensor == A.out)
+                    sole = false;
+            if (!sole)
+                continue;
+            head_with_next[i] = 1;
+            tensors[A.out]->elided = true;
+        }
+    }
     for (size_t t = 1; t < tensors.size(); ++t) {
         tensor_info& ti = *tensors[t];
         if (!ti.defined || ti.elided)
@@ -295,6 +325,75 @@ int hp_engine::build(const hp_engine_desc* d)
             p.out = to.view(L.out_coff);
             st.flops = 2.0 * opix * L.cout * L.kh * L.kw * 3;
             st.bytes = (double)ti.H * ti.W * 3 + opix * L.cout * 2 + nw * 4;
+        } else if (L.op == HP_OP_CONV && head_with_next[i]) {
+            const hp_layer& Pn = layers[i + 1];
+            tensor_info& tp = *tensors[Pn.out];
+            const int K1 = L.cin, KQ1 = K1 / 16, HID = L.cout;
+            const float* w1f = blob(L.w_off, (size_t)HID * K1, "weights", i);
+            const float* w2f = blob(Pn.w_off, (size_t)Pn.cout * HID, "weights", i + 1);
+            if (!w1f || !w2f)
+                return HP_ERR_INVALID;
+            std::vector<__half> w1p((size_t)HID * K1), w2p((size_t)64 * HID, __float2half(0.f));
+            for (int m = 0; m < HID; ++m)
+                for (int k = 0; k < K1; ++k)
+                    w1p[((((size_t)(m / 32) * KQ1 + k / 16) * 64) + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8] = __float2half(w1f[(size_t)m * K1 + k]);
+            for (int m = 0; m < Pn.cout; ++m)
+                for (int c = 0; c < HID; ++c) {
+                    const int wv = c / 128, ii = (c % 128) / 32, r32 = c % 32;
+                    const int hh = (r32 >> 2) & 1, r = (r32 & 3) + 4 * (r32 >> 3), ss = r >> 3, ee = r & 7;
+                    w2p[((((size_t)(m / 32) * 32 + 8 * wv + 2 * ii + ss) * 64) + hh * 32 + m % 32) * 8 + ee] = __float2half(w2f[(size_t)m * HID + c]);
+                }
+            std::vector<float> b1(HID, 0.f), b2(64, 0.f), alpha;
+            if (L.b_off >= 0) {
+                const float* bb = blob(L.b_off, HID, "bias", i);
+                if (!bb)
+                    return HP_ERR_INVALID;
+                std::copy(bb, bb + HID, b1.begin());
+            }
+            if (Pn.b_off >= 0) {
+                const float* bb = blob(Pn.b_off, Pn.cout, "bias", i + 1);
+                if (!bb)
+                    return HP_ERR_INVALID;
+                std::copy(bb, bb + Pn.cout, b2.begin());
+            }
+            st.op = OP_MLPHEAD;
+            auto& p = st.hp_;
+            void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
+            HP_TRY(upload(w1p.data(), w1p.size() * sizeof(__half), &d0));
+            HP_TRY(upload(b1.data(), b1.size() * sizeof(float), &d1));
+            HP_TRY(upload(w2p.data(), w2p.size() * sizeof(__half), &d2));
+            HP_TRY(upload(b2.data(), b2.size() * sizeof(float), &d3));
+            p.in = ti.view(L.in_coff);
+            p.H = ti.H, p.W = ti.W, p.K1 = K1;
+            p.w1 = (const __half*)d0, p.b1 = (const float*)d1, p.w2 = (const __half*)d2;
+            p.hi1 = L.act == HP_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+            auto& q = p.pw;
+            q.w = nullptr, q.w_layout = 0, q.bias = (const float*)d3, q.alpha = nullptr;
+            if (Pn.act == HP_ACT_PRELU) {
+                alpha.assign(64, 0.f);
+                const float* a = blob(Pn.alpha_off, Pn.cout, "prelu slopes", i + 1);
+                if (!a)
+                    return HP_ERR_INVALID;
+                std::copy(a, a + Pn.cout, alpha.begin());
+                void* da = nullptr;
+                HP_TRY(upload(alpha.data(), alpha.size() * sizeof(float), &da));
+                q.alpha = (const float*)da;
+            }
+            q.H = ti.H, q.W = ti.W, q.OH = ti.H, q.OW = ti.W, q.Cin = HID, q.Cout = Pn.cout, q.Cout_pad = 64;
+            q.KH = q.KW = 1, q.stride = 1, q.dil = 1, q.pad_t = q.pad_l = 0;
+            q.act = Pn.act, q.act_param = Pn.act_param;
+            q.res = hp::tview{ nullptr, 0, 0, 0, 0 }, q.res_before_act = 0;
+            q.out = tp.view(Pn.out_coff);
+            q.out_f32 = nullptr, q.dbg = nullptr;
+            for (auto& o : outputs)
+                if (o.fused_layer == (int)i + 1)
+                    q.out_f32 = o.buf->as<float>();
+            HP_REQUIRE(hp::set_act(q), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv", i + 1, Pn.act);
+            st.flops = 2.0 * opix * HID * K1 + 2.0 * opix * Pn.cout * HID;
+            st.bytes = (double)ti.H * ti.W * K1 * 2 + opix * Pn.cout * 2 + ((double)HID * K1 + (double)Pn.cout * HID) * 2;
+            steps.push_back(st);
+            ++i; // the second convolution is part of this step
+            continue;
         } else if (L.op == HP_OP_CONV) {
             const int cin_pad = round_up(L.cin, 32);
             HP_REQUIRE(L.in_coff % 8 == 0 && L.in_coff + cin_pad <= ti.cs, HP_ERR_INVALID,
@@ -493,6 +592,9 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     } else if (st.op == OP_SEPCONV) {
         st.sp.B = n, st.sp.pw.B = n, st.sp.pw.npix = n * st.sp.OH * st.sp.OW;
         HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
+    } else if (st.op == OP_MLPHEAD) {
+        st.hp_.B = n, st.hp_.pw.B = n;
+        HP_HIP_TRY(hp::launch_mlp_head(st.hp_, s));
     } else if (st.op == HP_OP_DWCONV) {
         st.dp.B = n;
         HP_HIP_TRY(hp::launch_dwconv3x3(st.dp, s));
@@ -685,7 +787,10 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
         HP_HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
         if (out && k < cap) {
             out[k].layer = st.layer, out[k].op = st.op;
-            out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp) : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp) : 0;
+            out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
+                : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
+                : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
+                                                    : 0;
             out[k].ms = ms / iters;
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
         }

@@ -328,10 +328,49 @@ def test_lw_openpose_fused_equals_unfused(hp, monkeypatch):
     w = m.init_weights(7)
     fr = _frames(2, 368, 432, seed=4)
     eng = E.Engine.from_model(m, w, max_batch=2)
-    assert sum(4000000 <= p["tile"] < 5000000 for p in eng.profile(2, 1)) == 10  # every MobileNet separable block with > 64 outputs
+    tiles = [p["tile"] for p in eng.profile(2, 1)]
+    assert sum(4000000 <= t < 5000000 for t in tiles) == 10  # every MobileNet separable block with > 64 outputs
+    assert sum(6000000 <= t < 7000000 for t in tiles) == 4   # init + refinement stage, conf + paf heads
     got = eng.inference(fr)
+    monkeypatch.setenv("HP_NO_FUSE_HEAD", "1")               # separable blocks fused, heads as two launches: same bits
+    mid = E.Engine.from_model(m, w, max_batch=2).inference(fr)
     monkeypatch.setenv("HP_NO_FUSE", "1")
     ref = E.Engine.from_model(m, w, max_batch=2).inference(fr)
     for b in range(2):
         for i in range(2):
-            assert np.array_equal(got[b][i][1], ref[b][i][1])
+            assert np.array_equal(mid[b][i][1], ref[b][i][1])
+            _close(got[b][i][1], ref[b][i][1])
+
+
+@pytest.mark.parametrize("k1,cout2,h,w", [(128, 19, 46, 54), (128, 38, 23, 29), (64, 64, 17, 12), (256, 5, 20, 31)])
+def test_fused_two_layer_head(hp, monkeypatch, k1, cout2, h, w):
+    """1x1 K1 -> 512 relu -> 1x1 512 -> cout2 as one launch (mlp_head_kernel): the hidden tensor never leaves the
+    registers.  Against the oracle (same fp16 rounding point for the hidden activations) and the two-launch schedule;
+    the second GEMM sums K in a different order, so the comparison with the unfused engine is a tolerance, not bits."""
+    net = Net(k1 + cout2)
+    a = net.conv(0, 3, k1, 3, 1)
+    cat = net.new_tensor()
+    net.conv(a, k1, 32, 1, out=cat, out_coff=0)
+    hid = net.conv(a, k1, 512, 1, act=E.ACT_RELU)
+    net.conv(hid, 512, cout2, 1, act=E.ACT_NONE, out=cat, out_coff=32)          # fp16 NHWC slice, read by the next conv
+    hid2 = net.conv(cat, 32 + cout2, 512, 1, act=E.ACT_RELU6) if (32 + cout2) in (64, 128, 256) else None
+    z = net.conv(cat, 32 + cout2, 24, 3, act=E.ACT_LEAKY, act_param=0.1)
+    hid3 = net.conv(a, k1, 512, 1, act=E.ACT_RELU)
+    y = net.conv(hid3, 512, cout2, 1, act=E.ACT_NONE)                           # fp32 NCHW network output written by the kernel
+    outs = [Out("y", y, 0, cout2), Out("z", z, 0, 24), Out("cat", cat, 0, 32 + cout2)]
+    if hid2 is not None:
+        y2 = net.conv(hid2, 512, 8, 1, act=E.ACT_LEAKY, act_param=0.2)
+        outs.append(Out("y2", y2, 0, 8))
+    fr = _frames(3, h, w, seed=k1)
+    eng, got, ref = _run_both(net, outs, fr, h, w)
+    _check(got, ref, 3)
+    n_heads = sum(6000000 <= p["tile"] < 7000000 for p in eng.profile(3, 1))
+    assert n_heads == (3 if hid2 is not None else 2)
+    monkeypatch.setenv("HP_NO_FUSE", "1")
+    eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 3)
+    got2 = eng2.inference(fr)
+    assert not any(p["tile"] >= 6000000 for p in eng2.profile(3, 1))
+    for b in range(3):
+        for (n1, a1), (n2, a2) in zip(got[b], got2[b]):
+            assert n1 == n2
+            _close(a1, a2)
