@@ -1653,6 +1653,11 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
     const int ty = t % tiles_y, b = t / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
     const conv_params& q = p.pw;
+    int dbg_i = 0;
+#define HP_STAMP()                                                                                                \
+    if (q.dbg && blockIdx.x == 0 && tid == 0)                                                                     \
+        q.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
 
     // ---- GEMM1 weights: fragments (row tile wave*4 + i, k16 step 0 and 1) in flight first
     const __half* w1 = p.w1 + ((size_t)(wave * TM) * KQ1 * 64 + lane) * 8;
@@ -1701,7 +1706,9 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
             for (int r = 0; r < 16; ++r)
                 acc[i][j][r] = 0.f;
     const int frow = lane & 31, fk = lane >> 5;
+    HP_STAMP();
     lds_barrier(); // the input tile is complete
+    HP_STAMP();
 
     // ---- GEMM1
 #pragma unroll
@@ -1722,6 +1729,7 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
         }
     }
 
+    HP_STAMP();
     // ---- hidden activations -> fp16 B fragments of GEMM2, then GEMM2 on this wavefront's 128 hidden rows
     floatx16 acc2[2][NT];
 #pragma unroll
@@ -1759,6 +1767,15 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
         }
     }
 
+    HP_STAMP();
+    // second-layer bias / slopes of the six float4 slots this wave will finish (host arrays are padded to 64 rows)
+    float4 bias4[6], slope4[6];
+#pragma unroll
+    for (int f6 = 0; f6 < 6; ++f6) {
+        const int f = wave * 6 + f6, m = ((f >> 2) / NT) * 32 + 8 * (f & 3) + 4 * fk;
+        bias4[f6] = *reinterpret_cast<const float4*>(q.bias + m);
+        slope4[f6] = q.alpha ? *reinterpret_cast<const float4*>(q.alpha + m) : make_float4(q.act_slope, q.act_slope, q.act_slope, q.act_slope);
+    }
     // ---- the four partial sums meet: wave w finishes float4 slots 6w .. 6w+5 of the 24 per lane
     __syncthreads(); // every wave is done with the input tile
     float4* const red = reinterpret_cast<float4*>(lds);
@@ -1771,6 +1788,7 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
                 red[((size_t)wave * 24 + (i2 * NT + j) * 4 + g) * 64 + lane]
                     = make_float4(acc2[i2][j][4 * g], acc2[i2][j][4 * g + 1], acc2[i2][j][4 * g + 2], acc2[i2][j][4 * g + 3]);
     __syncthreads();
+    HP_STAMP();
     const long plane = (long)q.OH * q.OW;
 #pragma unroll
     for (int f6 = 0; f6 < 6; ++f6) {
@@ -1785,21 +1803,38 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
         const int n = j * 32 + (lane & 31);
         const int oy = y0 + n / TW, ox = x0 + n % TW;
         if (m < q.Cout && oy < q.OH && ox < q.OW) {
-            const float vv[4] = { v.x, v.y, v.z, v.w };
+            const float vv[4] = { v.x + bias4[f6].x, v.y + bias4[f6].y, v.z + bias4[f6].z, v.w + bias4[f6].w };
+            const float sl[4] = { slope4[f6].x, slope4[f6].y, slope4[f6].z, slope4[f6].w };
+            __half* const o16 = q.out.p ? q.out.p + tv_off(q.out, b, oy, ox) + m : nullptr;
+            float* const o32 = q.out_f32 ? q.out_f32 + ((long)b * q.Cout + m) * plane + (long)oy * q.OW + ox : nullptr;
+            float xs[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (m + e < q.Cout) {
-                    float x = vv[e] + q.bias[m + e];
-                    const float sl = q.alpha ? q.alpha[m + e] : q.act_slope;
-                    x = x > 0.f ? fminf(x, q.act_hi) : x * sl;
-                    if (q.out.p)
-                        q.out.p[tv_off(q.out, b, oy, ox) + m + e] = __float2half(x);
-                    if (q.out_f32)
-                        q.out_f32[((long)b * q.Cout + m + e) * plane + (long)oy * q.OW + ox] = x;
+            for (int e = 0; e < 4; ++e)
+                xs[e] = vv[e] > 0.f ? fminf(vv[e], q.act_hi) : vv[e] * sl[e];
+            if (o16) {
+                if (m + 3 < q.Cout && ((q.out.coff | q.out.cs) & 3) == 0) { // whole, 8-byte aligned group
+                    half4 h4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        h4[e] = (_Float16)xs[e];
+                    *reinterpret_cast<half4*>(o16) = h4;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (m + e < q.Cout)
+                            o16[e] = __float2half(xs[e]);
                 }
+            }
+            if (o32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (m + e < q.Cout)
+                        o32[e * plane] = xs[e];
             }
         }
     }
+    HP_STAMP();
+#undef HP_STAMP
 }
 
 // 0: no fused head kernel for this pair

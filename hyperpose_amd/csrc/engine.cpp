@@ -28,6 +28,7 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 struct tensor_info {
     bool defined = false;
     bool elided = false;     // produced and consumed inside one fused launch: never materialised in HBM
+    bool unwritten = false;  // a network output nobody else reads: only its fp32 NCHW form is produced
     int H = 0, W = 0, C = 0; // C = total channels written
     int cs = 0;              // channel stride of the buffer
     int P = 0;               // zero halo (pixels) around every image: the largest padding any consumer needs
@@ -272,6 +273,17 @@ int hp_engine::build(const hp_engine_desc* d)
             o.fused_layer = last;
     }
 
+    // a tensor some layer reads (input or residual), or that an un-fused output conversion will read
+    auto tensor_is_read = [&](int t) {
+        for (const auto& L2 : layers)
+            if (L2.in == t || L2.res == t)
+                return true;
+        for (const auto& o : outputs)
+            if (o.tensor == t && o.fused_layer < 0)
+                return true;
+        return false;
+    };
+
     // ---- pass 2: pack weights, build the schedule
     auto blob = [&](int64_t off, size_t n, const char* what, size_t layer) -> const float* {
         if (off < 0 || (size_t)off + n > d->n_weights) {
@@ -388,6 +400,8 @@ int hp_engine::build(const hp_engine_desc* d)
             for (auto& o : outputs)
                 if (o.fused_layer == (int)i + 1)
                     q.out_f32 = o.buf->as<float>();
+            if (q.out_f32 && !tensor_is_read(Pn.out))
+                q.out.p = nullptr, tp.unwritten = true; // only the fp32 network output is wanted
             HP_REQUIRE(hp::set_act(q), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv", i + 1, Pn.act);
             st.flops = 2.0 * opix * HID * K1 + 2.0 * opix * Pn.cout * HID;
             st.bytes = (double)ti.H * ti.W * K1 * 2 + opix * Pn.cout * 2 + ((double)HID * K1 + (double)Pn.cout * HID) * 2;
@@ -439,6 +453,8 @@ int hp_engine::build(const hp_engine_desc* d)
             for (auto& o : outputs)
                 if (o.fused_layer == (int)i)
                     p.out_f32 = o.buf->as<float>();
+            if (p.out_f32 && !tensor_is_read(L.out) && tensors[L.out]->C == L.cout)
+                p.out.p = nullptr, to.unwritten = true; // only the fp32 network output is wanted
             HP_REQUIRE(hp::set_act(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
             // weights: the launcher says which packing its kernel for this shape reads
             p.B = max_batch, p.npix = max_batch * g.OH * g.OW;
@@ -750,6 +766,7 @@ int hp_engine_output_to_host(hp_engine* e, int i, int n, float* host)
 int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int shape[3])
 {
     HP_REQUIRE(e && tensor > 0 && tensor < (int)e->tensors.size() && e->tensors[tensor]->defined, HP_ERR_INVALID, "hp_engine_debug_tensor: bad tensor %d", tensor);
+    HP_REQUIRE(!e->tensors[tensor]->unwritten, HP_ERR_STATE, "hp_engine_debug_tensor: tensor %d exists only as the fp32 network output", tensor);
     HP_REQUIRE(!e->tensors[tensor]->elided, HP_ERR_STATE, "hp_engine_debug_tensor: tensor %d lives only inside a fused separable block (HP_NO_FUSE=1 materialises it)", tensor);
     const tensor_info& ti = *e->tensors[tensor];
     if (shape)

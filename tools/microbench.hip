@@ -158,6 +158,27 @@ int main(int argc, char** argv)
             CK(hipFree(dbg)); CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(dww)); CK(hipFree(pww)); CK(hipFree(dwb)); CK(hipFree(pwb));
         }
     }
+    {   // fused two-layer head 128 -> 512 -> 38
+        const int B = 8, H = 46, W = 54, K1 = 128, C2 = 38;
+        __half *in, *w1, *w2, *out; float *b1, *b2, *of;
+        CK(hipMalloc(&in, (size_t)B * H * W * K1 * 2)); CK(hipMalloc(&w1, 512 * K1 * 2)); CK(hipMalloc(&w2, 64 * 512 * 2));
+        CK(hipMalloc(&out, (size_t)B * H * W * 64 * 2)); CK(hipMalloc(&b1, 512 * 4)); CK(hipMalloc(&b2, 64 * 4)); CK(hipMalloc(&of, (size_t)B * C2 * H * W * 4));
+        CK(hipMemset(in, 0x11, (size_t)B * H * W * K1 * 2)); CK(hipMemset(w1, 0x11, 512 * K1 * 2)); CK(hipMemset(w2, 0x11, 64 * 512 * 2));
+        CK(hipMemset(b1, 0, 512 * 4)); CK(hipMemset(b2, 0, 64 * 4));
+        hp::head_params p{};
+        p.in = hp::tview{ in, K1, 0, W, H * W };
+        p.B = B, p.H = H, p.W = W, p.K1 = K1, p.w1 = w1, p.b1 = b1, p.hi1 = 1e30f, p.w2 = w2;
+        auto& q = p.pw;
+        q.bias = b2, q.alpha = nullptr, q.act = hp::ACT_NONE; hp::set_act(q);
+        q.B = B, q.OH = H, q.OW = W, q.Cout = C2, q.Cout_pad = 64, q.out = hp::tview{ out, 64, 0, W, H * W }, q.out_f32 = of, q.dbg = nullptr;
+        float ms = time_ms(s, 200, [&] { CK(hp::launch_mlp_head(p, s)); });
+        unsigned long long* dbg; CK(hipMalloc(&dbg, 64 * 8)); CK(hipMemset(dbg, 0, 64 * 8));
+        q.dbg = dbg; CK(hp::launch_mlp_head(p, s)); CK(hipStreamSynchronize(s));
+        unsigned long long h[64]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+        printf("mlp_head 128->512->38: %.1f us\n  timeline:", ms * 1e3);
+        for (int i = 1; i < 20 && h[i]; ++i) printf(" %llu", h[i] - h[i - 1]);
+        printf("\n");
+    }
     struct cfg { int cin, cout, k, H, W, B; };
     std::vector<cfg> cfgs = { {128, 128, 3, 46, 54, 8}, {512, 512, 1, 46, 54, 8}, {128, 512, 1, 46, 54, 8}, {128, 128, 1, 46, 54, 8},
                               {128, 128, 3, 46, 54, 32}, {512, 512, 1, 46, 54, 32}, {128, 128, 3, 46, 54, 1} };
