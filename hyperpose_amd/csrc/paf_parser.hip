@@ -462,6 +462,12 @@ __device__ __forceinline__ dpeak peak_by_id(const dpeak* __restrict__ sorted_f, 
     return sorted_f[(size_t)c * peak_cap + (id - s_start[c])];
 }
 
+// The walk over the connections is a sequential dependency chain; the dependent global loads inside it (the connection
+// itself and two peak scores per step) are staged in LDS first - every connection of the frame in walk order and the
+// score of every peak by id - so that the chain only touches LDS (126 -> 94 us per batch; the rest is LDS latency of
+// the human tables: a register-resident variant was tried and drowned in code size / scratch).
+constexpr int ASM_CONN_CAP = 2560;  // connections of one frame staged in LDS (30 KB); the rest is read from global
+constexpr int ASM_PEAK_CAP = 4096;  // peak scores staged by id (16 KB)
 __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restrict__ sorted, const int* __restrict__ pcount,
     int peak_cap, const dconn* __restrict__ conns, const int* __restrict__ conn_count, int res_w, int res_h,
     hp_human* __restrict__ humans, int* __restrict__ n_humans, int human_cap, int* __restrict__ flags)
@@ -471,6 +477,9 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
     __shared__ int s_n[MAXH];
     __shared__ int s_start[HP_COCO_N_PARTS + 1];
     __shared__ int s_keep[MAXH];
+    __shared__ int s_cstart[HP_COCO_N_PAIRS + 1];
+    __shared__ dconn s_conn[ASM_CONN_CAP];
+    __shared__ float s_pscore[ASM_PEAK_CAP];
     const int lane = threadIdx.x;
     const int f = blockIdx.x;
     const dpeak* sorted_f = sorted + (size_t)f * HP_COCO_N_PARTS * peak_cap;
@@ -485,21 +494,45 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
             acc += min(raw, peak_cap);
         }
         s_start[HP_COCO_N_PARTS] = acc;
+        int cacc = 0;
+        for (int l = 0; l < HP_COCO_N_PAIRS; ++l) {
+            s_cstart[l] = cacc;
+            cacc += conn_count[f * HP_COCO_N_PAIRS + l];
+        }
+        s_cstart[HP_COCO_N_PAIRS] = cacc;
     }
     __syncthreads();
+    // stage: connections in walk order, peak scores by id
+    for (int l = 0; l < HP_COCO_N_PAIRS; ++l) {
+        const int base = s_cstart[l], nc = s_cstart[l + 1] - base;
+        const dconn* cl = conns + ((size_t)f * HP_COCO_N_PAIRS + l) * peak_cap;
+        for (int i = lane; i < nc && base + i < ASM_CONN_CAP; i += 64)
+            s_conn[base + i] = cl[i];
+    }
+    for (int c = 0; c < HP_COCO_N_PARTS; ++c) {
+        const int base = s_start[c], np = s_start[c + 1] - base;
+        for (int i = lane; i < np && base + i < ASM_PEAK_CAP; i += 64)
+            s_pscore[base + i] = sorted_f[(size_t)c * peak_cap + i].score;
+    }
+    __syncthreads();
+    auto peak_score = [&](int part, int id) { // all_peaks[id].score for an id of part `part`
+        return id < ASM_PEAK_CAP ? s_pscore[id] : sorted_f[(size_t)part * peak_cap + (id - s_start[part])].score;
+    };
 
     int nh = 0;
     bool overflow = false;
     for (int pair_id = 0; pair_id < HP_COCO_N_PAIRS; ++pair_id) {
         const int p1 = c_pairs[pair_id][0], p2 = c_pairs[pair_id][1];
-        const int nc = conn_count[f * HP_COCO_N_PAIRS + pair_id];
+        const int cbase = s_cstart[pair_id], nc = s_cstart[pair_id + 1] - cbase;
         const dconn* cl = conns + ((size_t)f * HP_COCO_N_PAIRS + pair_id) * peak_cap;
         for (int ci = 0; ci < nc; ++ci) {
-            const dconn conn = cl[ci];
+            const dconn conn = cbase + ci < ASM_CONN_CAP ? s_conn[cbase + ci] : cl[ci];
             // which humans touch this connection (paf.cpp:164-168), lowest index first
             int total = 0, first = -1, second = -1;
 #pragma unroll
             for (int s = 0; s < MAXH / 64; ++s) {
+                if (s * 64 >= nh) // uniform: no human lives in this slice yet
+                    break;
                 const int h = s * 64 + lane;
                 const bool t = h < nh && (s_parts[h * HP_COCO_N_PARTS + p1] == conn.cid1 || s_parts[h * HP_COCO_N_PARTS + p2] == conn.cid2);
                 unsigned long long m = __ballot(t);
@@ -511,7 +544,7 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
                 if (m && second < 0)
                     second = s * 64 + __ffsll((long long)m) - 1;
             }
-            const float sc2 = sorted_f[(size_t)p2 * peak_cap + (conn.cid2 - s_start[p2])].score; // all_peaks[cid2].score
+            const float sc2 = peak_score(p2, conn.cid2); // all_peaks[cid2].score
             if (total == 1) {
                 if (lane == 0 && s_parts[first * HP_COCO_N_PARTS + p2] != conn.cid2) {
                     s_parts[first * HP_COCO_N_PARTS + p2] = conn.cid2;
@@ -544,7 +577,7 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
                     if (lane < HP_COCO_N_PARTS)
                         s_parts[nh * HP_COCO_N_PARTS + lane] = lane == p1 ? conn.cid1 : (lane == p2 ? conn.cid2 : -1);
                     if (lane == 0) {
-                        const float sc1 = sorted_f[(size_t)p1 * peak_cap + (conn.cid1 - s_start[p1])].score;
+                        const float sc1 = peak_score(p1, conn.cid1);
                         s_n[nh] = 2;
                         s_score[nh] = sc1 + sc2 + conn.score;
                     }
@@ -576,26 +609,27 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
     __syncthreads();
     if (lane == 0)
         n_humans[f] = kept;
+    // emission: (human, part) pairs spread over the wavefront
     hp_human* out = humans + (size_t)f * human_cap;
-    for (int i = 0; i < kept && i < human_cap; ++i) {
+    const int nout = min(kept, human_cap);
+    for (int e = lane; e < nout * HP_COCO_N_PARTS; e += 64) {
+        const int i = e / HP_COCO_N_PARTS, part = e - i * HP_COCO_N_PARTS;
         const int h = s_keep[i];
-        if (lane < HP_COCO_N_PARTS) {
-            hp_body_part bp;
-            bp.has_value = 0;
-            bp.x = 0.f, bp.y = 0.f, bp.score = 0.f;
-            const int id = s_parts[h * HP_COCO_N_PARTS + lane];
-            if (id != -1) {
-                const dpeak p = peak_by_id(sorted_f, s_start, peak_cap, id);
-                bp.has_value = 1;
-                bp.score = p.score;
-                bp.x = static_cast<float>(p.x) / res_w; // paf.cpp:367-368
-                bp.y = static_cast<float>(p.y) / res_h;
-            }
-            out[i].parts[lane] = bp;
+        hp_body_part bp;
+        bp.has_value = 0;
+        bp.x = 0.f, bp.y = 0.f, bp.score = 0.f;
+        const int id = s_parts[h * HP_COCO_N_PARTS + part];
+        if (id != -1) {
+            const dpeak p = peak_by_id(sorted_f, s_start, peak_cap, id);
+            bp.has_value = 1;
+            bp.score = p.score;
+            bp.x = static_cast<float>(p.x) / res_w; // paf.cpp:367-368
+            bp.y = static_cast<float>(p.y) / res_h;
         }
-        if (lane == 0)
-            out[i].score = s_score[h];
+        out[i].parts[part] = bp;
     }
+    for (int i = lane; i < nout; i += 64)
+        out[i].score = s_score[s_keep[i]];
 }
 
 // ---------------------------------------------------------------------------------------------------

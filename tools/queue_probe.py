@@ -8,8 +8,10 @@ ap.add_argument("--modes", default="injected")
 ap.add_argument("--tag", default="")
 ap.add_argument("--lanes", type=int, default=0)
 ap.add_argument("--paf-own-stream", action="store_true")
+ap.add_argument("--paf-shared-stream", type=int, default=0)
 ap.add_argument("--dummy-mb", type=float, default=0)
 ap.add_argument("--dummy-streams", type=int, default=0)
+ap.add_argument("--dummy-every", type=int, default=1)
 a = ap.parse_args()
 import bench
 from hyperpose_amd import _lib, synth
@@ -29,8 +31,9 @@ if a.engines_first:
         engs.append(Engine.from_model(model, w, max_batch=bench.BATCH))
         if a.dummy_mb:
             dummies.append(_lib.DevBuf(int(a.dummy_mb * (1 << 20))))
-        for _ in range(a.dummy_streams):
-            dummies.append(Paf(max_batch=1))
+        if len(engs) % a.dummy_every == 0:
+            for _ in range(a.dummy_streams):
+                dummies.append(Paf(max_batch=1))
     pipes = []
     for e in engs:
         p = bench.Pipe.__new__(bench.Pipe)
@@ -58,6 +61,17 @@ if a.paf_own_stream:
             p.paf.enqueue(p.conf_dev if injected else p.dnn_conf, p.paf_dev if injected else p.dnn_paf, bench.BATCH, p.conf_shape, p.paf_shape)
             p.busy = True
         p.submit = submit
+if a.paf_shared_stream:
+    import ctypes as C
+    from hyperpose_amd._lib import lib, check
+    shared = [pipes[i].paf.stream for i in range(a.paf_shared_stream)]
+    for k, p in enumerate(pipes):
+        def submit(frames_dev, injected, p=p, st=shared[k % len(shared)]):
+            p.eng.enqueue_u8(frames_dev, bench.BATCH)
+            check(lib().hp_stream_wait_stream(C.c_void_p(st), C.c_void_p(p.eng.stream)))
+            p.paf.enqueue(p.conf_dev if injected else p.dnn_conf, p.paf_dev if injected else p.dnn_paf, bench.BATCH, p.conf_shape, p.paf_shape, stream=st)
+            p.busy = True
+        p.submit = submit
 for mode in a.modes.split(","):
     if mode == "engine":
         def loop(n):
@@ -73,4 +87,4 @@ for mode in a.modes.split(","):
     loop(40)
     t0 = time.perf_counter(); loop(300); dt = time.perf_counter() - t0
     env = {k: v for k, v in os.environ.items() if k.startswith(("HP_", "GPU_MAX"))}
-    print(f"pipes={a.pipes} own={int(a.paf_own_stream)} lanes={a.lanes} ef={int(a.engines_first)} {env} {mode}: {bench.BATCH*300/dt:.0f} FPS {dt/300*1e6:.1f} us/batch", flush=True)
+    print(f"pipes={a.pipes} shared={a.paf_shared_stream} own={int(a.paf_own_stream)} lanes={a.lanes} ef={int(a.engines_first)} {env} {mode}: {bench.BATCH*300/dt:.0f} FPS {dt/300*1e6:.1f} us/batch", flush=True)
