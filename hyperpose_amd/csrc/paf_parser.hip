@@ -160,8 +160,14 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
         s_cy1[i] = g.c1_y[ry];
     }
     const float* plane = conf + ((size_t)f * g.J + k) * g.R * g.Cc;
-    for (int i = tid; i < nrows * g.Cc; i += PEAK_THREADS)
-        s_src[i] = plane[row_base * g.Cc + i];
+    float vmax = 0.f;
+    for (int i = tid; i < nrows * g.Cc; i += PEAK_THREADS) {
+        const float v = plane[row_base * g.Cc + i];
+        s_src[i] = v;
+        vmax = fmaxf(vmax, v); // NaN-safe for the purpose: a NaN source keeps the band alive below
+        if (!(v == v))
+            vmax = __builtin_huge_valf();
+    }
 
     // thread t owns column x0 - (KR + 1) + t of the strip's halo; columns outside the map read their reflection
     const int ux = x0 - (KR + 1) + tid;
@@ -172,7 +178,13 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
     // single-tap columns (x >= OpenCV's xmax) multiply by 1.f and add nothing: up_row keeps that form
     const float a0 = two_tap ? g.c0_x[rc] : 1.f, a1 = two_tap ? g.c1_x[rc] : 0.f;
     const int sx1 = two_tap ? sx + 1 : sx;
-    __syncthreads();
+    // Every smoothed value of this band is a chain of convex combinations of the source rows staged above (interpolation
+    // weights c0 + c1 = 1 and the Gaussian taps sum to 1, each within a few ulp; ~40 roundings of 2^-24 relative), so it
+    // cannot exceed max(0, max source) * (1 + 1e-5).  A band whose sources all stay below thresh / 1.001 therefore has no
+    // peak (the test is `smoothed > thresh`): skip it.  Real heat-maps are empty almost everywhere.
+    const bool skip = !DUMP && __syncthreads_or(vmax * 1.001f >= thresh) == 0;
+    if (skip)
+        return;
 
     // w[j] = (R[m-16+j], R[m-15+j]): overlapping pairs of the row-filtered column, logical rows m-16 .. m+1
     f32x2 w[KSIZE];
