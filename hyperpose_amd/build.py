@@ -25,6 +25,7 @@ COMMON = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-Wall", "-Wno-
 UNITS = [
     ("hp_runtime.cpp", []),
     ("preproc.hip", ["-ffp-contract=off"]),
+    ("resize.hip", ["-ffp-contract=off"]),
     ("paf_parser.hip", ["-ffp-contract=off"]),
     ("ppn_parser.hip", ["-ffp-contract=off"]),
     ("pifpaf_parser.hip", ["-ffp-contract=off"]),

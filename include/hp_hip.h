@@ -85,6 +85,19 @@ int hp_stream_wait_stream(void* waiter, void* signaler);
 int hp_preproc_u8hwc_to_f32nchw(const uint8_t* dev_hwc, int n, int h, int w, double factor, int flip_rb,
                                 float* dev_nchw, void* stream);
 
+/* ---- stream front-end geometry (reference: cv::resize at src/stream.cpp:93,101 and hyperpose::non_scaling_resize,
+ * include/hyperpose/utility/data.hpp:67, src/data.cpp:53-69; resume_ratio, include/hyperpose/utility/human.hpp:44-58).
+ * Images are 8-bit BGR HWC in DEVICE memory, row strides in bytes; results equal OpenCV's INTER_LINEAR bit for bit
+ * (restated in oracle/resize_oracle.cpp; parity unpinned: no OpenCV in the build image). */
+int hp_resize_u8c3(const uint8_t* dev_src, int sw, int sh, int src_stride, uint8_t* dev_dst, int dw, int dh, int dst_stride,
+                   void* stream);
+/* non_scaling_resize: aspect-preserving resize into the top-left corner, the rest filled with (b, g, r) */
+int hp_letterbox_u8c3(const uint8_t* dev_src, int sw, int sh, int src_stride, uint8_t* dev_dst, int dw, int dh, int dst_stride,
+                      int b, int g, int r, void* stream);
+void hp_letterbox_inner(int sw, int sh, int dw, int dh, int* inner_w, int* inner_h); /* size of the resized region */
+/* resume_ratio on n humans in place (host memory): undo the letterbox for (src = frame size, dst = network size) */
+void hp_resume_ratio(hp_human* humans, int n, int src_w, int src_h, int dst_w, int dst_h);
+
 /* ---- hyperpose::parser::paf (include/hyperpose/operator/parser/paf.hpp:17-93, src/paf.cpp) -------- */
 typedef struct hp_paf hp_paf;
 

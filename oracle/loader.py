@@ -179,3 +179,39 @@ def ref_pifpaf_process(paf, pif, net_h=385, net_w=385, thresh=0.1, cap=256, fast
     n = L.ref_pifpaf_process(net_h, net_w, C.c_float(thresh), _fp(paf), _fp(pif), fh, fw, out, cap)
     assert 0 <= n <= cap
     return np.frombuffer(out, dtype=HUMAN_DTYPE, count=n).copy()
+
+
+# ---------------------------------------------------------------- stream front-end (cv::resize / non_scaling_resize)
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def resize_linear_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv::resize(src, (dw, dh)) for an [h, w, 3] uint8 image (default INTER_LINEAR), restated."""
+    src = np.ascontiguousarray(src, np.uint8)
+    sh, sw, _ = src.shape
+    dst = np.zeros((dh, dw, 3), np.uint8)
+    lib().oracle_resize_linear_u8c3(_u8p(src), sw, sh, sw * 3, _u8p(dst), dw, dh, dw * 3)
+    return dst
+
+
+def letterbox_u8(src: np.ndarray, dw: int, dh: int, bgcolor=(0, 0, 0)) -> np.ndarray:
+    """hyperpose::non_scaling_resize (src/data.cpp:53-69)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    sh, sw, _ = src.shape
+    dst = np.zeros((dh, dw, 3), np.uint8)
+    lib().oracle_letterbox_u8c3(_u8p(src), sw, sh, _u8p(dst), dw, dh, int(bgcolor[0]), int(bgcolor[1]), int(bgcolor[2]))
+    return dst
+
+
+def letterbox_inner(sw: int, sh: int, dw: int, dh: int):
+    iw, ih = C.c_int(), C.c_int()
+    lib().oracle_letterbox_inner(sw, sh, dw, dh, C.byref(iw), C.byref(ih))
+    return iw.value, ih.value
+
+
+def resume_ratio(xy: np.ndarray, src_wh, dst_wh) -> np.ndarray:
+    """resume_ratio (human.hpp:44-58) on an [n, 2] float32 array of (x, y); returns a new array."""
+    out = np.ascontiguousarray(xy, np.float32).copy()
+    lib().oracle_resume_ratio(_fp(out), out.shape[0], int(src_wh[0]), int(src_wh[1]), int(dst_wh[0]), int(dst_wh[1]))
+    return out
