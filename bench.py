@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--pipes", type=int, default=PIPES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-from-host", action="store_true")
     return ap.parse_args()
 
 
@@ -122,6 +123,44 @@ def cpu_baseline(conf, paf, budget_s=12.0):
             "cores": threads, "kind": "port",
             "sample": f"{frames} injected 46x54 heat-map frames (the bench's 8 frames cycled), {threads} threads, "
                       f"single-thread latency {one * 1e3:.1f} ms/frame, restated reference (no OpenCV SIMD), -Ofast -march=x86-64-v3"}
+
+
+def from_host(model, weights, steps=160, frame_wh=(1280, 720)):
+    """PCIe-inclusive variant (NOT `value`): frames start in pinned HOST memory at camera size; per batch one H2D copy,
+    non_scaling_resize on the device, conv stack, parser, resume_ratio - hp_pipeline_*, the GPU form of hyperpose::stream."""
+    import ctypes as C
+
+    from hyperpose_amd import _lib
+    from hyperpose_amd.pipeline import Pipeline
+    w_, h_ = frame_wh
+    nbytes = w_ * h_ * 3
+    lib = _lib.lib()
+    host = C.c_void_p()
+    _lib.check(lib.hp_malloc_host(C.byref(host), C.c_size_t(nbytes * BATCH)))
+    rng = np.random.default_rng(7)
+    src = rng.integers(0, 256, nbytes * BATCH, dtype=np.uint8)
+    C.memmove(host, src.ctypes.data, src.nbytes)
+    ptrs = (C.POINTER(C.c_uint8) * BATCH)(*[C.cast(host.value + i * nbytes, C.POINTER(C.c_uint8)) for i in range(BATCH)])
+    ws, hs = (C.c_int * BATCH)(*([w_] * BATCH)), (C.c_int * BATCH)(*([h_] * BATCH))
+    pl = Pipeline(model, weights, max_batch=BATCH, n_pipes=PIPES, keep_ratio=True, max_frame_wh=frame_wh)
+
+    def loop(n):
+        for _ in range(n):
+            if pl.in_flight == pl.n_pipes:
+                pl.collect()
+            pl.submit_ptrs(ptrs, ws, hs, BATCH)
+        while pl.in_flight:
+            pl.collect()
+
+    loop(24)
+    t0 = time.perf_counter()
+    loop(steps)
+    dt = time.perf_counter() - t0
+    pl.close()
+    lib.hp_free_host(host)
+    return {"value": round(BATCH * steps / dt, 1), "unit": "frames/s", "steps": steps,
+            "what": f"{w_}x{h_} BGR frames in pinned host memory -> H2D ({nbytes * BATCH / 1e6:.1f} MB per batch) -> "
+                    "non_scaling_resize on the GPU -> conv stack -> PAF parser (the network's own heat-maps) -> resume_ratio -> humans on the host"}
 
 
 def roofline(pipe):
@@ -255,6 +294,9 @@ def main():
             out["roofline"] = roofline(pipes[0])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(conf, paf)
+        if world == 1 and not args.no_from_host:
+            del pipes[:]
+            out["from_host"] = from_host(model, w_host)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -32,6 +32,7 @@ UNITS = [
     ("conv_kernels.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),
+    ("pipeline.cpp", []),
 ]
 
 

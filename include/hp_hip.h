@@ -264,6 +264,22 @@ int hp_model_init_weights(const hp_model* m, uint64_t seed, float* blob, size_t 
 int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
                                 const float* weights, size_t n_weights);
 
+/* ---- hyperpose::stream on the GPU (reference include/hyperpose/stream/stream.hpp:119-390, src/stream.cpp:60-147): host frames of
+ * any size in, humans out, in submission order.  Each submit copies one batch (<= max_batch frames, 8-bit BGR HWC, packed rows) to
+ * the device and enqueues resize (keep_ratio = 0: cv::resize; 1: non_scaling_resize + resume_ratio on the way out) -> conv stack ->
+ * PAF parser on the stream of the next free engine+parser pair; `n_pipes` batches can be in flight.  Frames in pinned memory
+ * (hp_malloc_host) are copied from where they lie, others through a pinned staging buffer.  The network must have the two PAF
+ * outputs (conf, paf).  max_frame_bytes bounds width*height*3 of a submitted frame. */
+typedef struct hp_pipeline hp_pipeline;
+int hp_pipeline_create(hp_pipeline** out, const hp_engine_desc* desc, int n_pipes, int keep_ratio, float conf_thresh,
+                       float paf_thresh, size_t max_frame_bytes);
+void hp_pipeline_destroy(hp_pipeline* p);
+/* HP_ERR_STATE when all pipes are busy (collect first) */
+int hp_pipeline_submit(hp_pipeline* p, const uint8_t* const* frames, const int* widths, const int* heights, int n);
+/* waits for the OLDEST batch in flight; out[i * cap_per_frame + j], n_out[i] for i < *n_frames */
+int hp_pipeline_collect(hp_pipeline* p, hp_human* out, int cap_per_frame, int* n_out, int* n_frames);
+int hp_pipeline_in_flight(const hp_pipeline* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,5 +4,6 @@
 #include "operator/parser/paf.hpp"
 #include "operator/parser/pifpaf.hpp"
 #include "operator/parser/proposal_network.hpp"
+#include "stream/stream.hpp"
 #include "utility/data.hpp"
 #include "utility/human.hpp"

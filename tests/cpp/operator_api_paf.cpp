@@ -48,6 +48,24 @@ int main()
             return 6;
         humans += pp.process(out2[0]).size();
     }
+    {   // the stream operator (stream.hpp:119-145): frames of any size in, pose sets out in submission order
+        hp::hip_stream stream(hp::dnn::builtin_model{ "lw_openpose_mobilenet", {}, 7 }, cv::Size(96, 80), 4, /*keep_ratio*/ true, /*n_pipes*/ 2,
+            cv::Size(640, 480));
+        std::vector<cv::Mat> big;
+        for (int i = 0; i < 3; ++i) {
+            cv::Mat m(120 + 40 * i, 200 - 30 * i);
+            for (size_t k = 0; k < m.total() * 3; ++k)
+                m.data()[k] = (uint8_t)((k * 17 + i) & 255);
+            big.push_back(m);
+        }
+        stream.push(big);
+        stream.push({ big[1] });
+        if (stream.in_flight() != 2)
+            return 7;
+        const auto first = stream.pop(), second = stream.pop();
+        if (first.size() != 3 || second.size() != 1 || stream.in_flight() != 0)
+            return 8;
+    }
     bool threw = false;
     try {
         engine.inference(std::vector<cv::Mat>(5, batch[0]));
