@@ -88,6 +88,8 @@ struct hp_engine {
     int flip_rb = 1;
     float mean[3] = { 0, 0, 0 }, inv_std[3] = { 1, 1, 1 };
     std::vector<hp_layer> layers;
+    std::vector<hp_output_desc> out_descs; // as given (hp_engine_save)
+    std::vector<float> weights_blob;       // as given (hp_engine_save)
     std::vector<std::unique_ptr<tensor_info>> tensors;
     std::vector<out_info> outputs; // sorted by name
     std::vector<step> steps;
@@ -131,6 +133,8 @@ int hp_engine::build(const hp_engine_desc* d)
     for (int c = 0; c < 3; ++c)
         mean[c] = d->mean[c], inv_std[c] = d->inv_std[c];
     layers.assign(d->layers, d->layers + d->n_layers);
+    out_descs.assign(d->outputs, d->outputs + (d->outputs ? d->n_outputs : 0));
+    weights_blob.assign(d->weights, d->weights + d->n_weights);
 
     // ---- pass 1: tensor shapes
     int max_id = 0;
@@ -767,6 +771,71 @@ int hp_engine_create(hp_engine** out, const hp_engine_desc* desc)
     HP_TRY(e->build(desc));
     *out = e.release();
     return HP_OK;
+}
+
+// ---- serialized engines (reference: tensorrt::save, src/tensorrt.cpp:463-471; tensorrt_serialized + the deserialising
+// constructor, include/hyperpose/utility/model.hpp:27-32, src/tensorrt.cpp:225-252).  The file holds what hp_engine_create
+// was given - topology, outputs, pre-processing, fp32 weights - so loading rebuilds the identical engine without the model
+// source; the packing into kernel layouts happens at load (tens of ms), there is no per-device tuning cache to carry.
+namespace {
+constexpr char ENGINE_MAGIC[8] = { 'H', 'P', 'E', 'N', 'G', '0', '0', '1' };
+struct engine_file_header {
+    char magic[8];
+    int32_t layer_size, output_size; // sizeof(hp_layer) / sizeof(hp_output_desc): ABI guard
+    int32_t in_w, in_h, max_batch, flip_rb;
+    double factor;
+    float mean[3], inv_std[3];
+    int32_t n_layers, n_outputs;
+    uint64_t n_weights;
+};
+} // namespace
+
+int hp_engine_save(const hp_engine* e, const char* path)
+{
+    HP_REQUIRE(e && path, HP_ERR_INVALID, "hp_engine_save: null argument");
+    FILE* f = fopen(path, "wb");
+    HP_REQUIRE(f, HP_ERR_INVALID, "hp_engine_save: cannot open %s for writing", path);
+    engine_file_header h{};
+    memcpy(h.magic, ENGINE_MAGIC, 8);
+    h.layer_size = (int32_t)sizeof(hp_layer), h.output_size = (int32_t)sizeof(hp_output_desc);
+    h.in_w = e->in_w, h.in_h = e->in_h, h.max_batch = e->max_batch, h.flip_rb = e->flip_rb, h.factor = e->factor;
+    for (int c = 0; c < 3; ++c)
+        h.mean[c] = e->mean[c], h.inv_std[c] = e->inv_std[c];
+    h.n_layers = (int32_t)e->layers.size(), h.n_outputs = (int32_t)e->out_descs.size(), h.n_weights = e->weights_blob.size();
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    ok = ok && fwrite(e->layers.data(), sizeof(hp_layer), e->layers.size(), f) == e->layers.size();
+    ok = ok && fwrite(e->out_descs.data(), sizeof(hp_output_desc), e->out_descs.size(), f) == e->out_descs.size();
+    ok = ok && fwrite(e->weights_blob.data(), sizeof(float), e->weights_blob.size(), f) == e->weights_blob.size();
+    ok = (fclose(f) == 0) && ok;
+    HP_REQUIRE(ok, HP_ERR_INVALID, "hp_engine_save: short write to %s", path);
+    return HP_OK;
+}
+
+int hp_engine_load(hp_engine** out, const char* path, int max_batch)
+{
+    HP_REQUIRE(out && path, HP_ERR_INVALID, "hp_engine_load: null argument");
+    FILE* f = fopen(path, "rb");
+    HP_REQUIRE(f, HP_ERR_INVALID, "hp_engine_load: cannot open %s", path);
+    engine_file_header h{};
+    std::vector<hp_layer> layers;
+    std::vector<hp_output_desc> outs;
+    std::vector<float> w;
+    bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, ENGINE_MAGIC, 8) == 0 && h.layer_size == (int32_t)sizeof(hp_layer)
+        && h.output_size == (int32_t)sizeof(hp_output_desc) && h.n_layers > 0 && h.n_layers < (1 << 20) && h.n_outputs > 0
+        && h.n_outputs < 4096 && h.n_weights < ((uint64_t)1 << 34);
+    if (ok) {
+        layers.resize(h.n_layers), outs.resize(h.n_outputs), w.resize(h.n_weights);
+        ok = fread(layers.data(), sizeof(hp_layer), layers.size(), f) == layers.size()
+            && fread(outs.data(), sizeof(hp_output_desc), outs.size(), f) == outs.size() && fread(w.data(), sizeof(float), w.size(), f) == w.size();
+    }
+    fclose(f);
+    HP_REQUIRE(ok, HP_ERR_INVALID, "hp_engine_load: %s is not an engine file written by this library version", path);
+    hp_engine_desc d{};
+    d.in_w = h.in_w, d.in_h = h.in_h, d.max_batch = max_batch > 0 ? max_batch : h.max_batch, d.factor = h.factor, d.flip_rb = h.flip_rb;
+    for (int c = 0; c < 3; ++c)
+        d.mean[c] = h.mean[c], d.inv_std[c] = h.inv_std[c];
+    d.layers = layers.data(), d.n_layers = h.n_layers, d.outputs = outs.data(), d.n_outputs = h.n_outputs, d.weights = w.data(), d.n_weights = w.size();
+    return hp_engine_create(out, &d);
 }
 
 void hp_engine_destroy(hp_engine* e)

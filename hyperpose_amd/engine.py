@@ -120,6 +120,32 @@ class Engine:
         return cls(model.layers, model.outputs, weights, model.in_w, model.in_h, max_batch, factor, flip_rgb,
                    model.mean, model.inv_std)
 
+    def _adopt(self, handle, max_batch: int):
+        self._h = handle
+        w, h = C.c_int(), C.c_int()
+        check(lib().hp_engine_input_size(self._h, C.byref(w), C.byref(h)))
+        self.in_w, self.in_h, self.max_batch = w.value, h.value, lib().hp_engine_max_batch(self._h)
+        lib().hp_engine_stream.restype = C.c_void_p
+        self.stream = lib().hp_engine_stream(self._h)
+        self.outputs = []
+        for i in range(lib().hp_engine_num_outputs(self._h)):
+            name, shape, dev = C.c_char_p(), (C.c_int * 3)(), C.POINTER(C.c_float)()
+            check(lib().hp_engine_output(self._h, i, C.byref(name), shape, C.byref(dev)))
+            self.outputs.append((name.value.decode(), tuple(shape), C.cast(dev, C.c_void_p).value))
+
+    def save(self, path: str) -> None:
+        """``tensorrt::save`` (src/tensorrt.cpp:463-471): topology + pre-processing + weights in one file."""
+        check(lib().hp_engine_save(self._h, path.encode()))
+
+    @classmethod
+    def load(cls, path: str, max_batch: int = 0) -> "Engine":
+        """``tensorrt(tensorrt_serialized{path}, ...)`` (include/hyperpose/utility/model.hpp:27-32)."""
+        self = cls.__new__(cls)
+        handle = C.c_void_p()
+        check(lib().hp_engine_load(C.byref(handle), path.encode(), int(max_batch)))
+        self._adopt(handle, max_batch)
+        return self
+
     def close(self):
         if self._h:
             lib().hp_engine_destroy(self._h)

@@ -231,6 +231,11 @@ int hp_engine_set_graph(hp_engine* e, int enable); /* replay the schedule from a
  * [max_batch][C][H][W] of which the first n frames are valid after the last inference completed. */
 int hp_engine_num_outputs(const hp_engine* e);
 int hp_engine_output(const hp_engine* e, int i, const char** name, int shape[3], const float** dev);
+/* Serialized engines: tensorrt::save (include/hyperpose/operator/dnn/tensorrt.hpp:121-123, src/tensorrt.cpp:463-471) and the
+ * tensorrt_serialized constructor (include/hyperpose/utility/model.hpp:27-32, src/tensorrt.cpp:225-252).  The file carries the
+ * topology, outputs, pre-processing and fp32 weights the engine was created from; max_batch <= 0 keeps the saved one. */
+int hp_engine_save(const hp_engine* e, const char* path);
+int hp_engine_load(hp_engine** out, const char* path, int max_batch);
 int hp_engine_output_to_host(hp_engine* e, int i, int n, float* host); /* synchronises, then D2H */
 /* Read back an internal fp16 NHWC tensor as fp32 NCHW [n][C][H][W] (layer-wise parity tests only). */
 int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int shape[3]);

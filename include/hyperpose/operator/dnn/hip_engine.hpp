@@ -19,6 +19,9 @@
 namespace hyperpose {
 namespace dnn {
 
+    struct serialized_model { // hyperpose::dnn::tensorrt_serialized (utility/model.hpp:30-32)
+        std::string model_path;
+    };
     struct builtin_model {
         std::string arch;            // see hp_model_archs()
         std::vector<float> weights;  // empty: deterministic synthetic weights (seed below)
@@ -39,6 +42,23 @@ namespace dnn {
                 hp_model_init_weights(m_model, model.seed, w.data(), w.size());
             }
             if (hp_engine_create_from_model(&m_engine, m_model, max_batch_size, factor, flip_rgb ? 1 : 0, w.data(), w.size()) != HP_OK)
+                fatal(hp_last_error());
+        }
+        // tensorrt(const tensorrt_serialized&, ...) (include/hyperpose/operator/dnn/tensorrt.hpp:72-74, utility/model.hpp:27-32)
+        explicit hip_engine(const serialized_model& model, cv::Size input_size, int max_batch_size = 8, bool keep_ratio = false)
+            : m_inp_size(input_size), m_max_batch_size(max_batch_size), m_keep_ratio(keep_ratio)
+        {
+            if (hp_engine_load(&m_engine, model.model_path.c_str(), max_batch_size) != HP_OK)
+                fatal(hp_last_error());
+            int w = 0, h = 0;
+            hp_engine_input_size(m_engine, &w, &h);
+            if (w != input_size.width || h != input_size.height)
+                fatal("serialized engine was built for another input size");
+        }
+        // tensorrt::save (tensorrt.hpp:121-123)
+        void save(const std::string path)
+        {
+            if (hp_engine_save(m_engine, path.c_str()) != HP_OK)
                 fatal(hp_last_error());
         }
         hip_engine(const hip_engine&) = delete;

@@ -406,3 +406,26 @@ def test_fused_mobilenet_stem(hp, monkeypatch, c1, h, w, f32):
     _close(mid, eng2.debug_tensor(y, 3))
     for b in range(3):
         _close(got[b][0][1], got2[b][0][1])
+
+
+def test_engine_save_load_roundtrip(hp, tmp_path):
+    """tensorrt::save / tensorrt_serialized (src/tensorrt.cpp:225-252, :463-471): a saved engine reloads to the same bits."""
+    m = E.Model("lw_openpose_vggtiny", 128, 96)
+    w = m.init_weights(5)
+    eng = E.Engine.from_model(m, w, max_batch=3)
+    fr = _frames(3, 96, 128, seed=8)
+    got = eng.inference(fr)
+    path = str(tmp_path / "engine.hpe")
+    eng.save(path)
+    eng2 = E.Engine.load(path)
+    assert (eng2.in_w, eng2.in_h, eng2.max_batch) == (128, 96, 3) and [o[:2] for o in eng2.outputs] == [o[:2] for o in eng.outputs]
+    again = eng2.inference(fr)
+    for b in range(3):
+        for (n1, a1), (n2, a2) in zip(got[b], again[b]):
+            assert n1 == n2 and np.array_equal(a1, a2)
+    eng4 = E.Engine.load(path, max_batch=5)
+    assert eng4.max_batch == 5
+    bad = tmp_path / "bad.hpe"
+    bad.write_bytes(b"not an engine")
+    with pytest.raises(Exception):
+        E.Engine.load(str(bad))
