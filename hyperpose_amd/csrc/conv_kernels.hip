@@ -1326,23 +1326,28 @@ hipError_t launch_dwconv3x3(const dw_params& p_in, hipStream_t s)
 //            wavefront-wide 16-byte load is one fully coalesced 1 KB fragment that only this wavefront needs - no
 //            LDS staging, no barrier for A, re-issued for the next chunk as soon as its MFMAs are done.
 //   epilogue = conv_epilogue_staged (bias, activation, 16-byte NHWC stores, 64 * TM bytes contiguous per pixel).
-template <int TM, int NT, int TH, int TW, int S, int D, int CK>
-__global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int tiles_x, int tiles_y)
+template <int TM, int NT, int TH, int TW, int S, int D, int CK, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void sepconv_kernel(const sep_params p, int tiles_x, int tiles_y)
 {
+    // NW wavefronts split the output channels (32 * TM rows each).  NW = 8 (two wavefronts per SIMD covering each other's
+    // depthwise taps / LDS waits) and the two-slab TM = 2 form (two blocks per CU) were both tried: at <= 256 registers per
+    // lane the accumulators + weight prefetch + depthwise working set spill (300-490 B of scratch), so the kernel stays at
+    // one wavefront per SIMD and, consequently, alone on its CU
+    constexpr int NTHR = 64 * NW;
     constexpr int NPX = TH * TW;
     static_assert(NPX == NT * 32, "pixel tile = NT MFMA tiles");
     constexpr int IH = (TH - 1) * S + 2 * D + 1, IW = (TW - 1) * S + 2 * D + 1;
     constexpr int CG = CK / 8;                       // 16-byte channel groups per pixel and chunk
     constexpr int PIECES = IH * IW * CG;             // 16-byte pieces of one halo chunk
-    constexpr int NLD = (PIECES + 255) / 256;
-    constexpr int ITEMS = NPX * CG / 256;            // (pixel, channel group) depthwise items per thread and chunk
-    static_assert(NPX * CG % 256 == 0, "whole depthwise items per thread");
+    constexpr int NLD = (PIECES + NTHR - 1) / NTHR;
+    constexpr int ITEMS = (NPX * CG + NTHR - 1) / NTHR; // (pixel, channel group) depthwise items per thread and chunk
+    constexpr bool RAGGED = NPX * CG % NTHR != 0;       // the last item of the upper threads does not exist
     constexpr int KS = CK / 16;                      // k16 steps per chunk
     constexpr int HALO_BYTES = PIECES * 16;
     constexpr int B_BYTES = NPX * CK * 2;
     constexpr int DWW_BYTES = 9 * SEP_CMAX * 2 + SEP_CMAX * 4;
     constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * B_BYTES + DWW_BYTES;
-    constexpr int EPI_BYTES = 4 * stage_geom<TM>::SLAB;
+    constexpr int EPI_BYTES = NW * stage_geom<TM>::SLAB;
     constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const s_halo = lds; // two buffers: chunk k lives in buffer k & 1
@@ -1361,7 +1366,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int ti
     const int C = p.C, KQ = C / 16, NCH = C / CK;
 
     // ---- pointwise weights of chunk 0: a[ks][i] = fragment (32-row tile wave*TM + i, k16 step ks)
-    const int mt0 = (blockIdx.y * 4 + wave) * TM; // first 32-row tile of this wavefront (blockIdx.y: slab of 128 * TM output channels)
+    const int mt0 = (blockIdx.y * NW + wave) * TM; // first 32-row tile of this wavefront (blockIdx.y: slab of 128 * TM output channels)
     const __half* wfrag = p.pw.w + ((size_t)mt0 * KQ * 64 + lane) * 8;
     u32x4 a[KS][TM];
 #define HP_ALOAD(KSI, CHUNK)                                                                                      \
@@ -1377,7 +1382,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int ti
     unsigned hmask[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int i = min(tid + k * 256, PIECES - 1);
+        const int i = min(tid + k * NTHR, PIECES - 1);
         const int hp = i / CG, c = i - hp * CG;
         const int hy = hp / IW, hx = hp - hy * IW;
         const int y = iy0 + hy, x = ix0 + hx;
@@ -1395,9 +1400,9 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int ti
     HP_STAMP();
 
     // depthwise weights + bias -> LDS (once)
-    for (int i = tid; i < 9 * C / 8; i += 256)
+    for (int i = tid; i < 9 * C / 8; i += NTHR)
         reinterpret_cast<u32x4*>(s_dww)[i] = reinterpret_cast<const u32x4*>(p.dw_w)[i];
-    for (int i = tid; i < C / 4; i += 256)
+    for (int i = tid; i < C / 4; i += NTHR)
         reinterpret_cast<float4*>(s_dwb)[i] = reinterpret_cast<const float4*>(p.dw_bias)[i];
 
     floatx16 acc[TM][NT];
@@ -1416,7 +1421,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int ti
     int xoff[ITEMS], boff[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
-        const int pix = (tid + r * 256) / CG;
+        const int pix = min(tid + r * NTHR, NPX * CG - 1) / CG;
         const int py = pix / TW, px = pix - py * TW;
         xoff[r] = ((py * S) * IW + px * S) * CG * 16 + g * 16;
         boff[r] = lds_off<CK>(pix, g);
@@ -1474,7 +1479,8 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int ti
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         h[e] = (_Float16)dw_act<true>(v[e], 0.f, dw_hi);
-                    *reinterpret_cast<half8*>(bt_d + boff[r]) = h;
+                    if (!RAGGED || r + 1 < ITEMS || tid + r * NTHR < NPX * CG)
+                        *reinterpret_cast<half8*>(bt_d + boff[r]) = h;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1511,8 +1517,8 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int ti
         unsigned char* const dst = s_halo + (chunk & 1) * HALO_BYTES;
 #pragma unroll
         for (int k = 0; k < NLD; ++k)
-            if (tid + k * 256 < PIECES)
-                *reinterpret_cast<u32x4*>(dst + (size_t)(tid + k * 256) * 16) = hv[k] & hmask[k]; // mask HERE: the loads stay in flight
+            if (tid + k * NTHR < PIECES)
+                *reinterpret_cast<u32x4*>(dst + (size_t)(tid + k * NTHR) * 16) = hv[k] & hmask[k]; // mask HERE: the loads stay in flight
     };
 
     // ---- chunk 0: halo -> LDS, depthwise -> B[0]; chunk 1's halo lands meanwhile
@@ -1561,13 +1567,13 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const sep_params p, int ti
     conv_epilogue_staged<TM, NT>(p.pw, acc, mt0 * 32, lane, lds + wave * stage_geom<TM>::SLAB, pb, py, px, pv);
 }
 
-template <int TM, int NT, int TH, int TW, int S, int D, int CK>
+template <int TM, int NT, int TH, int TW, int S, int D, int CK, int NW = 4>
 static hipError_t launch_sep(const sep_params& p, hipStream_t s)
 {
     const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
     // blockIdx.y: slabs of 128 * TM output channels; each slab recomputes the depthwise tile (cheap next to a second
     // pass through the fabric) and two slabs of one CU cover each other's depthwise / MFMA / store phases
-    hipLaunchKernelGGL((sepconv_kernel<TM, NT, TH, TW, S, D, CK>), dim3(tiles_x * tiles_y * p.B, p.pw.Cout_pad / (128 * TM)), dim3(256), 0, s, p, tiles_x, tiles_y);
+    hipLaunchKernelGGL((sepconv_kernel<TM, NT, TH, TW, S, D, CK, NW>), dim3(tiles_x * tiles_y * p.B, p.pw.Cout_pad / (32 * NW * TM)), dim3(64 * NW), 0, s, p, tiles_x, tiles_y);
     return hipGetLastError();
 }
 

@@ -105,7 +105,7 @@ hipError_t launch_dwconv3x3(const dw_params& p, hipStream_t s);
 // Depthwise 3x3 + pointwise 1x1 fused (sepconv_kernel).  `pw` describes the pointwise half exactly like a 1x1
 // conv_params (Cin = C, bias, activation, out, OH/OW/npix) except that pw.w holds the weights in MFMA-fragment order:
 // half index (((m / 32) * (C / 16) + k / 16) * 64 + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8 for row m, input channel k.
-constexpr int SEP_CMAX = 1024;
+constexpr int SEP_CMAX = 512;
 struct sep_params {
     tview in;
     int B, H, W, OH, OW, C;
