@@ -194,14 +194,11 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
 
     auto up_row = [&](int i) { // row m_begin + i: HResizeLinear on the two source rows, then VResizeLinear
         const int r0 = s_r0[i], r1 = s_r1[i];
-        float h0, h1;
-        if (two_tap) {
-            h0 = s_src[r0 + sx] * a0 + s_src[r0 + sx1] * a1;
-            h1 = s_src[r1 + sx] * a0 + s_src[r1 + sx1] * a1;
-        } else {
-            h0 = s_src[r0 + sx] * 1.f;
-            h1 = s_src[r1 + sx] * 1.f;
-        }
+        // branch-free, same values: single-tap columns have a0 = 1, so t0 = S*1.f is already their result; the sum is
+        // only selected for two-tap columns
+        const float t0 = s_src[r0 + sx] * a0, t1 = s_src[r1 + sx] * a0;
+        const float u0 = s_src[r0 + sx1] * a1, u1 = s_src[r1 + sx1] * a1;
+        const float h0 = two_tap ? t0 + u0 : t0, h1 = two_tap ? t1 + u1 : t1;
         return h0 * s_cy0[i] + h1 * s_cy1[i];
     };
 
