@@ -1643,12 +1643,16 @@ hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 //          (head_params), 8 k16 steps per wavefront; the four partial sums meet through LDS.
 //   store: bias2 / activation, fp16 NHWC slice and / or fp32 NCHW network output.
 template <int NCH>
-__global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(256, 2) void mlp_head_kernel(const head_params p, int tiles_x, int tiles_y)
 {
-    constexpr int TH = 8, TW = 12, NPX = 96, NT = 3, TM = 4;
+    // 8 x 8 pixel tile and the hidden rows in two passes of 2 x 32 per wavefront: 64 + 64 accumulator registers instead
+    // of 192 + 96, so that the kernel fits half a CU (<= 256 registers, 64 KB of LDS) and shares it with whatever the
+    // other hardware queue is running - alone on its CU it cost its full duration end to end.
+    constexpr int TH = 8, TW = 8, NPX = 64, NT = 2, TP = 2; // TP = row tiles per pass (2 passes x 2 = 4 per wavefront)
     constexpr int K1 = NCH * 64, KQ1 = K1 / 16; // k16 steps of GEMM1
-    constexpr int X_BYTES = NCH * NPX * 128;    // NCH tiles [96 px][64 ch]
-    constexpr int RED_BYTES = 4 * 24 * 64 * 16; // [wave][float4 index][lane]
+    constexpr int X_BYTES = NCH * NPX * 128;    // NCH tiles [64 px][64 ch]
+    constexpr int NSLOT = 2 * NT * 4;           // float4 slots of the second GEMM's result per lane
+    constexpr int RED_BYTES = 4 * NSLOT * 64 * 16; // [wave][slot][lane]
     constexpr int LDS_BYTES = X_BYTES > RED_BYTES ? X_BYTES : RED_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -1665,11 +1669,12 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
         q.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
     HP_STAMP();
 
-    // ---- GEMM1 weights: fragments (row tile wave*4 + i, k16 step 0 and 1) in flight first
-    const __half* w1 = p.w1 + ((size_t)(wave * TM) * KQ1 * 64 + lane) * 8;
-    u32x4 a[2][TM];
+    // ---- GEMM1 weights of pass 0: fragments (row tile wave*4 + i, k16 step 0 and 1) in flight first
+    const __half* w1 = p.w1 + ((size_t)(wave * 4) * KQ1 * 64 + lane) * 8;
+    const __half* w2 = p.w2 + ((size_t)(wave * 8) * 64 + lane) * 8;
+    u32x4 a[2][TP];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TP; ++i) {
         a[0][i] = *reinterpret_cast<const u32x4*>(w1 + ((size_t)i * KQ1 + 0) * 512);
         a[1][i] = *reinterpret_cast<const u32x4*>(w1 + ((size_t)i * KQ1 + 1) * 512);
     }
@@ -1692,51 +1697,6 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
             *reinterpret_cast<u32x4*>(lds + (c >> 3) * (NPX * 128) + lds_off<64>(pix, c & 7)) = xv[k];
         }
     }
-    // GEMM2 weights of this wavefront's 8 k16 steps (2 row tiles each): requested now, needed after GEMM1
-    u32x4 a2[8][2];
-    {
-        const __half* w2 = p.w2 + ((size_t)(wave * 8) * 64 + lane) * 8;
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8)
-#pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
-                a2[s8][i2] = *reinterpret_cast<const u32x4*>(w2 + ((size_t)i2 * 32 + s8) * 512);
-    }
-
-    floatx16 acc[TM][NT];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[i][j][r] = 0.f;
-    const int frow = lane & 31, fk = lane >> 5;
-    HP_STAMP();
-    lds_barrier(); // the input tile is complete
-    HP_STAMP();
-
-    // ---- GEMM1
-#pragma unroll
-    for (int qs = 0; qs < KQ1; ++qs) {
-        half8 fb[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            fb[j] = *reinterpret_cast<const half8*>(lds + (qs / 4) * (NPX * 128) + lds_off<64>(j * 32 + frow, (qs % 4) * 2 + fk));
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            half8 fa;
-            __builtin_memcpy(&fa, &a[qs & 1][i], 16);
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
-            if (qs + 2 < KQ1)
-                a[qs & 1][i] = *reinterpret_cast<const u32x4*>(w1 + ((size_t)i * KQ1 + qs + 2) * 512);
-        }
-    }
-
-    HP_STAMP();
-    // ---- hidden activations -> fp16 B fragments of GEMM2, then GEMM2 on this wavefront's 128 hidden rows
     floatx16 acc2[2][NT];
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
@@ -1745,44 +1705,90 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc2[i2][j][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
     const float hi1 = p.hi1;
+    HP_STAMP();
+    lds_barrier(); // the input tile is complete
+    HP_STAMP();
+
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        float bs[16];
+    for (int pass = 0; pass < 2; ++pass) {
+        // GEMM2 weights of this pass (k16 steps 4 pass .. 4 pass + 3 of this wavefront, 2 row tiles): needed after GEMM1
+        u32x4 a2[4][2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 bv = *reinterpret_cast<const float4*>(p.b1 + wave * 128 + i * 32 + 8 * g + 4 * fk);
-            bs[4 * g] = bv.x, bs[4 * g + 1] = bv.y, bs[4 * g + 2] = bv.z, bs[4 * g + 3] = bv.w;
-        }
+        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            half8 hb[NT];
+            for (int i2 = 0; i2 < 2; ++i2)
+                a2[s4][i2] = *reinterpret_cast<const u32x4*>(w2 + ((size_t)i2 * 32 + pass * 4 + s4) * 512);
+        // ---- GEMM1 for hidden row tiles 2 pass, 2 pass + 1 of this wavefront
+        floatx16 acc[TP][NT];
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    hb[j][e] = (_Float16)__builtin_amdgcn_fmed3f(acc[i][j][8 * s + e] + bs[8 * s + e], 0.f, hi1);
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] = 0.f;
 #pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2) {
+        for (int qs = 0; qs < KQ1; ++qs) {
+            half8 fb[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                fb[j] = *reinterpret_cast<const half8*>(lds + (qs / 4) * (NPX * 128) + lds_off<64>(j * 32 + frow, (qs % 4) * 2 + fk));
+#pragma unroll
+            for (int i = 0; i < TP; ++i) {
                 half8 fa;
-                __builtin_memcpy(&fa, &a2[i * 2 + s][i2], 16);
+                __builtin_memcpy(&fa, &a[qs & 1][i], 16);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc2[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, hb[j], acc2[i2][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+                // two k16 steps ahead; the last two steps of pass 0 already fetch the first two of pass 1
+                const int qn = qs + 2 < KQ1 ? qs + 2 : qs + 2 - KQ1;
+                const int pn = qs + 2 < KQ1 ? pass : pass + 1;
+                if (pn < 2)
+                    a[qs & 1][i] = *reinterpret_cast<const u32x4*>(w1 + ((size_t)(pn * TP + i) * KQ1 + qn) * 512);
+            }
+        }
+        // ---- hidden activations -> fp16 B fragments, GEMM2 on these 64 hidden rows
+#pragma unroll
+        for (int i = 0; i < TP; ++i) {
+            float bs[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.b1 + wave * 128 + (pass * TP + i) * 32 + 8 * g + 4 * fk);
+                bs[4 * g] = bv.x, bs[4 * g + 1] = bv.y, bs[4 * g + 2] = bv.z, bs[4 * g + 3] = bv.w;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half8 hb[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        hb[j][e] = (_Float16)__builtin_amdgcn_fmed3f(acc[i][j][8 * s2 + e] + bs[8 * s2 + e], 0.f, hi1);
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    half8 fa;
+                    __builtin_memcpy(&fa, &a2[i * 2 + s2][i2], 16);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc2[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, hb[j], acc2[i2][j], 0, 0, 0);
+                }
             }
         }
     }
-
     HP_STAMP();
-    // second-layer bias / slopes of the six float4 slots this wave will finish (host arrays are padded to 64 rows)
-    float4 bias4[6], slope4[6];
+
+    // second-layer bias / slopes of the float4 slots this wave will finish (host arrays are padded to 64 rows)
+    constexpr int PERW = NSLOT / 4;
+    float4 bias4[PERW], slope4[PERW];
 #pragma unroll
-    for (int f6 = 0; f6 < 6; ++f6) {
-        const int f = wave * 6 + f6, m = ((f >> 2) / NT) * 32 + 8 * (f & 3) + 4 * fk;
+    for (int f6 = 0; f6 < PERW; ++f6) {
+        const int f = wave * PERW + f6, m = ((f >> 2) / NT) * 32 + 8 * (f & 3) + 4 * fk;
         bias4[f6] = *reinterpret_cast<const float4*>(q.bias + m);
         slope4[f6] = q.alpha ? *reinterpret_cast<const float4*>(q.alpha + m) : make_float4(q.act_slope, q.act_slope, q.act_slope, q.act_slope);
     }
-    // ---- the four partial sums meet: wave w finishes float4 slots 6w .. 6w+5 of the 24 per lane
+    // ---- the four partial sums meet: wave w finishes float4 slots PERW w .. PERW w + PERW - 1 of the NSLOT per lane
     __syncthreads(); // every wave is done with the input tile
     float4* const red = reinterpret_cast<float4*>(lds);
 #pragma unroll
@@ -1791,18 +1797,18 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(const head_params p, int 
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                red[((size_t)wave * 24 + (i2 * NT + j) * 4 + g) * 64 + lane]
+                red[((size_t)wave * NSLOT + (i2 * NT + j) * 4 + g) * 64 + lane]
                     = make_float4(acc2[i2][j][4 * g], acc2[i2][j][4 * g + 1], acc2[i2][j][4 * g + 2], acc2[i2][j][4 * g + 3]);
     __syncthreads();
     HP_STAMP();
     const long plane = (long)q.OH * q.OW;
 #pragma unroll
-    for (int f6 = 0; f6 < 6; ++f6) {
-        const int f = wave * 6 + f6, tile = f >> 2, g = f & 3, i2 = tile / NT, j = tile % NT;
-        float4 v = red[((size_t)0 * 24 + f) * 64 + lane];
+    for (int f6 = 0; f6 < PERW; ++f6) {
+        const int f = wave * PERW + f6, tile = f >> 2, g = f & 3, i2 = tile / NT, j = tile % NT;
+        float4 v = red[((size_t)0 * NSLOT + f) * 64 + lane];
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
-            const float4 o = red[((size_t)w * 24 + f) * 64 + lane];
+            const float4 o = red[((size_t)w * NSLOT + f) * 64 + lane];
             v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
         }
         const int m = i2 * 32 + 8 * g + 4 * fk;
@@ -1854,7 +1860,7 @@ int mlp_head_variant(int k1, int hidden, int cout2)
 
 hipError_t launch_mlp_head(const head_params& p, hipStream_t s)
 {
-    const int tiles_x = (p.W + 11) / 12, tiles_y = (p.H + 7) / 8;
+    const int tiles_x = (p.W + 7) / 8, tiles_y = (p.H + 7) / 8;
     const dim3 grid(tiles_x * tiles_y * p.B);
     switch (mlp_head_variant(p.K1, 512, p.pw.Cout)) {
     case 1:
