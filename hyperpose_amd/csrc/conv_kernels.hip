@@ -1610,7 +1610,8 @@ int sepconv_variant(const sep_params& p)
 
 hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 {
-    switch (sepconv_variant(p)) {
+    const int v = sepconv_variant(p);
+    switch (v) {
     case 1:
         return launch_sep<1, 12, 16, 24, 1, 1, 32>(p, s);
     case 2:
