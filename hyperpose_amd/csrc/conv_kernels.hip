@@ -1577,6 +1577,205 @@ static hipError_t launch_sep(const sep_params& p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The separable block cut to HALF a CU (<= 256 registers, < 80 KB of LDS) for 256 / 512 output channels at stride 1.
+// With two kernels in flight a CU is two slots; sepconv_kernel above (460 registers) holds both, so its whole duration
+// shows up end to end.  Same arithmetic, different cut, and deliberately plain code (rolled loops,
+// phases not interleaved) so that hipcc's register allocation stays small - the second block on the CU provides the
+// overlap that the in-wave interleave buys above:
+//   * 8 x 8 output pixels per block; the depthwise results of ALL K chunks stay in LDS (B_all: 64 px x C halves <= 64 KB);
+//   * output channels in NP passes of 256 (4 wavefronts x 2 row tiles): pass 0 = per chunk depthwise -> B_all, then its
+//     MFMAs; pass 1 = MFMAs only, straight out of B_all, no barrier.  64 accumulator registers, nothing recomputed;
+//   * pass 0 stores with the direct epilogue (B_all must survive), the last pass with the staged one.
+template <int NP, int D>
+__global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p, int tiles_x, int tiles_y)
+{
+    constexpr int TH = 8, TW = 8, NPX = 64, NT = 2, TP = 2, CK = 64, CG = 8, KS = 4;
+    constexpr int IH = TH + 2 * D, IW = TW + 2 * D;
+    constexpr int PIECES = IH * IW * CG, NLD = (PIECES + 255) / 256, ITEMS = NPX * CG / 256;
+    constexpr int HALO_BYTES = PIECES * 16, BCH_BYTES = NPX * CK * 2, BALL_BYTES = (SEP_CMAX / CK) * BCH_BYTES;
+    constexpr int DWW_BYTES = 9 * CK * 2, DWB_BYTES = CK * 4;
+    constexpr int MAIN_BYTES = BALL_BYTES + HALO_BYTES + 2 * DWW_BYTES + 2 * DWB_BYTES;
+    static_assert(4 * stage_geom<TP>::SLAB <= BALL_BYTES, "the last pass's epilogue slabs overlay B_all");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MAIN_BYTES];
+    unsigned char* const s_ball = lds;
+    unsigned char* const s_halo = lds + BALL_BYTES;
+    unsigned char* const s_dww = s_halo + HALO_BYTES;   // [2][9][64] halves
+    unsigned char* const s_dwb = s_dww + 2 * DWW_BYTES; // [2][64] floats
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1;
+    const int C = p.C, KQ = C / 16, NCH = C / CK, NSTEP = NP * NCH;
+
+    // pointwise weights of linear step L = pass * NCH + chunk: fragment (row tile pass*8 + wave*2 + i, k16 step chunk*4 + ks)
+    const __half* const wbase = p.pw.w + (size_t)lane * 8;
+    u32x4 a[KS][TP];
+    auto a_load = [&](int L, int ks) {
+        const int ps = L / NCH, kc = L - ps * NCH;
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+            a[ks][i] = *reinterpret_cast<const u32x4*>(wbase + ((size_t)(ps * 8 + wave * TP + i) * KQ + kc * KS + ks) * 512);
+    };
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        a_load(0, ks);
+
+    // halo chunk + depthwise weights / bias: global -> registers (one chunk ahead) -> LDS
+    u32x4 hv[NLD], wreg;
+    int hoff[NLD];
+    unsigned hmask = 0;
+    {
+        const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = min(tid + k * 256, PIECES - 1);
+            const int hp = i / CG, c = i - hp * CG;
+            const int hy = hp / IW, hx = hp - hy * IW;
+            const int y = iy0 + hy, x = ix0 + hx;
+            hmask |= (y <= ymax && x <= xmax) ? (1u << k) : 0u;
+            hoff[k] = (min(y, ymax) * p.in.wp + min(x, xmax)) * p.in.cs + c * 8;
+        }
+    }
+    const __half* const hbase = p.in.p + (size_t)b * p.in.img * p.in.cs + p.in.coff;
+    const bool w_thread = tid < 72, b_thread = tid >= 72 && tid < 88; // 72 x 16 B of [9][64] weights, 16 x 16 B of 64 biases
+    auto hload = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            hv[k] = *reinterpret_cast<const u32x4*>(hbase + hoff[k] + chunk * CK);
+        const void* src = w_thread ? (const void*)(p.dw_w + (size_t)(tid >> 3) * C + chunk * CK + (tid & 7) * 8)
+                                   : (const void*)(p.dw_bias + chunk * CK + (b_thread ? (tid - 72) * 4 : 0));
+        wreg = *reinterpret_cast<const u32x4*>(src);
+    };
+    auto to_lds = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (tid + k * 256 < PIECES)
+                *reinterpret_cast<u32x4*>(s_halo + (size_t)(tid + k * 256) * 16) = hv[k] & (((hmask >> k) & 1u) ? 0xffffffffu : 0u);
+        if (w_thread)
+            *reinterpret_cast<u32x4*>(s_dww + (chunk & 1) * DWW_BYTES + tid * 16) = wreg;
+        else if (b_thread)
+            *reinterpret_cast<u32x4*>(s_dwb + (chunk & 1) * DWB_BYTES + (tid - 72) * 16) = wreg;
+    };
+    hload(0);
+
+    floatx16 acc[TP][NT];
+    auto clear_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] = 0.f;
+    };
+    clear_acc();
+    const int g = tid % CG, frow = lane & 31, fk = lane >> 5;
+    const float dw_hi = p.dw_hi;
+
+    // depthwise taps of chunk kd -> B_all[kd] (same arithmetic as dwconv3x3_kernel / sepconv_kernel)
+    auto dw_chunk = [&](int kd) {
+        unsigned char* const bt = s_ball + kd * BCH_BYTES;
+        const float* bsrc = reinterpret_cast<const float*>(s_dwb + (kd & 1) * DWB_BYTES) + g * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
+        u32x4 wv[9];
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+            wv[t9] = *reinterpret_cast<const u32x4*>(s_dww + (kd & 1) * DWW_BYTES + (t9 * CK + g * 8) * 2);
+#pragma unroll 1
+        for (int r = 0; r < ITEMS; ++r) {
+            const int pix = (tid + r * 256) / CG;
+            const int py = pix / TW, px = pix - py * TW;
+            const unsigned char* xs = s_halo + ((py * IW + px) * CG + g) * 16;
+            u32x4 x[9];
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+                x[t9] = *reinterpret_cast<const u32x4*>(xs + (((t9 / 3) * D) * IW + (t9 % 3) * D) * CG * 16);
+            float v[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+                mac8_f16(v, x[t9], wv[t9]);
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                h[e] = (_Float16)dw_act<true>(v[e], 0.f, dw_hi);
+            *reinterpret_cast<half8*>(bt + lds_off<CK>(pix, g)) = h;
+        }
+    };
+    // MFMAs of linear step L out of B_all; the weights of step L+1 are requested as each k16 step's are consumed
+    auto mm_chunk = [&](int L) {
+        const unsigned char* const bt = s_ball + (L % NCH) * BCH_BYTES;
+        const int Ln = min(L + 1, NSTEP - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 fb[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                fb[j] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int i = 0; i < TP; ++i) {
+                half8 fa;
+                __builtin_memcpy(&fa, &a[ks][i], 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+            }
+            a_load(Ln, ks);
+        }
+    };
+
+    int pb[NT], py[NT], px[NT];
+    bool pv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + (lane & 31);
+        pb[j] = b;
+        py[j] = y0 + n / TW;
+        px[j] = x0 + n % TW;
+        pv[j] = py[j] < p.OH && px[j] < p.OW;
+    }
+
+    // ---- pass 0
+    to_lds(0);
+    hload(min(1, NCH - 1));
+    lds_barrier();
+#pragma unroll 1
+    for (int kc = 0; kc < NCH; ++kc) {
+        dw_chunk(kc);
+        lds_barrier(); // B_all[kc] complete; every thread is past its reads of halo chunk kc
+        if (kc + 1 < NCH) {
+            to_lds(kc + 1);
+            hload(min(kc + 2, NCH - 1));
+        }
+        mm_chunk(kc);
+        lds_barrier(); // halo chunk kc+1 and its depthwise weights visible
+    }
+    if (NP == 1) {
+        conv_epilogue_staged<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
+        return;
+    }
+    conv_epilogue<TP, NT, 0>(p.pw, acc, (wave * TP) * 32, lane, pb, py, px, pv);
+    // ---- pass 1: MFMAs only
+    clear_acc();
+#pragma unroll 1
+    for (int kc = 0; kc < NCH; ++kc)
+        mm_chunk(NCH + kc);
+    __syncthreads(); // every wave is done with B_all before the slabs overwrite it
+    conv_epilogue_staged<TP, NT>(p.pw, acc, (8 + wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
+}
+
+template <int NP, int D>
+static hipError_t launch_sep_slot(const sep_params& p, hipStream_t s)
+{
+    const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 7) / 8;
+    hipLaunchKernelGGL((sepconv_slot_kernel<NP, D>), dim3(tiles_x * tiles_y * p.B), dim3(256), 0, s, p, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
 // which instantiation serves (Cout_pad, stride, dilation, C); 0 = none (the engine then keeps the two launches)
 int sepconv_variant_for(int C, int cout_pad, int stride, int dil)
 {
@@ -1610,7 +1809,10 @@ int sepconv_variant(const sep_params& p)
 
 hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 {
+    static const bool slot = !getenv("HP_SEP_SLOT") || atoi(getenv("HP_SEP_SLOT")) != 0; // HP_SEP_SLOT=0: whole-CU form everywhere
     const int v = sepconv_variant(p);
+    if (slot && (v == 4 || v == 5)) // stride 1, dilation 1, 256 / 512 output channels: the half-CU form
+        return v == 4 ? launch_sep_slot<1, 1>(p, s) : launch_sep_slot<2, 1>(p, s);
     switch (v) {
     case 1:
         return launch_sep<1, 12, 16, 24, 1, 1, 32>(p, s);
