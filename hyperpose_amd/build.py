@@ -32,6 +32,7 @@ UNITS = [
     ("conv_kernels.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),
+    ("onnx_import.cpp", []),
     ("pipeline.cpp", []),
 ]
 

@@ -157,8 +157,16 @@ int hp_engine::build(const hp_engine_desc* d)
         const tensor_info& ti = *tensors[L.in];
         HP_REQUIRE(L.in_coff >= 0 && L.in_coff + L.cin <= ti.C, HP_ERR_INVALID, "layer %zu reads channels [%d,%d) of a %d-channel tensor", i, L.in_coff, L.in_coff + L.cin, ti.C);
         geo g;
-        same_pad(ti.H, L.kh, L.stride, L.dil, g.OH, g.pt);
-        same_pad(ti.W, L.kw, L.stride, L.dil, g.OW, g.pl);
+        if (L.pad_explicit) {
+            HP_REQUIRE(L.pad[0] >= 0 && L.pad[1] >= 0 && L.pad[2] >= 0 && L.pad[3] >= 0, HP_ERR_INVALID, "layer %zu: negative padding", i);
+            g.pt = L.pad[0], g.pl = L.pad[1];
+            g.OH = (ti.H + L.pad[0] + L.pad[2] - ((L.kh - 1) * L.dil + 1)) / L.stride + 1;
+            g.OW = (ti.W + L.pad[1] + L.pad[3] - ((L.kw - 1) * L.dil + 1)) / L.stride + 1;
+            HP_REQUIRE(g.OH >= 1 && g.OW >= 1, HP_ERR_INVALID, "layer %zu: empty output", i);
+        } else {
+            same_pad(ti.H, L.kh, L.stride, L.dil, g.OH, g.pt);
+            same_pad(ti.W, L.kw, L.stride, L.dil, g.OW, g.pl);
+        }
         geos[i] = g;
         tensor_info& to = *tensors[L.out];
         if (!to.defined)

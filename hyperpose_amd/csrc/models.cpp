@@ -8,7 +8,7 @@
 //   OpenPose (CMU) head         hyperpose/Model/openpose/model/openpose.py:13-198
 // The released weights are Google-Drive downloads (scripts/downloader.py:12-21) and there is no network, so
 // weights are synthetic: He-normal kernels from a counter-based generator (same numbers from C++ and Python).
-#include "hp_common.hpp"
+#include "model.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -16,69 +16,6 @@
 #include <string>
 #include <vector>
 
-struct hp_model {
-    std::string arch;
-    int in_w = 0, in_h = 0;
-    std::vector<hp_layer> layers;
-    std::vector<float> init_scale; // per layer multiplier on the He std (final linear heads are kept small)
-    std::vector<float> init_bias;  // per layer constant added to every bias (keeps sigmoid heads sparse with synthetic weights)
-    std::vector<hp_output_desc> outputs;
-    int64_t n_weights = 0;
-    int next_tensor = 1;
-    float mean[3] = { 0, 0, 0 }, inv_std[3] = { 1, 1, 1 };
-
-    int new_tensor() { return next_tensor++; }
-
-    // generic layer append; returns the output tensor id
-    int add(int op, int in, int in_coff, int cin, int cout, int k, int stride, int dil, int act, bool bias,
-        int out = -1, int out_coff = 0, int res = -1, int res_before_act = 0, float scale = 1.f, float act_param = 0.f)
-    {
-        hp_layer L;
-        memset(&L, 0, sizeof(L));
-        L.op = op, L.in = in, L.in_coff = in_coff, L.res = res, L.res_before_act = res_before_act;
-        L.out = out < 0 ? new_tensor() : out, L.out_coff = out_coff;
-        L.cin = cin, L.cout = cout, L.kh = k, L.kw = k, L.stride = stride, L.dil = dil, L.act = act, L.act_param = act_param;
-        L.w_off = -1, L.b_off = -1, L.alpha_off = -1;
-        if (op == HP_OP_CONV) {
-            L.w_off = n_weights;
-            n_weights += (int64_t)cout * k * k * cin;
-        } else if (op == HP_OP_DWCONV) {
-            L.w_off = n_weights;
-            n_weights += (int64_t)cin * k * k;
-        }
-        if (bias && op != HP_OP_MAXPOOL) {
-            L.b_off = n_weights;
-            n_weights += cout;
-        }
-        if (act == HP_ACT_PRELU) {
-            L.alpha_off = n_weights;
-            n_weights += cout;
-        }
-        layers.push_back(L);
-        init_scale.push_back(scale);
-        init_bias.push_back(0.f);
-        return L.out;
-    }
-    int conv(int in, int cin, int cout, int k, int act, int stride = 1, int dil = 1, int in_coff = 0)
-    {
-        return add(HP_OP_CONV, in, in_coff, cin, cout, k, stride, dil, act, true);
-    }
-    int dw_block(int in, int cin, int cout, int stride = 1, int dil = 1)
-    {
-        // dw_conv_block: DepthwiseConv2d(b=None)+BN+ReLU, Conv2d 1x1 (b=None)+BN+ReLU  (backbones.py:190-197)
-        const int t = add(HP_OP_DWCONV, in, 0, cin, cin, 3, stride, dil, HP_ACT_RELU, true);
-        return add(HP_OP_CONV, t, 0, cin, cout, 1, 1, 1, HP_ACT_RELU, true);
-    }
-    int pool(int in, int c, int k, int stride) { return add(HP_OP_MAXPOOL, in, 0, c, c, k, stride, 1, HP_ACT_NONE, false); }
-    void output(const char* name, int tensor, int coff, int channels, int act = HP_ACT_NONE)
-    {
-        hp_output_desc o;
-        memset(&o, 0, sizeof(o));
-        strncpy(o.name, name, sizeof(o.name) - 1);
-        o.tensor = tensor, o.coff = coff, o.channels = channels, o.act = act;
-        outputs.push_back(o);
-    }
-};
 
 namespace {
 
@@ -388,12 +325,13 @@ double hp_model_flops_per_frame(const hp_model* m)
 {
     if (!m)
         return 0;
-    // replay the SAME-padding shape propagation of engine.cpp
+    // replay the shape propagation of engine.cpp
     std::vector<int> H(m->next_tensor, 0), W(m->next_tensor, 0);
     H[0] = m->in_h, W[0] = m->in_w;
     double flops = 0;
     for (const hp_layer& L : m->layers) {
-        const int oh = (H[L.in] + L.stride - 1) / L.stride, ow = (W[L.in] + L.stride - 1) / L.stride;
+        int oh, ow;
+        hp_layer_out_size(L, H[L.in], W[L.in], oh, ow);
         H[L.out] = oh, W[L.out] = ow;
         if (L.op == HP_OP_CONV)
             flops += 2.0 * oh * ow * L.cout * L.kh * L.kw * L.cin;
@@ -429,7 +367,10 @@ int hp_model_init_weights(const hp_model* m, uint64_t seed, float* blob, size_t 
 int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
     const float* weights, size_t n_weights)
 {
-    HP_REQUIRE(out && m && weights, HP_ERR_INVALID, "hp_engine_create_from_model: null argument");
+    HP_REQUIRE(out && m, HP_ERR_INVALID, "hp_engine_create_from_model: null argument");
+    if (!weights) // imported models carry their own
+        weights = m->weights.data(), n_weights = m->weights.size();
+    HP_REQUIRE(weights && n_weights, HP_ERR_INVALID, "hp_engine_create_from_model: a built-in topology needs a weight blob");
     hp_engine_desc d;
     memset(&d, 0, sizeof(d));
     d.in_w = m->in_w, d.in_h = m->in_h, d.max_batch = max_batch, d.factor = factor, d.flip_rb = flip_rb;

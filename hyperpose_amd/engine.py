@@ -21,7 +21,7 @@ class Layer(C.Structure):
                 ("res_before_act", C.c_int32), ("out", C.c_int32), ("out_coff", C.c_int32), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32),
                 ("act", C.c_int32), ("act_param", C.c_float), ("w_off", C.c_int64), ("b_off", C.c_int64),
-                ("alpha_off", C.c_int64)]
+                ("alpha_off", C.c_int64), ("pad_explicit", C.c_int32), ("pad", C.c_int32 * 4)]
 
 
 class OutputDesc(C.Structure):
@@ -44,9 +44,14 @@ class LayerTime(C.Structure):
 
 
 def make_layer(op, in_, out, cin, cout, k=1, stride=1, dil=1, act=ACT_NONE, in_coff=0, out_coff=0, res=-1,
-               res_before_act=0, w_off=-1, b_off=-1, alpha_off=-1, act_param=0.0) -> Layer:
-    return Layer(op, in_, in_coff, res, res_before_act, out, out_coff, cin, cout, k, k, stride, dil, act, act_param,
-                 w_off, b_off, alpha_off)
+               res_before_act=0, w_off=-1, b_off=-1, alpha_off=-1, act_param=0.0, pads=None) -> Layer:
+    """``pads`` = (top, left, bottom, right) as in ONNX; None = TF "SAME"."""
+    L = Layer(op, in_, in_coff, res, res_before_act, out, out_coff, cin, cout, k, k, stride, dil, act, act_param,
+              w_off, b_off, alpha_off)
+    if pads is not None:
+        L.pad_explicit = 1
+        L.pad[:] = [int(v) for v in pads]
+    return L
 
 
 class Model:
@@ -56,6 +61,32 @@ class Model:
         self._h = C.c_void_p()
         self.arch, self.in_w, self.in_h = arch, in_w, in_h
         check(lib().hp_model_build(C.byref(self._h), arch.encode(), in_w, in_h))
+        self._read()
+
+    @classmethod
+    def from_onnx(cls, model, in_w: int = 0, in_h: int = 0) -> "Model":
+        """``hyperpose::dnn::onnx{path}`` (include/hyperpose/utility/model.hpp:23-25): a path or the file's bytes.  The input
+        size is the caller's, as in ``tensorrt(onnx, cv::Size, ...)``; 0, 0 takes the static size stored in the graph.  The
+        imported weights are ``self.weights``."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        if isinstance(model, (bytes, bytearray, memoryview)):
+            buf = bytes(model)
+            check(lib().hp_model_from_onnx(C.byref(self._h), buf, C.c_size_t(len(buf)), int(in_w), int(in_h)))
+            self.arch = "onnx"
+        else:
+            check(lib().hp_model_from_onnx_file(C.byref(self._h), str(model).encode(), int(in_w), int(in_h)))
+            self.arch = "onnx:" + str(model)
+        w, h = C.c_int(), C.c_int()
+        check(lib().hp_model_input_size(self._h, C.byref(w), C.byref(h)))
+        self.in_w, self.in_h = w.value, h.value
+        self._read()
+        blob, n = C.POINTER(C.c_float)(), C.c_size_t()
+        check(lib().hp_model_weights(self._h, C.byref(blob), C.byref(n)))
+        self.weights = np.ctypeslib.as_array(blob, shape=(n.value,)).copy()
+        return self
+
+    def _read(self):
         lp, n = C.POINTER(Layer)(), C.c_int(0)
         check(lib().hp_model_layers(self._h, C.byref(lp), C.byref(n)))
         self.layers = [lp[i] for i in range(n.value)]

@@ -161,8 +161,8 @@ int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* 
 /* ---- hyperpose::dnn engine: replaces dnn::tensorrt (include/hyperpose/operator/dnn/tensorrt.hpp:33-141,
  * src/tensorrt.cpp).  The network is a static list of layers over numbered tensors (tensor 0 = the input
  * image); weights are one fp32 blob in the layouts below.  TensorRT's UFF/ONNX parsing is replaced by the
- * built-in topology builders (hp_model_*) that restate hyperpose/Model/<arch>.py; ONNX import is a later row
- * (SURVEY.md 8f).  Activations live in HBM as NHWC fp16 (fp32 accumulate on MFMA); network outputs are
+ * built-in topology builders (hp_model_*) that restate hyperpose/Model/<arch>.py, and by hp_model_from_onnx
+ * (SURVEY.md 8f-1).  Activations live in HBM as NHWC fp16 (fp32 accumulate on MFMA); network outputs are
  * fp32 NCHW, the layout of feature_map_t. */
 enum { HP_OP_CONV = 1, HP_OP_DWCONV = 2, HP_OP_MAXPOOL = 3 };
 enum { HP_ACT_NONE = 0, HP_ACT_RELU = 1, HP_ACT_RELU6 = 2, HP_ACT_LEAKY = 3, HP_ACT_PRELU = 4, HP_ACT_SIGMOID = 5, HP_ACT_SOFTPLUS = 6 };
@@ -174,12 +174,15 @@ typedef struct hp_layer {
     int32_t res_before_act;  /* 1: act(conv + res) (ResNet); 0: act(conv) + res (LW-OpenPose blocks) */
     int32_t out, out_coff;   /* tensor written and its first channel (concat by offset) */
     int32_t cin, cout;
-    int32_t kh, kw, stride, dil; /* padding is TF "SAME": out = ceil(in/stride), extra pad bottom/right */
+    int32_t kh, kw, stride, dil; /* padding is TF "SAME" (out = ceil(in/stride), extra pad bottom/right) unless pad_explicit */
     int32_t act;             /* HP_ACT_* applied after bias (BatchNorm is folded into w/bias by the caller) */
     float act_param;         /* LeakyReLU slope */
     int64_t w_off;           /* float offset in the blob: CONV [cout][kh][kw][cin]; DWCONV [c][kh][kw] */
     int64_t b_off;           /* bias [cout], or -1 for zeros */
     int64_t alpha_off;       /* PReLU slopes [cout], or -1 */
+    int32_t pad_explicit;    /* 1: pad[] = {top, left, bottom, right} as in an ONNX Conv / MaxPool `pads` attribute,
+                              * out = floor((in + pad_before + pad_after - ((k-1)*dil+1)) / stride) + 1; 0: TF "SAME" */
+    int32_t pad[4];
 } hp_layer;
 
 typedef struct hp_output_desc {
@@ -265,7 +268,17 @@ double hp_model_flops_per_frame(const hp_model* m);     /* 2*MACs of all CONV/DW
 /* Deterministic synthetic weights (there is no network to fetch the released models): He-normal conv
  * kernels from a counter-based generator keyed by (seed, layer, index), small biases, PReLU slopes 0.25. */
 int hp_model_init_weights(const hp_model* m, uint64_t seed, float* blob, size_t n);
-/* Convenience: build an engine for a built-in topology with blob weights. */
+/* ONNX import: what nvonnxparser does for dnn::tensorrt(const onnx&, cv::Size, ...) (include/hyperpose/operator/dnn/tensorrt.hpp:53-62,
+ * include/hyperpose/utility/model.hpp:23-25, src/tensorrt.cpp:162-223).  The file / buffer is a serialized ONNX ModelProto with ONE
+ * input of 3 channels (N,3,H,W, 3,H,W, or N,H,W,3 followed by a Transpose); in_w x in_h is the caller's input size as in the reference
+ * (0,0 = take the static size stored in the graph).  Supported operators and how they are lowered onto hp_layer: see the header of
+ * hyperpose_amd/csrc/onnx_import.cpp; anything else returns HP_ERR_INVALID with the node and operator named in hp_last_error().
+ * The model owns the imported weights: pass weights = NULL to hp_engine_create_from_model, or read them with hp_model_weights. */
+int hp_model_from_onnx(hp_model** out, const void* data, size_t size, int in_w, int in_h);
+int hp_model_from_onnx_file(hp_model** out, const char* path, int in_w, int in_h);
+int hp_model_weights(const hp_model* m, const float** blob, size_t* n); /* blob = NULL for built-in topologies */
+int hp_model_input_size(const hp_model* m, int* w, int* h);
+/* Convenience: build an engine for a topology with blob weights (NULL = the model's own, imported models only). */
 int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
                                 const float* weights, size_t n_weights);
 

@@ -4,8 +4,8 @@
 // dnn::tensorrt (include/hyperpose/operator/dnn/tensorrt.hpp:44-74): (model, cv::Size input_size,
 // int max_batch_size = 8, bool keep_ratio = false, double factor = 1./255, bool flip_rgb = true).
 // `using tensorrt = hip_engine;` under HYPERPOSE_TENSORRT_COMPAT keeps existing call sites compiling.
-// The model descriptor names a built-in topology + a flat fp32 weight blob (the .trt / ONNX files of the
-// reference cannot be read here; ONNX import is SURVEY.md 8f-1).
+// Model descriptors: dnn::onnx{path} as in the reference (utility/model.hpp:23-25), a serialized engine file, or a built-in
+// topology + a flat fp32 weight blob (UFF files are TensorRT-only and not read).
 #pragma once
 #include <cstdint>
 #include <cstdlib>
@@ -20,6 +20,9 @@ namespace hyperpose {
 namespace dnn {
 
     struct serialized_model { // hyperpose::dnn::tensorrt_serialized (utility/model.hpp:30-32)
+        std::string model_path;
+    };
+    struct onnx { // hyperpose::dnn::onnx (utility/model.hpp:23-25)
         std::string model_path;
     };
     struct builtin_model {
@@ -42,6 +45,18 @@ namespace dnn {
                 hp_model_init_weights(m_model, model.seed, w.data(), w.size());
             }
             if (hp_engine_create_from_model(&m_engine, m_model, max_batch_size, factor, flip_rgb ? 1 : 0, w.data(), w.size()) != HP_OK)
+                fatal(hp_last_error());
+        }
+        // tensorrt(const onnx&, cv::Size input_size, int max_batch_size = 8, bool keep_ratio = false, data_type, double factor = 1./255,
+        // bool flip_rgb = true) (include/hyperpose/operator/dnn/tensorrt.hpp:53-62; the data_type argument has no meaning here:
+        // activations are fp16 with fp32 accumulation)
+        explicit hip_engine(const onnx& onnx_model, cv::Size input_size, int max_batch_size = 8, bool keep_ratio = false,
+            double factor = 1. / 255, bool flip_rgb = true)
+            : m_inp_size(input_size), m_max_batch_size(max_batch_size), m_keep_ratio(keep_ratio)
+        {
+            if (hp_model_from_onnx_file(&m_model, onnx_model.model_path.c_str(), input_size.width, input_size.height) != HP_OK)
+                fatal(hp_last_error());
+            if (hp_engine_create_from_model(&m_engine, m_model, max_batch_size, factor, flip_rgb ? 1 : 0, nullptr, 0) != HP_OK)
                 fatal(hp_last_error());
         }
         // tensorrt(const tensorrt_serialized&, ...) (include/hyperpose/operator/dnn/tensorrt.hpp:72-74, utility/model.hpp:27-32)

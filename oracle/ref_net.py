@@ -60,8 +60,13 @@ def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, fram
     tensors = {0: x0}
     for L in layers:
         x = tensors[L.in_][:, L.in_coff:L.in_coff + L.cin]
-        oh, pt, pb = _same_pad(x.shape[2], L.kh, L.stride, L.dil)
-        ow, pl, pr = _same_pad(x.shape[3], L.kw, L.stride, L.dil)
+        if getattr(L, "pad_explicit", 0):
+            pt, pl, pb, pr = (int(v) for v in L.pad)
+            oh = (x.shape[2] + pt + pb - ((L.kh - 1) * L.dil + 1)) // L.stride + 1
+            ow = (x.shape[3] + pl + pr - ((L.kw - 1) * L.dil + 1)) // L.stride + 1
+        else:
+            oh, pt, pb = _same_pad(x.shape[2], L.kh, L.stride, L.dil)
+            ow, pl, pr = _same_pad(x.shape[3], L.kw, L.stride, L.dil)
         first = (L.in_ == 0)
         if L.op == OP_MAXPOOL:
             xp = F.pad(x, (pl, pr, pt, pb), value=float("-inf"))

@@ -6,7 +6,7 @@
 
 #include <cstdio>
 
-int main()
+int main(int argc, char** argv)
 {
     if (hp_init(0) != HP_OK) {
         std::printf("NO_DEVICE %s\n", hp_last_error());
@@ -65,6 +65,18 @@ int main()
         const auto first = stream.pop(), second = stream.pop();
         if (first.size() != 3 || second.size() != 1 || stream.in_flight() != 0)
             return 8;
+    }
+    if (argc > 1) { // dnn::onnx{path}: the reference's model descriptor (examples/operator_api_batched_images_paf.example.cpp:40-47)
+        hp::dnn::tensorrt onnx_engine(hp::dnn::onnx{ argv[1] }, cv::Size(48, 64), 2);
+        hp::parser::paf onnx_parser{};
+        cv::Mat m(64, 48);
+        for (size_t k = 0; k < m.total() * 3; ++k)
+            m.data()[k] = (uint8_t)((k * 29) & 255);
+        auto out = onnx_engine.inference({ m, m });
+        if (out.size() != 2 || out[0].size() != 2 || out[0][0].name() != "conf" || out[0][1].name() != "paf")
+            return 9;
+        if (out[0][0].shape() != std::vector<int>{ 5, 16, 12 } || out[0][1].shape() != std::vector<int>{ 6, 16, 12 })
+            return 10;
     }
     bool threw = false;
     try {

@@ -24,7 +24,7 @@ def test_mirror_headers_compile():
 @pytest.mark.gpu
 def test_operator_api_flow_runs():
     _build()
-    out = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([BIN, os.path.join(ROOT, "tests", "golden", "onnx", "mobile_paf.onnx")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     tag, n_packets, humans, threw = out.stdout.split()[-4:]
     assert tag == "OK" and int(n_packets) == 3 and int(threw) == 1

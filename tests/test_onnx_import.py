@@ -1,0 +1,122 @@
+"""CPU: ONNX import (hp_model_from_onnx, the job of nvonnxparser in src/tensorrt.cpp:162-223) — no GPU needed, the importer
+is host code.  The lowered layer list is evaluated by the fp32 torch oracle (oracle/ref_net.py) and must reproduce the
+outputs PyTorch computed for the very module the file was exported from (tests/golden/onnx/*.npz), to fp32 round-off:
+|err| <= 1e-4 * max|ref|."""
+import os
+
+import numpy as np
+import pytest
+
+from hyperpose_amd import engine as E
+from hyperpose_amd._lib import HpError
+from oracle import ref_net
+
+import onnx_writer as W
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "onnx")
+CASES = ["mobile_paf", "resnet_ppn", "vgg_stages", "unfolded"]
+
+
+def _oracle(m, image):
+    return ref_net.run(m.layers, m.outputs, m.weights, frames_f32=image, mean=m.mean, inv_std=m.inv_std, match_fp16=False)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_pytorch_exports_match_pytorch(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    m = E.Model.from_onnx(os.path.join(GOLD, name + ".onnx"))
+    assert (m.in_h, m.in_w) == z["image"].shape[2:]
+    out = _oracle(m, z["image"])
+    assert sorted(out) == sorted(k for k in z.files if k != "image")
+    for k, v in out.items():
+        assert v.shape == z[k].shape
+        assert np.abs(v - z[k]).max() <= 1e-4 * np.abs(z[k]).max(), k
+
+
+def test_lowering_shapes_the_graph_for_the_engine():
+    """What the lowering is expected to produce for the LightWeight-OpenPose-like export: BatchNorm gone, activations fused,
+    concat members written in place at channel offsets, the residual add fused into the later convolution."""
+    m = E.Model.from_onnx(os.path.join(GOLD, "mobile_paf.onnx"))
+    ops = [L.op for L in m.layers]
+    assert len(m.layers) == 21 and ops.count(E.OP_DWCONV) == 3 and ops.count(E.OP_MAXPOOL) == 0
+    concat_reader = [L for L in m.layers if L.cin == 43]
+    assert len(concat_reader) == 1
+    writers = sorted((L.out_coff, L.cout) for L in m.layers if L.out == concat_reader[0].in_)
+    assert writers == [(0, 32), (32, 5), (37, 6)]
+    res = [L for L in m.layers if L.res >= 0]
+    assert len(res) == 1 and res[0].res_before_act == 0 and res[0].dil == 2
+    assert [L.act for L in m.layers if L.op == E.OP_DWCONV] == [E.ACT_RELU, E.ACT_RELU6, E.ACT_RELU]
+    # PyTorch's symmetric padding at stride 2 on an even size is NOT TensorFlow's SAME: kept as explicit pads
+    s2 = [L for L in m.layers if L.stride == 2]
+    assert all(L.pad_explicit and list(L.pad) == [1, 1, 1, 1] for L in s2) and len(s2) == 2
+    assert all(not L.pad_explicit for L in m.layers if L.stride == 1)
+    # ResNet export: Add -> Relu becomes act(conv + res)
+    r = E.Model.from_onnx(os.path.join(GOLD, "resnet_ppn.onnx"))
+    assert [L.res_before_act for L in r.layers if L.res >= 0] == [1, 1, 1]
+    assert [o.act for o in r.outputs] == [E.ACT_SIGMOID, E.ACT_NONE]
+    # VGG export: Pad(0,1,0,1) + VALID stride-2 conv is recognised as SAME; normalisation lands in mean / inv_std
+    v = E.Model.from_onnx(os.path.join(GOLD, "vgg_stages.onnx"))
+    assert all(not L.pad_explicit for L in v.layers)
+    np.testing.assert_allclose(v.mean, [0.485, 0.456, 0.406], rtol=1e-6)
+    np.testing.assert_allclose(v.inv_std, [1 / 0.229, 1 / 0.224, 1 / 0.225], rtol=1e-6)
+
+
+def test_bytes_and_input_size_rules():
+    raw = open(os.path.join(GOLD, "mobile_paf.onnx"), "rb").read()
+    m = E.Model.from_onnx(raw)  # static 64 x 48 in the file
+    assert (m.in_w, m.in_h) == (48, 64)
+    assert (E.Model.from_onnx(raw, 48, 64).in_w, E.Model.from_onnx(raw, 48, 64).in_h) == (48, 64)
+    with pytest.raises(HpError, match="fixed to 48x64"):  # src/tensorrt.cpp:190-205: the profile must fit the network
+        E.Model.from_onnx(raw, 64, 64)
+    for cut in (10, len(raw) // 2, len(raw) - 7):
+        with pytest.raises(HpError):
+            E.Model.from_onnx(raw[:cut])
+    with pytest.raises(HpError):
+        E.Model.from_onnx(b"\x00" * 64)
+    with pytest.raises(HpError, match="cannot open"):
+        E.Model.from_onnx("/nonexistent/model.onnx")
+
+
+def _hand_model(extra_nodes=(), extra_inputs=(), h=8, w="W", out="y", opset=11, final="r"):
+    rng = np.random.default_rng(3)
+    wt = rng.normal(0, 0.3, (8, 3, 3, 3)).astype(np.float32)
+    bs = rng.normal(0, 0.1, 8).astype(np.float32)
+    nodes = [W.node("Conv", ["x", "w", "b"], ["c"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_str("auto_pad", "SAME_UPPER"),
+                                                      W.attr_ints("strides", [2, 2])], name="conv0"),
+             W.node("LeakyRelu", ["c"], ["r"], [W.attr_float("alpha", 0.2)])]
+    nodes += list(extra_nodes)
+    nodes.append(W.node("Identity", [final], [out]))
+    init = [W.tensor("w", wt.shape, wt.ravel().tolist()), W.tensor("b", [8], bs.tolist(), raw=True)]
+    inputs = [W.value_info("x", ["N", 3, h, w])] + list(extra_inputs)
+    return W.model(nodes, init, inputs, [W.value_info(out, ["N", 8, "h", "w"])], opset), wt, bs
+
+
+def test_hand_written_file_other_encodings():
+    """float_data / unpacked repeated fields / symbolic H,W / auto_pad SAME_UPPER: the encodings PyTorch does not emit."""
+    import torch
+    import torch.nn.functional as F
+    raw, wt, bs = _hand_model()
+    with pytest.raises(HpError, match="dynamic"):
+        E.Model.from_onnx(raw)
+    m = E.Model.from_onnx(raw, 10, 8)
+    assert len(m.layers) == 1 and m.layers[0].act == E.ACT_LEAKY and abs(m.layers[0].act_param - 0.2) < 1e-7
+    assert not m.layers[0].pad_explicit and m.layers[0].stride == 2
+    x = np.random.default_rng(0).random((1, 3, 8, 10), dtype=np.float32)
+    ref = F.leaky_relu(F.conv2d(F.pad(torch.from_numpy(x), (0, 1, 0, 1)), torch.from_numpy(wt), torch.from_numpy(bs), stride=2), 0.2)
+    np.testing.assert_allclose(_oracle(m, x)["y"], ref.numpy(), atol=1e-5)
+
+
+def test_unsupported_graphs_fail_with_the_node_named():
+    raw, _, _ = _hand_model(extra_nodes=[W.node("Softmax", ["r"], ["s"], [W.attr_int("axis", 1)], name="sm")], final="s")
+    with pytest.raises(HpError, match=r"'sm' \(Softmax\): operator not supported"):
+        E.Model.from_onnx(raw, 10, 8)
+    raw, _, _ = _hand_model(extra_inputs=[W.value_info("x2", ["N", 3, 8, 8])])
+    with pytest.raises(HpError, match="2 inputs"):  # src/tensorrt.cpp:179-180
+        E.Model.from_onnx(raw, 10, 8)
+    raw, _, _ = _hand_model(extra_nodes=[W.node("Sigmoid", ["r"], ["s"]), W.node("Relu", ["s"], ["t"], name="after")], final="t")
+    with pytest.raises(HpError, match="after.*Sigmoid / Softplus"):
+        E.Model.from_onnx(raw, 10, 8)
+    # one channel too many for the network input (src/tensorrt.cpp:192-194)
+    bad = W.model([W.node("Identity", ["x"], ["y"])], [], [W.value_info("x", ["N", 4, 8, 8])], [W.value_info("y", ["N", 4, 8, 8])])
+    with pytest.raises(HpError, match="channel dimension must be 3"):
+        E.Model.from_onnx(bad)

@@ -1,0 +1,46 @@
+"""GPU: imported ONNX models run by the HIP engine vs (a) PyTorch's fp32 outputs of the exported module (fp16 storage bound:
+1e-2 of the output range) and (b) the torch oracle evaluated with the engine's fp16 storage points (2e-3: summation order only)."""
+import os
+
+import numpy as np
+import pytest
+
+from hyperpose_amd import engine as E
+from oracle import ref_net
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "onnx")
+
+
+@pytest.mark.parametrize("name", ["mobile_paf", "resnet_ppn", "vgg_stages", "unfolded"])
+def test_imported_model_on_the_engine(hp, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    m = E.Model.from_onnx(os.path.join(GOLD, name + ".onnx"))
+    eng = E.Engine.from_model(m, m.weights, max_batch=2)
+    got = eng.inference_f32(z["image"])
+    tight = ref_net.run(m.layers, m.outputs, m.weights, frames_f32=z["image"], mean=m.mean, inv_std=m.inv_std, match_fp16=True)
+    for b in range(2):
+        assert [nm for nm, _ in got[b]] == sorted(tight)
+        for nm, arr in got[b]:
+            scale = np.abs(z[nm]).max()
+            assert np.abs(arr - z[nm][b]).max() <= 1e-2 * scale + 1e-3, (nm, "vs PyTorch fp32")
+            assert np.abs(arr - tight[nm][b]).max() <= 2e-3 * scale + 1e-3, (nm, "vs fp16-matched oracle")
+
+
+def test_imported_model_u8_frames_and_serialized_engine(hp, tmp_path):
+    """The whole reference flow on an imported file: u8 BGR frames -> (flip, 1/255, in-graph normalisation) -> outputs; then
+    tensorrt::save / tensorrt_serialized (examples/gen_serialized_engine.example.cpp:30-60) round-trips it."""
+    m = E.Model.from_onnx(os.path.join(GOLD, "vgg_stages.onnx"))
+    frames = np.random.default_rng(5).integers(0, 256, (2, m.in_h, m.in_w, 3), dtype=np.uint8)
+    eng = E.Engine.from_model(m, m.weights, max_batch=2)
+    got = eng.inference(frames)
+    ref = ref_net.run(m.layers, m.outputs, m.weights, frames_u8=frames, mean=m.mean, inv_std=m.inv_std, match_fp16=True)
+    for b in range(2):
+        for nm, arr in got[b]:
+            assert np.abs(arr - ref[nm][b]).max() <= 2e-3 * np.abs(ref[nm]).max() + 1e-3, nm
+    path = str(tmp_path / "vgg_stages.hpeng")
+    eng.save(path)
+    again = E.Engine.load(path).inference(frames)
+    for b in range(2):
+        for (n0, a0), (n1, a1) in zip(got[b], again[b]):
+            assert n0 == n1 and np.array_equal(a0, a1)
