@@ -542,7 +542,8 @@ struct lowering {
     hp_model& m;
     std::vector<float>& blob;
     std::map<std::string, val> vals;
-    std::map<std::string, int> uses;
+    std::map<std::string, int> uses;      // consumers of every value (node inputs + graph outputs)
+    std::map<std::string, int> remaining; // ... that have not been lowered yet
     std::map<int, int> tensor_c;      // channels of each tensor
     std::map<int, int> last_writer;   // last layer writing into each tensor
     std::set<int> in_concat;          // tensors that are concat targets (or members moved into one)
@@ -894,6 +895,8 @@ struct lowering {
             }
             if (x.kind == val::IMAGE) {
                 val y = x;
+                if (x.pad[0] | x.pad[1] | x.pad[2] | x.pad[3])
+                    fail(&n, "input normalisation after a Pad node (the padding would no longer be zero)");
                 for (int k = 0; k < 3; ++k)
                     y.a[k] = x.a[k] * s[k], y.b[k] = x.b[k] * s[k] + t[k];
                 vals[n.out.at(0)] = y;
@@ -938,54 +941,123 @@ struct lowering {
         vals[n.out.at(0)] = y;
     }
 
+    // can the producer of v write its result at channel `off` of another tensor instead (no copy)?
+    bool movable(const val& v, int off) const
+    {
+        const int old = v.tensor;
+        auto tc = tensor_c.find(old);
+        if (v.producer < 0 || v.coff != 0 || m.layers[v.producer].out_coff != 0 || tc == tensor_c.end() || tc->second != v.C || in_concat.count(old))
+            return false;
+        if (m.layers[v.producer].op != HP_OP_CONV && off % 8)
+            return false; // depthwise / pool kernels store 8 channels at a time
+        for (const hp_layer& L : m.layers) {
+            if (L.in == old && (L.in_coff + off) % 8)
+                return false; // readers of the moved map need 8-aligned channel offsets
+            if (L.res == old && off != 0)
+                return false; // residual inputs are read from channel 0
+            if (L.out == old && &L != &m.layers[v.producer])
+                return false;
+        }
+        return true;
+    }
+    void move_into(const val& v, int T, int off)
+    {
+        const int old = v.tensor;
+        for (hp_layer& L : m.layers) {
+            if (L.in == old)
+                L.in = T, L.in_coff += off;
+            if (L.res == old)
+                L.res = T;
+        }
+        hp_layer& P = m.layers[v.producer];
+        P.out = T, P.out_coff = off;
+        for (auto& kv : vals)
+            if (kv.second.kind == val::MAP && kv.second.tensor == old)
+                kv.second.tensor = T, kv.second.coff += off;
+        last_writer[T] = std::max(last_writer.count(T) ? last_writer[T] : -1, v.producer);
+        last_writer.erase(old), tensor_c.erase(old);
+    }
+
+    // Multi-stage heads (OpenPose: every stage reads concat(stage outputs, backbone features)): when one input already sits
+    // in an earlier concatenation at the offset it would get here, and what the other slots of that tensor hold is dead by the
+    // time their new contents are produced, the new members are written over the old ones - the features are never copied.
+    bool concat_in_place(const o_node& n, const std::vector<val>& in, const std::vector<int>& offs, int total, val& y)
+    {
+        for (size_t j = 0; j < in.size(); ++j) {
+            const int T = in[j].tensor;
+            if (!in_concat.count(T) || in[j].coff != offs[j] || tensor_c[T] != total)
+                continue;
+            bool ok = true;
+            for (size_t k = 0; k < in.size() && ok; ++k) {
+                if (in[k].tensor == T && in[k].coff == offs[k])
+                    continue; // already in place
+                if (!movable(in[k], offs[k])) {
+                    ok = false;
+                    break;
+                }
+                const int lo = offs[k], hi = offs[k] + in[k].C, pk = in[k].producer;
+                for (size_t i = 0; i < m.layers.size() && ok; ++i) {
+                    const hp_layer& L = m.layers[i];
+                    const bool reads = (L.in == T && L.in_coff < hi && L.in_coff + L.cin > lo) || (L.res == T && L.cout > lo);
+                    const bool writes = L.out == T && L.out_coff < hi && L.out_coff + L.cout > lo;
+                    if ((reads || writes) && (int)i >= pk)
+                        ok = false; // somebody still touches the old contents after the new ones are written
+                }
+                for (const auto& kv : vals) {
+                    const val& o = kv.second;
+                    if (o.kind == val::MAP && o.tensor == T && o.coff < hi && o.coff + o.C > lo && remaining[kv.first] > 0)
+                        ok = false; // a node further down (or a graph output) still wants the old contents
+                }
+            }
+            if (!ok)
+                continue;
+            for (size_t k = 0; k < in.size(); ++k) {
+                if (in[k].tensor == T && in[k].coff == offs[k])
+                    continue;
+                const int lo = offs[k], hi = offs[k] + in[k].C;
+                for (auto& kv : vals)
+                    if (kv.second.kind == val::MAP && kv.second.tensor == T && kv.second.coff < hi && kv.second.coff + kv.second.C > lo)
+                        kv.second.kind = val::NONE; // overwritten from here on
+                move_into(in[k], T, offs[k]);
+            }
+            y.kind = val::MAP, y.tensor = T, y.coff = 0, y.C = total, y.H = in[j].H, y.W = in[j].W, y.producer = -1;
+            (void)n;
+            return true;
+        }
+        return false;
+    }
+
     void concat(const o_node& n)
     {
         if (n.geti("axis", 1) != 1)
             fail(&n, "only channel concatenation (axis = 1) is supported");
-        const int T = m.new_tensor();
-        int off = 0, H = 0, W = 0;
+        std::vector<val> in;
+        std::vector<int> offs;
+        int total = 0;
         for (size_t k = 0; k < n.in.size(); ++k) {
-            val v = get(n, k);
+            const val v = get(n, k);
             need_map(n, v);
-            if (k == 0)
-                H = v.H, W = v.W;
-            if (v.H != H || v.W != W)
+            if (v.H != get(n, 0).H || v.W != get(n, 0).W)
                 fail(&n, "inputs differ in size");
-            const int old = v.tensor;
-            bool move = v.producer >= 0 && v.coff == 0 && m.layers[v.producer].out_coff == 0 && tensor_c[old] == v.C && !in_concat.count(old);
-            if (move && m.layers[v.producer].op != HP_OP_CONV && off % 8)
-                move = false;
-            if (move)
-                for (const hp_layer& L : m.layers) {
-                    if (L.in == old && (L.in_coff + off) % 8)
-                        move = false; // readers of the moved map need 8-aligned channel offsets
-                    if (L.res == old && off != 0)
-                        move = false; // residual inputs are read from channel 0
-                    if (L.out == old && &L != &m.layers[v.producer])
-                        move = false;
-                }
-            if (move) {
-                for (hp_layer& L : m.layers) {
-                    if (L.in == old)
-                        L.in = T, L.in_coff += off;
-                    if (L.res == old)
-                        L.res = T;
-                }
-                hp_layer& P = m.layers[v.producer];
-                P.out = T, P.out_coff = off;
-                for (auto& kv : vals)
-                    if (kv.second.kind == val::MAP && kv.second.tensor == old)
-                        kv.second.tensor = T, kv.second.coff += off;
-                last_writer[T] = std::max(last_writer.count(T) ? last_writer[T] : -1, v.producer);
-                last_writer.erase(old), tensor_c.erase(old);
-            } else
-                identity(n, v, T, off);
-            off += v.C;
+            in.push_back(v), offs.push_back(total);
+            total += v.C;
         }
-        tensor_c[T] = off;
-        in_concat.insert(T);
         val y;
-        y.kind = val::MAP, y.tensor = T, y.C = off, y.H = H, y.W = W;
+        if (concat_in_place(n, in, offs, total, y)) {
+            vals[n.out.at(0)] = y;
+            return;
+        }
+        const int T = m.new_tensor();
+        for (size_t k = 0; k < in.size(); ++k) {
+            const val v = get(n, k); // (re-read: an earlier member of this very concat may have moved it)
+            if (movable(v, offs[k]))
+                move_into(v, T, offs[k]);
+            else
+                identity(n, v, T, offs[k]);
+        }
+        tensor_c[T] = total;
+        in_concat.insert(T);
+        y.kind = val::MAP, y.tensor = T, y.C = total, y.H = in[0].H, y.W = in[0].W;
         vals[n.out.at(0)] = y;
     }
 
@@ -1068,7 +1140,7 @@ struct lowering {
         }
         if (p.size() != 8 || p[0] || p[1] || p[4] || p[5] || value != 0.f)
             fail(&n, "only zero padding of H and W of a 4-D map is supported");
-        if (x.kind != val::MAP)
+        if (x.kind != val::MAP && !(x.kind == val::IMAGE && !x.nhwc))
             fail(&n, "expects a feature map");
         x.pad[0] += (int)p[2], x.pad[1] += (int)p[3], x.pad[2] += (int)p[6], x.pad[3] += (int)p[7];
         x.producer = -1; // nothing may be folded through the padding
@@ -1117,6 +1189,7 @@ struct lowering {
                 ++uses[s];
         for (const auto& o : g.outputs)
             ++uses[o.name];
+        remaining = uses;
 
         for (const auto& n : g.nodes) {
             if (n.out.empty())
@@ -1192,6 +1265,8 @@ struct lowering {
                 vals[n.out[0]] = x;
             } else
                 fail(&n, "operator not supported by the importer");
+            for (const auto& s : n.in)
+                --remaining[s];
         }
 
         // ---- outputs

@@ -120,3 +120,26 @@ def test_unsupported_graphs_fail_with_the_node_named():
     bad = W.model([W.node("Identity", ["x"], ["y"])], [], [W.value_info("x", ["N", 4, 8, 8])], [W.value_info("y", ["N", 4, 8, 8])])
     with pytest.raises(HpError, match="channel dimension must be 3"):
         E.Model.from_onnx(bad)
+
+
+@pytest.mark.parametrize("arch,w,h", [("lw_openpose_mobilenet", 64, 48), ("lw_openpose_vggtiny", 48, 64), ("openpose_vgg19", 64, 64)])
+def test_reference_topologies_survive_export_and_import(arch, w, h, tmp_path):
+    """The reference's PAF topologies (hyperpose/Model/openpose/model/*.py as restated by hp_model_build) written as a
+    torch module, exported by PyTorch to ONNX and imported again give the built-in layer list back — same layers, same
+    wiring, same weights — so an imported model runs the same fused schedule as the built-in one."""
+    import torch_from_layers as T
+    m = E.Model(arch, w, h)
+    blob = m.init_weights(11)
+    path = str(tmp_path / (arch + ".onnx"))
+    T.export(m.layers, m.outputs, blob, h, w, path, m.mean, m.inv_std)
+    im = E.Model.from_onnx(path, w, h)
+    assert T.signature(im.layers) == T.signature(m.layers)
+    assert [(o.name, o.coff, o.channels, o.act) for o in im.outputs] == [(o.name, o.coff, o.channels, o.act) for o in m.outputs]
+    np.testing.assert_allclose(im.mean, m.mean, atol=1e-6)
+    np.testing.assert_allclose(im.inv_std, m.inv_std, rtol=1e-6)
+    for a, b in zip(im.layers, m.layers):  # weights: same values in the engine's layout
+        if a.op == E.OP_MAXPOOL:
+            continue
+        n = a.cout * a.kh * a.kw * (a.cin if a.op == E.OP_CONV else 1)
+        assert np.array_equal(im.weights[a.w_off:a.w_off + n], blob[b.w_off:b.w_off + n])
+        assert np.array_equal(im.weights[a.b_off:a.b_off + a.cout], blob[b.b_off:b.b_off + b.cout])

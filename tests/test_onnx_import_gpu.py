@@ -44,3 +44,24 @@ def test_imported_model_u8_frames_and_serialized_engine(hp, tmp_path):
     for b in range(2):
         for (n0, a0), (n1, a1) in zip(got[b], again[b]):
             assert n0 == n1 and np.array_equal(a0, a1)
+
+
+def test_config1_model_from_onnx_runs_the_same_schedule(hp, tmp_path):
+    """BASELINE.json config[1] (LW-OpenPose / MobilenetDilated at 432 x 368) arriving as an ONNX file: the imported engine
+    launches the same kernels as the built-in topology (same per-step tile codes: fused separable blocks, fused heads, direct
+    3x3) and its outputs are bit-identical."""
+    import torch_from_layers as T
+    m = E.Model("lw_openpose_mobilenet", 432, 368)
+    blob = m.init_weights(20240)
+    path = str(tmp_path / "lw_openpose.onnx")
+    T.export(m.layers, m.outputs, blob, 368, 432, path, m.mean, m.inv_std)
+    im = E.Model.from_onnx(path, 432, 368)
+    assert T.signature(im.layers) == T.signature(m.layers)
+    frames = np.random.default_rng(1).integers(0, 256, (2, 368, 432, 3), dtype=np.uint8)
+    a = E.Engine.from_model(m, blob, max_batch=2)
+    b = E.Engine.from_model(im, im.weights, max_batch=2)
+    ga, gb = a.inference(frames), b.inference(frames)
+    for f in range(2):
+        for (n0, x0), (n1, x1) in zip(ga[f], gb[f]):
+            assert n0 == n1 and np.array_equal(x0, x1)
+    assert [(t["op"], t["tile"]) for t in a.profile(2, 1)] == [(t["op"], t["tile"]) for t in b.profile(2, 1)]
