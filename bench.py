@@ -164,9 +164,13 @@ def from_host(model, weights, steps=160, frame_wh=(1280, 720)):
 
 
 def roofline(pipe):
-    """Per-layer HIP-event timing on the engine stream (hp_engine_profile); the dominant kernel is the MFMA
-    implicit-GEMM conv.  achieved = algorithmic FLOPs of its launches / their summed duration."""
-    prof = pipe.eng.profile(BATCH, iters=20)
+    """Per-launch HIP-event timing on the engine stream, the schedule run in order with an event between consecutive
+    launches (hp_engine_profile_sequence: every kernel sees the cache state of a real inference, which is what
+    rocprofv3's per-kernel averages over this bench see too).  achieved = algorithmic FLOPs of the dominant kernel's
+    launches / their summed duration.  `back_to_back_us` is the same kernel re-launched 20 times in a row (weights warm
+    in L2) for comparison."""
+    prof = pipe.eng.profile(BATCH, iters=20, in_sequence=True)
+    warm = pipe.eng.profile(BATCH, iters=20)
     mfma = [p for p in prof if p["tile"] != 0]
     by_tile = {}
     for p in mfma:
@@ -210,6 +214,7 @@ def roofline(pipe):
         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
         "kernel": label,
         "launches_per_step": dom["n"], "avg_launch_us": round(dom["ms"] / dom["n"] * 1e3, 2),
+        "back_to_back_us": round(sum(p["ms"] for p in warm if p["tile"] == dom_tile) / dom["n"] * 1e3, 2),
         "flops_per_launch": round(dom["flops"] / dom["n"]),
         "all_mfma_convs": {"achieved": round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2), "ms_per_step": round(mfma_ms, 4),
                            "launches_per_step": len(mfma)},

@@ -1584,24 +1584,27 @@ static hipError_t launch_sep(const sep_params& p, hipStream_t s)
 // phases not interleaved) so that hipcc's register allocation stays small - the second block on the CU provides the
 // overlap that the in-wave interleave buys above:
 //   * 8 x 8 output pixels per block; the depthwise results of ALL K chunks stay in LDS (B_all: 64 px x C halves <= 64 KB);
-//   * output channels in NP passes of 256 (4 wavefronts x 2 row tiles): pass 0 = per chunk depthwise -> B_all, then its
-//     MFMAs; pass 1 = MFMAs only, straight out of B_all, no barrier.  64 accumulator registers, nothing recomputed;
+//   * output channels in NP passes of 4 wavefronts x TP row tiles (128 or 256): pass 0 = per chunk depthwise -> B_all, then
+//     its MFMAs; pass 1 = MFMAs only, straight out of B_all, no barrier.  <= 64 accumulator registers, nothing recomputed;
 //   * pass 0 stores with the direct epilogue (B_all must survive), the last pass with the staged one.
-template <int NP, int D>
+// S = stride, D = dilation of the depthwise taps, CMAX = the largest channel count the instance holds (sizes B_all),
+// CKH = channels per staged halo chunk (64 = one MFMA K chunk; 32 halves the halo buffer so that the dilated 512-channel
+// block still fits 80 KB: two halo chunks then feed one K chunk).
+template <int NP, int TP, int S, int D, int CMAX, int CKH = 64>
 __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p, int tiles_x, int tiles_y)
 {
-    constexpr int TH = 8, TW = 8, NPX = 64, NT = 2, TP = 2, CK = 64, CG = 8, KS = 4;
-    constexpr int IH = TH + 2 * D, IW = TW + 2 * D;
+    constexpr int TH = 8, TW = 8, NPX = 64, NT = 2, CK = 64, CG = CKH / 8, KS = 4, HPK = CK / CKH;
+    constexpr int IH = (TH - 1) * S + 2 * D + 1, IW = (TW - 1) * S + 2 * D + 1;
     constexpr int PIECES = IH * IW * CG, NLD = (PIECES + 255) / 256, ITEMS = NPX * CG / 256;
-    constexpr int HALO_BYTES = PIECES * 16, BCH_BYTES = NPX * CK * 2, BALL_BYTES = (SEP_CMAX / CK) * BCH_BYTES;
-    constexpr int DWW_BYTES = 9 * CK * 2, DWB_BYTES = CK * 4;
+    constexpr int HALO_BYTES = PIECES * 16, BCH_BYTES = NPX * CK * 2, BALL_BYTES = (CMAX / CK) * BCH_BYTES;
+    constexpr int DWW_BYTES = 9 * CKH * 2, DWB_BYTES = CKH * 4;
     constexpr int MAIN_BYTES = BALL_BYTES + HALO_BYTES + 2 * DWW_BYTES + 2 * DWB_BYTES;
-    static_assert(4 * stage_geom<TP>::SLAB <= BALL_BYTES, "the last pass's epilogue slabs overlay B_all");
+    static_assert(4 * stage_geom<TP>::SLAB <= MAIN_BYTES, "the last pass's epilogue slabs overlay B_all and the halo buffer");
     __shared__ __attribute__((aligned(16))) unsigned char lds[MAIN_BYTES];
     unsigned char* const s_ball = lds;
     unsigned char* const s_halo = lds + BALL_BYTES;
-    unsigned char* const s_dww = s_halo + HALO_BYTES;   // [2][9][64] halves
-    unsigned char* const s_dwb = s_dww + 2 * DWW_BYTES; // [2][64] floats
+    unsigned char* const s_dww = s_halo + HALO_BYTES;   // [2][9][CKH] halves
+    unsigned char* const s_dwb = s_dww + 2 * DWW_BYTES; // [2][CKH] floats
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int t = blockIdx.x;
@@ -1619,7 +1622,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         const int ps = L / NCH, kc = L - ps * NCH;
 #pragma unroll
         for (int i = 0; i < TP; ++i)
-            a[ks][i] = *reinterpret_cast<const u32x4*>(wbase + ((size_t)(ps * 8 + wave * TP + i) * KQ + kc * KS + ks) * 512);
+            a[ks][i] = *reinterpret_cast<const u32x4*>(wbase + ((size_t)(ps * 4 * TP + wave * TP + i) * KQ + kc * KS + ks) * 512);
     };
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -1630,7 +1633,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     int hoff[NLD];
     unsigned hmask = 0;
     {
-        const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
+        const int iy0 = y0 * S - p.pad_t, ix0 = x0 * S - p.pad_l;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int i = min(tid + k * 256, PIECES - 1);
@@ -1642,13 +1645,14 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         }
     }
     const __half* const hbase = p.in.p + (size_t)b * p.in.img * p.in.cs + p.in.coff;
-    const bool w_thread = tid < 72, b_thread = tid >= 72 && tid < 88; // 72 x 16 B of [9][64] weights, 16 x 16 B of 64 biases
+    constexpr int NWT = 9 * CG, NBT = CKH / 4; // 16-B pieces of the [9][CKH] weights and of the CKH biases
+    const bool w_thread = tid < NWT, b_thread = tid >= NWT && tid < NWT + NBT;
     auto hload = [&](int chunk) {
 #pragma unroll
         for (int k = 0; k < NLD; ++k)
-            hv[k] = *reinterpret_cast<const u32x4*>(hbase + hoff[k] + chunk * CK);
-        const void* src = w_thread ? (const void*)(p.dw_w + (size_t)(tid >> 3) * C + chunk * CK + (tid & 7) * 8)
-                                   : (const void*)(p.dw_bias + chunk * CK + (b_thread ? (tid - 72) * 4 : 0));
+            hv[k] = *reinterpret_cast<const u32x4*>(hbase + hoff[k] + chunk * CKH);
+        const void* src = w_thread ? (const void*)(p.dw_w + (size_t)(tid / CG) * C + chunk * CKH + (tid % CG) * 8)
+                                   : (const void*)(p.dw_bias + chunk * CKH + (b_thread ? (tid - NWT) * 4 : 0));
         wreg = *reinterpret_cast<const u32x4*>(src);
     };
     auto to_lds = [&](int chunk) {
@@ -1659,7 +1663,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         if (w_thread)
             *reinterpret_cast<u32x4*>(s_dww + (chunk & 1) * DWW_BYTES + tid * 16) = wreg;
         else if (b_thread)
-            *reinterpret_cast<u32x4*>(s_dwb + (chunk & 1) * DWB_BYTES + (tid - 72) * 16) = wreg;
+            *reinterpret_cast<u32x4*>(s_dwb + (chunk & 1) * DWB_BYTES + (tid - NWT) * 16) = wreg;
     };
     hload(0);
 
@@ -1677,20 +1681,21 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     const int g = tid % CG, frow = lane & 31, fk = lane >> 5;
     const float dw_hi = p.dw_hi;
 
-    // depthwise taps of chunk kd -> B_all[kd] (same arithmetic as dwconv3x3_kernel / sepconv_kernel)
+    // depthwise taps of halo chunk kd -> its CKH columns of B_all[kd / HPK] (same arithmetic as dwconv3x3_kernel / sepconv_kernel)
     auto dw_chunk = [&](int kd) {
-        unsigned char* const bt = s_ball + kd * BCH_BYTES;
+        unsigned char* const bt = s_ball + (kd / HPK) * BCH_BYTES;
+        const int gcol = (kd % HPK) * CG + g;
         const float* bsrc = reinterpret_cast<const float*>(s_dwb + (kd & 1) * DWB_BYTES) + g * 8;
         const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
         u32x4 wv[9];
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
-            wv[t9] = *reinterpret_cast<const u32x4*>(s_dww + (kd & 1) * DWW_BYTES + (t9 * CK + g * 8) * 2);
+            wv[t9] = *reinterpret_cast<const u32x4*>(s_dww + (kd & 1) * DWW_BYTES + (t9 * CKH + g * 8) * 2);
 #pragma unroll 1
         for (int r = 0; r < ITEMS; ++r) {
             const int pix = (tid + r * 256) / CG;
             const int py = pix / TW, px = pix - py * TW;
-            const unsigned char* xs = s_halo + ((py * IW + px) * CG + g) * 16;
+            const unsigned char* xs = s_halo + ((py * S * IW + px * S) * CG + g) * 16;
             u32x4 x[9];
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9)
@@ -1703,7 +1708,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 h[e] = (_Float16)dw_act<true>(v[e], 0.f, dw_hi);
-            *reinterpret_cast<half8*>(bt + lds_off<CK>(pix, g)) = h;
+            *reinterpret_cast<half8*>(bt + lds_off<CK>(pix, gcol)) = h;
         }
     };
     // MFMAs of linear step L out of B_all; the weights of step L+1 are requested as each k16 step's are consumed
@@ -1740,19 +1745,21 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     }
 
     // ---- pass 0
+    const int NHC = NCH * HPK; // halo chunks
     to_lds(0);
-    hload(min(1, NCH - 1));
+    hload(min(1, NHC - 1));
     lds_barrier();
 #pragma unroll 1
-    for (int kc = 0; kc < NCH; ++kc) {
-        dw_chunk(kc);
-        lds_barrier(); // B_all[kc] complete; every thread is past its reads of halo chunk kc
-        if (kc + 1 < NCH) {
-            to_lds(kc + 1);
-            hload(min(kc + 2, NCH - 1));
+    for (int hc = 0; hc < NHC; ++hc) {
+        dw_chunk(hc);
+        lds_barrier(); // these columns of B_all complete; every thread is past its reads of halo chunk hc
+        if (hc + 1 < NHC) {
+            to_lds(hc + 1);
+            hload(min(hc + 2, NHC - 1));
         }
-        mm_chunk(kc);
-        lds_barrier(); // halo chunk kc+1 and its depthwise weights visible
+        if (hc % HPK == HPK - 1)
+            mm_chunk(hc / HPK);
+        lds_barrier(); // halo chunk hc+1 and its depthwise weights visible
     }
     if (NP == 1) {
         conv_epilogue_staged<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
@@ -1765,14 +1772,14 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     for (int kc = 0; kc < NCH; ++kc)
         mm_chunk(NCH + kc);
     __syncthreads(); // every wave is done with B_all before the slabs overwrite it
-    conv_epilogue_staged<TP, NT>(p.pw, acc, (8 + wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
+    conv_epilogue_staged<TP, NT>(p.pw, acc, (4 * TP + wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
 }
 
-template <int NP, int D>
+template <int NP, int TP, int S, int D, int CMAX, int CKH = 64>
 static hipError_t launch_sep_slot(const sep_params& p, hipStream_t s)
 {
     const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 7) / 8;
-    hipLaunchKernelGGL((sepconv_slot_kernel<NP, D>), dim3(tiles_x * tiles_y * p.B), dim3(256), 0, s, p, tiles_x, tiles_y);
+    hipLaunchKernelGGL((sepconv_slot_kernel<NP, TP, S, D, CMAX, CKH>), dim3(tiles_x * tiles_y * p.B), dim3(256), 0, s, p, tiles_x, tiles_y);
     return hipGetLastError();
 }
 
@@ -1811,8 +1818,31 @@ hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 {
     static const bool slot = !getenv("HP_SEP_SLOT") || atoi(getenv("HP_SEP_SLOT")) != 0; // HP_SEP_SLOT=0: whole-CU form everywhere
     const int v = sepconv_variant(p);
-    if (slot && (v == 4 || v == 5)) // stride 1, dilation 1, 256 / 512 output channels: the half-CU form
-        return v == 4 ? launch_sep_slot<1, 1>(p, s) : launch_sep_slot<2, 1>(p, s);
+    static const int slot_mask = getenv("HP_SEP_SLOT_MASK") ? atoi(getenv("HP_SEP_SLOT_MASK")) : 0x7e; // bit v: variant v in half-CU form
+    if (slot && ((slot_mask >> v) & 1) && p.C % 64 == 0) {
+        switch (v) { // <passes, row tiles per wavefront, stride, dilation, max channels, halo chunk>
+        case 1:
+            if (p.C <= 128)
+                return launch_sep_slot<1, 1, 1, 1, 128>(p, s);
+            break;
+        case 2:
+            if (p.C <= 128)
+                return launch_sep_slot<1, 1, 2, 1, 128>(p, s);
+            break;
+        case 3:
+            if (p.C <= 128)
+                return launch_sep_slot<2, 1, 2, 1, 128>(p, s); // (one pass of two row tiles spills next to the 17 x 17 halo prefetch)
+            break;
+        case 4:
+            if (p.C <= 256)
+                return launch_sep_slot<1, 2, 1, 1, 256>(p, s);
+            break;
+        case 5:
+            return launch_sep_slot<2, 2, 1, 1, 512>(p, s);
+        case 6:
+            return launch_sep_slot<2, 2, 1, 2, 512, 32>(p, s);
+        }
+    }
     switch (v) {
     case 1:
         return launch_sep<1, 12, 16, 24, 1, 1, 32>(p, s);

@@ -1020,4 +1020,54 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
     return HP_OK;
 }
 
+int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* out, int cap, int* n_out)
+{
+    HP_REQUIRE(e && n >= 1 && n <= e->max_batch && iters >= 1 && n_out, HP_ERR_INVALID, "hp_engine_profile_sequence: bad argument");
+    const size_t need = (size_t)e->max_batch * e->in_h * e->in_w * 3 * sizeof(float);
+    if (e->in_stage.bytes < need)
+        HP_TRY(e->in_stage.alloc(need));
+    const uint8_t* u8 = e->in_stage.as<uint8_t>();
+    const size_t ns = e->steps.size();
+    std::vector<hipEvent_t> ev(ns + 1, nullptr);
+    std::vector<double> acc(ns, 0.0);
+    int rc = HP_OK;
+    for (auto& x : ev)
+        if (hipEventCreate(&x) != hipSuccess)
+            rc = HP_ERR_HIP;
+    for (int it = -1; it < iters && rc == HP_OK; ++it) { // it == -1: warm-up pass
+        (void)hipEventRecord(ev[0], e->stream);
+        for (size_t k = 0; k < ns && rc == HP_OK; ++k) {
+            rc = e->run_step(e->steps[k], u8, nullptr, n, e->stream);
+            (void)hipEventRecord(ev[k + 1], e->stream);
+        }
+        if (rc == HP_OK && hipEventSynchronize(ev[ns]) != hipSuccess)
+            rc = HP_ERR_HIP;
+        for (size_t k = 0; k < ns && rc == HP_OK && it >= 0; ++k) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            acc[k] += ms;
+        }
+    }
+    for (auto& x : ev)
+        if (x)
+            (void)hipEventDestroy(x);
+    HP_REQUIRE(rc == HP_OK, rc, "hp_engine_profile_sequence: launch or event failure");
+    int k = 0;
+    for (auto& st : e->steps) {
+        if (out && k < cap) {
+            out[k].layer = st.layer, out[k].op = st.op;
+            out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
+                : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
+                : st.op == OP_STEM           ? 7000000
+                : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
+                                                    : 0;
+            out[k].ms = (float)(acc[k] / iters);
+            out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
+        }
+        ++k;
+    }
+    *n_out = k;
+    return HP_OK;
+}
+
 } // extern "C"
