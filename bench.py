@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
+    ap.add_argument("--no-dnn-output", action="store_true", help="skip the second timed phase (parser fed by the network's own heat-maps)")
     return ap.parse_args()
 
 
@@ -276,7 +277,7 @@ def main():
         return dt, nh
 
     dt, n_humans = timed(True)
-    dt_dnn, n_humans_dnn = timed(False)
+    dt_dnn, n_humans_dnn = (None, 0) if args.no_dnn_output else timed(False)
 
     total_frames = BATCH * args.steps * world
     fps = total_frames / dt
@@ -291,7 +292,7 @@ def main():
                    "pipes_per_gpu": len(pipes), "parser_input": "injected synthetic heat-maps (1-16 people/frame); full conv stack also runs",
                    "humans_per_step": n_humans / max(1, args.steps),
                    "gflop_per_frame": round(model.flops_per_frame / 1e9, 2)},
-        "fps_dnn_output": round(total_frames / dt_dnn, 1),
+        "fps_dnn_output": round(total_frames / dt_dnn, 1) if dt_dnn else None,
         "conv_tflops_end_to_end": round(fps * model.flops_per_frame / 1e12, 2),
     }
     if rank == 0:

@@ -8,7 +8,7 @@ repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python $repo/bench.py --steps 12 --warmup 3 --pipes 1 --no-cpu-baseline --no-roofline --no-from-host"
+cmd="python $repo/bench.py --steps 12 --warmup 3 --pipes 1 --no-cpu-baseline --no-roofline --no-from-host --no-dnn-output"
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- $cmd > /dev/null 2>&1
 cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
