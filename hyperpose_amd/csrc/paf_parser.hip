@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict_
     int n = s_ncand;
     if (n > cand_cap) {
         if (tid == 0)
-            atomicOr(flags, 2);
+            atomicOr(flags + f, 2);
         n = cand_cap;
     }
 
@@ -477,9 +477,13 @@ __device__ __forceinline__ dpeak peak_by_id(const dpeak* __restrict__ sorted_f, 
 // the human tables: a register-resident variant was tried and drowned in code size / scratch).
 constexpr int ASM_CONN_CAP = 2560;  // connections of one frame staged in LDS (30 KB); the rest is read from global
 constexpr int ASM_PEAK_CAP = 4096;  // peak scores staged by id (16 KB)
-__global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restrict__ sorted, const int* __restrict__ pcount,
+// The results go straight to the (pinned, device-mapped) host buffers - `humans`, `n_humans` and `host_flags` are host
+// pointers - so no copy kernels follow; and the block leaves this frame's peak counters and overflow flags zeroed for the
+// next batch (it is their last reader), so no memset precedes the next one.
+__global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restrict__ sorted, int* __restrict__ pcount,
     int peak_cap, const dconn* __restrict__ conns, const int* __restrict__ conn_count, int res_w, int res_h,
-    hp_human* __restrict__ humans, int* __restrict__ n_humans, int human_cap, int* __restrict__ flags)
+    hp_human* __restrict__ humans, int* __restrict__ n_humans, int human_cap, int* __restrict__ flags, int* __restrict__ host_flags,
+    int* __restrict__ pcount_last)
 {
     __shared__ int s_parts[MAXH * HP_COCO_N_PARTS];
     __shared__ float s_score[MAXH];
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
             s_start[c] = acc;
             const int raw = pcount[f * HP_COCO_N_PARTS + c];
             if (raw > peak_cap)
-                atomicOr(flags, 1);
+                atomicOr(flags + f, 1);
             acc += min(raw, peak_cap);
         }
         s_start[HP_COCO_N_PARTS] = acc;
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
         }
     }
     if (overflow && lane == 0)
-        atomicOr(flags, 4);
+        atomicOr(flags + f, 4);
 
     // remove_if (paf.cpp:226-230), survivors keep their relative order
     int kept = 0;
@@ -639,6 +643,13 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
     }
     for (int i = lane; i < nout; i += 64)
         out[i].score = s_score[s_keep[i]];
+    __syncthreads();
+    if (lane == 0)
+        host_flags[f] = atomicExch(flags + f, 0);
+    if (lane < HP_COCO_N_PARTS) {
+        pcount_last[f * HP_COCO_N_PARTS + lane] = pcount[f * HP_COCO_N_PARTS + lane]; // kept for hp_paf_debug_peaks
+        pcount[f * HP_COCO_N_PARTS + lane] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -714,8 +725,8 @@ struct hp_paf {
 
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    hp::dev_buf tables, plist, sorted, pcount, conns, conn_count, flags, humans, n_humans, in_conf, in_paf;
-    hp::host_buf h_humans, h_counts; // h_counts: [n_humans(max_batch) | flags(1)]
+    hp::dev_buf tables, plist, sorted, pcount, pcount_last, conns, conn_count, flags, in_conf, in_paf;
+    hp::host_buf h_humans, h_counts; // h_counts: [n_humans(max_batch) | flags(max_batch)], written by the assemble kernel
     int pending = 0; // frames of the enqueued, not yet collected batch
     int last_n = 0;  // frames of the last completed batch (debug taps)
 
@@ -783,13 +794,16 @@ int hp_paf::shape(const int cs[3], const int ps[3])
     HP_TRY(plist.alloc(B * HP_COCO_N_PARTS * peak_cap * sizeof(dpeak)));
     HP_TRY(sorted.alloc(B * HP_COCO_N_PARTS * peak_cap * sizeof(dpeak)));
     HP_TRY(pcount.alloc(B * HP_COCO_N_PARTS * sizeof(int)));
+    HP_TRY(pcount_last.alloc(B * HP_COCO_N_PARTS * sizeof(int)));
     HP_TRY(conns.alloc(B * HP_COCO_N_PAIRS * peak_cap * sizeof(dconn)));
     HP_TRY(conn_count.alloc(B * HP_COCO_N_PAIRS * sizeof(int)));
-    HP_TRY(flags.alloc(sizeof(int)));
-    HP_TRY(humans.alloc(B * human_cap * sizeof(hp_human)));
-    HP_TRY(n_humans.alloc(B * sizeof(int)));
+    HP_TRY(flags.alloc(B * sizeof(int)));
     HP_TRY(h_humans.alloc(B * human_cap * sizeof(hp_human)));
-    HP_TRY(h_counts.alloc((B + 1) * sizeof(int)));
+    HP_TRY(h_counts.alloc(2 * B * sizeof(int)));
+    // invariant between batches: peak counters and overflow flags are zero (the assemble kernel restores it)
+    HP_HIP_TRY(hipMemset(pcount.p, 0, B * HP_COCO_N_PARTS * sizeof(int)));
+    HP_HIP_TRY(hipMemset(flags.p, 0, B * sizeof(int)));
+    memset(h_counts.p, 0, 2 * B * sizeof(int));
     shaped = true;
     return HP_OK;
 }
@@ -865,8 +879,7 @@ int hp_paf_enqueue(hp_paf* p, int n, const float* dev_conf, const int conf_shape
     HP_TRY(p->shape(conf_shape, paf_shape));
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
 
-    HP_HIP_TRY(hipMemsetAsync(p->pcount.p, 0, (size_t)n * HP_COCO_N_PARTS * sizeof(int), s));
-    HP_HIP_TRY(hipMemsetAsync(p->flags.p, 0, sizeof(int), s));
+    // (pcount / flags are zero here: zeroed at creation and re-zeroed by every assemble launch)
     HP_TRY(launch_peaks(p, n, dev_conf, s, nullptr, nullptr, HP_COCO_N_PARTS));
     hipLaunchKernelGGL(paf_sort_kernel, dim3(HP_COCO_N_PARTS, n), dim3(256), p->peak_cap * sizeof(int), s,
         p->plist.as<dpeak>(), p->pcount.as<int>(), p->peak_cap, p->sorted.as<dpeak>());
@@ -874,12 +887,9 @@ int hp_paf_enqueue(hp_paf* p, int n, const float* dev_conf, const int conf_shape
         p->sorted.as<dpeak>(), p->pcount.as<int>(), p->peak_cap, p->cand_cap, p->conns.as<dconn>(), p->conn_count.as<int>(),
         p->flags.as<int>());
     hipLaunchKernelGGL(paf_assemble_kernel, dim3(n), dim3(64), 0, s, p->sorted.as<dpeak>(), p->pcount.as<int>(), p->peak_cap,
-        p->conns.as<dconn>(), p->conn_count.as<int>(), p->res_w, p->res_h, p->humans.as<hp_human>(), p->n_humans.as<int>(),
-        p->human_cap, p->flags.as<int>());
+        p->conns.as<dconn>(), p->conn_count.as<int>(), p->res_w, p->res_h, p->h_humans.as<hp_human>(), p->h_counts.as<int>(),
+        p->human_cap, p->flags.as<int>(), p->h_counts.as<int>() + p->max_batch, p->pcount_last.as<int>());
     HP_HIP_TRY(hipGetLastError());
-    HP_HIP_TRY(hipMemcpyAsync(p->h_humans.p, p->humans.p, (size_t)n * p->human_cap * sizeof(hp_human), hipMemcpyDeviceToHost, s));
-    HP_HIP_TRY(hipMemcpyAsync(p->h_counts.p, p->n_humans.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-    HP_HIP_TRY(hipMemcpyAsync(p->h_counts.as<int>() + p->max_batch, p->flags.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HP_HIP_TRY(hipEventRecord(p->done, s));
     p->pending = n;
     return HP_OK;
@@ -893,7 +903,9 @@ int hp_paf_collect(hp_paf* p, hp_human* out, int cap_per_frame, int* n_out)
     const int n = p->pending;
     p->pending = 0;
     p->last_n = n;
-    const int fl = p->h_counts.as<int>()[p->max_batch];
+    int fl = 0;
+    for (int f = 0; f < n; ++f)
+        fl |= p->h_counts.as<int>()[p->max_batch + f];
     HP_REQUIRE(fl == 0, HP_ERR_CAPACITY, "paf: device list overflow (flags=%d: 1=peaks/part>%d, 2=candidates/limb>%d, 4=humans>%d)",
         fl, p->peak_cap, p->cand_cap, MAXH);
     int rc = HP_OK;
@@ -937,7 +949,7 @@ int hp_paf_debug_peaks(hp_paf* p, int frame, hp_peak* out, int cap, int* n)
     HP_REQUIRE(p && n && p->shaped, HP_ERR_INVALID, "hp_paf_debug_peaks: bad argument");
     HP_REQUIRE(frame >= 0 && frame < p->last_n && p->pending == 0, HP_ERR_STATE, "hp_paf_debug_peaks: no completed batch holds frame %d", frame);
     std::vector<int> cnt(HP_COCO_N_PARTS);
-    HP_HIP_TRY(hipMemcpy(cnt.data(), p->pcount.as<int>() + frame * HP_COCO_N_PARTS, cnt.size() * 4, hipMemcpyDeviceToHost));
+    HP_HIP_TRY(hipMemcpy(cnt.data(), p->pcount_last.as<int>() + frame * HP_COCO_N_PARTS, cnt.size() * 4, hipMemcpyDeviceToHost));
     std::vector<dpeak> buf(p->peak_cap);
     int id = 0;
     for (int k = 0; k < HP_COCO_N_PARTS; ++k) {
@@ -985,6 +997,7 @@ int hp_paf_debug_maps(hp_paf* p, const float* host_conf, const int conf_shape[3]
     HP_HIP_TRY(hipMemcpy(din.p, host_conf, in_b, hipMemcpyHostToDevice));
     HP_HIP_TRY(hipMemsetAsync(p->pcount.p, 0, (size_t)HP_COCO_N_PARTS * sizeof(int), p->stream));
     HP_TRY(launch_peaks(p, 1, din.as<float>(), p->stream, dup.as<float>(), dsm.as<float>(), p->g.J));
+    HP_HIP_TRY(hipMemsetAsync(p->pcount.p, 0, (size_t)HP_COCO_N_PARTS * sizeof(int), p->stream)); // restore the invariant
     HP_HIP_TRY(hipStreamSynchronize(p->stream));
     if (host_up)
         HP_HIP_TRY(hipMemcpy(host_up, dup.p, out_b, hipMemcpyDeviceToHost));
