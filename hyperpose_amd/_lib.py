@@ -80,7 +80,7 @@ def lib() -> C.CDLL:
 
 def check(rc: int) -> int:
     if rc < 0:
-        raise HpError(rc, lib().hp_last_error().decode())
+        raise HpError(rc, lib().hp_last_error().decode("utf-8", "replace"))
     return rc
 
 

@@ -519,11 +519,20 @@ bool parse_model(const uint8_t* data, size_t size, o_graph& g, std::string& why)
 struct lower_error {
     std::string msg;
 };
+std::string printable(std::string s) // names come from the file: keep error messages plain ASCII and short
+{
+    if (s.size() > 80)
+        s = s.substr(0, 77) + "...";
+    for (char& c : s)
+        if (c < 0x20 || c > 0x7e)
+            c = '?';
+    return s;
+}
 [[noreturn]] void fail(const o_node* n, const std::string& what)
 {
     if (n)
-        throw lower_error{ "onnx: node '" + (n->name.empty() ? (n->out.empty() ? std::string("?") : n->out[0]) : n->name) + "' (" + n->op + "): " + what };
-    throw lower_error{ "onnx: " + what };
+        throw lower_error{ printable("onnx: node '" + (n->name.empty() ? (n->out.empty() ? std::string("?") : n->out[0]) : n->name) + "' (" + n->op + "): ") + printable(what) };
+    throw lower_error{ "onnx: " + printable(what) };
 }
 
 struct val {
@@ -1307,18 +1316,21 @@ struct lowering {
 
 int import_bytes(hp_model** out, const uint8_t* data, size_t size, int in_w, int in_h)
 {
-    o_graph g;
-    std::string why;
-    HP_REQUIRE(parse_model(data, size, g, why), HP_ERR_INVALID, "onnx: %s", why.c_str());
     auto m = std::make_unique<hp_model>();
-    m->arch = "onnx:" + g.name;
     try {
+        o_graph g;
+        std::string why;
+        if (!parse_model(data, size, g, why))
+            throw lower_error{ "onnx: " + printable(why) };
+        m->arch = "onnx:" + printable(g.name);
         lowering lw(g, *m);
         lw.run(in_w, in_h);
     } catch (const lower_error& e) {
         HP_REQUIRE(false, HP_ERR_INVALID, "%s", e.msg.c_str());
     } catch (const std::out_of_range&) {
         HP_REQUIRE(false, HP_ERR_INVALID, "onnx: a tensor holds fewer values than its shape says");
+    } catch (const std::exception& e) { // bad_alloc / length_error from absurd sizes in a corrupted file
+        HP_REQUIRE(false, HP_ERR_INVALID, "onnx: malformed model (%s)", e.what());
     }
     *out = m.release();
     return HP_OK;

@@ -143,3 +143,32 @@ def test_reference_topologies_survive_export_and_import(arch, w, h, tmp_path):
         n = a.cout * a.kh * a.kw * (a.cin if a.op == E.OP_CONV else 1)
         assert np.array_equal(im.weights[a.w_off:a.w_off + n], blob[b.w_off:b.w_off + n])
         assert np.array_equal(im.weights[a.b_off:a.b_off + a.cout], blob[b.b_off:b.b_off + b.cout])
+
+
+def test_corrupted_files_never_crash_the_importer():
+    """Model files are untrusted input: any corruption must come back as an error code (or a valid model), never as a crash,
+    hang or allocation blow-up.  400 single-byte / truncation / splice mutations of two fixtures."""
+    rng = np.random.default_rng(2024)
+    ok = bad = 0
+    for name in ("unfolded", "resnet_ppn"):
+        raw = bytearray(open(os.path.join(GOLD, name + ".onnx"), "rb").read())
+        head = min(len(raw), 6000)  # structure lives in the first KBs of unfolded; weights dominate resnet_ppn
+        for it in range(200):
+            m = bytearray(raw)
+            kind = it % 4
+            if kind == 0:
+                m[int(rng.integers(0, head))] = int(rng.integers(0, 256))
+            elif kind == 1:
+                for _ in range(8):
+                    m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 2:
+                m = m[:int(rng.integers(1, len(m)))]
+            else:
+                a, b = sorted(int(x) for x in rng.integers(0, head, 2))
+                m = m[:a] + m[b:]
+            try:
+                E.Model.from_onnx(bytes(m), 32, 24) if name == "unfolded" else E.Model.from_onnx(bytes(m))
+                ok += 1
+            except HpError:
+                bad += 1
+    assert ok + bad == 400 and bad > 50
