@@ -1876,7 +1876,7 @@ hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 //          (head_params), 8 k16 steps per wavefront; the four partial sums meet through LDS.
 //   store: bias2 / activation, fp16 NHWC slice and / or fp32 NCHW network output.
 template <int NCH>
-__global__ __launch_bounds__(256, 2) void mlp_head_kernel(const head_params p, int tiles_x, int tiles_y)
+__device__ __forceinline__ void mlp_head_body(const head_params& p, int tiles_x, int tiles_y)
 {
     // 8 x 8 pixel tile and the hidden rows in two passes of 2 x 32 per wavefront: 64 + 64 accumulator registers instead
     // of 192 + 96, so that the kernel fits half a CU (<= 256 registers, 64 KB of LDS) and shares it with whatever the
@@ -2089,6 +2089,40 @@ int mlp_head_variant(int k1, int hidden, int cout2)
     if (off || hidden != 512 || cout2 > 64 || cout2 < 1)
         return 0;
     return k1 == 64 ? 1 : k1 == 128 ? 2 : k1 == 256 ? 4 : 0;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void mlp_head_kernel(const head_params p, int tiles_x, int tiles_y)
+{
+    mlp_head_body<NCH>(p, tiles_x, tiles_y);
+}
+// Two heads that read the same feature map (the conf / paf branches of one stage) in ONE launch: blockIdx.y picks the head.
+// Each is a grid of ~340 latency-bound blocks on 512 half-CU slots, so together they take about as long as one alone.
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void mlp_head_pair_kernel(const head_params p0, const head_params p1, int tiles_x, int tiles_y)
+{
+    mlp_head_body<NCH>(blockIdx.y ? p1 : p0, tiles_x, tiles_y);
+}
+
+hipError_t launch_mlp_head_pair(const head_params& p0, const head_params& p1, hipStream_t s)
+{
+    const int tiles_x = (p0.W + 7) / 8, tiles_y = (p0.H + 7) / 8;
+    const dim3 grid(tiles_x * tiles_y * p0.B, 2);
+    const int v = mlp_head_variant(p0.K1, 512, p0.pw.Cout);
+    if (v == 0 || v != mlp_head_variant(p1.K1, 512, p1.pw.Cout) || p0.H != p1.H || p0.W != p1.W || p0.B != p1.B)
+        return hipErrorInvalidValue;
+    switch (v) {
+    case 1:
+        hipLaunchKernelGGL((mlp_head_pair_kernel<1>), grid, dim3(256), 0, s, p0, p1, tiles_x, tiles_y);
+        break;
+    case 2:
+        hipLaunchKernelGGL((mlp_head_pair_kernel<2>), grid, dim3(256), 0, s, p0, p1, tiles_x, tiles_y);
+        break;
+    default:
+        hipLaunchKernelGGL((mlp_head_pair_kernel<4>), grid, dim3(256), 0, s, p0, p1, tiles_x, tiles_y);
+        break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_mlp_head(const head_params& p, hipStream_t s)

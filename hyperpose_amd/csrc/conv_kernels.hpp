@@ -138,6 +138,8 @@ struct head_params {
 };
 int mlp_head_variant(int k1, int hidden, int cout2);
 hipError_t launch_mlp_head(const head_params& p, hipStream_t s);
+// two heads on the same input, same K1 / geometry, in one launch (blockIdx.y = head)
+hipError_t launch_mlp_head_pair(const head_params& p0, const head_params& p1, hipStream_t s);
 
 // MobileNet stem (stem_kernel): first conv 3 -> 32 (3x3, stride 2) + depthwise 3x3 (relu / relu6) + pointwise 1x1
 // 32 -> <= 64.  fc: the first conv exactly as for launch_first_conv (fc.out unused).  pw: the pointwise conv as a

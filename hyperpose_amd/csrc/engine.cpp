@@ -66,6 +66,8 @@ struct step {
     hp::sep_params sp{}; // op == OP_SEPCONV: depthwise layer `layer` fused with the pointwise layer `layer + 1`
     hp::stem_params stp{}; // op == OP_STEM: layers 0, 1, 2 (first conv + depthwise + pointwise) as one launch
     hp::head_params hp_{}; // op == OP_MLPHEAD: 1x1 conv `layer` (-> 512, relu) fused with the 1x1 conv `layer + 1`
+    hp::head_params hp2_{}; // ... and, when `paired`, the sibling head on the same input (layers `layer + 2`, `layer + 3`)
+    bool paired = false;
     double flops = 0, bytes = 0; // per frame
 };
 constexpr int OP_SEPCONV = 100; // schedule-only op codes (not part of the hp_layer ABI)
@@ -704,6 +706,20 @@ int hp_engine::build(const hp_engine_desc* d)
         }
         steps.push_back(st);
     }
+    // sibling heads (conf / paf branch of one stage: same input, same geometry, neither reads the other) share a launch
+    if (!getenv("HP_NO_PAIR_HEADS")) {
+        for (size_t k = 0; k + 1 < steps.size(); ++k) {
+            step &a = steps[k], &b = steps[k + 1];
+            if (a.op != OP_MLPHEAD || b.op != OP_MLPHEAD || a.paired)
+                continue;
+            const auto &x = a.hp_, &y = b.hp_;
+            if (x.in.p != y.in.p || x.in.coff != y.in.coff || x.K1 != y.K1 || x.H != y.H || x.W != y.W || x.pw.Cout > 64 || y.pw.Cout > 64)
+                continue;
+            a.hp2_ = b.hp_, a.paired = true;
+            a.flops += b.flops, a.bytes += b.bytes;
+            steps.erase(steps.begin() + k + 1);
+        }
+    }
     HP_REQUIRE(!steps.empty() && (steps[0].first || steps[0].op == OP_STEM), HP_ERR_INVALID, "engine: the first layer must be a CONV reading tensor 0");
 
     HP_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -747,7 +763,11 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
         HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
     } else if (st.op == OP_MLPHEAD) {
         st.hp_.B = n, st.hp_.pw.B = n;
-        HP_HIP_TRY(hp::launch_mlp_head(st.hp_, s));
+        if (st.paired) {
+            st.hp2_.B = n, st.hp2_.pw.B = n;
+            HP_HIP_TRY(hp::launch_mlp_head_pair(st.hp_, st.hp2_, s));
+        } else
+            HP_HIP_TRY(hp::launch_mlp_head(st.hp_, s));
     } else if (st.op == HP_OP_DWCONV) {
         st.dp.B = n;
         HP_HIP_TRY(hp::launch_dwconv3x3(st.dp, s));

@@ -330,8 +330,15 @@ def test_lw_openpose_fused_equals_unfused(hp, monkeypatch):
     eng = E.Engine.from_model(m, w, max_batch=2)
     tiles = [p["tile"] for p in eng.profile(2, 1)]
     assert sum(4000000 <= t < 5000000 for t in tiles) == 10  # every MobileNet separable block with > 64 outputs
-    assert sum(6000000 <= t < 7000000 for t in tiles) == 4   # init + refinement stage, conf + paf heads
+    assert sum(6000000 <= t < 7000000 for t in tiles) == 2   # init + refinement stage: conf + paf heads share a launch
     got = eng.inference(fr)
+    monkeypatch.setenv("HP_NO_PAIR_HEADS", "1")              # one launch per head: same bits
+    solo = E.Engine.from_model(m, w, max_batch=2)
+    assert sum(6000000 <= t < 7000000 for t in [p["tile"] for p in solo.profile(2, 1)]) == 4
+    for a, b in zip(got, solo.inference(fr)):
+        for (n0, x0), (n1, x1) in zip(a, b):
+            assert n0 == n1 and np.array_equal(x0, x1)
+    monkeypatch.delenv("HP_NO_PAIR_HEADS")
     monkeypatch.setenv("HP_NO_FUSE_HEAD", "1")               # separable blocks fused, heads as two launches: same bits
     mid = E.Engine.from_model(m, w, max_batch=2).inference(fr)
     monkeypatch.setenv("HP_NO_FUSE", "1")
