@@ -69,6 +69,9 @@ int conv_weight_layout(const conv_params& p);
 // tuning aid (tools/microbench): force the 3x3 halo tile variant (0: 128 ch x 8x16 px, 1: 64 ch x 16x12 px, -1: auto)
 void debug_force_halo_variant(int v);
 
+// set by hp_engine_profile_sequence around one step: the next launch records its own begin / end into these events
+extern thread_local hipEvent_t prof_start, prof_stop;
+
 struct first_conv_params {
     const uint8_t* in_u8; // [B][H][W][3] or nullptr
     const float* in_f32;  // [B][3][H][W] (already scaled / ordered) or nullptr

@@ -1048,29 +1048,36 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
         HP_TRY(e->in_stage.alloc(need));
     const uint8_t* u8 = e->in_stage.as<uint8_t>();
     const size_t ns = e->steps.size();
-    std::vector<hipEvent_t> ev(ns + 1, nullptr);
+    // one (start, stop) event pair per step; the launch itself records them (hipExtLaunchKernelGGL), so they bracket the
+    // kernel's own execution and no packet is inserted between consecutive kernels
+    std::vector<hipEvent_t> ev0(ns, nullptr), ev1(ns, nullptr);
     std::vector<double> acc(ns, 0.0);
     int rc = HP_OK;
-    for (auto& x : ev)
-        if (hipEventCreate(&x) != hipSuccess)
+    for (size_t k = 0; k < ns; ++k)
+        if (hipEventCreate(&ev0[k]) != hipSuccess || hipEventCreate(&ev1[k]) != hipSuccess)
             rc = HP_ERR_HIP;
     for (int it = -1; it < iters && rc == HP_OK; ++it) { // it == -1: warm-up pass
-        (void)hipEventRecord(ev[0], e->stream);
         for (size_t k = 0; k < ns && rc == HP_OK; ++k) {
+            hp::prof_start = ev0[k], hp::prof_stop = ev1[k];
             rc = e->run_step(e->steps[k], u8, nullptr, n, e->stream);
-            (void)hipEventRecord(ev[k + 1], e->stream);
+            hp::prof_start = hp::prof_stop = nullptr;
         }
-        if (rc == HP_OK && hipEventSynchronize(ev[ns]) != hipSuccess)
+        if (rc == HP_OK && hipStreamSynchronize(e->stream) != hipSuccess)
             rc = HP_ERR_HIP;
         for (size_t k = 0; k < ns && rc == HP_OK && it >= 0; ++k) {
             float ms = 0;
-            (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            if (hipEventElapsedTime(&ms, ev0[k], ev1[k]) != hipSuccess)
+                rc = HP_ERR_HIP;
             acc[k] += ms;
         }
     }
-    for (auto& x : ev)
-        if (x)
-            (void)hipEventDestroy(x);
+    hp::prof_start = hp::prof_stop = nullptr;
+    for (size_t k = 0; k < ns; ++k) {
+        if (ev0[k])
+            (void)hipEventDestroy(ev0[k]);
+        if (ev1[k])
+            (void)hipEventDestroy(ev1[k]);
+    }
     HP_REQUIRE(rc == HP_OK, rc, "hp_engine_profile_sequence: launch or event failure");
     int k = 0;
     for (auto& st : e->steps) {

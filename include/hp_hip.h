@@ -251,10 +251,10 @@ typedef struct hp_layer_time {
     double flops, bytes;     /* algorithmic FLOPs and compulsory HBM bytes (inputs + weights + outputs once) */
 } hp_layer_time;
 int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int cap, int* n_out);
-/* Same table, but measured IN SEQUENCE: the whole schedule runs `iters` times with an event between consecutive launches, so
- * every kernel sees the cache state it sees in a real inference (the back-to-back form above re-runs one layer with its
- * weights warm in L2 and reads ~10-15 % faster for the weight-heavy 3x3 layers).  This is the form that agrees with the
- * per-kernel averages of `rocprofv3 --kernel-trace --stats` over the bench. */
+/* Same table, but measured IN SEQUENCE: the whole schedule runs `iters` times in order and every launch records its own begin /
+ * end timestamps (hipExtLaunchKernelGGL start / stop events: the numbers rocprofv3's kernel trace reports, no packets added
+ * between the kernels), so every kernel sees the cache state it sees in a real inference.  The back-to-back form above
+ * re-runs one layer with its weights warm in L2 and reads ~10-15 % faster for the weight-heavy 3x3 layers. */
 int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* out, int cap, int* n_out);
 
 /* ---- built-in topologies (restating hyperpose/Model/<arch>.py) --------------------- */
