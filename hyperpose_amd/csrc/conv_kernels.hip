@@ -759,15 +759,17 @@ __global__ __launch_bounds__(256 * KG) void conv3x3_halo_kernel(const conv_param
 // static halo tile in LDS, and nothing synchronises them between the prologue and the final exchange of the K-halves
 // (each wavefront keeps the three pixel tiles it will store and hands the other three to its partner).
 // LDS = the halo tile only (64.5 KB at CIN = 128): two blocks, or one block and any other conv kernel, share a CU.
-template <int CIN>
+template <int CIN, int TH>
 __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(const conv_params p, int tiles_x, int tiles_y)
 {
-    constexpr int TH = 16, TW = 12, HPH = TH + 2, HPW = TW + 2, NT = 6;
+    // TH = 16: 192 pixels (6 column tiles of 32) per block; TH = 8: 96 pixels (3) - twice the blocks, two per CU
+    constexpr int TW = 12, HPH = TH + 2, HPW = TW + 2, NT = TH * TW / 32;
+    constexpr int K0 = (NT + 1) / 2, K1 = NT / 2; // column tiles the K-half 0 / 1 wavefront finishes (3 + 3, or 2 + 1)
     constexpr int CHP = CIN / 8;       // 16-byte chunks per halo pixel
     constexpr int KQ = CIN / 16;       // k16 steps per tap
     constexpr int NS = KQ / 2;         // ... per tap and K-half
     constexpr int HALO_BYTES = HPH * HPW * CIN * 2;
-    constexpr int RED_BYTES = 4 * 3 * 16 * 64 * 4; // each wave parks 3 accumulator tiles
+    constexpr int RED_BYTES = 4 * K0 * 16 * 64 * 4; // each wave parks up to K0 accumulator tiles
     constexpr int EPI_BYTES = 4 * stage_geom<1>::SLAB;
     constexpr int LDS_BYTES = HALO_BYTES > RED_BYTES + EPI_BYTES ? HALO_BYTES : RED_BYTES + EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -887,40 +889,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(const conv_param
     HP_STAMP();
 #undef HP_TAP
 
-    // ---- the K-halves meet: wave (wm, kg) keeps pixel tiles 3*kg .. 3*kg+2 and parks the other three for its partner
+    // ---- the K-halves meet: wave (wm, 0) finishes column tiles 0 .. K0-1, wave (wm, 1) tiles K0 .. NT-1; each parks the
+    // tiles the other one finishes (slot j of a wave's parking area = the j-th tile of its partner)
     __syncthreads(); // every wave is done with the halo tile
     HP_STAMP();
-    float4* const park = reinterpret_cast<float4*>(lds) + (size_t)wave * (3 * 4 * 64) + lane;
-    const float4* const take = reinterpret_cast<const float4*>(lds) + (size_t)(wave ^ 2) * (3 * 4 * 64) + lane;
+    float4* const park = reinterpret_cast<float4*>(lds) + (size_t)wave * (K0 * 4 * 64) + lane;
+    const float4* const take = reinterpret_cast<const float4*>(lds) + (size_t)(wave ^ 2) * (K0 * 4 * 64) + lane;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < K0; ++j) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const floatx16& give = kg ? acc[j] : acc[K0 + j < NT ? K0 + j : NT - 1];
+        if (kg || j < K1) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const floatx16& give = kg ? acc[j] : acc[3 + j];
-            park[(j * 4 + g4) * 64] = make_float4(give[4 * g4], give[4 * g4 + 1], give[4 * g4 + 2], give[4 * g4 + 3]);
+            for (int g4 = 0; g4 < 4; ++g4)
+                park[(j * 4 + g4) * 64] = make_float4(give[4 * g4], give[4 * g4 + 1], give[4 * g4 + 2], give[4 * g4 + 3]);
         }
+    }
     __syncthreads();
-    floatx16 mine[1][3];
-    int pb[3], py[3], px[3];
-    bool pv[3];
+    floatx16 mine[1][K0];
+    int pb[K0], py[K0], px[K0];
+    bool pv[K0];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < K0; ++j) {
+        const int jt = K0 + j < NT ? K0 + j : NT - 1; // (kg = 1 has no K0-th tile when NT is odd: masked below)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4 o = take[(j * 4 + g4) * 64];
-            const floatx16& keep = kg ? acc[3 + j] : acc[j];
+            const floatx16& keep = kg ? acc[jt] : acc[j];
             mine[0][j][4 * g4] = keep[4 * g4] + o.x, mine[0][j][4 * g4 + 1] = keep[4 * g4 + 1] + o.y;
             mine[0][j][4 * g4 + 2] = keep[4 * g4 + 2] + o.z, mine[0][j][4 * g4 + 3] = keep[4 * g4 + 3] + o.w;
         }
         pb[j] = b;
-        py[j] = y0 + (kg ? brow[3 + j] : brow[j]);
-        px[j] = x0 + (kg ? bcol[3 + j] : bcol[j]);
-        pv[j] = py[j] < p.OH && px[j] < p.OW;
+        py[j] = y0 + (kg ? brow[jt] : brow[j]);
+        px[j] = x0 + (kg ? bcol[jt] : bcol[j]);
+        pv[j] = py[j] < p.OH && px[j] < p.OW && (!kg || j < K1);
     }
     HP_STAMP();
 #undef HP_STAMP
     // the slabs live behind the parking area: no wave can still be reading what another overwrites
-    conv_epilogue_staged<1, 3>(p, mine, m0 + wm * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+    conv_epilogue_staged<1, K0>(p, mine, m0 + wm * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
 }
 
 // fast epilogue (aligned fp16 NHWC vectors) when every 8-channel chunk is whole and 16-byte aligned
@@ -1041,12 +1049,17 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
     if (p.w_layout == 1) {
         if (!(use_halo(p) && fast_epilogue(p)))
             return hipErrorInvalidValue; // fragment-ordered weights only fit the direct kernel
-        const int tiles_x = (p.OW + 11) / 12, tiles_y = (p.OH + 15) / 16;
+        static const int th = getenv("HP_DIRECT_TH") ? atoi(getenv("HP_DIRECT_TH")) : 16; // experiment: 8 = half-height tiles
+        const int tiles_x = (p.OW + 11) / 12, tiles_y = th == 8 ? (p.OH + 7) / 8 : (p.OH + 15) / 16;
         dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / 64);
-        if (p.Cin == 128)
-            HP_LAUNCH((conv3x3_direct_kernel<128>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        if (p.Cin == 128 && th == 8)
+            HP_LAUNCH((conv3x3_direct_kernel<128, 8>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        else if (p.Cin == 128)
+            HP_LAUNCH((conv3x3_direct_kernel<128, 16>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        else if (th == 8)
+            HP_LAUNCH((conv3x3_direct_kernel<64, 8>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
         else
-            HP_LAUNCH((conv3x3_direct_kernel<64>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+            HP_LAUNCH((conv3x3_direct_kernel<64, 16>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
         return hipGetLastError();
     }
     if (use_halo(p)) {
