@@ -129,3 +129,26 @@ def test_preproc_matches_oracle(hp):
     for flip in (True, False):
         out = preproc_u8hwc_to_f32nchw(img, 1 / 255, flip)
         assert _same(out, loader.nhwc_u8_to_nchw_f32(img, 1 / 255, flip))
+
+
+def test_state_between_batches(hp):
+    """The assemble kernel leaves the peak counters and overflow flags zeroed for the next batch (no memsets between
+    batches): batches of different sizes through ONE parser, an overflowing batch in between, each clean batch still bit-exact."""
+    from hyperpose_amd.parser import Paf
+    rng = synth.rng_for(1, salt=33)
+    conf, paf, _ = synth.paf_maps(rng, 8, people=(5, 1, 0, 9, 2, 7, 3, 12))
+    p = Paf(max_batch=8)
+    for lo, hi in ((0, 8), (3, 5), (5, 6), (0, 8), (6, 8)):
+        humans = p.process_batch(conf[lo:hi], paf[lo:hi])
+        for f in range(hi - lo):
+            _check_frame(p, f, conf[lo + f], paf[lo + f], humans[f])
+    # a frame that overflows the per-part peak list: reported as a capacity error ...
+    noisy = np.zeros_like(conf[:1])
+    noisy[:, :, ::2, ::2] = 1.0  # a bright cell every 2 x 2 feature cells: 23 x 27 = 621 maxima per part > 512
+    with pytest.raises(hp.HpError) as e:
+        p.process_batch(noisy, paf[:1])
+    assert e.value.code == hp.HP_ERR_CAPACITY
+    # ... and the parser is clean again afterwards
+    humans = p.process_batch(conf[:4], paf[:4])
+    for f in range(4):
+        _check_frame(p, f, conf[f], paf[f], humans[f])
