@@ -1166,8 +1166,174 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const first_conv_params
     }
 }
 
+// The common first layer - 3 x 3 taps, stride 1 or 2, <= 64 output channels in multiples of 8 - on the fp32 matrix pipe.
+// A block owns 8 rows x 32 columns of output pixels: (1) its input patch is converted ONCE (src/data.cpp:48's scaling,
+// mean / std, zero outside the image = the convolution's padding) into fp32 in LDS - the scalar kernel converts every input
+// value 9 x (taps) x Cout/8 (threads per pixel) times; (2) each wavefront computes rows of 32 pixels as
+// D[32 ch][32 px] = bias + W[32][28] x X[28][32 px] with v_mfma_f32_32x32x2f32 (k = (ky*3 + kx)*3 + c, 14 steps of 2, the
+// weights in 14 registers per lane, the im2col operand one ds_read_b32 per step); (3) the two half-wavefronts swap
+// 4-channel groups so that every lane stores 16-byte NHWC pieces.  All arithmetic stays fp32; the MFMA accumulates k in
+// order, so results differ from first_conv_kernel's fmaf chain in the last bit only (below the fp16 rounding of the store).
+template <int MT, int S, bool CLAMP> // CLAMP: the activation is none / relu / relu6 = one v_med3_f32 against [lo, hi]
+__global__ __launch_bounds__(256) void first_conv_mfma_kernel(const first_conv_params p, int tiles_x, int tiles_y, float lo, float hi)
+{
+    constexpr int TH = 8, TW = 32, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, IWC = IW * 3;
+    __shared__ float s_x[IH * IWC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
+
+    // weights / bias of this lane (requested first: their latency hides behind the patch conversion)
+    float wa[MT][14], bs[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int co = mt * 32 + col;
+#pragma unroll
+        for (int s2 = 0; s2 < 14; ++s2) {
+            const int k = 2 * s2 + hh;
+            wa[mt][s2] = (k < 27 && co < p.Cout) ? p.w[(size_t)co * 27 + k] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { // accumulator registers 4g .. 4g+3 = channels mt*32 + 8g + 4hh + (0..3)
+            const int ch = mt * 32 + 8 * g + 4 * hh;
+            const float4 bv = ch + 3 < p.Cout ? *reinterpret_cast<const float4*>(p.bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bs[mt][4 * g] = bv.x, bs[mt][4 * g + 1] = bv.y, bs[mt][4 * g + 2] = bv.z, bs[mt][4 * g + 3] = bv.w;
+        }
+    }
+    // (1) the patch: all loads first (clamped addresses, one memory round trip), then the conversions and the LDS stores
+    {
+        constexpr int NIT = (IH * IW + 255) / 256;
+        float raw[NIT][3];
+        bool ok[NIT];
+        const int c0 = p.flip_rb ? 2 : 0, c2 = p.flip_rb ? 0 : 2;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(tid + it * 256, IH * IW - 1);
+            const int py = i / IW, px = i - py * IW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            ok[it] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+            if (p.in_u8) {
+                const uint8_t* q = p.in_u8 + (((size_t)b * p.H + cy) * p.W + cx) * 3;
+                raw[it][0] = (float)q[c0], raw[it][1] = (float)q[1], raw[it][2] = (float)q[c2]; // exact: 0 .. 255
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    raw[it][c] = p.in_f32[(((size_t)b * 3 + c) * p.H + cy) * p.W + cx];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < IH * IW) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float x = p.in_u8 ? (float)((double)raw[it][c] * p.factor) : raw[it][c]; // src/data.cpp:48
+                    s_x[i * 3 + c] = ok[it] ? (x - p.mean[c]) * p.inv_std[c] : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // (2) two rows of 32 pixels per wavefront
+#pragma unroll 1
+    for (int rr = 0; rr < TH / 4; ++rr) {
+        const int row = wave * (TH / 4) + rr, oy = oy0 + row, ox = ox0 + col;
+        if (oy >= p.OH) // uniform per wavefront
+            break;
+        const float* xb = s_x + (row * S) * IWC + (col * S) * 3;
+        float xv[14];
+#pragma unroll
+        for (int s2 = 0; s2 < 14; ++s2) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int k0 = 2 * s2, k1 = min(2 * s2 + 1, 26);
+            const int o0 = (k0 / 9) * IWC + ((k0 / 3) % 3) * 3 + k0 % 3, o1 = (k1 / 9) * IWC + ((k1 / 3) % 3) * 3 + k1 % 3;
+            const float x = xb[hh ? o1 : o0];
+            xv[s2] = (2 * s2 + hh < 27) ? x : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt * 32 >= p.Cout)
+                break;
+            floatx16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                d[r] = bs[mt][r];
+#pragma unroll
+            for (int s2 = 0; s2 < 14; ++s2)
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[mt][s2], xv[s2], d, 0, 0, 0);
+            // (3) d[4g + e] = channel mt*32 + 8g + 4hh + e of pixel `col`.  Half 0 keeps groups 0, 1 and half 1 groups 2, 3:
+            // each sends the other its two foreign groups and ends with 8 consecutive channels per group.
+            unsigned mine[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v0 = d[4 * g + 2 * e], v1 = d[4 * g + 2 * e + 1];
+                    const _Float16 h0 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v0, lo, hi) : apply_act(v0, p.act, p.act_param, 0.f));
+                    const _Float16 h1 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v1, lo, hi) : apply_act(v1, p.act, p.act_param, 0.f));
+                    unsigned short ul, uh;
+                    __builtin_memcpy(&ul, &h0, 2), __builtin_memcpy(&uh, &h1, 2);
+                    mine[g][e] = (unsigned)ul | ((unsigned)uh << 16);
+                }
+            unsigned got[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    got[q][e] = (unsigned)__shfl_xor((int)(hh ? mine[q][e] : mine[2 + q][e]), 32);
+            if (ox < p.OW) {
+                __half* const op = p.out.p + tv_off(p.out, b, oy, ox) + mt * 32;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = 2 * hh + q; // the group this lane stores
+                    u32x4 v;
+                    v[0] = hh ? got[q][0] : mine[q][0], v[1] = hh ? got[q][1] : mine[q][1];
+                    v[2] = hh ? mine[2 + q][0] : got[q][0], v[3] = hh ? mine[2 + q][1] : got[q][1];
+                    if (mt * 32 + 8 * g < p.Cout)
+                        *reinterpret_cast<u32x4*>(op + 8 * g) = v;
+                }
+            }
+        }
+    }
+}
+
 hipError_t launch_first_conv(const first_conv_params& p, hipStream_t s)
 {
+    static const bool no_mfma = getenv("HP_FIRST_MFMA") && atoi(getenv("HP_FIRST_MFMA")) == 0;
+    if (!no_mfma && p.KH == 3 && p.KW == 3 && (p.stride == 1 || p.stride == 2) && p.Cout % 8 == 0 && p.Cout <= 64 && p.out.coff % 8 == 0
+        && p.out.cs % 8 == 0) {
+        const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
+        const dim3 grid(tiles_x * tiles_y * p.B);
+        const bool clamp = p.act == ACT_NONE || p.act == ACT_RELU || p.act == ACT_RELU6;
+        const float lo = p.act == ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = p.act == ACT_RELU6 ? 6.f : __builtin_huge_valf();
+        const int mt = p.Cout <= 32 ? 1 : 2;
+#define HP_FC(MT_, S_, C_) HP_LAUNCH((first_conv_mfma_kernel<MT_, S_, C_>), grid, dim3(256), 0, s, p, tiles_x, tiles_y, lo, hi)
+#define HP_FC2(MT_, S_)        \
+    do {                       \
+        if (clamp)             \
+            HP_FC(MT_, S_, true);  \
+        else                   \
+            HP_FC(MT_, S_, false); \
+    } while (0)
+        if (mt == 1 && p.stride == 2)
+            HP_FC2(1, 2);
+        else if (mt == 1)
+            HP_FC2(1, 1);
+        else if (p.stride == 2)
+            HP_FC2(2, 2);
+        else
+            HP_FC2(2, 1);
+#undef HP_FC2
+#undef HP_FC
+        return hipGetLastError();
+    }
     const int G = (p.Cout + 7) / 8;
     if (G > 256)
         return hipErrorInvalidValue;
