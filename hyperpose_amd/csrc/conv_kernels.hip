@@ -1241,6 +1241,7 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const first_conv_p
     __syncthreads();
 
     // (2) two rows of 32 pixels per wavefront
+    const unsigned hmask = hh ? 0xffffffffu : 0u;
 #pragma unroll 1
     for (int rr = 0; rr < TH / 4; ++rr) {
         const int row = wave * (TH / 4) + rr, oy = oy0 + row, ox = ox0 + col;
@@ -1287,15 +1288,15 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const first_conv_p
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
-                    got[q][e] = (unsigned)__shfl_xor((int)(hh ? mine[q][e] : mine[2 + q][e]), 32);
+                    got[q][e] = (unsigned)__shfl_xor((int)((mine[q][e] & hmask) | (mine[2 + q][e] & ~hmask)), 32); // (a ?: on array elements becomes a scratch round trip)
             if (ox < p.OW) {
                 __half* const op = p.out.p + tv_off(p.out, b, oy, ox) + mt * 32;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int g = 2 * hh + q; // the group this lane stores
                     u32x4 v;
-                    v[0] = hh ? got[q][0] : mine[q][0], v[1] = hh ? got[q][1] : mine[q][1];
-                    v[2] = hh ? mine[2 + q][0] : got[q][0], v[3] = hh ? mine[2 + q][1] : got[q][1];
+                    v[0] = (got[q][0] & hmask) | (mine[q][0] & ~hmask), v[1] = (got[q][1] & hmask) | (mine[q][1] & ~hmask);
+                    v[2] = (mine[2 + q][0] & hmask) | (got[q][0] & ~hmask), v[3] = (mine[2 + q][1] & hmask) | (got[q][1] & ~hmask);
                     if (mt * 32 + 8 * g < p.Cout)
                         *reinterpret_cast<u32x4*>(op + 8 * g) = v;
                 }
