@@ -1863,17 +1863,18 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     };
     hload(0);
 
-    floatx16 acc[TP][NT];
-    auto clear_acc = [&]() {
+    floatx16 acc[TP][NT], acc1[NP == 2 ? TP : 1][NT]; // pass 0 / pass 1 results: both are stored after pass 1, through the then
+                                                        // dead B_all (a direct epilogue for pass 0 cost 21 k of the block's 61 k cycles)
 #pragma unroll
-        for (int i = 0; i < TP; ++i)
+    for (int i = 0; i < TP; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[i][j][r] = 0.f;
-    };
-    clear_acc();
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if (NP == 2)
+                    acc1[i][j][r] = 0.f;
+            }
     const int g = tid % CG, frow = lane & 31, fk = lane >> 5;
     const float dw_hi = p.dw_hi;
 
@@ -1908,7 +1909,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         }
     };
     // MFMAs of linear step L out of B_all; the weights of step L+1 are requested as each k16 step's are consumed
-    auto mm_chunk = [&](int L) {
+    auto mm_chunk = [&](int L, floatx16 (&acc)[TP][NT]) {
         const unsigned char* const bt = s_ball + (L % NCH) * BCH_BYTES;
         const int Ln = min(L + 1, NSTEP - 1);
 #pragma unroll
@@ -1941,34 +1942,54 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     }
 
     // ---- pass 0
+    int dbg_i = 0;
+#define HP_STAMP()                                                   \
+    if (p.pw.dbg && blockIdx.x == 0 && tid == 0 && dbg_i < 40)       \
+        p.pw.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
     const int NHC = NCH * HPK; // halo chunks
+    HP_STAMP();
     to_lds(0);
     hload(min(1, NHC - 1));
     lds_barrier();
+    HP_STAMP();
 #pragma unroll 1
     for (int hc = 0; hc < NHC; ++hc) {
         dw_chunk(hc);
+        HP_STAMP();
         lds_barrier(); // these columns of B_all complete; every thread is past its reads of halo chunk hc
+        HP_STAMP();
         if (hc + 1 < NHC) {
             to_lds(hc + 1);
             hload(min(hc + 2, NHC - 1));
         }
+        HP_STAMP();
         if (hc % HPK == HPK - 1)
-            mm_chunk(hc / HPK);
+            mm_chunk(hc / HPK, acc);
+        HP_STAMP();
         lds_barrier(); // halo chunk hc+1 and its depthwise weights visible
+        HP_STAMP();
     }
     if (NP == 1) {
         conv_epilogue_staged<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
+        HP_STAMP();
         return;
     }
-    conv_epilogue<TP, NT, 0>(p.pw, acc, (wave * TP) * 32, lane, pb, py, px, pv);
+    if (p.pw.dbg && blockIdx.x == 0 && tid == 0)
+        p.pw.dbg[41] = __builtin_amdgcn_s_memtime();
     // ---- pass 1: MFMAs only
-    clear_acc();
+    if constexpr (NP == 2) {
 #pragma unroll 1
-    for (int kc = 0; kc < NCH; ++kc)
-        mm_chunk(NCH + kc);
-    __syncthreads(); // every wave is done with B_all before the slabs overwrite it
-    conv_epilogue_staged<TP, NT>(p.pw, acc, (4 * TP + wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
+        for (int kc = 0; kc < NCH; ++kc)
+            mm_chunk(NCH + kc, acc1);
+        if (p.pw.dbg && blockIdx.x == 0 && tid == 0)
+            p.pw.dbg[42] = __builtin_amdgcn_s_memtime();
+        __syncthreads(); // every wave is done with B_all before the slabs overwrite it
+        conv_epilogue_staged<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
+        conv_epilogue_staged<TP, NT>(p.pw, acc1, (4 * TP + wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
+        if (p.pw.dbg && blockIdx.x == 0 && tid == 0)
+            p.pw.dbg[43] = __builtin_amdgcn_s_memtime();
+    }
+#undef HP_STAMP
 }
 
 template <int NP, int TP, int S, int D, int CMAX, int CKH = 64>

@@ -761,6 +761,24 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     } else if (st.op == OP_SEPCONV) {
         st.sp.B = n, st.sp.pw.B = n, st.sp.pw.npix = n * st.sp.OH * st.sp.OW;
         HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
+        if (getenv("HP_SEP_DBG")) { // block timeline (s_memtime deltas of block 0, thread 0) of every separable block, printed per launch
+            unsigned long long* dbg = nullptr;
+            HP_HIP_TRY(hipMalloc(&dbg, 64 * 8));
+            HP_HIP_TRY(hipMemset(dbg, 0, 64 * 8));
+            st.sp.pw.dbg = dbg;
+            HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
+            HP_HIP_TRY(hipStreamSynchronize(s));
+            unsigned long long h[64];
+            HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "sep layer %d C=%d timeline:", st.layer, st.sp.C);
+            for (int i = 1; i < 40 && h[i]; ++i)
+                fprintf(stderr, " %llu", h[i] - h[i - 1]);
+            if (h[41])
+                fprintf(stderr, " | total-to-epi0 %llu pass1 %llu epi1 %llu | total %llu", h[41] - h[0], h[42] - h[41], h[43] - h[42], h[43] - h[0]);
+            fprintf(stderr, "\n");
+            st.sp.pw.dbg = nullptr;
+            (void)hipFree(dbg);
+        }
     } else if (st.op == OP_MLPHEAD) {
         st.hp_.B = n, st.hp_.pw.B = n;
         if (st.paired) {
