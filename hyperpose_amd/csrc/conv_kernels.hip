@@ -1809,21 +1809,21 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     const int ty = t % tiles_y, b = t / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
     const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1;
-    const int C = p.C, KQ = C / 16, NCH = C / CK, NSTEP = NP * NCH;
+    const int C = p.C, KQ = C / 16, NCH = C / CK;
 
-    // pointwise weights of linear step L = pass * NCH + chunk: fragment (row tile pass*8 + wave*2 + i, k16 step chunk*4 + ks)
-    const __half* const wbase = p.pw.w + (size_t)lane * 8;
+    // pointwise weights of (pass, K chunk): fragment (row tile pass*4*TP + wave*TP + i, k16 step chunk*4 + ks).  One pointer per
+    // chunk, constant offsets per (i, ks): no per-load index arithmetic in the MFMA phase (it is issue-bound)
+    const __half* const wbase = p.pw.w + (size_t)lane * 8 + (size_t)(wave * TP) * KQ * 512;
+    const size_t pass_stride = (size_t)4 * TP * KQ * 512, row_stride = (size_t)KQ * 512;
     u32x4 a[KS][TP];
-    auto a_load = [&](int L, int ks) {
-        const int ps = L / NCH, kc = L - ps * NCH;
+    auto a_load = [&](const __half* wp, int ks) {
 #pragma unroll
         for (int i = 0; i < TP; ++i)
-            a[ks][i] = *reinterpret_cast<const u32x4*>(wbase + ((size_t)(ps * 4 * TP + wave * TP + i) * KQ + kc * KS + ks) * 512);
+            a[ks][i] = *reinterpret_cast<const u32x4*>(wp + i * row_stride + ks * 512);
     };
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-        a_load(0, ks);
-
+        a_load(wbase, ks);
     // halo chunk + depthwise weights / bias: global -> registers (one chunk ahead) -> LDS
     u32x4 hv[NLD], wreg;
     int hoff[NLD];
@@ -1908,10 +1908,12 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
             *reinterpret_cast<half8*>(bt + lds_off<CK>(pix, gcol)) = h;
         }
     };
-    // MFMAs of linear step L out of B_all; the weights of step L+1 are requested as each k16 step's are consumed
-    auto mm_chunk = [&](int L, floatx16 (&acc)[TP][NT]) {
-        const unsigned char* const bt = s_ball + (L % NCH) * BCH_BYTES;
-        const int Ln = min(L + 1, NSTEP - 1);
+    // MFMAs of (pass ps, K chunk kc) out of B_all; the weights of the following step are requested as each k16 step's are consumed
+    auto mm_chunk = [&](int ps, int kc, floatx16 (&acc)[TP][NT]) {
+        const unsigned char* const bt = s_ball + kc * BCH_BYTES;
+        const bool wrap = kc + 1 == NCH;
+        const int ps2 = wrap ? min(ps + 1, NP - 1) : ps, kc2 = wrap ? (ps + 1 < NP ? 0 : kc) : kc + 1;
+        const __half* const wn = wbase + ps2 * pass_stride + (size_t)kc2 * (KS * 512);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             half8 fb[NT];
@@ -1926,7 +1928,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
             }
-            a_load(Ln, ks);
+            a_load(wn, ks);
         }
     };
 
@@ -1964,7 +1966,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         }
         HP_STAMP();
         if (hc % HPK == HPK - 1)
-            mm_chunk(hc / HPK, acc);
+            mm_chunk(0, hc / HPK, acc);
         HP_STAMP();
         lds_barrier(); // halo chunk hc+1 and its depthwise weights visible
         HP_STAMP();
@@ -1980,7 +1982,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     if constexpr (NP == 2) {
 #pragma unroll 1
         for (int kc = 0; kc < NCH; ++kc)
-            mm_chunk(NCH + kc, acc1);
+            mm_chunk(1, kc, acc1);
         if (p.pw.dbg && blockIdx.x == 0 && tid == 0)
             p.pw.dbg[42] = __builtin_amdgcn_s_memtime();
         __syncthreads(); // every wave is done with B_all before the slabs overwrite it
