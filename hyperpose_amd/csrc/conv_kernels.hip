@@ -2002,11 +2002,117 @@ static hipError_t launch_sep_slot(const sep_params& p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The first separable block of the MobileNet backbones (32 channels in, <= 64 out, stride 1, at half the input resolution:
+// the two largest activations of the network): depthwise 3x3 + pointwise 1x1 in one small block.  8 x 8 output pixels; the
+// 10 x 10 x 32 halo tile goes to LDS once, one thread = one pixel x 8 channels of depthwise taps (same arithmetic as
+// dwconv3x3_kernel), the pointwise GEMM is K = 32: two MFMAs per wavefront (2 row tiles x 2 pixel halves).  ~30 KB of LDS,
+// < 128 registers: several blocks per CU, so loads, taps and stores of different blocks overlap.
+__global__ __launch_bounds__(256) void sepconv_c32_kernel(const sep_params p, int tiles_x, int tiles_y)
+{
+    constexpr int TH = 8, TW = 8, C = 32, CG = 4, IH = TH + 2, IW = TW + 2, PIECES = IH * IW * CG, NLD = (PIECES + 255) / 256;
+    constexpr int HALO_BYTES = PIECES * 16, B_BYTES = TH * TW * C * 2, DWW_BYTES = 9 * C * 2, DWB_BYTES = C * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_BYTES + B_BYTES + DWW_BYTES + DWB_BYTES + 4 * stage_geom<1>::SLAB];
+    unsigned char* const s_halo = lds;
+    unsigned char* const s_b = s_halo + HALO_BYTES;
+    unsigned char* const s_dww = s_b + B_BYTES;
+    unsigned char* const s_dwb = s_dww + DWW_BYTES;
+    unsigned char* const s_slab = s_dwb + DWB_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1;
+
+    // pointwise weights: row tile wm, k16 steps 0 and 1 (fragment order, Cin = 32)
+    u32x4 a[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        a[ks] = *reinterpret_cast<const u32x4*>(p.pw.w + ((size_t)(wm * 2 + ks) * 64 + lane) * 8);
+
+    // halo tile + depthwise weights / bias -> LDS
+    {
+        const __half* const hbase = p.in.p + (size_t)b * p.in.img * p.in.cs + p.in.coff;
+        const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
+        u32x4 hv[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = min(tid + k * 256, PIECES - 1);
+            const int hp = i / CG, c = i - hp * CG;
+            const int hy = hp / IW, hx = hp - hy * IW;
+            const int y = iy0 + hy, x = ix0 + hx;
+            const bool ok = y <= ymax && x <= xmax; // y, x >= -halo: inside the zero halo of the HBM tensor
+            const u32x4 v = *reinterpret_cast<const u32x4*>(hbase + (size_t)(min(y, ymax) * p.in.wp + min(x, xmax)) * p.in.cs + c * 8);
+            hv[k] = v & (ok ? 0xffffffffu : 0u);
+        }
+        u32x4 wreg = { 0, 0, 0, 0 };
+        if (tid < 36)
+            wreg = *reinterpret_cast<const u32x4*>(p.dw_w + (size_t)(tid / CG) * C + (tid % CG) * 8);
+        else if (tid < 44)
+            wreg = *reinterpret_cast<const u32x4*>(p.dw_bias + (tid - 36) * 4);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (tid + k * 256 < PIECES)
+                *reinterpret_cast<u32x4*>(s_halo + (size_t)(tid + k * 256) * 16) = hv[k];
+        if (tid < 36)
+            *reinterpret_cast<u32x4*>(s_dww + tid * 16) = wreg;
+        else if (tid < 44)
+            *reinterpret_cast<u32x4*>(s_dwb + (tid - 36) * 16) = wreg;
+    }
+    lds_barrier();
+    // depthwise taps: one item per thread
+    {
+        const int g = tid % CG, pix = tid / CG;
+        const int py = pix / TW, px = pix - py * TW;
+        const float* bsrc = reinterpret_cast<const float*>(s_dwb) + g * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
+        const unsigned char* xs = s_halo + ((py * IW + px) * CG + g) * 16;
+        float v[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+            const u32x4 x = *reinterpret_cast<const u32x4*>(xs + ((t9 / 3) * IW + (t9 % 3)) * CG * 16);
+            const u32x4 w = *reinterpret_cast<const u32x4*>(s_dww + (t9 * C + g * 8) * 2);
+            mac8_f16(v, x, w);
+        }
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            h[e] = (_Float16)dw_act<true>(v[e], 0.f, p.dw_hi);
+        *reinterpret_cast<half8*>(s_b + lds_off<32>(pix, g)) = h;
+    }
+    lds_barrier();
+    // pointwise: D[32 rows of tile wm][32 pixels of half wn], K = 32
+    floatx16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        acc[0][0][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const half8 fb = *reinterpret_cast<const half8*>(s_b + lds_off<32>(wn * 32 + frow, ks * 2 + fk));
+        half8 fa;
+        __builtin_memcpy(&fa, &a[ks], 16);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[0][0], 0, 0, 0);
+    }
+    int pb[1], py1[1], px1[1];
+    bool pv[1];
+    const int n = wn * 32 + frow;
+    pb[0] = b, py1[0] = y0 + n / TW, px1[0] = x0 + n % TW;
+    pv[0] = py1[0] < p.OH && px1[0] < p.OW;
+    conv_epilogue_staged<1, 1>(p.pw, acc, wm * 32, lane, s_slab + wave * stage_geom<1>::SLAB, pb, py1, px1, pv);
+}
+
 // which instantiation serves (Cout_pad, stride, dilation, C); 0 = none (the engine then keeps the two launches)
-int sepconv_variant_for(int C, int cout_pad, int stride, int dil)
+int sepconv_variant_for(int C, int cout_pad, int stride, int dil, int cout)
 {
     if (C > SEP_CMAX || C % 32 || cout_pad % 128)
         return 0;
+    if (C == 32 && cout > 0 && cout <= 64 && stride == 1 && dil == 1)
+        return 7; // sepconv_c32_kernel
     const int tm = cout_pad / 128;
     if (tm == 1 && stride == 1 && dil == 1)
         return 1;
@@ -2030,13 +2136,18 @@ int sepconv_variant(const sep_params& p)
     const conv_params& q = p.pw;
     if (q.res.p || q.out_f32 || !fast_epilogue(q) || p.in.coff % 8 || p.halo < p.dil || p.dw_slope != 0.f)
         return 0;
-    return sepconv_variant_for(p.C, q.Cout_pad, p.stride, p.dil);
+    return sepconv_variant_for(p.C, q.Cout_pad, p.stride, p.dil, q.Cout);
 }
 
 hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 {
     static const bool slot = !getenv("HP_SEP_SLOT") || atoi(getenv("HP_SEP_SLOT")) != 0; // HP_SEP_SLOT=0: whole-CU form everywhere
     const int v = sepconv_variant(p);
+    if (v == 7) {
+        const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 7) / 8;
+        HP_LAUNCH(sepconv_c32_kernel, dim3(tiles_x * tiles_y * p.B), dim3(256), 0, s, p, tiles_x, tiles_y);
+        return hipGetLastError();
+    }
     static const int slot_mask = getenv("HP_SEP_SLOT_MASK") ? atoi(getenv("HP_SEP_SLOT_MASK")) : 0x7e; // bit v: variant v in half-CU form
     if (slot && ((slot_mask >> v) & 1) && p.C % 64 == 0) {
         switch (v) { // <passes, row tiles per wavefront, stride, dilation, max channels, halo chunk>

@@ -121,7 +121,7 @@ struct sep_params {
 };
 // 0 when no fused instantiation serves this pair (the caller keeps dwconv3x3 + conv_mfma)
 int sepconv_variant(const sep_params& p);
-int sepconv_variant_for(int C, int cout_pad, int stride, int dil); // the pointer-free part of the same decision
+int sepconv_variant_for(int C, int cout_pad, int stride, int dil, int cout = 0); // the pointer-free part of the same decision (cout: true output channels, 0 = unknown)
 hipError_t launch_sepconv(const sep_params& p, hipStream_t s);
 
 // Two chained 1x1 convolutions K1 -> 512 (relu family) -> Cout2 <= 64 in one launch (mlp_head_kernel).

@@ -213,8 +213,10 @@ int hp_engine::build(const hp_engine_desc* d)
             if (!sole)
                 continue;
             const int cout_pad = round_up(Bn.cout, 128);
-            if (Bn.cout <= 64 || !hp::sepconv_variant_for(A.cin, cout_pad, A.stride, A.dil))
-                continue; // (<= 64 output channels would idle half of the fused kernel's wavefronts: measured slower than two launches)
+            const int variant = hp::sepconv_variant_for(A.cin, cout_pad, A.stride, A.dil, Bn.cout);
+            const bool stem_wanted = i == 1 && getenv("HP_FUSE_STEM") && atoi(getenv("HP_FUSE_STEM")); // the opt-in stem kernel takes layers 0..2
+            if (!variant || (Bn.cout <= 64 && variant != 7) || (variant == 7 && (getenv("HP_NO_FUSE_C32") || stem_wanted)))
+                continue; // (<= 64 output channels idle half of the general fused kernels' wavefronts - slower than two launches - except in the dedicated 32-channel form)
             fuse_with_next[i] = 1;
             tensors[A.out]->elided = true;
         }
