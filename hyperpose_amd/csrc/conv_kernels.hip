@@ -2475,219 +2475,6 @@ hipError_t launch_mlp_head(const head_params& p, hipStream_t s)
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------
-// MobileNet stem in ONE launch: first conv (u8 / f32 image -> 32 channels, 3x3 stride 2, pre-processing fused) +
-// depthwise 3x3 + pointwise 1x1 (32 -> <= 64) (backbones.py MobilenetDilated: conv_block + the first dw_conv_block).
-// At 368x432 these three layers write 20 + 20 + 40 MB per batch of 8 and read most of it back; fused, the image
-// (3.8 MB) goes in and the 64-channel tensor (40 MB) comes out.
-//   block = 8 x 16 output pixels.  (1) the 21 x 37 x 3 input patch is normalised once into LDS (zeros outside the
-//   image = the first conv's zero padding), (2) 256 threads evaluate the first conv on the 10 x 18 halo tile the
-//   depthwise stage needs (same fp32 FMA order as first_conv_kernel; zeros outside the map = the depthwise padding)
-//   into an fp16 tile in LDS, (3) depthwise taps as in sepconv_kernel -> swizzled B tile, (4) four wavefronts as
-//   2 (32-row tiles) x 2 (64-pixel halves) run the K = 32 pointwise GEMM with fragment-ordered weights from L2,
-//   (5) shared staged epilogue.  ~45 KB of LDS, 3-4 blocks per CU.
-__global__ __launch_bounds__(256, 2) void stem_kernel(const stem_params p, int tiles_x, int tiles_y)
-{
-    constexpr int TH = 8, TW = 16, NPX = TH * TW, FH = TH + 2, FW = TW + 2, FPX = FH * FW; // F = first-conv halo tile
-    constexpr int IH = 2 * FH + 1, IW = 2 * FW + 1;                                         // input patch (stride 2, 3x3)
-    constexpr int C0 = 32, CG = 4;
-    constexpr int X_BYTES = IH * IW * 3 * 4, W0_BYTES = 27 * C0 * 4, F_BYTES = FPX * C0 * 2, B_BYTES = NPX * C0 * 2;
-    constexpr int DW_BYTES = 9 * C0 * 2 + C0 * 4;
-    constexpr int MAIN_BYTES = X_BYTES + W0_BYTES + F_BYTES + B_BYTES + DW_BYTES;
-    constexpr int EPI_BYTES = 4 * stage_geom<1>::SLAB;
-    constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    float* const s_x = reinterpret_cast<float*>(lds);                        // [IH][IW][3] normalised input
-    float* const s_w0 = reinterpret_cast<float*>(lds + X_BYTES);             // [27][32]
-    unsigned char* const s_f = lds + X_BYTES + W0_BYTES;                     // [FPX][32] halves
-    unsigned char* const s_b = s_f + F_BYTES;                                // B tile, lds_off<32>
-    __half* const s_dww = reinterpret_cast<__half*>(s_b + B_BYTES);          // [9][32]
-    float* const s_dwb = reinterpret_cast<float*>(s_dww + 9 * C0);           // [32]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const first_conv_params& fc = p.fc;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y, b = t / tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;            // output tile origin
-    const int fy0 = y0 - 1, fx0 = x0 - 1;            // first-conv halo tile origin (depthwise pad 1)
-    const int iy0 = fy0 * 2 - fc.pad_t, ix0 = fx0 * 2 - fc.pad_l;
-
-    int dbg_i = 0;
-#define HP_STAMP()                                                                                                \
-    if (p.pw.dbg && blockIdx.x == 0 && tid == 0)                                                                  \
-        p.pw.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
-    HP_STAMP();
-    // pointwise weights of this wave (row tile wm, k16 steps 0 / 1): requested first
-    const int wm = wave >> 1, wn = wave & 1;
-    u32x4 a[2];
-    a[0] = *reinterpret_cast<const u32x4*>(p.pw.w + ((size_t)(wm * 2 + 0) * 64 + lane) * 8);
-    a[1] = *reinterpret_cast<const u32x4*>(p.pw.w + ((size_t)(wm * 2 + 1) * 64 + lane) * 8);
-
-    // ---- (1) input patch, normalised; first-conv weights [co][27] -> [27][co]; depthwise weights
-    for (int i = tid; i < IH * IW; i += 256) {
-        const int py = i / IW, px = i - py * IW;
-        const int iy = iy0 + py, ix = ix0 + px;
-        float v[3] = { 0.f, 0.f, 0.f };
-        if (iy >= 0 && iy < fc.H && ix >= 0 && ix < fc.W) {
-            if (fc.in_u8) {
-                const uint8_t* q = fc.in_u8 + (((size_t)b * fc.H + iy) * fc.W + ix) * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float x = (float)((double)q[fc.flip_rb ? 2 - c : c] * fc.factor); // src/data.cpp:48
-                    v[c] = (x - fc.mean[c]) * fc.inv_std[c];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    v[c] = (fc.in_f32[(((size_t)b * 3 + c) * fc.H + iy) * fc.W + ix] - fc.mean[c]) * fc.inv_std[c];
-            }
-        }
-        s_x[i * 3 + 0] = v[0], s_x[i * 3 + 1] = v[1], s_x[i * 3 + 2] = v[2];
-    }
-    for (int i = tid; i < 27 * C0; i += 256) {
-        const int co = i % C0, k = i / C0;
-        s_w0[i] = fc.w[(size_t)co * 27 + k];
-    }
-    for (int i = tid; i < 9 * C0 / 8; i += 256)
-        reinterpret_cast<u32x4*>(s_dww)[i] = reinterpret_cast<const u32x4*>(p.dw_w)[i];
-    if (tid < C0 / 4)
-        reinterpret_cast<float4*>(s_dwb)[tid] = reinterpret_cast<const float4*>(p.dw_bias)[tid];
-    HP_STAMP();
-    __syncthreads();
-    HP_STAMP();
-
-    // ---- (2) first conv on the halo tile as an fp32 MFMA (v_mfma_f32_32x32x2f32: an fmaf chain over k, the same sum
-    // as first_conv_kernel's, not fp16): D[32 ch][32 px] = bias + W[32][28] x X[28][32 px], k = (ky*3 + kx)*3 + c, 14 steps of 2.
-    // Weights live in 14 registers per lane; the B operand is gathered from the normalised patch in LDS.
-    {
-        const int mrow = lane & 31, hh = lane >> 5;
-        float wa[14];
-#pragma unroll
-        for (int s2 = 0; s2 < 14; ++s2) {
-            const int k = 2 * s2 + hh;
-            wa[s2] = k < 27 ? s_w0[k * C0 + mrow] : 0.f;
-        }
-        float bs[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 bv = *reinterpret_cast<const float4*>(fc.bias + 8 * g + 4 * hh);
-            bs[4 * g] = bv.x, bs[4 * g + 1] = bv.y, bs[4 * g + 2] = bv.z, bs[4 * g + 3] = bv.w;
-        }
-        for (int tile = wave; tile * 32 < FPX; tile += 4) {
-            const int fp = min(tile * 32 + mrow, FPX - 1);
-            const int fy = fp / FW, fx = fp - fy * FW;
-            const float* xb = s_x + ((2 * fy) * IW + 2 * fx) * 3;
-            floatx16 d;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                d[r] = bs[r];
-#pragma unroll
-            for (int s2 = 0; s2 < 14; ++s2) {
-                // k = 2 s2 + hh -> (tap, c); offsets of both halves are compile-time, the lane picks its half
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int k0 = 2 * s2, k1 = min(2 * s2 + 1, 26);
-                const int o0 = ((k0 / 9) * IW + (k0 / 3) % 3) * 3 + k0 % 3, o1 = ((k1 / 9) * IW + (k1 / 3) % 3) * 3 + k1 % 3;
-                const float xv = xb[hh ? o1 : o0];
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s2], (2 * s2 + hh < 27) ? xv : 0.f, d, 0, 0, 0);
-            }
-            const int oy = fy0 + fy, ox = fx0 + fx;
-            const bool inside = oy >= 0 && oy < fc.OH && ox >= 0 && ox < fc.OW;
-            if (tile * 32 + mrow < FPX) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    half4 h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        h[e] = inside ? (_Float16)apply_act(d[4 * g + e], fc.act, fc.act_param, 0.f) : (_Float16)0.f; // outside the map: the depthwise conv's zero padding
-                    *reinterpret_cast<half4*>(s_f + ((size_t)fp * C0 + 8 * g + 4 * hh) * 2) = h;
-                }
-            }
-        }
-    }
-    HP_STAMP();
-    __syncthreads();
-    HP_STAMP();
-
-    // ---- (3) depthwise 3x3 -> B tile
-    {
-        const int g = tid % CG;
-        const float4 b0 = *reinterpret_cast<const float4*>(s_dwb + g * 8), b1 = *reinterpret_cast<const float4*>(s_dwb + g * 8 + 4);
-        u32x4 wv[9];
-#pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9)
-            wv[t9] = *reinterpret_cast<const u32x4*>(s_dww + t9 * C0 + g * 8);
-#pragma unroll
-        for (int r = 0; r < NPX * CG / 256; ++r) {
-            const int pix = (tid + r * 256) / CG;
-            const int py = pix / TW, px = pix - py * TW;
-            u32x4 x[9];
-#pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9)
-                x[t9] = *reinterpret_cast<const u32x4*>(s_f + (((py + t9 / 3) * FW + px + t9 % 3) * CG + g) * 16);
-            float v[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
-#pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9)
-                mac8_f16(v, x[t9], wv[t9]);
-            half8 h;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                h[e] = (_Float16)dw_act<true>(v[e], 0.f, p.dw_hi);
-            *reinterpret_cast<half8*>(s_b + lds_off<32>(pix, g)) = h;
-        }
-    }
-    HP_STAMP();
-    __syncthreads();
-    HP_STAMP();
-
-    // ---- (4) pointwise GEMM: wave (wm, wn) = rows 32 wm .. +31 x pixels 64 wn .. +63, K = 32
-    floatx16 acc[1][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            acc[0][j][r] = 0.f;
-    const int frow = lane & 31, fk = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        half8 fa;
-        __builtin_memcpy(&fa, &a[ks], 16);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const half8 fb = *reinterpret_cast<const half8*>(s_b + lds_off<32>(wn * 64 + j * 32 + frow, ks * 2 + fk));
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[0][j], 0, 0, 0);
-        }
-    }
-    int pb[2], py[2], px[2];
-    bool pv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = wn * 64 + j * 32 + (lane & 31);
-        pb[j] = b;
-        py[j] = y0 + n / TW;
-        px[j] = x0 + n % TW;
-        pv[j] = py[j] < p.pw.OH && px[j] < p.pw.OW;
-    }
-    HP_STAMP();
-    __syncthreads(); // the main-loop LDS is dead: the slabs may overwrite it
-    conv_epilogue_staged<1, 2>(p.pw, acc, wm * 32, lane, lds + wave * stage_geom<1>::SLAB, pb, py, px, pv);
-    HP_STAMP();
-#undef HP_STAMP
-}
-
-bool stem_supported(int c0, int k, int stride, int c1, int dw_stride, int dw_dil)
-{
-    return c0 == 32 && k == 3 && stride == 2 && c1 > 32 && c1 <= 64 && c1 % 8 == 0 && dw_stride == 1 && dw_dil == 1;
-}
-
-hipError_t launch_stem(const stem_params& p, hipStream_t s)
-{
-    const int tiles_x = (p.pw.OW + 15) / 16, tiles_y = (p.pw.OH + 7) / 8;
-    HP_LAUNCH(stem_kernel, dim3(tiles_x * tiles_y * p.fc.B), dim3(256), 0, s, p, tiles_x, tiles_y);
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool_kernel(const pool_params p)

@@ -144,19 +144,6 @@ hipError_t launch_mlp_head(const head_params& p, hipStream_t s);
 // two heads on the same input, same K1 / geometry, in one launch (blockIdx.y = head)
 hipError_t launch_mlp_head_pair(const head_params& p0, const head_params& p1, hipStream_t s);
 
-// MobileNet stem (stem_kernel): first conv 3 -> 32 (3x3, stride 2) + depthwise 3x3 (relu / relu6) + pointwise 1x1
-// 32 -> <= 64.  fc: the first conv exactly as for launch_first_conv (fc.out unused).  pw: the pointwise conv as a
-// conv_params (bias padded to 64, activation, out, Cout, OH, OW) with pw.w in MFMA-fragment order for Cin = 32:
-// half index (((m / 32) * 2 + k / 16) * 64 + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8, rows padded to 64.
-struct stem_params {
-    first_conv_params fc;
-    const __half* dw_w;   // [9][32]
-    const float* dw_bias; // [32]
-    float dw_hi;          // depthwise activation = clamp(x, 0, dw_hi)
-    conv_params pw;
-};
-bool stem_supported(int c0, int k, int stride, int c1, int dw_stride, int dw_dil);
-hipError_t launch_stem(const stem_params& p, hipStream_t s);
 
 struct pool_params {
     tview in;

@@ -64,7 +64,6 @@ struct step {
     hp::dw_params dp{};
     hp::pool_params pp{};
     hp::sep_params sp{}; // op == OP_SEPCONV: depthwise layer `layer` fused with the pointwise layer `layer + 1`
-    hp::stem_params stp{}; // op == OP_STEM: layers 0, 1, 2 (first conv + depthwise + pointwise) as one launch
     hp::head_params hp_{}; // op == OP_MLPHEAD: 1x1 conv `layer` (-> 512, relu) fused with the 1x1 conv `layer + 1`
     hp::head_params hp2_{}; // ... and, when `paired`, the sibling head on the same input (layers `layer + 2`, `layer + 3`)
     bool paired = false;
@@ -72,7 +71,6 @@ struct step {
 };
 constexpr int OP_SEPCONV = 100; // schedule-only op codes (not part of the hp_layer ABI)
 constexpr int OP_MLPHEAD = 101;
-constexpr int OP_STEM = 102;
 
 void same_pad(int in, int k, int stride, int dil, int& out, int& pad_before)
 {
@@ -214,38 +212,11 @@ int hp_engine::build(const hp_engine_desc* d)
                 continue;
             const int cout_pad = round_up(Bn.cout, 128);
             const int variant = hp::sepconv_variant_for(A.cin, cout_pad, A.stride, A.dil, Bn.cout);
-            const bool stem_wanted = i == 1 && getenv("HP_FUSE_STEM") && atoi(getenv("HP_FUSE_STEM")); // the opt-in stem kernel takes layers 0..2
-            if (!variant || (Bn.cout <= 64 && variant != 7) || (variant == 7 && (getenv("HP_NO_FUSE_C32") || stem_wanted)))
+            if (!variant || (Bn.cout <= 64 && variant != 7) || (variant == 7 && getenv("HP_NO_FUSE_C32")))
                 continue; // (<= 64 output channels idle half of the general fused kernels' wavefronts - slower than two launches - except in the dedicated 32-channel form)
             fuse_with_next[i] = 1;
             tensors[A.out]->elided = true;
         }
-    }
-    // ---- MobileNet stem: layers 0..2 = first conv (3 -> 32, 3x3 s2) + depthwise 3x3 + pointwise 1x1 (-> <= 64)
-    bool fuse_stem = false;
-    // (opt-in, HP_FUSE_STEM=1: measured 74 us against 67 us for the three separate launches at 368x432x8 - the fused
-    // kernel's depthwise stage and epilogue still need work)
-    if (!getenv("HP_NO_FUSE") && getenv("HP_FUSE_STEM") && atoi(getenv("HP_FUSE_STEM")) && layers.size() >= 3) {
-        const hp_layer &A = layers[0], &D = layers[1], &Pw = layers[2];
-        bool ok = A.op == HP_OP_CONV && A.in == 0 && A.kh == 3 && A.kw == 3 && A.dil == 1 && A.res < 0 && A.act != HP_ACT_PRELU && A.out_coff == 0
-            && D.op == HP_OP_DWCONV && D.in == A.out && D.in_coff == 0 && D.kh == 3 && D.kw == 3 && D.cin == A.cout && D.out_coff == 0
-            && (D.act == HP_ACT_RELU || D.act == HP_ACT_RELU6)
-            && Pw.op == HP_OP_CONV && Pw.kh == 1 && Pw.kw == 1 && Pw.stride == 1 && Pw.in == D.out && Pw.in_coff == 0 && Pw.cin == D.cout
-            && Pw.res < 0 && Pw.out != D.out && Pw.out != A.out && Pw.out_coff % 8 == 0 && Pw.act != HP_ACT_SIGMOID && Pw.act != HP_ACT_SOFTPLUS
-            && hp::stem_supported(A.cout, A.kh, A.stride, Pw.cout, D.stride, D.dil)
-            && tensors[A.out]->C == A.cout && tensors[D.out]->C == D.cout && !fuse_with_next[1];
-        for (size_t j = 0; ok && j < layers.size(); ++j) {
-            const hp_layer& Lj = layers[j];
-            if (j != 1 && (Lj.in == A.out || Lj.res == A.out || (j != 0 && Lj.out == A.out)))
-                ok = false;
-            if (j != 2 && (Lj.in == D.out || Lj.res == D.out || (j != 1 && Lj.out == D.out)))
-                ok = false;
-        }
-        for (int o = 0; ok && o < d->n_outputs; ++o)
-            if (d->outputs[o].tensor == A.out || d->outputs[o].tensor == D.out || d->outputs[o].tensor == Pw.out)
-                ok = false;
-        if (ok)
-            fuse_stem = true, tensors[A.out]->elided = true, tensors[D.out]->elided = true;
     }
     // ---- two-layer heads: 1x1 K1 -> 512 (relu) whose only consumer is the next layer, a 1x1 512 -> <= 64 channels
     std::vector<char> head_with_next(layers.size(), 0);
@@ -353,80 +324,6 @@ int hp_engine::build(const hp_engine_desc* d)
         step st;
         st.layer = (int)i, st.op = L.op;
         const double opix = (double)g.OH * g.OW;
-        if (i == 0 && fuse_stem) {
-            const hp_layer &D = layers[1], &Pn = layers[2];
-            tensor_info& tp = *tensors[Pn.out];
-            HP_REQUIRE(L.cin == 3 && L.in_coff == 0, HP_ERR_INVALID, "layer 0: the network input has 3 channels");
-            const float* w0 = blob(L.w_off, (size_t)L.cout * 27, "weights", 0);
-            const float* wd = blob(D.w_off, (size_t)D.cin * 9, "weights", 1);
-            const float* wp = blob(Pn.w_off, (size_t)Pn.cout * D.cout, "weights", 2);
-            if (!w0 || !wd || !wp)
-                return HP_ERR_INVALID;
-            auto get_bias = [&](const hp_layer& Lx, size_t li, size_t padded, std::vector<float>& out) -> int {
-                out.assign(padded, 0.f);
-                if (Lx.b_off >= 0) {
-                    const float* bb = blob(Lx.b_off, Lx.cout, "bias", li);
-                    if (!bb)
-                        return HP_ERR_INVALID;
-                    std::copy(bb, bb + Lx.cout, out.begin());
-                }
-                return HP_OK;
-            };
-            std::vector<float> b0, bd, bp, alpha;
-            HP_TRY(get_bias(L, 0, 32, b0));
-            HP_TRY(get_bias(D, 1, 32, bd));
-            HP_TRY(get_bias(Pn, 2, 64, bp));
-            std::vector<__half> dpacked((size_t)9 * 32), ppacked((size_t)64 * 32, __float2half(0.f));
-            for (int c = 0; c < 32; ++c)
-                for (int t = 0; t < 9; ++t)
-                    dpacked[(size_t)t * 32 + c] = __float2half(wd[(size_t)c * 9 + t]);
-            for (int m = 0; m < Pn.cout; ++m)
-                for (int k = 0; k < 32; ++k)
-                    ppacked[((((size_t)(m / 32) * 2 + k / 16) * 64) + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8] = __float2half(wp[(size_t)m * 32 + k]);
-            st.op = OP_STEM;
-            auto& sp = st.stp;
-            void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr, *d4 = nullptr, *d5 = nullptr;
-            HP_TRY(upload(w0, (size_t)L.cout * 27 * sizeof(float), &d0));
-            HP_TRY(upload(b0.data(), b0.size() * sizeof(float), &d1));
-            HP_TRY(upload(dpacked.data(), dpacked.size() * sizeof(__half), &d2));
-            HP_TRY(upload(bd.data(), bd.size() * sizeof(float), &d3));
-            HP_TRY(upload(ppacked.data(), ppacked.size() * sizeof(__half), &d4));
-            HP_TRY(upload(bp.data(), bp.size() * sizeof(float), &d5));
-            auto& fcp = sp.fc;
-            fcp.factor = factor, fcp.flip_rb = flip_rb;
-            for (int c = 0; c < 3; ++c)
-                fcp.mean[c] = mean[c], fcp.inv_std[c] = inv_std[c];
-            fcp.H = ti.H, fcp.W = ti.W, fcp.OH = g.OH, fcp.OW = g.OW, fcp.Cout = L.cout, fcp.KH = 3, fcp.KW = 3, fcp.stride = L.stride;
-            fcp.pad_t = g.pt, fcp.pad_l = g.pl, fcp.act = L.act, fcp.act_param = L.act_param;
-            fcp.w = (const float*)d0, fcp.bias = (const float*)d1;
-            sp.dw_w = (const __half*)d2, sp.dw_bias = (const float*)d3;
-            sp.dw_hi = D.act == HP_ACT_RELU6 ? 6.f : __builtin_huge_valf();
-            auto& q = sp.pw;
-            q.w = (const __half*)d4, q.w_layout = 1, q.bias = (const float*)d5, q.alpha = nullptr;
-            if (Pn.act == HP_ACT_PRELU) {
-                alpha.assign(64, 0.f);
-                const float* a = blob(Pn.alpha_off, Pn.cout, "prelu slopes", 2);
-                if (!a)
-                    return HP_ERR_INVALID;
-                std::copy(a, a + Pn.cout, alpha.begin());
-                void* da = nullptr;
-                HP_TRY(upload(alpha.data(), alpha.size() * sizeof(float), &da));
-                q.alpha = (const float*)da;
-            }
-            q.H = g.OH, q.W = g.OW, q.OH = g.OH, q.OW = g.OW, q.Cin = 32, q.Cout = Pn.cout, q.Cout_pad = 64;
-            q.KH = q.KW = 1, q.stride = 1, q.dil = 1, q.pad_t = q.pad_l = 0;
-            q.act = Pn.act, q.act_param = Pn.act_param;
-            q.res = hp::tview{ nullptr, 0, 0, 0, 0 }, q.res_before_act = 0;
-            q.out = tp.view(Pn.out_coff);
-            q.out_f32 = nullptr, q.dbg = nullptr;
-            HP_REQUIRE(hp::set_act(q), HP_ERR_INVALID, "layer 2: activation %d cannot be fused into a dense conv", Pn.act);
-            st.first = false;
-            st.flops = 2.0 * opix * L.cout * 27 + 2.0 * opix * 32 * 9 + 2.0 * opix * Pn.cout * 32;
-            st.bytes = (double)ti.H * ti.W * 3 + opix * Pn.cout * 2;
-            steps.push_back(st);
-            i += 2; // the depthwise and pointwise layers are part of this step
-            continue;
-        }
         if (L.op == HP_OP_CONV && L.in == 0) {
             HP_REQUIRE(L.cin == 3 && L.in_coff == 0, HP_ERR_INVALID, "layer %zu: the network input has 3 channels", i);
             HP_REQUIRE(L.dil == 1 && L.res < 0 && L.act != HP_ACT_PRELU, HP_ERR_INVALID, "layer %zu: unsupported first-layer options", i);
@@ -722,7 +619,7 @@ int hp_engine::build(const hp_engine_desc* d)
             steps.erase(steps.begin() + k + 1);
         }
     }
-    HP_REQUIRE(!steps.empty() && (steps[0].first || steps[0].op == OP_STEM), HP_ERR_INVALID, "engine: the first layer must be a CONV reading tensor 0");
+    HP_REQUIRE(!steps.empty() && steps[0].first, HP_ERR_INVALID, "engine: the first layer must be a CONV reading tensor 0");
 
     HP_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HP_HIP_TRY(hipEventCreate(&ev0));
@@ -732,29 +629,7 @@ int hp_engine::build(const hp_engine_desc* d)
 
 int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hipStream_t s)
 {
-    if (st.op == OP_STEM) {
-        st.stp.fc.in_u8 = u8, st.stp.fc.in_f32 = f32, st.stp.fc.B = n, st.stp.pw.B = n;
-        HP_HIP_TRY(hp::launch_stem(st.stp, s));
-        if (getenv("HP_STEM_DBG")) { // one-off block timeline (s_memtime deltas) of block 0
-            unsigned long long* dbg = nullptr;
-            HP_HIP_TRY(hipMalloc(&dbg, 64 * 8));
-            HP_HIP_TRY(hipMemset(dbg, 0, 64 * 8));
-            st.stp.pw.dbg = dbg;
-            HP_HIP_TRY(hp::launch_stem(st.stp, s));
-            HP_HIP_TRY(hipStreamSynchronize(s));
-            unsigned long long h[64];
-            HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-            fprintf(stderr, "stem timeline:");
-            for (int i = 1; i < 20 && h[i]; ++i)
-                fprintf(stderr, " %llu", h[i] - h[i - 1]);
-            fprintf(stderr, "  epilogue:");
-            for (int i = 41; i < 56 && h[i]; ++i)
-                fprintf(stderr, " %llu", h[i] - h[i - 1]);
-            fprintf(stderr, "\n");
-            st.stp.pw.dbg = nullptr;
-            (void)hipFree(dbg);
-        }
-    } else if (st.first) {
+    if (st.first) {
         st.fp.in_u8 = u8, st.fp.in_f32 = f32, st.fp.B = n;
         HP_HIP_TRY(hp::launch_first_conv(st.fp, s));
     } else if (st.op == HP_OP_CONV) {
@@ -1048,7 +923,6 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
             out[k].layer = st.layer, out[k].op = st.op;
             out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
-                : st.op == OP_STEM           ? 7000000
                 : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
                                                     : 0;
             out[k].ms = ms / iters;
@@ -1105,7 +979,6 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
             out[k].layer = st.layer, out[k].op = st.op;
             out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
-                : st.op == OP_STEM           ? 7000000
                 : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
                                                     : 0;
             out[k].ms = (float)(acc[k] / iters);

@@ -383,38 +383,6 @@ def test_fused_two_layer_head(hp, monkeypatch, k1, cout2, h, w):
             _close(a1, a2)
 
 
-@pytest.mark.parametrize("c1,h,w,f32", [(64, 61, 77, False), (48, 40, 56, False), (64, 36, 44, True)])
-def test_fused_mobilenet_stem(hp, monkeypatch, c1, h, w, f32):
-    """first conv (3 -> 32, 3x3 stride 2, pre-processing fused) + depthwise 3x3 + pointwise 1x1 as one launch
-    (stem_kernel), odd and even input sizes (SAME pads 1/1 vs 0/1): vs the oracle and vs the three-launch schedule."""
-    net = Net(c1)
-    a = net.conv(0, 3, 32, 3, 2, act=E.ACT_RELU)
-    d = net.conv(a, 32, 32, 3, 1, op=E.OP_DWCONV, act=E.ACT_RELU6)
-    y = net.conv(d, 32, c1, 1, act=E.ACT_RELU)
-    z = net.conv(y, c1, 32, 3, act=E.ACT_NONE)
-    outs = [Out("z", z, 0, 32)]
-    if f32:
-        fr = np.random.default_rng(c1).normal(size=(3, 3, h, w)).astype(np.float32)
-        kw = {}
-    else:
-        fr = _frames(3, h, w, seed=c1)
-        kw = dict(flip_rgb=True, mean=(0.4, 0.45, 0.5), inv_std=(2., 3., 4.))
-    monkeypatch.setenv("HP_FUSE_STEM", "1")  # opt-in in round 1 (not yet faster than the three launches)
-    eng, got, ref = _run_both(net, outs, fr, h, w, f32=f32, **kw)
-    _check(got, ref, 3)
-    mid = eng.debug_tensor(y, 3)  # before profile(), which re-runs the net on its own staging buffer
-    assert [p["tile"] for p in eng.profile(3, 1)][0] == 7000000
-    monkeypatch.setenv("HP_FUSE_STEM", "0")
-    eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 3, **kw)
-    assert eng2.profile(3, 1)[0]["tile"] == 0
-    got2 = eng2.inference_f32(fr) if f32 else eng2.inference(fr)
-    # the fused first conv sums its 27 taps as an fp32 MFMA chain, the stand-alone kernel with VALU FMAs: same
-    # mathematics, roundings may differ in the last fp32 bit before the fp16 store
-    _close(mid, eng2.debug_tensor(y, 3))
-    for b in range(3):
-        _close(got[b][0][1], got2[b][0][1])
-
-
 def test_engine_save_load_roundtrip(hp, tmp_path):
     """tensorrt::save / tensorrt_serialized (src/tensorrt.cpp:225-252, :463-471): a saved engine reloads to the same bits."""
     m = E.Model("lw_openpose_vggtiny", 128, 96)
