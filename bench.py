@@ -287,7 +287,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16 (fp32 accumulate; parser fp32)", "data": "synthetic",
         "config": {"workload": "configs[1]: Lightweight-OpenPose (MobilenetDilated) + PAF parser, batch 8 @ 368x432 per GPU, "
-                               "frames u8 HWC resident in HBM, humans copied back to host",
+                               "frames u8 HWC resident in HBM, humans written to pinned host memory",
                    "global_batch": BATCH * world, "parallelism": f"frame-sharded x{world}, no steady-state collective",
                    "pipes_per_gpu": len(pipes), "parser_input": "injected synthetic heat-maps (1-16 people/frame); full conv stack also runs",
                    "humans_per_step": n_humans / max(1, args.steps),
