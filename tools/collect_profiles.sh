@@ -40,4 +40,37 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pass
                    "MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 16-B/lane streams at 1/2)", "kernels": res}, open(out, "w"), indent=1)
 print("pmc kernels:", len(res))
 PY
+# third counter pass: where the wave cycles go (SQ) and how busy the matrix pipe is
+rm -rf /tmp/prof_sq
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_sq -- $cmd > /dev/null 2>&1
+python - "$out/${tag}_pmc_sq.json" $(find /tmp/prof_sq -name "*counter_collection.csv" | head -1) "$out/${tag}_kernel_stats.csv" <<'PY'
+import csv, json, sys
+out, path, stats = sys.argv[1:4]
+dur = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(stats))}
+agg = {}
+for r in csv.DictReader(open(path)):
+    d = agg.setdefault(r["Kernel_Name"], {})
+    c = r["Counter_Name"]
+    d[c] = d.get(c, 0.0) + float(r["Counter_Value"])
+    d["n_" + c] = d.get("n_" + c, 0) + 1
+res = {}
+for k, d in agg.items():
+    e = {c: d[c] / d["n_" + c] for c in d if not c.startswith("n_")}
+    e["launches"] = max(d[c] for c in d if c.startswith("n_"))
+    # SQ_VALU_MFMA_BUSY_CYCLES = matrix-pipe busy cycles summed over the 1024 SIMDs (32 per 32x32x16 f16 MFMA); the duration is the
+    # kernel's average in the un-instrumented kernel-trace pass (counter passes serialise and slow the kernels), at the 2.4 GHz peak clock
+    if k in dur:
+        e["avg_duration_us"] = dur[k] / 1e3
+        e["mfma_busy_frac"] = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * dur[k] * 2.4)
+    if e.get("SQ_WAVE_CYCLES"):
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if c in e:
+                e[c + "_share_of_wave_cycles"] = e[c] / e["SQ_WAVE_CYCLES"]
+    res[k] = e
+json.dump({"note": "rocprofv3 --pmc (one pass, SQ + GRBM) over `python bench.py --steps 12 --warmup 3 --pipes 1 ...`; per-launch averages; "
+                   "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * avg_duration * 2.4 GHz), duration from the kernel-trace pass (derived here: ROCm 7.2 has no gfx950 derived-metric section); "
+                   "SQ_WAIT_ANY = wave parked (s_waitcnt / barrier), SQ_WAIT_INST_ANY = issue stall, SQ_ACTIVE_INST_ANY = issuing (quad-cycle units, MI355X_MICROARCH.md)",
+           "kernels": res}, open(out, "w"), indent=1)
+print("sq kernels:", len(res))
+PY
 head -12 $out/${tag}_kernel_stats.csv | cut -c1-150
