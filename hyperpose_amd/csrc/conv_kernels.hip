@@ -2522,6 +2522,52 @@ hipError_t launch_maxpool(const pool_params& p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Integer up-scaling (HP_OP_UPSAMPLE): one thread = one output pixel x 8 channels.  Bilinear = half-pixel centres, source
+// coordinate clamped at 0, the far neighbour clamped to the last row / column (tf.image.resize, ONNX Resize half_pixel,
+// torch align_corners = False all agree for integer scales); interpolation in fp32, one rounding to fp16.
+__global__ __launch_bounds__(256) void upsample_kernel(const pool_params p)
+{
+    const int CG = p.C / 8, sc = p.stride;
+    const float inv = 1.f / (float)sc;
+    const long total = (long)p.B * p.OH * p.OW * CG;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        const long n = i / CG;
+        const int ox = (int)(n % p.OW);
+        const long t = n / p.OW;
+        const int oy = (int)(t % p.OH), b = (int)(t / p.OH);
+        half8 h;
+        if (p.k == 0) {
+            h = *reinterpret_cast<const half8*>(p.in.p + tv_off(p.in, b, oy / sc, ox / sc) + cg * 8);
+        } else {
+            const float sy = fmaxf(((float)oy + 0.5f) * inv - 0.5f, 0.f), sx = fmaxf(((float)ox + 0.5f) * inv - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = min(y0 + 1, p.H - 1), x1 = min(x0 + 1, p.W - 1);
+            const float fy = sy - (float)y0, fx = sx - (float)x0;
+            const half8 a = *reinterpret_cast<const half8*>(p.in.p + tv_off(p.in, b, y0, x0) + cg * 8);
+            const half8 bq = *reinterpret_cast<const half8*>(p.in.p + tv_off(p.in, b, y0, x1) + cg * 8);
+            const half8 c = *reinterpret_cast<const half8*>(p.in.p + tv_off(p.in, b, y1, x0) + cg * 8);
+            const half8 d = *reinterpret_cast<const half8*>(p.in.p + tv_off(p.in, b, y1, x1) + cg * 8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float top = (float)a[r] * (1.f - fx) + (float)bq[r] * fx;
+                const float bot = (float)c[r] * (1.f - fx) + (float)d[r] * fx;
+                h[r] = (_Float16)(top * (1.f - fy) + bot * fy);
+            }
+        }
+        *reinterpret_cast<half8*>(p.out.p + tv_off(p.out, b, oy, ox) + cg * 8) = h;
+    }
+}
+
+hipError_t launch_upsample(const pool_params& p, hipStream_t s)
+{
+    const long total = (long)p.B * p.OH * p.OW * (p.C / 8);
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 16);
+    HP_LAUNCH(upsample_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void output_transform_kernel(tview in, int B, int H, int W, out_xform x, float* __restrict__ out)
 {
     const int sc = x.shuffle, CO = x.C / (sc * sc), OH = x.out_h, OW = x.out_w;

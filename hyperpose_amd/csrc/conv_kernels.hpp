@@ -152,6 +152,8 @@ struct pool_params {
     tview out;
 };
 hipError_t launch_maxpool(const pool_params& p, hipStream_t s);
+// HP_OP_UPSAMPLE with the same parameter block: stride = integer scale, k = 0 nearest / 1 bilinear (half-pixel centres)
+hipError_t launch_upsample(const pool_params& p, hipStream_t s);
 
 // fp16 NHWC view -> fp32 NCHW network output (for outputs not produced by a conv epilogue): optional pixel shuffle x2,
 // crop, element-wise / per-component sigmoid / softplus, and the PoseProposal restore_coor affine map.

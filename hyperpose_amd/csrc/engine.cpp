@@ -152,12 +152,18 @@ int hp_engine::build(const hp_engine_desc* d)
         const hp_layer& L = layers[i];
         HP_REQUIRE(L.in >= 0 && L.in <= max_id && tensors[L.in]->defined, HP_ERR_INVALID, "layer %zu reads undefined tensor %d", i, L.in);
         HP_REQUIRE(L.out > 0, HP_ERR_INVALID, "layer %zu: bad output tensor %d", i, L.out);
-        HP_REQUIRE(L.op == HP_OP_CONV || L.op == HP_OP_DWCONV || L.op == HP_OP_MAXPOOL, HP_ERR_INVALID, "layer %zu: unknown op %d", i, L.op);
-        HP_REQUIRE(L.stride >= 1 && L.kh >= 1 && L.kw >= 1 && L.dil >= 1, HP_ERR_INVALID, "layer %zu: bad geometry", i);
+        HP_REQUIRE(L.op == HP_OP_CONV || L.op == HP_OP_DWCONV || L.op == HP_OP_MAXPOOL || L.op == HP_OP_UPSAMPLE, HP_ERR_INVALID, "layer %zu: unknown op %d", i, L.op);
+        if (L.op == HP_OP_UPSAMPLE)
+            HP_REQUIRE(L.stride >= 1 && L.stride <= 16 && (L.kh == 0 || L.kh == 1) && L.in != 0 && L.res < 0 && L.act == HP_ACT_NONE, HP_ERR_INVALID,
+                "layer %zu: up-sampling takes an integer scale 1..16 in `stride`, kh = 0 (nearest) or 1 (bilinear), a feature-map input and no activation / residual", i);
+        else
+            HP_REQUIRE(L.stride >= 1 && L.kh >= 1 && L.kw >= 1 && L.dil >= 1, HP_ERR_INVALID, "layer %zu: bad geometry", i);
         const tensor_info& ti = *tensors[L.in];
         HP_REQUIRE(L.in_coff >= 0 && L.in_coff + L.cin <= ti.C, HP_ERR_INVALID, "layer %zu reads channels [%d,%d) of a %d-channel tensor", i, L.in_coff, L.in_coff + L.cin, ti.C);
         geo g;
-        if (L.pad_explicit) {
+        if (L.op == HP_OP_UPSAMPLE) {
+            g.OH = ti.H * L.stride, g.OW = ti.W * L.stride, g.pt = g.pl = 0;
+        } else if (L.pad_explicit) {
             HP_REQUIRE(L.pad[0] >= 0 && L.pad[1] >= 0 && L.pad[2] >= 0 && L.pad[3] >= 0, HP_ERR_INVALID, "layer %zu: negative padding", i);
             g.pt = L.pad[0], g.pl = L.pad[1];
             g.OH = (ti.H + L.pad[0] + L.pad[2] - ((L.kh - 1) * L.dil + 1)) / L.stride + 1;
@@ -179,7 +185,7 @@ int hp_engine::build(const hp_engine_desc* d)
         }
         if (L.op != HP_OP_CONV)
             HP_REQUIRE(L.cin == L.cout, HP_ERR_INVALID, "layer %zu: depthwise/pool need cin == cout", i);
-        if (L.op != HP_OP_MAXPOOL && L.in != 0) {
+        if (L.op != HP_OP_MAXPOOL && L.op != HP_OP_UPSAMPLE && L.in != 0) {
             // halo this consumer needs on its input: SAME padding before / after in both dimensions
             const int pb_y = std::max((g.OH - 1) * L.stride + (L.kh - 1) * L.dil + 1 - ti.H - g.pt, 0);
             const int pb_x = std::max((g.OW - 1) * L.stride + (L.kw - 1) * L.dil + 1 - ti.W - g.pl, 0);
@@ -593,6 +599,14 @@ int hp_engine::build(const hp_engine_desc* d)
             p.out = to.view(L.out_coff);
             st.flops = 2.0 * opix * L.cin * 9;
             st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cin * 2;
+        } else if (L.op == HP_OP_UPSAMPLE) {
+            HP_REQUIRE(L.cin % 8 == 0 && L.in_coff % 8 == 0 && L.out_coff % 8 == 0, HP_ERR_INVALID, "layer %zu: up-sampling needs 8-aligned channels", i);
+            auto& p = st.pp;
+            p.in = ti.view(L.in_coff);
+            p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.C = L.cin, p.k = L.kh, p.stride = L.stride, p.pad_t = p.pad_l = 0;
+            p.out = to.view(L.out_coff);
+            st.flops = 0;
+            st.bytes = (double)ti.H * ti.W * L.cin * 2 + opix * L.cin * 2;
         } else { // max-pool
             HP_REQUIRE(L.cin % 8 == 0 && L.in_coff % 8 == 0 && L.out_coff % 8 == 0 && L.kh == L.kw, HP_ERR_INVALID, "layer %zu: bad pool", i);
             auto& p = st.pp;
@@ -666,6 +680,9 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     } else if (st.op == HP_OP_DWCONV) {
         st.dp.B = n;
         HP_HIP_TRY(hp::launch_dwconv3x3(st.dp, s));
+    } else if (st.op == HP_OP_UPSAMPLE) {
+        st.pp.B = n;
+        HP_HIP_TRY(hp::launch_upsample(st.pp, s));
     } else {
         st.pp.B = n;
         HP_HIP_TRY(hp::launch_maxpool(st.pp, s));

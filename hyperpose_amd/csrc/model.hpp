@@ -11,7 +11,9 @@
 // output size of a layer on an H x W input (TF "SAME" or the explicit ONNX-style pads; same rule as engine.cpp pass 1)
 inline void hp_layer_out_size(const hp_layer& L, int H, int W, int& OH, int& OW)
 {
-    if (L.pad_explicit) {
+    if (L.op == HP_OP_UPSAMPLE) {
+        OH = H * L.stride, OW = W * L.stride;
+    } else if (L.pad_explicit) {
         OH = (H + L.pad[0] + L.pad[2] - ((L.kh - 1) * L.dil + 1)) / L.stride + 1;
         OW = (W + L.pad[1] + L.pad[3] - ((L.kw - 1) * L.dil + 1)) / L.stride + 1;
     } else {
@@ -50,7 +52,7 @@ struct hp_model {
             L.w_off = n_weights;
             n_weights += (int64_t)cin * k * k;
         }
-        if (bias && op != HP_OP_MAXPOOL) {
+        if (bias && op != HP_OP_MAXPOOL && op != HP_OP_UPSAMPLE) {
             L.b_off = n_weights;
             n_weights += cout;
         }

@@ -347,7 +347,7 @@ int hp_model_init_weights(const hp_model* m, uint64_t seed, float* blob, size_t 
     HP_REQUIRE(n >= (size_t)m->n_weights, HP_ERR_INVALID, "hp_model_init_weights: blob too small (%zu < %lld)", n, (long long)m->n_weights);
     for (size_t li = 0; li < m->layers.size(); ++li) {
         const hp_layer& L = m->layers[li];
-        if (L.op == HP_OP_MAXPOOL)
+        if (L.op == HP_OP_MAXPOOL || L.op == HP_OP_UPSAMPLE)
             continue;
         const int fan_in = L.op == HP_OP_CONV ? L.kh * L.kw * L.cin : L.kh * L.kw;
         const size_t nw = L.op == HP_OP_CONV ? (size_t)L.cout * L.kh * L.kw * L.cin : (size_t)L.cin * L.kh * L.kw;

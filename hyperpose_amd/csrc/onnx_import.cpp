@@ -11,6 +11,7 @@
 //   Sigmoid, Softplus ..................... output post-ops (only on graph outputs, as the engine evaluates them in fp32 there)
 //   Add of two maps ....................... the later convolution's residual input
 //   Concat(axis 1) ........................ producers retargeted to write at a channel offset of one tensor (no copy)
+//   Resize / Upsample by an integer factor (nearest, or linear with half-pixel centres) ... HP_OP_UPSAMPLE
 //   MaxPool, Pad (merged into its consumer), Identity / Dropout, scalar or per-channel arithmetic on the input image
 //   (folded into the engine's mean / inv_std), Transpose NHWC->NCHW directly on the input.
 // Whatever does not fit a fused form falls back to an identity 1x1 convolution carrying the activation / residual /
@@ -695,7 +696,7 @@ struct lowering {
             return false;
         const hp_layer& L = m.layers[v.producer];
         auto u = uses.find(name);
-        return L.op != HP_OP_MAXPOOL && L.act == HP_ACT_NONE && L.res < 0 && u != uses.end() && u->second == 1;
+        return L.op != HP_OP_MAXPOOL && L.op != HP_OP_UPSAMPLE && L.act == HP_ACT_NONE && L.res < 0 && u != uses.end() && u->second == 1;
     }
 
     // identity 1x1 convolution reading v: the general carrier for an activation, a residual add or a copy
@@ -831,6 +832,62 @@ struct lowering {
         L.out = m.new_tensor();
         val y;
         y.kind = val::MAP, y.tensor = L.out, y.C = x.C, y.H = OH, y.W = OW;
+        y.producer = emit(L);
+        vals[n.out.at(0)] = y;
+    }
+
+    // Resize (opset >= 10) / Upsample (7-9) by an integer factor, equal in H and W: nearest (asymmetric + floor, what PyTorch and
+    // tf2onnx emit) or linear with half-pixel centres
+    void resize(const o_node& n)
+    {
+        val x = get(n, 0);
+        need_map(n, x);
+        const o_attr* ma = n.attr("mode");
+        const std::string mode = ma ? ma->s : "nearest";
+        const o_attr* ca = n.attr("coordinate_transformation_mode");
+        const std::string ctm = ca ? ca->s : (n.op == "Upsample" ? "asymmetric" : "half_pixel");
+        std::vector<float> scales;
+        std::vector<int64_t> sizes;
+        if (n.op == "Upsample") {
+            if (const o_attr* a = n.attr("scales"))
+                scales = a->floats;
+            else if (has_in(n, 1) && get(n, 1).kind == val::CONST)
+                scales = get(n, 1).c->f;
+        } else {
+            const size_t si = n.in.size() >= 3 ? 2 : 1; // opset 10: (X, scales); opset 11+: (X, roi, scales, sizes)
+            if (has_in(n, si) && get(n, si).kind == val::CONST && get(n, si).c->count() > 0)
+                scales = get(n, si).c->f;
+            else if (has_in(n, 3) && get(n, 3).kind == val::CONST)
+                sizes = get(n, 3).c->i;
+        }
+        int sc = 0;
+        if (scales.size() == 4 && scales[0] == 1.f && scales[1] == 1.f && scales[2] == scales[3] && scales[2] == std::floor(scales[2]))
+            sc = (int)scales[2];
+        else if (sizes.size() == 4 && sizes[2] % x.H == 0 && sizes[3] % x.W == 0 && sizes[2] / x.H == sizes[3] / x.W && sizes[1] == x.C)
+            sc = (int)(sizes[2] / x.H);
+        if (sc < 1 || sc > 16)
+            fail(&n, "only constant integer scales 1..16, equal in H and W, are supported");
+        int kind;
+        if (mode == "nearest") {
+            if (ctm != "asymmetric")
+                fail(&n, "nearest with coordinate_transformation_mode '" + ctm + "'");
+            const o_attr* nm = n.attr("nearest_mode");
+            if (nm && nm->s != "floor")
+                fail(&n, "nearest_mode '" + nm->s + "'");
+            kind = 0;
+        } else if (mode == "linear") {
+            if (ctm != "half_pixel" && ctm != "pytorch_half_pixel")
+                fail(&n, "linear with coordinate_transformation_mode '" + ctm + "'");
+            kind = 1;
+        } else
+            fail(&n, "mode '" + mode + "'");
+        hp_layer L;
+        memset(&L, 0, sizeof(L));
+        L.op = HP_OP_UPSAMPLE, L.in = x.tensor, L.in_coff = x.coff, L.res = -1, L.cin = L.cout = x.C;
+        L.kh = kind, L.kw = 1, L.stride = sc, L.dil = 1, L.w_off = L.b_off = L.alpha_off = -1;
+        L.out = m.new_tensor();
+        val y;
+        y.kind = val::MAP, y.tensor = L.out, y.C = x.C, y.H = x.H * sc, y.W = x.W * sc;
         y.producer = emit(L);
         vals[n.out.at(0)] = y;
     }
@@ -1215,6 +1272,8 @@ struct lowering {
                 conv(n);
             else if (op == "MaxPool")
                 maxpool(n);
+            else if (op == "Resize" || op == "Upsample")
+                resize(n);
             else if (op == "BatchNormalization")
                 batchnorm(n);
             else if (op == "Relu")

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import as_ptr, check, lib
 
-OP_CONV, OP_DWCONV, OP_MAXPOOL = 1, 2, 3
+OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE = 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY, ACT_PRELU, ACT_SIGMOID, ACT_SOFTPLUS = range(7)
 
 

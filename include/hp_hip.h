@@ -164,7 +164,10 @@ int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* 
  * built-in topology builders (hp_model_*) that restate hyperpose/Model/<arch>.py, and by hp_model_from_onnx
  * (SURVEY.md 8f-1).  Activations live in HBM as NHWC fp16 (fp32 accumulate on MFMA); network outputs are
  * fp32 NCHW, the layout of feature_map_t. */
-enum { HP_OP_CONV = 1, HP_OP_DWCONV = 2, HP_OP_MAXPOOL = 3 };
+enum { HP_OP_CONV = 1, HP_OP_DWCONV = 2, HP_OP_MAXPOOL = 3,
+       HP_OP_UPSAMPLE = 4 }; /* integer up-scaling by `stride` (UpSampling2d of the MobilenetSmall backbone, hyperpose/Model/backbones.py:325,339; ONNX
+                              * Resize / Upsample): kh = 0 nearest (source = floor(dst / scale)), kh = 1 bilinear with half-pixel centres
+                              * (tf.image.resize / align_corners = False); cin == cout, no weights, no activation */
 enum { HP_ACT_NONE = 0, HP_ACT_RELU = 1, HP_ACT_RELU6 = 2, HP_ACT_LEAKY = 3, HP_ACT_PRELU = 4, HP_ACT_SIGMOID = 5, HP_ACT_SOFTPLUS = 6 };
 
 typedef struct hp_layer {

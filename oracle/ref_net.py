@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from . import loader
 
-OP_CONV, OP_DWCONV, OP_MAXPOOL = 1, 2, 3
+OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE = 1, 2, 3, 4
 
 
 def _same_pad(size, k, s, d):
@@ -60,7 +60,12 @@ def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, fram
     tensors = {0: x0}
     for L in layers:
         x = tensors[L.in_][:, L.in_coff:L.in_coff + L.cin]
-        if getattr(L, "pad_explicit", 0):
+        if L.op == OP_UPSAMPLE:  # integer scale in `stride`; kh = 0 nearest, 1 bilinear with half-pixel centres
+            y = F.interpolate(x, scale_factor=L.stride, mode="nearest") if L.kh == 0 else \
+                F.interpolate(x, scale_factor=L.stride, mode="bilinear", align_corners=False)
+            oh, ow = y.shape[2], y.shape[3]
+            pt = pl = pb = pr = 0
+        elif getattr(L, "pad_explicit", 0):
             pt, pl, pb, pr = (int(v) for v in L.pad)
             oh = (x.shape[2] + pt + pb - ((L.kh - 1) * L.dil + 1)) // L.stride + 1
             ow = (x.shape[3] + pl + pr - ((L.kw - 1) * L.dil + 1)) // L.stride + 1
@@ -68,7 +73,9 @@ def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, fram
             oh, pt, pb = _same_pad(x.shape[2], L.kh, L.stride, L.dil)
             ow, pl, pr = _same_pad(x.shape[3], L.kw, L.stride, L.dil)
         first = (L.in_ == 0)
-        if L.op == OP_MAXPOOL:
+        if L.op == OP_UPSAMPLE:
+            pass
+        elif L.op == OP_MAXPOOL:
             xp = F.pad(x, (pl, pr, pt, pb), value=float("-inf"))
             y = F.max_pool2d(xp, L.kh, L.stride)
         else:

@@ -128,6 +128,31 @@ class VggStages(nn.Module):
         return b, c
 
 
+class SmallUpsample(nn.Module):
+    """MobilenetSmall-style feature pyramid (hyperpose/Model/backbones.py:301-341): concat(maxpool(early), middle, upsample(late)),
+    the late map up-sampled x2 bilinearly (TensorLayer UpSampling2d) in one head and by nearest neighbour in the other."""
+
+    def __init__(self):
+        super().__init__()
+        self.c0 = conv_bn(3, 16, 3, 2)
+        self.c1 = conv_bn(16, 16, 3, 1)
+        self.c2 = conv_bn(16, 32, 3, 2)
+        self.c3 = conv_bn(32, 64, 3, 2)
+        self.pool = nn.MaxPool2d(2, 2)
+        self.up_lin = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False)
+        self.up_nn = nn.Upsample(scale_factor=2, mode="nearest")
+        self.head_a = nn.Conv2d(16 + 32 + 64, 8, 1)
+        self.head_b = nn.Conv2d(64, 8, 3, 1, 1)
+
+    def forward(self, x):
+        e = self.c1(self.c0(x))
+        m = self.c2(e)
+        l = self.c3(m)
+        a = self.head_a(torch.cat([self.pool(e), m, self.up_lin(l)], 1))
+        b = self.head_b(self.up_nn(l))
+        return a, b
+
+
 class Unfolded(nn.Module):
     """Exported WITHOUT the exporter's constant folding: the normalisation constants and the PReLU slope reach the graph
     through Sub / Div / Unsqueeze nodes on initializers."""
@@ -171,6 +196,7 @@ CASES = [
     # (opset 10: Pad carries its amounts as an attribute; from opset 11 PyTorch computes them with a shape subgraph)
     ("vgg_stages", VggStages, (48, 64), ["stage2", "stage3"], dict(opset_version=10, dynamic_batch=True)),
     ("unfolded", Unfolded, (24, 32), ["out"], dict(opset_version=13, dynamic_batch=False, fold=False)),
+    ("small_upsample", SmallUpsample, (48, 64), ["pyramid", "fine"], dict(opset_version=11, dynamic_batch=False)),
 ]
 
 

@@ -170,6 +170,20 @@ def test_depthwise_pool_residual_concat_prelu(hp):
     _check(got, ref, 2)
 
 
+@pytest.mark.parametrize("kind,scale,c,h,w", [(0, 2, 32, 11, 9), (1, 2, 32, 11, 9), (1, 3, 16, 7, 10), (0, 4, 8, 5, 6), (1, 2, 72, 23, 27)])
+def test_upsample(hp, kind, scale, c, h, w):
+    """HP_OP_UPSAMPLE (nearest / bilinear with half-pixel centres) vs torch.nn.functional.interpolate, also into a channel offset."""
+    net = Net(seed=scale * 10 + kind)
+    t = net.conv(0, 3, c, 3, act=E.ACT_RELU)
+    cat = net.new_tensor()
+    up = E.make_layer(E.OP_UPSAMPLE, t, cat, c, c, 1, scale, 1, E.ACT_NONE, out_coff=8)
+    up.kh = kind
+    net.layers.append(up)
+    _, got, ref = _run_both(net, [Out("up", cat, 8, c)], _frames(2, h, w, seed=3), h, w)
+    assert got[0][0][1].shape == (c, h * scale, w * scale)
+    _check(got, ref, 2)
+
+
 def test_lw_openpose_small_end_to_end(hp):
     m = E.Model("lw_openpose_mobilenet", 96, 80)
     w = m.init_weights(3)

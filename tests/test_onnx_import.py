@@ -14,7 +14,7 @@ from oracle import ref_net
 import onnx_writer as W
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "onnx")
-CASES = ["mobile_paf", "resnet_ppn", "vgg_stages", "unfolded"]
+CASES = ["mobile_paf", "resnet_ppn", "vgg_stages", "unfolded", "small_upsample"]
 
 
 def _oracle(m, image):
@@ -59,6 +59,26 @@ def test_lowering_shapes_the_graph_for_the_engine():
     assert all(not L.pad_explicit for L in v.layers)
     np.testing.assert_allclose(v.mean, [0.485, 0.456, 0.406], rtol=1e-6)
     np.testing.assert_allclose(v.inv_std, [1 / 0.229, 1 / 0.224, 1 / 0.225], rtol=1e-6)
+
+
+def test_resize_lowering_and_its_limits():
+    """Resize by an integer factor becomes HP_OP_UPSAMPLE writing straight into the concatenation; other Resize forms are refused."""
+    m = E.Model.from_onnx(os.path.join(GOLD, "small_upsample.onnx"))
+    ups = [L for L in m.layers if L.op == E.OP_UPSAMPLE]
+    assert [(L.kh, L.stride, L.cin) for L in ups] == [(1, 2, 64), (0, 2, 64)]
+    cat = [L for L in m.layers if L.cin == 112][0]
+    assert sorted((L.out_coff, L.cout) for L in m.layers if L.out == cat.in_) == [(0, 16), (16, 32), (48, 64)]
+    assert not any(L.op == E.OP_CONV and L.kh == 1 and L.cin == L.cout == 64 for L in m.layers)  # no identity copies
+    x = W.value_info("x", ["N", 3, 8, 8])
+    conv = W.node("Conv", ["x", "w"], ["c"], [W.attr_ints("kernel_shape", [1, 1])])
+    w = W.tensor("w", [8, 3, 1, 1], [0.1] * 24)
+    for scales, kw, msg in (([1.0, 1.0, 1.5, 1.5], {}, "integer scales"), ([1.0, 1.0, 2.0, 3.0], {}, "integer scales"),
+                            ([1.0, 1.0, 2.0, 2.0], {"ctm": "align_corners"}, "align_corners")):
+        attrs = [W.attr_str("mode", "linear"), W.attr_str("coordinate_transformation_mode", kw.get("ctm", "half_pixel"))]
+        raw = W.model([conv, W.node("Resize", ["c", "", "s"], ["y"], attrs, name="rz")],
+                      [w, W.tensor("s", [4], scales)], [x], [W.value_info("y", ["N", 8, "h", "w"])])
+        with pytest.raises(HpError, match=msg):
+            E.Model.from_onnx(raw)
 
 
 def test_bytes_and_input_size_rules():

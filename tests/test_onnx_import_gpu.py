@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "onnx")
 
 
-@pytest.mark.parametrize("name", ["mobile_paf", "resnet_ppn", "vgg_stages", "unfolded"])
+@pytest.mark.parametrize("name", ["mobile_paf", "resnet_ppn", "vgg_stages", "unfolded", "small_upsample"])
 def test_imported_model_on_the_engine(hp, name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     m = E.Model.from_onnx(os.path.join(GOLD, name + ".onnx"))
