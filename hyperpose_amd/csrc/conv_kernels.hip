@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const first_conv_p
 
 hipError_t launch_first_conv(const first_conv_params& p, hipStream_t s)
 {
-    static const bool no_mfma = getenv("HP_FIRST_MFMA") && atoi(getenv("HP_FIRST_MFMA")) == 0;
+    const bool no_mfma = getenv("HP_FIRST_MFMA") && atoi(getenv("HP_FIRST_MFMA")) == 0;
     if (!no_mfma && p.KH == 3 && p.KW == 3 && (p.stride == 1 || p.stride == 2) && p.Cout % 8 == 0 && p.Cout <= 64 && p.out.coff % 8 == 0
         && p.out.cs % 8 == 0) {
         const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;

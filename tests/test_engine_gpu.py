@@ -114,6 +114,31 @@ def test_first_conv_u8_and_f32(hp):
     _check(got, ref, 2)
 
 
+@pytest.mark.parametrize("stride,cout,act,h,w,f32", [
+    (2, 32, E.ACT_RELU, 64, 96, False),   # whole 8 x 32 tiles
+    (2, 16, E.ACT_RELU6, 33, 47, False),  # ragged tiles, half a row tile of output channels
+    (1, 24, E.ACT_NONE, 19, 70, False),   # stride 1, 24 channels: three 8-channel groups
+    (1, 64, E.ACT_LEAKY, 21, 40, False),  # two row tiles, the general (non-clamp) activation path
+    (2, 40, E.ACT_RELU, 30, 34, True),    # f32 NCHW input, second row tile partly filled
+])
+def test_first_conv_matrix_pipe_shapes(hp, monkeypatch, stride, cout, act, h, w, f32):
+    """first_conv_mfma_kernel (3x3, stride 1 / 2, <= 64 outputs) vs the oracle and vs the scalar first_conv_kernel (HP_FIRST_MFMA=0):
+    both accumulate in fp32; they may differ in the last bit before the fp16 store."""
+    net = Net(7)
+    t = net.conv(0, 3, cout, 3, stride, act=act, act_param=0.1)
+    z = net.conv(t, cout, 8, 1, act=E.ACT_NONE)
+    outs = [Out("y", t, 0, cout), Out("z", z, 0, 8)]
+    fr = np.random.default_rng(9).normal(size=(2, 3, h, w)).astype(np.float32) if f32 else _frames(2, h, w, seed=5)
+    kw = {} if f32 else dict(mean=(0.485, 0.456, 0.406), inv_std=(4.0, 4.5, 4.4))
+    eng, got, ref = _run_both(net, outs, fr, h, w, f32=f32, **kw)
+    _check(got, ref, 2)
+    monkeypatch.setenv("HP_FIRST_MFMA", "0")
+    _, scalar, _ = _run_both(net, outs, fr, h, w, f32=f32, **kw)
+    for b in range(2):
+        for (n0, a0), (n1, a1) in zip(got[b], scalar[b]):
+            _close(a0, a1, rel=1e-3, abs_=1e-3)
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,dil", [
     (32, 64, 1, 1, 1), (64, 128, 1, 1, 1), (128, 128, 3, 1, 1), (128, 512, 1, 1, 1), (512, 19, 1, 1, 1),
     (512, 38, 1, 1, 1), (64, 64, 3, 2, 1), (96, 128, 3, 1, 2), (128, 128, 7, 1, 1), (256, 200, 3, 1, 1),
