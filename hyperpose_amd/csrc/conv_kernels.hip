@@ -2003,24 +2003,32 @@ static hipError_t launch_sep_slot(const sep_params& p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The first separable block of the MobileNet backbones (32 channels in, <= 64 out, stride 1, at half the input resolution:
-// the two largest activations of the network): depthwise 3x3 + pointwise 1x1 in one small block.  8 x 8 output pixels; the
-// 10 x 10 x 32 halo tile goes to LDS once, one thread = one pixel x 8 channels of depthwise taps (same arithmetic as
-// dwconv3x3_kernel), the pointwise GEMM is K = 32: two MFMAs per wavefront (2 row tiles x 2 pixel halves).  ~30 KB of LDS,
-// < 128 registers: several blocks per CU, so loads, taps and stores of different blocks overlap.
-__global__ __launch_bounds__(256) void sepconv_c32_kernel(const sep_params p, int tiles_x, int tiles_y)
+// The separable blocks of the high-resolution end of the MobileNet backbones (32 -> 64 at 184x216, 64 -> 128 stride 2,
+// 128 -> 128 at 92x108: the largest activations of the network, little arithmetic per byte) as ONE small block per 8 x 8
+// output pixels with ALL channels of the tile in LDS at once: halo tile -> LDS, depthwise taps (one thread = one pixel x 8
+// channels per item, same arithmetic as dwconv3x3_kernel) -> swizzled B tile, pointwise GEMM with K = C (2 / 4 / 8 k16 steps,
+// fragment-ordered weights straight from L2), staged epilogue.  No K chunks, two barriers, < 128 registers and < 50 KB of LDS:
+// three or more blocks per CU, so loads, taps and stores of different blocks overlap.
+//   C = input channels (32 / 64 / 128), S = stride, RT = 32-row tiles of output channels (2: <= 64 outputs, wavefronts as
+//   2 row tiles x 2 pixel halves; 4: <= 128 outputs, one row tile x both pixel halves per wavefront).
+template <int C, int S, int RT>
+__global__ __launch_bounds__(256) void sepconv_small_kernel(const sep_params p, int tiles_x, int tiles_y)
 {
-    constexpr int TH = 8, TW = 8, C = 32, CG = 4, IH = TH + 2, IW = TW + 2, PIECES = IH * IW * CG, NLD = (PIECES + 255) / 256;
+    constexpr int TH = 8, TW = 8, CG = C / 8, KQ = C / 16, NT = RT == 4 ? 2 : 1;
+    constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, PIECES = IH * IW * CG, NLD = (PIECES + 255) / 256;
+    constexpr int ITEMS = TH * TW * CG / 256;
     constexpr int HALO_BYTES = PIECES * 16, B_BYTES = TH * TW * C * 2, DWW_BYTES = 9 * C * 2, DWB_BYTES = C * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_BYTES + B_BYTES + DWW_BYTES + DWB_BYTES + 4 * stage_geom<1>::SLAB];
+    constexpr int SLAB_BYTES = 4 * stage_geom<1>::SLAB;
+    constexpr bool OVERLAY = HALO_BYTES >= SLAB_BYTES; // the epilogue slabs reuse the halo tile (dead after the taps) when it is large enough
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_BYTES + B_BYTES + DWW_BYTES + DWB_BYTES + (OVERLAY ? 0 : SLAB_BYTES)];
     unsigned char* const s_halo = lds;
     unsigned char* const s_b = s_halo + HALO_BYTES;
     unsigned char* const s_dww = s_b + B_BYTES;
     unsigned char* const s_dwb = s_dww + DWW_BYTES;
-    unsigned char* const s_slab = s_dwb + DWB_BYTES;
+    unsigned char* const s_slab = OVERLAY ? s_halo : s_dwb + DWB_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = RT == 4 ? wave : (wave & 1), wn = RT == 4 ? 0 : (wave >> 1); // row tile, first pixel tile
     int t = blockIdx.x;
     const int tx = t % tiles_x;
     t /= tiles_x;
@@ -2028,16 +2036,16 @@ __global__ __launch_bounds__(256) void sepconv_c32_kernel(const sep_params p, in
     const int y0 = ty * TH, x0 = tx * TW;
     const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1;
 
-    // pointwise weights: row tile wm, k16 steps 0 and 1 (fragment order, Cin = 32)
-    u32x4 a[2];
+    // pointwise weights: row tile wm, all k16 steps (fragment order)
+    u32x4 a[KQ];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-        a[ks] = *reinterpret_cast<const u32x4*>(p.pw.w + ((size_t)(wm * 2 + ks) * 64 + lane) * 8);
+    for (int ks = 0; ks < KQ; ++ks)
+        a[ks] = *reinterpret_cast<const u32x4*>(p.pw.w + ((size_t)(wm * KQ + ks) * 64 + lane) * 8);
 
     // halo tile + depthwise weights / bias -> LDS
     {
         const __half* const hbase = p.in.p + (size_t)b * p.in.img * p.in.cs + p.in.coff;
-        const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
+        const int iy0 = y0 * S - p.pad_t, ix0 = x0 * S - p.pad_l;
         u32x4 hv[NLD];
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
@@ -2049,61 +2057,95 @@ __global__ __launch_bounds__(256) void sepconv_c32_kernel(const sep_params p, in
             const u32x4 v = *reinterpret_cast<const u32x4*>(hbase + (size_t)(min(y, ymax) * p.in.wp + min(x, xmax)) * p.in.cs + c * 8);
             hv[k] = v & (ok ? 0xffffffffu : 0u);
         }
-        u32x4 wreg = { 0, 0, 0, 0 };
-        if (tid < 36)
-            wreg = *reinterpret_cast<const u32x4*>(p.dw_w + (size_t)(tid / CG) * C + (tid % CG) * 8);
-        else if (tid < 44)
-            wreg = *reinterpret_cast<const u32x4*>(p.dw_bias + (tid - 36) * 4);
+        constexpr int NWT = 9 * CG, NBT = C / 4; // 16-byte pieces of the [9][C] weights and of the C biases
+        u32x4 wreg[(NWT + NBT + 255) / 256];
+#pragma unroll
+        for (int k = 0; k < (NWT + NBT + 255) / 256; ++k) {
+            const int i = tid + k * 256;
+            wreg[k] = u32x4{ 0, 0, 0, 0 };
+            if (i < NWT)
+                wreg[k] = *reinterpret_cast<const u32x4*>(p.dw_w + (size_t)(i / CG) * C + (i % CG) * 8);
+            else if (i < NWT + NBT)
+                wreg[k] = *reinterpret_cast<const u32x4*>(p.dw_bias + (i - NWT) * 4);
+        }
 #pragma unroll
         for (int k = 0; k < NLD; ++k)
             if (tid + k * 256 < PIECES)
                 *reinterpret_cast<u32x4*>(s_halo + (size_t)(tid + k * 256) * 16) = hv[k];
-        if (tid < 36)
-            *reinterpret_cast<u32x4*>(s_dww + tid * 16) = wreg;
-        else if (tid < 44)
-            *reinterpret_cast<u32x4*>(s_dwb + (tid - 36) * 16) = wreg;
+#pragma unroll
+        for (int k = 0; k < (NWT + NBT + 255) / 256; ++k) {
+            const int i = tid + k * 256;
+            if (i < NWT)
+                *reinterpret_cast<u32x4*>(s_dww + i * 16) = wreg[k];
+            else if (i < NWT + NBT)
+                *reinterpret_cast<u32x4*>(s_dwb + (i - NWT) * 16) = wreg[k];
+        }
     }
     lds_barrier();
-    // depthwise taps: one item per thread
+    // depthwise taps
     {
-        const int g = tid % CG, pix = tid / CG;
-        const int py = pix / TW, px = pix - py * TW;
+        const int g = tid % CG;
         const float* bsrc = reinterpret_cast<const float*>(s_dwb) + g * 8;
         const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
-        const unsigned char* xs = s_halo + ((py * IW + px) * CG + g) * 16;
-        float v[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+        u32x4 wv[9];
 #pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9) {
-            const u32x4 x = *reinterpret_cast<const u32x4*>(xs + ((t9 / 3) * IW + (t9 % 3)) * CG * 16);
-            const u32x4 w = *reinterpret_cast<const u32x4*>(s_dww + (t9 * C + g * 8) * 2);
-            mac8_f16(v, x, w);
+        for (int t9 = 0; t9 < 9; ++t9)
+            wv[t9] = *reinterpret_cast<const u32x4*>(s_dww + (t9 * C + g * 8) * 2);
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const int pix = (tid + r * 256) / CG;
+            const int py = pix / TW, px = pix - py * TW;
+            const unsigned char* xs = s_halo + ((py * S * IW + px * S) * CG + g) * 16;
+            float v[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const u32x4 x = *reinterpret_cast<const u32x4*>(xs + ((t9 / 3) * IW + (t9 % 3)) * CG * 16);
+                mac8_f16(v, x, wv[t9]);
+            }
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                h[e] = (_Float16)dw_act<true>(v[e], 0.f, p.dw_hi);
+            *reinterpret_cast<half8*>(s_b + lds_off<C>(pix, g)) = h;
         }
-        half8 h;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            h[e] = (_Float16)dw_act<true>(v[e], 0.f, p.dw_hi);
-        *reinterpret_cast<half8*>(s_b + lds_off<32>(pix, g)) = h;
     }
     lds_barrier();
-    // pointwise: D[32 rows of tile wm][32 pixels of half wn], K = 32
-    floatx16 acc[1][1];
+    // pointwise: D[32 rows of tile wm][NT x 32 pixels], K = C
+    floatx16 acc[1][NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        acc[0][0][r] = 0.f;
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[0][j][r] = 0.f;
     const int frow = lane & 31, fk = lane >> 5;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const half8 fb = *reinterpret_cast<const half8*>(s_b + lds_off<32>(wn * 32 + frow, ks * 2 + fk));
+    for (int ks = 0; ks < KQ; ++ks) {
         half8 fa;
         __builtin_memcpy(&fa, &a[ks], 16);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[0][0], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const half8 fb = *reinterpret_cast<const half8*>(s_b + lds_off<C>((wn + j) * 32 + frow, ks * 2 + fk));
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[0][j], 0, 0, 0);
+        }
     }
-    int pb[1], py1[1], px1[1];
-    bool pv[1];
-    const int n = wn * 32 + frow;
-    pb[0] = b, py1[0] = y0 + n / TW, px1[0] = x0 + n % TW;
-    pv[0] = py1[0] < p.OH && px1[0] < p.OW;
-    conv_epilogue_staged<1, 1>(p.pw, acc, wm * 32, lane, s_slab + wave * stage_geom<1>::SLAB, pb, py1, px1, pv);
+    int pb[NT], py1[NT], px1[NT];
+    bool pv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = (wn + j) * 32 + frow;
+        pb[j] = b, py1[j] = y0 + n / TW, px1[j] = x0 + n % TW;
+        pv[j] = py1[j] < p.OH && px1[j] < p.OW;
+    }
+    // (where the slabs overlay the halo tile: the barrier after the taps already put every wavefront past its reads of it)
+    conv_epilogue_staged<1, NT>(p.pw, acc, wm * 32, lane, s_slab + wave * stage_geom<1>::SLAB, pb, py1, px1, pv);
+}
+
+template <int C, int S, int RT>
+static hipError_t launch_sep_small(const sep_params& p, hipStream_t s)
+{
+    const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 7) / 8;
+    HP_LAUNCH((sepconv_small_kernel<C, S, RT>), dim3(tiles_x * tiles_y * p.B), dim3(256), 0, s, p, tiles_x, tiles_y);
+    return hipGetLastError();
 }
 
 // which instantiation serves (Cout_pad, stride, dilation, C); 0 = none (the engine then keeps the two launches)
@@ -2143,10 +2185,16 @@ hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 {
     static const bool slot = !getenv("HP_SEP_SLOT") || atoi(getenv("HP_SEP_SLOT")) != 0; // HP_SEP_SLOT=0: whole-CU form everywhere
     const int v = sepconv_variant(p);
-    if (v == 7) {
-        const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 7) / 8;
-        HP_LAUNCH(sepconv_c32_kernel, dim3(tiles_x * tiles_y * p.B), dim3(256), 0, s, p, tiles_x, tiles_y);
-        return hipGetLastError();
+    if (v == 7)
+        return launch_sep_small<32, 1, 2>(p, s);
+    static const int small_mask = getenv("HP_SEP_SMALL_MASK") ? atoi(getenv("HP_SEP_SMALL_MASK")) : 0x6; // bit v: variant v as one all-channels block
+    if (slot && ((small_mask >> v) & 1) && p.pw.Cout <= 128) {
+        if (v == 1 && p.C == 128)
+            return launch_sep_small<128, 1, 4>(p, s);
+        if (v == 1 && p.C == 64)
+            return launch_sep_small<64, 1, 4>(p, s);
+        if (v == 2 && p.C == 64)
+            return launch_sep_small<64, 2, 4>(p, s);
     }
     static const int slot_mask = getenv("HP_SEP_SLOT_MASK") ? atoi(getenv("HP_SEP_SLOT_MASK")) : 0x7e; // bit v: variant v in half-CU form
     if (slot && ((slot_mask >> v) & 1) && p.C % 64 == 0) {
