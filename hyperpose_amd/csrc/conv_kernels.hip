@@ -2154,7 +2154,7 @@ int sepconv_variant_for(int C, int cout_pad, int stride, int dil, int cout)
     if (C > SEP_CMAX || C % 32 || cout_pad % 128)
         return 0;
     if (C == 32 && cout > 0 && cout <= 64 && stride == 1 && dil == 1)
-        return 7; // sepconv_c32_kernel
+        return 7; // sepconv_small_kernel<32, 1, 2>
     const int tm = cout_pad / 128;
     if (tm == 1 && stride == 1 && dil == 1)
         return 1;

@@ -337,7 +337,7 @@ def test_pifpaf_resnet50_end_to_end(hp):
     (96, 72, 1, 1, 21, 30),      # ragged channels: Cout not a multiple of 32, C = 3 chunks of 32
     (128, 128, 1, 1, 29, 35),    # variant 1 in its half-CU form (C a multiple of 64), ragged edge tiles
     (64, 128, 2, 1, 46, 54),     # variant 2, even input (SAME pads 0/1)
-    (32, 64, 1, 1, 37, 45),      # variant 7: the 32-channel block (sepconv_c32_kernel), odd sizes
+    (32, 64, 1, 1, 37, 45),      # variant 7: the 32-channel block (sepconv_small_kernel), odd sizes
     (32, 40, 1, 1, 16, 24),      # variant 7 with fewer than 64 outputs
 ])
 def test_fused_separable_block(hp, monkeypatch, c, cout, stride, dil, h, w):
