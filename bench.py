@@ -189,7 +189,10 @@ def roofline(pipe):
     halo = {3064192: (64, 16, 12), 3128128: (128, 8, 16)}
     sep = {1: (1, 12, 16, 24, 1, 1, 32), 2: (1, 6, 8, 24, 2, 1, 32), 3: (2, 3, 8, 12, 2, 1, 64), 4: (2, 3, 8, 12, 1, 1, 64),
            5: (4, 3, 8, 12, 1, 1, 64), 6: (4, 3, 8, 12, 1, 2, 64)}
-    if dom_tile >= 5000000:
+    if 5100000 <= dom_tile < 5200000:
+        key = "conv1x1_small_kernel"
+        label = "conv1x1_small_kernel (64 pixels x all input channels in LDS, fragment-ordered weights from L2)"
+    elif dom_tile >= 5000000:
         key = "conv3x3_direct_kernel<128>"
         label = "conv3x3_direct_kernel<CIN=128> (64 cout x 16x12 px tile, input halo tile in LDS, weights in MFMA-fragment order straight from L2)"
     elif dom_tile >= 4000000:

@@ -939,12 +939,15 @@ static bool fast_epilogue(const conv_params& p)
 }
 
 static bool use_halo(const conv_params& p);
+static bool use_small1x1(const conv_params& p);
 static bool fast_epilogue(const conv_params& p);
 static int halo_variant(const conv_params& p);
 // 1: the weights of this convolution are to be packed in MFMA-fragment order for conv3x3_direct_kernel
 int conv_weight_layout(const conv_params& p)
 {
     static const int off = getenv("HP_HALO_DIRECT") ? !atoi(getenv("HP_HALO_DIRECT")) : 0;
+    if (use_small1x1(p) && fast_epilogue(p))
+        return 1;
     return !off && use_halo(p) && fast_epilogue(p) && halo_variant(p) == 1 ? 1 : 0;
 }
 
@@ -1023,8 +1026,83 @@ bool set_act(conv_params& p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small 1x1 convolutions (<= 256 input channels -> <= 128 outputs, stride 1: the entry convolutions of the refinement blocks):
+// one block = 64 consecutive pixels, their activations go global -> LDS once (all channels, rows padded by 16 bytes instead of
+// swizzled), the weights come from L2 in MFMA-fragment order (w_layout 1), one wavefront per 32-row tile of output channels,
+// two column tiles each.  One barrier, < 128 registers, <= 53 KB of LDS: three blocks per CU.  The generic implicit-GEMM
+// kernel stages A and B through LDS in K steps with a barrier each; at 0.65 GFLOP per launch that structure is all overhead.
+template <int KP>
+__global__ __launch_bounds__(256) void conv1x1_small_kernel(const conv_params p)
+{
+    constexpr int NPX = 64, NT = 2, CG = KP / 8, KQ = KP / 16, ROW = KP * 2 + 16, NLD = NPX * CG / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPX * ROW + 4 * stage_geom<1>::SLAB];
+    unsigned char* const s_b = lds;
+    unsigned char* const s_slab = lds + NPX * ROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * NPX, HW = p.OH * p.OW;
+
+    u32x4 a[KQ];
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks)
+        a[ks] = *reinterpret_cast<const u32x4*>(p.w + ((size_t)(wave * KQ + ks) * 64 + lane) * 8);
+    {
+        u32x4 hv[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * 256, pix = i / CG, c = i - pix * CG;
+            const int n = min(n0 + pix, p.npix - 1);
+            const int b = n / HW, r = n - b * HW, y = r / p.OW, x = r - y * p.OW;
+            hv[k] = *reinterpret_cast<const u32x4*>(p.in.p + tv_off(p.in, b, y, x) + c * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * 256, pix = i / CG, c = i - pix * CG;
+            *reinterpret_cast<u32x4*>(s_b + pix * ROW + c * 16) = hv[k];
+        }
+    }
+    lds_barrier();
+    floatx16 acc[1][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[0][j][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks) {
+        half8 fa;
+        __builtin_memcpy(&fa, &a[ks], 16);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const half8 fb = *reinterpret_cast<const half8*>(s_b + (j * 32 + frow) * ROW + (ks * 2 + fk) * 16);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[0][j], 0, 0, 0);
+        }
+    }
+    int pb[NT], py[NT], px[NT];
+    bool pv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 32 + frow, nc = min(n, p.npix - 1);
+        pb[j] = nc / HW;
+        const int r = nc - pb[j] * HW;
+        py[j] = r / p.OW, px[j] = r - py[j] * p.OW;
+        pv[j] = n < p.npix;
+    }
+    conv_epilogue_staged<1, NT>(p, acc, wave * 32, lane, s_slab + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+}
+
+static bool use_small1x1(const conv_params& p)
+{
+    static const bool off = getenv("HP_NO_SMALL_1X1") != nullptr;
+    return !off && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.Cout_pad == 128 && (p.Cin == 64 || p.Cin == 128 || p.Cin == 192 || p.Cin == 256)
+        && p.in.coff % 8 == 0 && p.in.cs - p.in.coff >= p.Cin && p.OH == p.H && p.OW == p.W;
+}
+
 int conv_mfma_tile(const conv_params& p)
 {
+    if (p.w_layout == 1 && p.KH == 1)
+        return 5100000 + p.Cin; // conv1x1_small_kernel
     if (p.w_layout == 1)
         return 5000000 + 64 * 1000 + 192;
     if (use_halo(p))
@@ -1046,6 +1124,18 @@ int conv_mfma_tile(const conv_params& p)
 
 hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
 {
+    if (p.w_layout == 1 && p.KH == 1) {
+        if (!(use_small1x1(p) && fast_epilogue(p)))
+            return hipErrorInvalidValue;
+        const dim3 grid((p.npix + 63) / 64);
+        switch (p.Cin) {
+        case 64: HP_LAUNCH((conv1x1_small_kernel<64>), grid, dim3(256), 0, s, p); break;
+        case 128: HP_LAUNCH((conv1x1_small_kernel<128>), grid, dim3(256), 0, s, p); break;
+        case 192: HP_LAUNCH((conv1x1_small_kernel<192>), grid, dim3(256), 0, s, p); break;
+        default: HP_LAUNCH((conv1x1_small_kernel<256>), grid, dim3(256), 0, s, p); break;
+        }
+        return hipGetLastError();
+    }
     if (p.w_layout == 1) {
         if (!(use_halo(p) && fast_epilogue(p)))
             return hipErrorInvalidValue; // fragment-ordered weights only fit the direct kernel
