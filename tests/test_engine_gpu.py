@@ -447,3 +447,22 @@ def test_engine_save_load_roundtrip(hp, tmp_path):
     bad.write_bytes(b"not an engine")
     with pytest.raises(Exception):
         E.Engine.load(str(bad))
+
+
+def test_partial_batches_are_frame_independent(hp):
+    """A max_batch = 8 engine fed 1, 3, 5 and 8 frames (the stream API's ragged last batch, src/stream.cpp) returns for every frame the
+    bits it returns for that frame alone - no kernel of the LW-OpenPose schedule mixes frames or depends on the batch size."""
+    m = E.Model("lw_openpose_mobilenet", 96, 80)
+    w = m.init_weights(3)
+    eng = E.Engine.from_model(m, w, max_batch=8)
+    fr = _frames(8, 80, 96, seed=11)
+    full = eng.inference(fr)
+    for n in (1, 3, 5):
+        part = eng.inference(fr[:n])
+        assert len(part) == n
+        for b in range(n):
+            for (n0, a0), (n1, a1) in zip(part[b], full[b]):
+                assert n0 == n1 and np.array_equal(a0, a1), (n, b, n0)
+    solo = eng.inference(fr[6:7])
+    for (n0, a0), (n1, a1) in zip(solo[0], full[6]):
+        assert np.array_equal(a0, a1)
