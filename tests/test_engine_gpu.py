@@ -466,3 +466,15 @@ def test_partial_batches_are_frame_independent(hp):
     solo = eng.inference(fr[6:7])
     for (n0, a0), (n1, a1) in zip(solo[0], full[6]):
         assert np.array_equal(a0, a1)
+
+
+def test_profile_in_sequence_reports_every_step(hp):
+    """hp_engine_profile_sequence (kernels' own begin / end timestamps, schedule order) lists the same steps as the back-to-back
+    profile, with positive durations of the same order of magnitude."""
+    m = E.Model("lw_openpose_mobilenet", 96, 80)
+    eng = E.Engine.from_model(m, m.init_weights(3), max_batch=2)
+    a, b = eng.profile(2, 3), eng.profile(2, 3, in_sequence=True)
+    assert [(p["layer"], p["op"], p["tile"]) for p in a] == [(p["layer"], p["op"], p["tile"]) for p in b]
+    assert all(p["ms"] > 0 for p in b)
+    ta, tb = sum(p["ms"] for p in a), sum(p["ms"] for p in b)
+    assert 0.2 * ta < tb < 5 * ta
