@@ -140,6 +140,13 @@ int hp_engine::build(const hp_engine_desc* d)
     int max_id = 0;
     for (const auto& L : layers)
         max_id = std::max({ max_id, L.in, L.out, L.res });
+    HP_REQUIRE(max_id < (1 << 16) && d->n_layers < (1 << 16), HP_ERR_INVALID, "engine: %d layers / tensor id %d: not a plausible network", d->n_layers, max_id);
+    for (size_t i = 0; i < layers.size(); ++i) {
+        const hp_layer& L = layers[i];
+        HP_REQUIRE(L.cin > 0 && L.cout > 0 && L.cin <= (1 << 16) && L.cout <= (1 << 16) && L.kh >= 0 && L.kh <= 31 && L.kw >= 0 && L.kw <= 31
+                && L.stride >= 1 && L.stride <= 64 && L.dil >= 0 && L.dil <= 64,
+            HP_ERR_INVALID, "layer %zu: implausible channel count / geometry", i);
+    }
     tensors.resize(max_id + 1);
     for (auto& t : tensors)
         t = std::make_unique<tensor_info>();
@@ -708,7 +715,11 @@ int hp_engine_create(hp_engine** out, const hp_engine_desc* desc)
 {
     HP_REQUIRE(out && desc, HP_ERR_INVALID, "hp_engine_create: null argument");
     std::unique_ptr<hp_engine> e(new hp_engine());
-    HP_TRY(e->build(desc));
+    try { // descriptions come from files (hp_engine_load, ONNX import): absurd sizes must come back as error codes
+        HP_TRY(e->build(desc));
+    } catch (const std::exception& ex) {
+        HP_REQUIRE(false, HP_ERR_INVALID, "hp_engine_create: %s", ex.what());
+    }
     *out = e.release();
     return HP_OK;
 }
@@ -763,6 +774,13 @@ int hp_engine_load(hp_engine** out, const char* path, int max_batch)
     bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, ENGINE_MAGIC, 8) == 0 && h.layer_size == (int32_t)sizeof(hp_layer)
         && h.output_size == (int32_t)sizeof(hp_output_desc) && h.n_layers > 0 && h.n_layers < (1 << 20) && h.n_outputs > 0
         && h.n_outputs < 4096 && h.n_weights < ((uint64_t)1 << 34);
+    if (ok) { // the counts must account for the file exactly before anything is allocated from them
+        const long at = ftell(f);
+        ok = fseek(f, 0, SEEK_END) == 0;
+        const long size = ftell(f);
+        ok = ok && fseek(f, at, SEEK_SET) == 0
+            && (uint64_t)size == (uint64_t)at + (uint64_t)h.n_layers * sizeof(hp_layer) + (uint64_t)h.n_outputs * sizeof(hp_output_desc) + h.n_weights * sizeof(float);
+    }
     if (ok) {
         layers.resize(h.n_layers), outs.resize(h.n_outputs), w.resize(h.n_weights);
         ok = fread(layers.data(), sizeof(hp_layer), layers.size(), f) == layers.size()

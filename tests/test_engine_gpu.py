@@ -478,3 +478,29 @@ def test_profile_in_sequence_reports_every_step(hp):
     assert all(p["ms"] > 0 for p in b)
     ta, tb = sum(p["ms"] for p in a), sum(p["ms"] for p in b)
     assert 0.2 * ta < tb < 5 * ta
+
+
+def test_corrupted_engine_files_are_rejected_not_crashed(hp, tmp_path):
+    """Serialized engines are files: truncations and flipped header / layer bytes must come back as errors (or as a network that
+    still builds), never as a crash or an allocation blow-up."""
+    m = E.Model("lw_openpose_vggtiny", 64, 48)
+    eng = E.Engine.from_model(m, m.init_weights(1), max_batch=1)
+    path = str(tmp_path / "e.hpeng")
+    eng.save(path)
+    raw = bytearray(open(path, "rb").read())
+    rng = np.random.default_rng(1)
+    bad = 0
+    for it in range(60):
+        mut = bytearray(raw)
+        if it % 3 == 0:
+            mut = mut[:int(rng.integers(1, len(mut)))]
+        else:
+            for _ in range(4):
+                mut[int(rng.integers(0, 4096))] = int(rng.integers(0, 256))  # header + first layers
+        p2 = str(tmp_path / "m.hpeng")
+        open(p2, "wb").write(bytes(mut))
+        try:
+            E.Engine.load(p2).close()
+        except hp.HpError:
+            bad += 1
+    assert bad >= 20
