@@ -99,4 +99,23 @@ struct host_buf {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Host worker pool for the order-dependent parser tails (PoseProposal limb selection / merge, PifPaf grow / soft-NMS): frames are
+// independent, so hp_*_collect hands frame indices to a few persistent threads, the way the reference replicates its parser per
+// pool thread (include/hyperpose/utility/thread_pool.hpp:21, include/hyperpose/stream/stream.hpp:139-144).  The calling thread
+// takes part; run() returns when every frame is done.  `fn(frame, worker)`: worker in [0, workers()) selects per-thread scratch.
+// HP_PARSER_THREADS overrides the default min(8, hardware threads).
+class frame_pool {
+public:
+    static frame_pool& instance();
+    int workers() const { return n_threads_ + 1; }
+    void run(int n_frames, void (*fn)(int frame, int worker, void* ctx), void* ctx);
+    ~frame_pool();
+
+private:
+    frame_pool();
+    struct impl;
+    impl* d_;
+    int n_threads_;
+};
+
 } // namespace hp

@@ -3,6 +3,13 @@
 // (src/tensorrt.cpp:106-118 `cuda_dep`).
 #include "hp_common.hpp"
 
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 namespace hp {
 
 static thread_local char g_err[512] = "";
@@ -16,6 +23,89 @@ void set_error(const char* fmt, ...)
 }
 
 const char* last_error() { return g_err; }
+
+struct frame_pool::impl {
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    // one job at a time (run() holds `busy`); generation wakes the workers
+    std::mutex busy;
+    unsigned long generation = 0;
+    bool stop = false;
+    int n_frames = 0, active = 0;
+    std::atomic<int> next{ 0 };
+    void (*fn)(int, int, void*) = nullptr;
+    void* ctx = nullptr;
+};
+
+frame_pool::frame_pool()
+    : d_(new impl())
+{
+    int n = (int)std::thread::hardware_concurrency();
+    n = n <= 0 ? 4 : (n > 8 ? 8 : n);
+    if (const char* e = getenv("HP_PARSER_THREADS"))
+        n = atoi(e) < 1 ? 1 : (atoi(e) > 64 ? 64 : atoi(e));
+    n_threads_ = n - 1; // the caller is the n-th worker
+    for (int t = 0; t < n_threads_; ++t)
+        d_->threads.emplace_back([this, t] {
+            unsigned long seen = 0;
+            for (;;) {
+                std::unique_lock<std::mutex> lk(d_->m);
+                d_->cv_work.wait(lk, [&] { return d_->stop || d_->generation != seen; });
+                if (d_->stop)
+                    return;
+                seen = d_->generation;
+                lk.unlock();
+                for (int f; (f = d_->next.fetch_add(1)) < d_->n_frames;)
+                    d_->fn(f, t + 1, d_->ctx);
+                lk.lock();
+                if (--d_->active == 0)
+                    d_->cv_done.notify_one();
+            }
+        });
+}
+
+frame_pool::~frame_pool()
+{
+    {
+        std::lock_guard<std::mutex> lk(d_->m);
+        d_->stop = true;
+    }
+    d_->cv_work.notify_all();
+    for (auto& t : d_->threads)
+        t.join();
+    delete d_;
+}
+
+frame_pool& frame_pool::instance()
+{
+    static frame_pool pool;
+    return pool;
+}
+
+void frame_pool::run(int n_frames, void (*fn)(int, int, void*), void* ctx)
+{
+    if (n_frames <= 0)
+        return;
+    if (n_frames == 1 || n_threads_ == 0) {
+        for (int f = 0; f < n_frames; ++f)
+            fn(f, 0, ctx);
+        return;
+    }
+    std::lock_guard<std::mutex> job(d_->busy);
+    {
+        std::lock_guard<std::mutex> lk(d_->m);
+        d_->n_frames = n_frames, d_->fn = fn, d_->ctx = ctx;
+        d_->next.store(0);
+        d_->active = n_threads_;
+        ++d_->generation;
+    }
+    d_->cv_work.notify_all();
+    for (int f; (f = d_->next.fetch_add(1)) < n_frames;)
+        fn(f, 0, ctx);
+    std::unique_lock<std::mutex> lk(d_->m);
+    d_->cv_done.wait(lk, [&] { return d_->active == 0; });
+}
 
 } // namespace hp
 

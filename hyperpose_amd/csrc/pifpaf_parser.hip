@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64) void pp_caf_kernel(const float* __restrict__ pa
 }
 
 // frame f's arena slice: [seeds x 5 floats][list 0 x 9 floats][list 1]...; offsets are a prefix over frames
-__global__ void pp_offsets_kernel(int n, int seed_cap, int* __restrict__ hdr, int* __restrict__ total)
+__global__ void pp_offsets_kernel(int n, int seed_cap, long long arena_cap, int* __restrict__ hdr, int* __restrict__ total)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
@@ -253,6 +253,13 @@ __global__ void pp_offsets_kernel(int n, int seed_cap, int* __restrict__ hdr, in
         long long sz = (long long)h[0] * 5;
         for (int l = 0; l < 2 * NB; ++l)
             sz += (long long)h[1 + l] * 9;
+        if (off + sz > arena_cap) { // the frame's lists do not fit: it is reported, not packed
+            h[40] |= 2;
+            sz = 0;
+            h[0] = 0;
+            for (int l = 0; l < 2 * NB; ++l)
+                h[1 + l] = 0;
+        }
         off += sz;
     }
     *total = (int)off;
@@ -623,10 +630,12 @@ struct hp_pifpaf {
     bool shaped = false;
     pp_geom g{};
     hipStream_t stream = nullptr;
-    hp::dev_buf cells, ncells, seeds, lists, hdr, total, arena, in_paf, in_pif;
-    hp::host_buf h_hdr, h_total, h_arena;
-    size_t arena_cap = 0; // floats
-    occupancy occ;
+    hipEvent_t done = nullptr;
+    hp::dev_buf cells, ncells, seeds, lists, hdr, total, in_paf, in_pif;
+    hp::host_buf h_hdr, h_arena; // the pack kernel writes the dense arena straight into pinned host memory
+    size_t arena_cap = 0;        // floats
+    std::vector<occupancy> occ;  // one per pool worker
+    int pending = 0;
 };
 
 extern "C" {
@@ -637,6 +646,8 @@ int hp_pifpaf_create(hp_pifpaf** out, int net_h, int net_w, float thresh, int ma
     std::unique_ptr<hp_pifpaf> p(new hp_pifpaf());
     p->net_h = net_h, p->net_w = net_w, p->thresh = thresh, p->max_batch = max_batch;
     HP_HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HP_HIP_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+    p->occ.resize(hp::frame_pool::instance().workers());
     *out = p.release();
     return HP_OK;
 }
@@ -649,15 +660,21 @@ void hp_pifpaf_destroy(hp_pifpaf* p)
         (void)hipStreamSynchronize(p->stream);
         (void)hipStreamDestroy(p->stream);
     }
+    if (p->done) {
+        (void)hipEventSynchronize(p->done);
+        (void)hipEventDestroy(p->done);
+    }
     delete p;
 }
 
-int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* pif, int fh, int fw, int on_device, hp_human* out,
-    int cap_per_frame, int* n_out)
+void* hp_pifpaf_stream(hp_pifpaf* p) { return p ? (void*)p->stream : nullptr; }
+
+static int pifpaf_launch(hp_pifpaf* p, int n, const float* paf, const float* pif, int fh, int fw, int on_device, hipStream_t s)
 {
-    HP_REQUIRE(p && paf && pif && n_out, HP_ERR_INVALID, "hp_pifpaf_process_batch: null argument");
-    HP_REQUIRE(n >= 1 && n <= p->max_batch, HP_ERR_CAPACITY, "hp_pifpaf_process_batch: batch %d > max_batch %d", n, p->max_batch);
+    HP_REQUIRE(p && paf && pif, HP_ERR_INVALID, "hp_pifpaf: null argument");
+    HP_REQUIRE(n >= 1 && n <= p->max_batch, HP_ERR_CAPACITY, "hp_pifpaf: batch %d > max_batch %d", n, p->max_batch);
     HP_REQUIRE(fh >= 2 && fw >= 2, HP_ERR_INVALID, "pifpaf: bad field size %dx%d", fh, fw);
+    HP_REQUIRE(p->pending == 0, HP_ERR_STATE, "hp_pifpaf: a batch is already in flight, collect it first");
     if (p->shaped)
         HP_REQUIRE(p->g.H == fh && p->g.W == fw, HP_ERR_STATE, "pifpaf: field size changed after the first call");
     const size_t HW = (size_t)fh * fw, B = p->max_batch;
@@ -671,15 +688,12 @@ int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* 
         HP_TRY(p->lists.alloc(B * NB * 2 * HW * 9 * sizeof(float)));
         HP_TRY(p->hdr.alloc(B * HDR * sizeof(int)));
         HP_TRY(p->total.alloc(sizeof(int)));
-        p->arena_cap = B * ((size_t)p->seed_cap * 5 + 4 * HW * 9); // generous; checked against `total` below
-        HP_TRY(p->arena.alloc(p->arena_cap * sizeof(float)));
+        p->arena_cap = B * ((size_t)p->seed_cap * 5 + 4 * HW * 9); // generous; a frame that does not fit is flagged by pp_offsets_kernel
         HP_TRY(p->h_hdr.alloc(p->hdr.bytes));
-        HP_TRY(p->h_total.alloc(sizeof(int)));
-        HP_TRY(p->h_arena.alloc(p->arena.bytes));
+        HP_TRY(p->h_arena.alloc(p->arena_cap * sizeof(float)));
         p->shaped = true;
     }
     const float *dpaf = paf, *dpif = pif;
-    hipStream_t s = p->stream;
     if (!on_device) {
         const size_t pb = (size_t)NB * 9 * HW * sizeof(float), ib = (size_t)NK * 5 * HW * sizeof(float);
         if (p->in_paf.bytes < pb * B)
@@ -696,38 +710,76 @@ int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* 
         p->seed_cap, p->hdr.as<int>());
     hipLaunchKernelGGL(pp_caf_kernel, dim3(NB, n), dim3(64), 0, s, dpaf, p->g, p->cells.as<pp_cell>(), p->ncells.as<int>(), p->lists.as<float>(),
         p->hdr.as<int>());
-    hipLaunchKernelGGL(pp_offsets_kernel, dim3(1), dim3(1), 0, s, n, p->seed_cap, p->hdr.as<int>(), p->total.as<int>());
+    hipLaunchKernelGGL(pp_offsets_kernel, dim3(1), dim3(1), 0, s, n, p->seed_cap, (long long)p->arena_cap, p->hdr.as<int>(), p->total.as<int>());
+    hipLaunchKernelGGL(pp_pack_kernel, dim3(1 + 2 * NB, n), dim3(256), 0, s, p->g, p->seed_cap, p->hdr.as<int>(), p->seeds.as<pp_seed>(),
+        p->lists.as<float>(), p->h_arena.as<float>());
     HP_HIP_TRY(hipGetLastError());
     HP_HIP_TRY(hipMemcpyAsync(p->h_hdr.p, p->hdr.p, (size_t)n * HDR * sizeof(int), hipMemcpyDeviceToHost, s));
-    HP_HIP_TRY(hipMemcpyAsync(p->h_total.p, p->total.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    HP_HIP_TRY(hipStreamSynchronize(s));
-    const size_t total = (size_t)p->h_total.as<int>()[0];
-    HP_REQUIRE(total <= p->arena_cap, HP_ERR_CAPACITY, "pifpaf: %zu floats of compacted lists exceed the arena (%zu)", total, p->arena_cap);
-    if (total > 0) {
-        hipLaunchKernelGGL(pp_pack_kernel, dim3(1 + 2 * NB, n), dim3(256), 0, s, p->g, p->seed_cap, p->hdr.as<int>(), p->seeds.as<pp_seed>(),
-            p->lists.as<float>(), p->arena.as<float>());
-        HP_HIP_TRY(hipGetLastError());
-        HP_HIP_TRY(hipMemcpyAsync(p->h_arena.p, p->arena.p, total * sizeof(float), hipMemcpyDeviceToHost, s));
-        HP_HIP_TRY(hipStreamSynchronize(s));
-    }
+    HP_HIP_TRY(hipEventRecord(p->done, s));
+    p->pending = n;
+    return HP_OK;
+}
+
+int hp_pifpaf_enqueue(hp_pifpaf* p, int n, const float* dev_paf, const float* dev_pif, int fh, int fw, void* stream)
+{
+    return pifpaf_launch(p, n, dev_paf, dev_pif, fh, fw, 1, stream ? (hipStream_t)stream : (p ? p->stream : nullptr));
+}
+
+namespace {
+struct pifpaf_job {
+    hp_pifpaf* p;
+    hp_human* out;
+    int cap;
+    int* n_out;
+    std::vector<int> rc;
+};
+void pifpaf_frame(int f, int worker, void* ctx)
+{
+    pifpaf_job& j = *static_cast<pifpaf_job*>(ctx);
+    hp_pifpaf* p = j.p;
+    const int* hdr = p->h_hdr.as<int>() + (size_t)f * HDR;
+    if (hdr[40] != 0)
+        j.rc[f] = hdr[40] & 2 ? 3 : 1;
+    std::vector<hp_human> humans;
+    decode_frame(p->g, hdr, p->h_arena.as<float>(), p->thresh, p->net_w, p->net_h, p->occ[worker], humans);
+    j.n_out[f] = (int)humans.size();
+    if ((int)humans.size() > j.cap && !j.rc[f])
+        j.rc[f] = 2;
+    if (j.out)
+        std::copy(humans.begin(), humans.begin() + std::min<size_t>(humans.size(), j.cap), j.out + (size_t)f * j.cap);
+}
+} // namespace
+
+int hp_pifpaf_collect(hp_pifpaf* p, hp_human* out, int cap_per_frame, int* n_out)
+{
+    HP_REQUIRE(p && n_out, HP_ERR_INVALID, "hp_pifpaf_collect: null argument");
+    HP_REQUIRE(p->pending > 0, HP_ERR_STATE, "hp_pifpaf_collect: nothing was enqueued");
+    const int n = p->pending;
+    p->pending = 0;
+    HP_HIP_TRY(hipEventSynchronize(p->done));
+    pifpaf_job job{ p, out, cap_per_frame, n_out, std::vector<int>(n, 0) };
+    hp::frame_pool::instance().run(n, pifpaf_frame, &job);
     int rc = HP_OK;
-    for (int f = 0; f < n; ++f) {
-        const int* hdr = p->h_hdr.as<int>() + (size_t)f * HDR;
-        if (hdr[40] != 0) {
+    for (int f = 0; f < n; ++f)
+        if (job.rc[f] == 1) {
             hp::set_error("pifpaf: frame %d has more than %d seeds", f, p->seed_cap);
             rc = HP_ERR_CAPACITY;
-        }
-        std::vector<hp_human> humans;
-        decode_frame(p->g, hdr, p->h_arena.as<float>(), p->thresh, p->net_w, p->net_h, p->occ, humans);
-        n_out[f] = (int)humans.size();
-        if ((int)humans.size() > cap_per_frame) {
-            hp::set_error("pifpaf: frame %d has %zu humans, capacity %d", f, humans.size(), cap_per_frame);
+        } else if (job.rc[f] == 3) {
+            hp::set_error("pifpaf: the compacted lists of frame %d exceed the arena (%zu floats for the batch)", f, p->arena_cap);
+            rc = HP_ERR_CAPACITY;
+        } else if (job.rc[f] == 2) {
+            hp::set_error("pifpaf: frame %d has %d humans, capacity %d", f, n_out[f], cap_per_frame);
             rc = HP_ERR_CAPACITY;
         }
-        if (out)
-            std::copy(humans.begin(), humans.begin() + std::min<size_t>(humans.size(), cap_per_frame), out + (size_t)f * cap_per_frame);
-    }
     return rc;
+}
+
+int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* pif, int fh, int fw, int on_device, hp_human* out,
+    int cap_per_frame, int* n_out)
+{
+    HP_REQUIRE(p && n_out, HP_ERR_INVALID, "hp_pifpaf_process_batch: null argument");
+    HP_TRY(pifpaf_launch(p, n, paf, pif, fh, fw, on_device, p->stream));
+    return hp_pifpaf_collect(p, out, cap_per_frame, n_out);
 }
 
 } // extern "C"

@@ -318,8 +318,13 @@ struct hp_ppn {
     int net_w, net_h, max_batch;
     float point_thresh, limb_thresh, nms_thresh;
     hipStream_t stream = nullptr;
-    hp::dev_buf hdr, boxes, cands, in[7];
+    hipEvent_t done = nullptr;
+    hp::dev_buf in[7];
+    // the kernel writes its compacted lists straight into pinned host memory: only the used prefix of every fixed-capacity row
+    // crosses PCIe, and there is no copy to wait for between the kernel and the host tail
     hp::host_buf h_hdr, h_boxes, h_cands;
+    int pending = 0; // frames enqueued and not yet collected
+    int K = 0;
 };
 
 extern "C" {
@@ -331,13 +336,11 @@ int hp_ppn_create(hp_ppn** out, int net_w, int net_h, float point_thresh, float 
     p->net_w = net_w, p->net_h = net_h, p->max_batch = max_batch;
     p->point_thresh = point_thresh, p->limb_thresh = limb_thresh, p->nms_thresh = nms_thresh;
     HP_HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HP_HIP_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
     const size_t B = max_batch;
-    HP_TRY(p->hdr.alloc(B * HDR * sizeof(int)));
-    HP_TRY(p->boxes.alloc(B * PPN_K * PPN_MAXB * sizeof(ppn_box)));
-    HP_TRY(p->cands.alloc(B * PPN_LIMBS * PPN_MAXC * sizeof(ppn_cand)));
-    HP_TRY(p->h_hdr.alloc(p->hdr.bytes));
-    HP_TRY(p->h_boxes.alloc(p->boxes.bytes));
-    HP_TRY(p->h_cands.alloc(p->cands.bytes));
+    HP_TRY(p->h_hdr.alloc(B * HDR * sizeof(int)));
+    HP_TRY(p->h_boxes.alloc(B * PPN_K * PPN_MAXB * sizeof(ppn_box)));
+    HP_TRY(p->h_cands.alloc(B * PPN_LIMBS * PPN_MAXC * sizeof(ppn_cand)));
     *out = p.release();
     return HP_OK;
 }
@@ -350,8 +353,14 @@ void hp_ppn_destroy(hp_ppn* p)
         (void)hipStreamSynchronize(p->stream);
         (void)hipStreamDestroy(p->stream);
     }
+    if (p->done) {
+        (void)hipEventSynchronize(p->done);
+        (void)hipEventDestroy(p->done);
+    }
     delete p;
 }
+
+void* hp_ppn_stream(hp_ppn* p) { return p ? (void*)p->stream : nullptr; }
 
 int hp_ppn_set_thresholds(hp_ppn* p, float point_thresh, float limb_thresh, float nms_thresh)
 {
@@ -360,11 +369,12 @@ int hp_ppn_set_thresholds(hp_ppn* p, float point_thresh, float limb_thresh, floa
     return HP_OK;
 }
 
-int hp_ppn_process_batch(hp_ppn* p, int n, const float* const tensors[7], const int conf_shape[3], const int edge_shape[5],
-    int on_device, hp_human* out, int cap_per_frame, int* n_out)
+static int ppn_launch(hp_ppn* p, int n, const float* const tensors[7], const int conf_shape[3], const int edge_shape[5], int on_device,
+    hipStream_t s)
 {
-    HP_REQUIRE(p && tensors && conf_shape && edge_shape && n_out, HP_ERR_INVALID, "hp_ppn_process_batch: null argument");
-    HP_REQUIRE(n >= 1 && n <= p->max_batch, HP_ERR_CAPACITY, "hp_ppn_process_batch: batch %d > max_batch %d", n, p->max_batch);
+    HP_REQUIRE(p && tensors && conf_shape && edge_shape, HP_ERR_INVALID, "hp_ppn: null argument");
+    HP_REQUIRE(n >= 1 && n <= p->max_batch, HP_ERR_CAPACITY, "hp_ppn: batch %d > max_batch %d", n, p->max_batch);
+    HP_REQUIRE(p->pending == 0, HP_ERR_STATE, "hp_ppn: a batch is already in flight, collect it first");
     ppn_geom g;
     g.K = conf_shape[0], g.gh = conf_shape[1], g.gw = conf_shape[2];
     g.E = edge_shape[0], g.nh = edge_shape[1], g.nw = edge_shape[2];
@@ -384,7 +394,7 @@ int hp_ppn_process_batch(hp_ppn* p, int n, const float* const tensors[7], const 
             const size_t per = t == 6 ? edge_b : map_b;
             if (p->in[t].bytes < per * p->max_batch)
                 HP_TRY(p->in[t].alloc(per * p->max_batch));
-            HP_HIP_TRY(hipMemcpyAsync(p->in[t].p, tensors[t], per * n, hipMemcpyHostToDevice, p->stream));
+            HP_HIP_TRY(hipMemcpyAsync(p->in[t].p, tensors[t], per * n, hipMemcpyHostToDevice, s));
             d[t] = p->in[t].as<float>();
         }
     }
@@ -392,48 +402,78 @@ int hp_ppn_process_batch(hp_ppn* p, int n, const float* const tensors[7], const 
     const size_t lds = ((size_t)PPN_K * g.gh * g.gw + (size_t)PPN_K * PPN_MAXB) * sizeof(ppn_box);
     HP_REQUIRE(lds <= 150 * 1024, HP_ERR_INVALID, "ppn: grid too large for the LDS work lists");
     HP_HIP_TRY(hipFuncSetAttribute((const void*)ppn_extract_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ppn_extract_kernel, dim3(n), dim3(256), lds, p->stream, d[0], d[2], d[3], d[4], d[5], d[6], g, p->hdr.as<int>(),
-        p->boxes.as<ppn_box>(), p->cands.as<ppn_cand>());
+    hipLaunchKernelGGL(ppn_extract_kernel, dim3(n), dim3(256), lds, s, d[0], d[2], d[3], d[4], d[5], d[6], g, p->h_hdr.as<int>(),
+        p->h_boxes.as<ppn_box>(), p->h_cands.as<ppn_cand>());
     HP_HIP_TRY(hipGetLastError());
-    HP_HIP_TRY(hipMemcpyAsync(p->h_hdr.p, p->hdr.p, (size_t)n * HDR * sizeof(int), hipMemcpyDeviceToHost, p->stream));
-    HP_HIP_TRY(hipStreamSynchronize(p->stream));
-    // only the used prefix of every fixed-capacity row crosses PCIe (2-D copies: width = longest list of the batch)
-    int max_b = 0, max_c = 0;
-    for (int f = 0; f < n; ++f) {
-        const int* hdr = p->h_hdr.as<int>() + (size_t)f * HDR;
-        for (int c = 0; c < PPN_K; ++c)
-            max_b = std::max(max_b, hdr[c]);
-        for (int l = 0; l < PPN_LIMBS; ++l)
-            max_c = std::max(max_c, hdr[PPN_K + l]);
+    HP_HIP_TRY(hipEventRecord(p->done, s));
+    p->pending = n;
+    p->K = g.K;
+    return HP_OK;
+}
+
+int hp_ppn_enqueue(hp_ppn* p, int n, const float* const dev_tensors[7], const int conf_shape[3], const int edge_shape[5], void* stream)
+{
+    return ppn_launch(p, n, dev_tensors, conf_shape, edge_shape, 1, stream ? (hipStream_t)stream : (p ? p->stream : nullptr));
+}
+
+namespace {
+struct ppn_job {
+    hp_ppn* p;
+    hp_human* out;
+    int cap;
+    int* n_out;
+    std::vector<int> rc;
+};
+void ppn_frame(int f, int, void* ctx)
+{
+    ppn_job& j = *static_cast<ppn_job*>(ctx);
+    hp_ppn* p = j.p;
+    const int* hdr = p->h_hdr.as<int>() + (size_t)f * HDR;
+    if (hdr[PPN_K + PPN_LIMBS] != 0) {
+        j.rc[f] = 1;
+        j.n_out[f] = 0;
+        return;
     }
-    if (max_b > 0)
-        HP_HIP_TRY(hipMemcpy2DAsync(p->h_boxes.p, PPN_MAXB * sizeof(ppn_box), p->boxes.p, PPN_MAXB * sizeof(ppn_box), (size_t)max_b * sizeof(ppn_box),
-            (size_t)n * PPN_K, hipMemcpyDeviceToHost, p->stream));
-    if (max_c > 0)
-        HP_HIP_TRY(hipMemcpy2DAsync(p->h_cands.p, PPN_MAXC * sizeof(ppn_cand), p->cands.p, PPN_MAXC * sizeof(ppn_cand), (size_t)max_c * sizeof(ppn_cand),
-            (size_t)n * PPN_LIMBS, hipMemcpyDeviceToHost, p->stream));
-    HP_HIP_TRY(hipStreamSynchronize(p->stream));
+    std::vector<hp_human> poses;
+    assemble_frame(hdr, p->h_boxes.as<ppn_box>() + (size_t)f * PPN_K * PPN_MAXB, p->h_cands.as<ppn_cand>() + (size_t)f * PPN_LIMBS * PPN_MAXC,
+        p->net_w, p->net_h, p->K, poses);
+    j.n_out[f] = (int)poses.size();
+    if ((int)poses.size() > j.cap)
+        j.rc[f] = 2;
+    if (j.out)
+        std::copy(poses.begin(), poses.begin() + std::min<size_t>(poses.size(), j.cap), j.out + (size_t)f * j.cap);
+}
+} // namespace
+
+int hp_ppn_collect(hp_ppn* p, hp_human* out, int cap_per_frame, int* n_out)
+{
+    HP_REQUIRE(p && n_out, HP_ERR_INVALID, "hp_ppn_collect: null argument");
+    HP_REQUIRE(p->pending > 0, HP_ERR_STATE, "hp_ppn_collect: nothing was enqueued");
+    const int n = p->pending;
+    p->pending = 0;
+    HP_HIP_TRY(hipEventSynchronize(p->done));
+    ppn_job job{ p, out, cap_per_frame, n_out, std::vector<int>(n, 0) };
+    hp::frame_pool::instance().run(n, ppn_frame, &job);
     int rc = HP_OK;
-    for (int f = 0; f < n; ++f) {
-        const int* hdr = p->h_hdr.as<int>() + (size_t)f * HDR;
-        if (hdr[PPN_K + PPN_LIMBS] != 0) {
-            hp::set_error("ppn: frame %d overflowed a device list (flags=%d: 1=survivors/class>%d, 2=candidates/limb>%d)", f, hdr[PPN_K + PPN_LIMBS], PPN_MAXB, PPN_MAXC);
+    for (int f = 0; f < n; ++f)
+        if (job.rc[f] == 1) {
+            const int* hdr = p->h_hdr.as<int>() + (size_t)f * HDR;
+            hp::set_error("ppn: frame %d overflowed a device list (flags=%d: 1=survivors/class>%d, 2=candidates/limb>%d)", f, hdr[PPN_K + PPN_LIMBS],
+                PPN_MAXB, PPN_MAXC);
             rc = HP_ERR_CAPACITY;
-            n_out[f] = 0;
-            continue;
-        }
-        std::vector<hp_human> poses;
-        assemble_frame(hdr, p->h_boxes.as<ppn_box>() + (size_t)f * PPN_K * PPN_MAXB, p->h_cands.as<ppn_cand>() + (size_t)f * PPN_LIMBS * PPN_MAXC,
-            p->net_w, p->net_h, g.K, poses);
-        n_out[f] = (int)poses.size();
-        if ((int)poses.size() > cap_per_frame) {
-            hp::set_error("ppn: frame %d has %zu humans, capacity %d", f, poses.size(), cap_per_frame);
+        } else if (job.rc[f] == 2) {
+            hp::set_error("ppn: frame %d has %d humans, capacity %d", f, n_out[f], cap_per_frame);
             rc = HP_ERR_CAPACITY;
         }
-        if (out)
-            std::copy(poses.begin(), poses.begin() + std::min<size_t>(poses.size(), cap_per_frame), out + (size_t)f * cap_per_frame);
-    }
     return rc;
+}
+
+int hp_ppn_process_batch(hp_ppn* p, int n, const float* const tensors[7], const int conf_shape[3], const int edge_shape[5],
+    int on_device, hp_human* out, int cap_per_frame, int* n_out)
+{
+    HP_REQUIRE(p && n_out, HP_ERR_INVALID, "hp_ppn_process_batch: null argument");
+    HP_TRY(ppn_launch(p, n, tensors, conf_shape, edge_shape, on_device, p->stream));
+    return hp_ppn_collect(p, out, cap_per_frame, n_out);
 }
 
 } // extern "C"

@@ -173,6 +173,20 @@ class PoseProposal:
     def process(self, tensors):
         return self.process_batch([np.asarray(t)[None] for t in tensors])[0]
 
+    def enqueue(self, dev_tensors, n: int, conf_shape, edge_shape, stream=None):
+        """Asynchronous half: launch on ``stream`` (None = the parser's own stream) and return at once."""
+        ptrs = (C.c_void_p * 7)(*[as_ptr(t).value for t in dev_tensors])
+        cs, es = (C.c_int * 3)(*conf_shape), (C.c_int * 5)(*edge_shape)
+        check(lib().hp_ppn_enqueue(self._h, n, ptrs, cs, es, C.c_void_p(stream) if stream else None))
+        self._pending = n
+
+    def collect(self):
+        n = self._pending
+        check(lib().hp_ppn_collect(self._h, self._out, self.cap, self._n))
+        self._pending = 0
+        arr = np.frombuffer(self._out, dtype=HUMAN_DTYPE)
+        return [arr[f * self.cap: f * self.cap + self._n[f]].copy() for f in range(n)]
+
 
 class PifPaf:
     """``hyperpose::parser::pifpaf(h, w, thresh=0.1)`` (reference include/hyperpose/operator/parser/pifpaf.hpp:8-26).
@@ -210,3 +224,14 @@ class PifPaf:
 
     def process(self, paf, pif):
         return self.process_batch(np.asarray(paf)[None], np.asarray(pif)[None])[0]
+
+    def enqueue(self, dev_paf, dev_pif, n: int, fh: int, fw: int, stream=None):
+        check(lib().hp_pifpaf_enqueue(self._h, n, as_ptr(dev_paf), as_ptr(dev_pif), fh, fw, C.c_void_p(stream) if stream else None))
+        self._pending = n
+
+    def collect(self):
+        n = self._pending
+        check(lib().hp_pifpaf_collect(self._h, self._out, self.cap, self._n))
+        self._pending = 0
+        arr = np.frombuffer(self._out, dtype=HUMAN_DTYPE)
+        return [arr[f * self.cap: f * self.cap + self._n[f]].copy() for f in range(n)]

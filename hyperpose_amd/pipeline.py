@@ -10,10 +10,20 @@ from ._lib import HUMAN_DTYPE, Human, check, lib
 from .engine import EngineDesc, Layer, OutputDesc
 
 
+class ParserDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("thresh", C.c_float * 3), ("res_w", C.c_int32), ("res_h", C.c_int32)]
+
+
+PARSER_PAF, PARSER_PPN, PARSER_PIFPAF = 0, 1, 2
+
+
 class Pipeline:
+    """``parser`` selects the hyperpose::parser the stream ends in: "paf" (conf_thresh, paf_thresh), "ppn" (thresholds =
+    (point, limb, nms), default 0.10 / 0.05 / 0.3) or "pifpaf" (thresholds = (thresh,), default 0.1)."""
+
     def __init__(self, model, weights: np.ndarray, max_batch: int = 8, n_pipes: int = 4, keep_ratio: bool = False,
                  conf_thresh: float = 0.05, paf_thresh: float = 0.05, max_frame_wh=(1920, 1080), factor: float = 1.0 / 255,
-                 flip_rgb: bool = True, cap_per_frame: int = 128):
+                 flip_rgb: bool = True, cap_per_frame: int = 128, parser: str = "paf", thresholds=None):
         self._h = C.c_void_p()
         weights = np.ascontiguousarray(weights, np.float32)
         larr = (Layer * len(model.layers))(*model.layers)
@@ -21,8 +31,13 @@ class Pipeline:
         d = EngineDesc(model.in_w, model.in_h, max_batch, factor, int(flip_rgb), (C.c_float * 3)(*model.mean),
                        (C.c_float * 3)(*model.inv_std), larr, len(model.layers), oarr, len(model.outputs),
                        weights.ctypes.data_as(C.POINTER(C.c_float)), weights.size)
-        check(lib().hp_pipeline_create(C.byref(self._h), C.byref(d), n_pipes, int(keep_ratio), C.c_float(conf_thresh),
-                                       C.c_float(paf_thresh), C.c_size_t(max_frame_wh[0] * max_frame_wh[1] * 3)))
+        kind = {"paf": PARSER_PAF, "ppn": PARSER_PPN, "pifpaf": PARSER_PIFPAF}[parser]
+        th = thresholds if thresholds is not None else {PARSER_PAF: (conf_thresh, paf_thresh, 0.0), PARSER_PPN: (0.10, 0.05, 0.3),
+                                                        PARSER_PIFPAF: (0.1, 0.0, 0.0)}[kind]
+        th = tuple(th) + (0.0,) * (3 - len(th))
+        pd = ParserDesc(kind, (C.c_float * 3)(*th), -1, -1)
+        check(lib().hp_pipeline_create_ex(C.byref(self._h), C.byref(d), C.byref(pd), n_pipes, int(keep_ratio),
+                                          C.c_size_t(max_frame_wh[0] * max_frame_wh[1] * 3)))
         self.max_batch, self.n_pipes, self.cap = max_batch, n_pipes, cap_per_frame
         self._out = (Human * (max_batch * cap_per_frame))()
         self._n = (C.c_int * max_batch)()

@@ -146,6 +146,12 @@ int hp_ppn_set_thresholds(hp_ppn* p, float point_thresh, float limb_thresh, floa
  * {E,nh,nw,gh,gw}; on_device != 0: device pointers.  out: host [n*cap_per_frame]; n_out: host [n]. */
 int hp_ppn_process_batch(hp_ppn* p, int n, const float* const tensors[7], const int conf_shape[3], const int edge_shape[5],
                          int on_device, hp_human* out, int cap_per_frame, int* n_out);
+/* Asynchronous halves (same contract as hp_paf_enqueue / hp_paf_collect): enqueue launches the extraction kernel on `stream`
+ * (NULL = the parser's own), which writes its compacted lists straight into pinned host memory, and returns at once; collect waits
+ * for that batch and runs the order-dependent tail of its frames on the library's host worker pool. */
+void* hp_ppn_stream(hp_ppn* p);
+int hp_ppn_enqueue(hp_ppn* p, int n, const float* const dev_tensors[7], const int conf_shape[3], const int edge_shape[5], void* stream);
+int hp_ppn_collect(hp_ppn* p, hp_human* out, int cap_per_frame, int* n_out);
 
 /* ---- hyperpose::parser::pifpaf (include/hyperpose/operator/parser/pifpaf.hpp:8-26, src/pifpaf.cpp,
  * src/pifpaf_decoder/openpifpaf_postprocessor.cpp).  GPU: PIF cell compaction, seed and CAF scoring with the
@@ -157,6 +163,11 @@ void hp_pifpaf_destroy(hp_pifpaf* p);
 /* pifpaf::process(paf, pif) (src/pifpaf.cpp:7 — the .cpp argument order): paf [n,19,9,fh,fw], pif [n,17,5,fh,fw]. */
 int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* pif, int fh, int fw, int on_device,
                             hp_human* out, int cap_per_frame, int* n_out);
+/* Asynchronous halves: enqueue = the five kernels + the packed lists written into pinned host memory, on `stream` (NULL = the
+ * parser's own); collect = wait + grow / soft-NMS of every frame on the host worker pool. */
+void* hp_pifpaf_stream(hp_pifpaf* p);
+int hp_pifpaf_enqueue(hp_pifpaf* p, int n, const float* dev_paf, const float* dev_pif, int fh, int fw, void* stream);
+int hp_pifpaf_collect(hp_pifpaf* p, hp_human* out, int cap_per_frame, int* n_out);
 
 /* ---- hyperpose::dnn engine: replaces dnn::tensorrt (include/hyperpose/operator/dnn/tensorrt.hpp:33-141,
  * src/tensorrt.cpp).  The network is a static list of layers over numbered tensors (tensor 0 = the input
@@ -297,6 +308,19 @@ int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batc
  * (hp_malloc_host) are copied from where they lie, others through a pinned staging buffer.  The network must have the two PAF
  * outputs (conf, paf).  max_frame_bytes bounds width*height*3 of a submitted frame. */
 typedef struct hp_pipeline hp_pipeline;
+/* which hyperpose::parser the pipeline ends in, with that parser's constructor arguments:
+ *   HP_PARSER_PAF     thresh = {conf_thresh, paf_thresh}, res_w / res_h = resolution_size (-1 = default)     paf.hpp:27
+ *   HP_PARSER_PPN     thresh = {point_thresh, limb_thresh, nms_thresh}; net_resolution = the engine's input size   proposal_network.hpp:26
+ *   HP_PARSER_PIFPAF  thresh = {thresh}; (h, w) = the engine's input size                                    pifpaf.hpp:10 */
+enum { HP_PARSER_PAF = 0, HP_PARSER_PPN = 1, HP_PARSER_PIFPAF = 2 };
+typedef struct hp_parser_desc {
+    int32_t kind;
+    float thresh[3];
+    int32_t res_w, res_h;
+} hp_parser_desc;
+int hp_pipeline_create_ex(hp_pipeline** out, const hp_engine_desc* desc, const hp_parser_desc* parser, int n_pipes, int keep_ratio,
+                          size_t max_frame_bytes);
+/* the PAF form of hp_pipeline_create_ex */
 int hp_pipeline_create(hp_pipeline** out, const hp_engine_desc* desc, int n_pipes, int keep_ratio, float conf_thresh,
                        float paf_thresh, size_t max_frame_bytes);
 void hp_pipeline_destroy(hp_pipeline* p);
