@@ -1,32 +1,47 @@
 #!/usr/bin/env python
 """bench.py — end-to-end FPS of the hot path on N MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4}] [--scaling {weak,strong}] [--extra 2,3,4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch: BASELINE config 1, Lightweight-OpenPose (MobilenetDilated
-backbone) + PAF parser, batch 8 @ 368x432 per GPU:
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N ranks
+(one process per GPU, RCCL) and prints the ranks' ONE JSON line; under an external launcher it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* as usual.
+
+One "step" = one pass of the hot path over one batch.  The headline (`value`) is BASELINE.json configs[1]:
+Lightweight-OpenPose (MobilenetDilated backbone) + PAF parser, batch 8 @ 368x432 per GPU:
     u8 HWC frames already resident in HBM -> (pre-processing fused into the first conv) -> conv stack on MFMA
-    -> conf/paf fp32 maps in HBM -> PAF parser kernels -> hp_human lists copied back to pinned host memory.
-Frames shard over GPUs (weak scaling: every rank processes its own batch of 8 per step); the only collective is
-the one-time RCCL broadcast of the weight blob from rank 0 (outside the timed region).  Timing: W untimed steps
-(followed by 0.3 s of the same loop, also untimed, so that the clocks have settled whatever W is), then exactly K
-steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks, rank 0 prints ONE JSON line.
+    -> conf/paf fp32 maps in HBM -> PAF parser kernels -> hp_human lists written to pinned host memory.
+Frames shard over GPUs with no steady-state collective; the only collective is the one-time RCCL broadcast of the weight
+blob from rank 0 (outside the timed region).  `--scaling weak` (default): every rank processes its own full batch per
+step; `--scaling strong`: the configuration's global batch is split contiguously over the ranks (32 -> 4,
+64 -> 8 frames per GPU).  Timing: W untimed steps (followed by 0.3 s of the same loop, also untimed, so that the clocks
+have settled whatever W is), then exactly K steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks, rank 0
+prints ONE JSON line.
 
-Parser input: the network has synthetic (random) weights, so its own heat-maps contain no people.  The headline
-`value` therefore runs the FULL conv stack AND parses seeded synthetic heat-maps with 1-16 people per frame that
-are resident in HBM ("injected" mode: strictly more parser work, nothing skipped); the same loop parsing the
-network's own output is reported as `fps_dnn_output`.
+The other BASELINE configurations are measured the same way and reported under `workloads` in the same line
+(`--extra`, default 2,3,4 at N = 1 and 3,4 strong-scaled at N > 1): configs[2] OpenPose-VGG19 + PAF, batch 16 @ 432x768;
+configs[3] PoseProposal ResNet-50 + NMS decoder, batch 32 @ 384x384; configs[4] OpenPifPaf ResNet-50 + seed/grow
+decoder, batch 64 @ 385x385 - each with its own `roofline` and (N = 1) `cpu_baseline`.
 
-Extra objects: `roofline` for the dominant kernel (MFMA implicit-GEMM conv; per-layer HIP-event timing on the
-engine stream) and `cpu_baseline` (the restated reference PAF parser on this box's host cores, rank 0, N=1).
+Parser input: the networks have synthetic (random) weights, so their own heat-maps contain no people.  Every timed step
+runs the FULL conv stack AND parses seeded synthetic heat-maps with several people per frame that are resident in HBM
+("injected": strictly more parser work, nothing skipped); the same loop parsing the network's own output is reported as
+`fps_dnn_output`.
+
+Extra objects: `roofline` for the dominant kernel (per-launch timestamps in schedule order), `cpu_baseline` (the
+reference's CPU parser on this box's host cores, rank 0, N = 1), `h2d_inclusive` (the same step with network-sized u8
+frames starting in pinned HOST memory - the PCIe-inclusive rate, never `value`) and `from_host` (1280x720 camera frames
+through the GPU letterbox).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,58 +50,115 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH = 8
-IN_H, IN_W = 368, 432
-ARCH = "lw_openpose_mobilenet"
 PEAK_F16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 # Independent engine+parser instances per GPU, one HIP stream each, batches round-robin over them.  Throughput depends
-# on how those streams land on the runtime's 4 hardware queues (measured on MI355X, tools/queue_probe.py, us/batch):
+# on how those streams land on the runtime's hardware queues (measured on MI355X, tools/queue_probe.py, us/batch, config 1):
 # 4 pipes on 2 queues (2+2) 606-617 | 3 pipes on 3 queues 657-667 | 6 pipes on 2 queues 668 | 4 pipes on 4 queues 790-820
 # | 4 pipes on 1 queue 1030.  ROCm hands out hardware queues round-robin per created stream; every Pipe below creates an
-# engine stream and then a (spare) parser stream, which puts the four engine streams on queues 0,2,0,2.
-PIPES = 4
+# engine stream and then a parser stream, which puts the engine streams on alternating queues.
+CONFIGS = {
+    1: dict(label="configs[1]: Lightweight-OpenPose (MobilenetDilated) + PAF parser, batch 8 @ 368x432", arch="lw_openpose_mobilenet",
+            w=432, h=368, batch=8, parser="paf", pipes=4, seed=20241, steps=400, people=(1, 2, 4, 8, 16, 3, 5, 6)),
+    2: dict(label="configs[2]: OpenPose-COCO (VGG19) + PAF parser, batch 16 @ 432x768", arch="openpose_vgg19",
+            w=768, h=432, batch=16, parser="paf", pipes=2, seed=20242, steps=24, people=(2, 4, 8, 16)),
+    3: dict(label="configs[3]: PoseProposal ResNet-50 + NMS decoder, batch 32 @ 384x384", arch="pose_proposal_resnet50",
+            w=384, h=384, batch=32, parser="ppn", pipes=2, seed=20243, steps=60, people=(1, 2, 3, 4)),
+    4: dict(label="configs[4]: OpenPifPaf ResNet-50 + pif/paf seed-grow decoder, batch 64 @ 385x385", arch="pifpaf_resnet50",
+            w=385, h=385, batch=64, parser="pifpaf", pipes=2, seed=20244, steps=16, people=(1, 2, 3, 4)),
+}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps of the headline workload (default: per config)")
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--pipes", type=int, default=PIPES)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="headline workload (BASELINE.json configs index)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--extra", default=None, help="comma-separated configs also measured and reported under `workloads` ('' = none)")
+    ap.add_argument("--pipes", type=int, default=0, help="engine+parser pairs per GPU (0 = per config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
     ap.add_argument("--no-dnn-output", action="store_true", help="skip the second timed phase (parser fed by the network's own heat-maps)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ multi-GPU launch
+def respawn(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run N ranks of this file under torch.distributed.run (RCCL over xGMI,
+    rendezvous on 127.0.0.1) and hand their stdout (rank 0's JSON line) through."""
+    from hyperpose_amd import _lib
+    have = _lib.lib().hp_device_count()
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but only {max(have, 0)} HIP device(s) are visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def rank_plan(cfg_batch: int, scaling: str, rank: int, world: int):
+    """(frames this rank processes per step, global frames per step).  weak: every rank its own full batch; strong: the
+    configuration's batch split contiguously (hyperpose_amd.dist.shard)."""
+    from hyperpose_amd import dist as hd
+    if scaling == "strong":
+        _, cnt = hd.shard(cfg_batch, rank, world)
+        return cnt, cfg_batch
+    return cfg_batch, cfg_batch * world
+
+
+# ------------------------------------------------------------------------------------------------ one workload
 class Pipe:
     """engine + parser sharing one stream; at most one batch in flight per pipe."""
 
-    def __init__(self, model, weights, conf_dev, paf_dev):
+    def __init__(self, cfg, model, weights, injected, batch):
         from hyperpose_amd.engine import Engine
-        from hyperpose_amd.parser import Paf
-        self.eng = Engine.from_model(model, weights, max_batch=BATCH)
-        self.paf = Paf(max_batch=BATCH)
+        from hyperpose_amd import parser as P
+        self.kind, self.batch = cfg["parser"], batch
+        self.eng = Engine.from_model(model, weights, max_batch=batch)
         self.stream = self.eng.stream
-        self.conf_dev, self.paf_dev = conf_dev, paf_dev
+        outs = self.eng.outputs  # sorted by name = the parsers' argument order
+        if self.kind == "paf":
+            self.par = P.Paf(max_batch=batch)
+            (_, self.s0, d0), (_, self.s1, d1) = outs
+            self.dnn = (d0, d1)
+        elif self.kind == "ppn":
+            self.par = P.PoseProposal((cfg["w"], cfg["h"]), max_batch=batch)
+            self.dnn = [d for _, _, d in outs]
+            self.s0 = outs[0][1]
+            e = outs[6][1]
+            nn = int(round((e[0] // 17) ** 0.5))
+            self.s1 = (17, nn, nn, e[1], e[2])
+        else:
+            self.par = P.PifPaf(cfg["h"], cfg["w"], max_batch=batch)
+            self.dnn = (outs[0][2], outs[1][2])
+            self.s0 = outs[1][1]  # pif [85, fh, fw]
+        self.inj = injected
         self.busy = False
-        outs = {n: (s, p) for n, s, p in self.eng.outputs}
-        self.conf_shape, self.dnn_conf = outs["conf"]
-        self.paf_shape, self.dnn_paf = outs["paf"]
 
     def submit(self, frames_dev, injected: bool):
-        self.eng.enqueue_u8(frames_dev, BATCH)
-        if injected:
-            self.paf.enqueue(self.conf_dev, self.paf_dev, BATCH, self.conf_shape, self.paf_shape, stream=self.stream)
+        n = self.batch
+        self.eng.enqueue_u8(frames_dev, n)
+        src = self.inj if injected else self.dnn
+        if self.kind == "paf":
+            self.par.enqueue(src[0], src[1], n, self.s0, self.s1, stream=self.stream)
+        elif self.kind == "ppn":
+            self.par.enqueue(src, n, self.s0, self.s1, stream=self.stream)
         else:
-            self.paf.enqueue(self.dnn_conf, self.dnn_paf, BATCH, self.conf_shape, self.paf_shape, stream=self.stream)
+            self.par.enqueue(src[0], src[1], n, self.s0[1], self.s0[2], stream=self.stream)
         self.busy = True
 
     def collect(self):
         if not self.busy:
             return 0
-        humans = self.paf.collect()
+        humans = self.par.collect()
         self.busy = False
         return sum(len(h) for h in humans)
 
@@ -102,33 +174,67 @@ def run_loop(pipes, frames_dev, steps, injected):
     return n_humans
 
 
-def cpu_baseline(conf, paf, budget_s=12.0):
-    """The restated reference PAF parser (oracle/, reference shipping flags -Ofast) on this host's cores:
-    the reference's own parallel model = one parser replica per pool thread, frames round-robin
-    (include/hyperpose/utility/thread_pool.hpp:21, stream.hpp:139-144)."""
+def synth_inputs(cfg, batch, rank):
+    """Per-rank seeded synthetic inputs of one workload: u8 frames + the parser's injected tensors (host numpy)."""
+    from hyperpose_amd import synth
+    idx = [k for k, v in CONFIGS.items() if v is cfg][0]
+    rng = synth.rng_for(idx, salt=rank)
+    frames = synth.images_u8(rng, batch, cfg["h"], cfg["w"])
+    if cfg["parser"] == "paf":
+        conf, paf, _ = synth.paf_maps(rng, batch, cfg["h"] // 8, cfg["w"] // 8, people=cfg["people"])
+        maps = [conf, paf]
+    elif cfg["parser"] == "ppn":
+        maps = synth.ppn_maps(rng, batch, net=cfg["w"], grid=cfg["w"] // 32, people=cfg["people"])
+    else:
+        f = (cfg["w"] - 1) // 8 + 1
+        maps = list(synth.pifpaf_maps(rng, batch, f, f, people=cfg["people"]))
+    return frames, maps
+
+
+def cpu_baseline(cfg, maps, budget_s=8.0):
+    """The reference's CPU parser on this host's cores with the reference's shipping flags (-Ofast) and its own parallel
+    model: one parser replica per pool thread, frames round-robin (include/hyperpose/utility/thread_pool.hpp:21,
+    stream.hpp:139-144).  PAF = the restated parser ("port": src/paf.cpp needs OpenCV / stdtensor, absent here);
+    PoseProposal / PifPaf = the reference's own sources compiled in oracle/_ref ("reference")."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import loader
     ncpu = os.cpu_count() or 1
-    threads = min(14, ncpu + 2, max(1, ncpu))
-    loader.paf_process(conf[0], paf[0], fast=True)  # warm / build
+    threads = max(1, min(14, ncpu + 2, ncpu))
+    kind = cfg["parser"]
+    nb = maps[0].shape[0]
+    if kind == "paf":
+        def one(i):
+            return len(loader.paf_process(maps[0][i], maps[1][i], fast=True)[0])
+        what, tag = "restated reference PAF parser (no OpenCV SIMD), -Ofast -march=x86-64-v3", "port"
+    elif kind == "ppn":
+        if loader.ref_lib(fast=True) is None:
+            return None
+        def one(i):
+            return len(loader.ref_ppn_process([m[i] for m in maps], net_w=cfg["w"], net_h=cfg["h"], fast=True))
+        what, tag = "reference src/pose_proposal.cpp compiled in oracle/_ref, -Ofast", "reference"
+    else:
+        if loader.ref_lib(fast=True) is None:
+            return None
+        def one(i):
+            return len(loader.ref_pifpaf_process(maps[0][i], maps[1][i], net_h=cfg["h"], net_w=cfg["w"], fast=True))
+        what, tag = "reference src/pifpaf.cpp + src/pifpaf_decoder compiled in oracle/_ref, -Ofast", "reference"
+    one(0)  # warm / build
     t0 = time.perf_counter()
-    loader.paf_process(conf[0], paf[0], fast=True)
-    one = time.perf_counter() - t0
-    frames = int(max(threads * 2, min(400, budget_s / max(one, 1e-4) * threads)))
-    idx = [i % conf.shape[0] for i in range(frames)]
+    one(0)
+    lat = time.perf_counter() - t0
+    frames = int(max(threads * 2, min(400, budget_s / max(lat, 1e-4) * threads)))
+    idx = [i % nb for i in range(frames)]
     with ThreadPoolExecutor(threads) as ex:
         t0 = time.perf_counter()
-        list(ex.map(lambda i: len(loader.paf_process(conf[i], paf[i], fast=True)[0]), idx))
+        list(ex.map(one, idx))
         dt = time.perf_counter() - t0
-    return {"value": round(frames / dt, 2), "unit": "frames/s (PAF parse only; the reference's DNN stage is TensorRT and has no CPU path)",
-            "cores": threads, "kind": "port",
-            "sample": f"{frames} injected 46x54 heat-map frames (the bench's 8 frames cycled), {threads} threads, "
-                      f"single-thread latency {one * 1e3:.1f} ms/frame, restated reference (no OpenCV SIMD), -Ofast -march=x86-64-v3"}
+    return {"value": round(frames / dt, 2), "unit": "frames/s (parser only; the reference's DNN stage is TensorRT and has no CPU path)",
+            "cores": threads, "host_cores": ncpu, "kind": tag,
+            "sample": f"{frames} injected heat-map frames of this workload (its {nb} frames cycled), {threads} threads on a host with "
+                      f"{ncpu} logical cores, single-thread latency {lat * 1e3:.2f} ms/frame, {what}"}
 
 
-def from_host(model, weights, steps=160, frame_wh=(1280, 720)):
-    """PCIe-inclusive variant (NOT `value`): frames start in pinned HOST memory at camera size; per batch one H2D copy,
-    non_scaling_resize on the device, conv stack, parser, resume_ratio - hp_pipeline_*, the GPU form of hyperpose::stream."""
+def _host_pipeline_rate(model, weights, cfg, batch, pipes, steps, frame_wh, keep_ratio):
     import ctypes as C
 
     from hyperpose_amd import _lib
@@ -137,46 +243,99 @@ def from_host(model, weights, steps=160, frame_wh=(1280, 720)):
     nbytes = w_ * h_ * 3
     lib = _lib.lib()
     host = C.c_void_p()
-    _lib.check(lib.hp_malloc_host(C.byref(host), C.c_size_t(nbytes * BATCH)))
-    rng = np.random.default_rng(7)
-    src = rng.integers(0, 256, nbytes * BATCH, dtype=np.uint8)
+    _lib.check(lib.hp_malloc_host(C.byref(host), C.c_size_t(nbytes * batch)))
+    src = np.random.default_rng(7).integers(0, 256, nbytes * batch, dtype=np.uint8)
     C.memmove(host, src.ctypes.data, src.nbytes)
-    ptrs = (C.POINTER(C.c_uint8) * BATCH)(*[C.cast(host.value + i * nbytes, C.POINTER(C.c_uint8)) for i in range(BATCH)])
-    ws, hs = (C.c_int * BATCH)(*([w_] * BATCH)), (C.c_int * BATCH)(*([h_] * BATCH))
-    pl = Pipeline(model, weights, max_batch=BATCH, n_pipes=PIPES, keep_ratio=True, max_frame_wh=frame_wh)
+    ptrs = (C.POINTER(C.c_uint8) * batch)(*[C.cast(host.value + i * nbytes, C.POINTER(C.c_uint8)) for i in range(batch)])
+    ws, hs = (C.c_int * batch)(*([w_] * batch)), (C.c_int * batch)(*([h_] * batch))
+    pl = Pipeline(model, weights, max_batch=batch, n_pipes=pipes, keep_ratio=keep_ratio, max_frame_wh=frame_wh, parser=cfg["parser"])
 
     def loop(n):
         for _ in range(n):
             if pl.in_flight == pl.n_pipes:
                 pl.collect()
-            pl.submit_ptrs(ptrs, ws, hs, BATCH)
+            pl.submit_ptrs(ptrs, ws, hs, batch)
         while pl.in_flight:
             pl.collect()
 
-    loop(24)
+    loop(max(8, steps // 8))
     t0 = time.perf_counter()
     loop(steps)
     dt = time.perf_counter() - t0
     pl.close()
     lib.hp_free_host(host)
-    return {"value": round(BATCH * steps / dt, 1), "unit": "frames/s", "steps": steps,
-            "what": f"{w_}x{h_} BGR frames in pinned host memory -> H2D ({nbytes * BATCH / 1e6:.1f} MB per batch) -> "
-                    "non_scaling_resize on the GPU -> conv stack -> PAF parser (the network's own heat-maps) -> resume_ratio -> humans on the host"}
+    return batch * steps / dt, nbytes * batch
 
 
-def roofline(pipe):
-    """Per-launch HIP-event timing on the engine stream, the schedule run in order with an event between consecutive
-    launches (hp_engine_profile_sequence: every kernel sees the cache state of a real inference, which is what
-    rocprofv3's per-kernel averages over this bench see too).  achieved = algorithmic FLOPs of the dominant kernel's
-    launches / their summed duration.  `back_to_back_us` is the same kernel re-launched 20 times in a row (weights warm
-    in L2) for comparison."""
-    prof = pipe.eng.profile(BATCH, iters=20, in_sequence=True)
-    warm = pipe.eng.profile(BATCH, iters=20)
+def h2d_inclusive(model, weights, cfg, batch, pipes, steps):
+    """SURVEY.md 8d / BASELINE.md 4.5: the same step with the u8 frames starting in pinned HOST memory at network size (one H2D copy
+    per batch straight into the network's input buffer, then conv stack + parser on the network's own heat-maps, humans back on the
+    host) - hp_pipeline_*.  PCIe-inclusive, therefore NOT `value`."""
+    fps, nb = _host_pipeline_rate(model, weights, cfg, batch, pipes, steps, (cfg["w"], cfg["h"]), False)
+    return {"value": round(fps, 1), "unit": "frames/s", "steps": steps,
+            "what": f"network-sized {cfg['w']}x{cfg['h']} u8 BGR frames in pinned host memory -> ONE H2D copy per batch ({nb / 1e6:.2f} MB) -> conv stack -> "
+                    "parser (the network's own heat-maps) -> humans on the host; compare with fps_dnn_output (same work, frames resident)"}
+
+
+def from_host(model, weights, cfg, batch, pipes, steps=120, frame_wh=(1280, 720)):
+    """Camera-sized frames: per batch H2D copies, non_scaling_resize on the device, conv stack, parser, resume_ratio - the GPU form of
+    hyperpose::stream (NOT `value`)."""
+    fps, nb = _host_pipeline_rate(model, weights, cfg, batch, pipes, steps, frame_wh, True)
+    return {"value": round(fps, 1), "unit": "frames/s", "steps": steps,
+            "what": f"{frame_wh[0]}x{frame_wh[1]} BGR frames in pinned host memory -> H2D ({nb / 1e6:.1f} MB per batch) -> "
+                    "non_scaling_resize on the GPU -> conv stack -> parser (the network's own heat-maps) -> resume_ratio -> humans on the host"}
+
+
+def kernel_label(tile: int):
+    """(substring of the kernel symbol as rocprofv3 prints it, human-readable label) for a profile row's `tile` code."""
+    halo = {3064192: (64, 16, 12), 3128128: (128, 8, 16)}
+    sep = {1: (1, 12, 16, 24, 1, 1, 32), 2: (1, 6, 8, 24, 2, 1, 32), 3: (2, 3, 8, 12, 2, 1, 64), 4: (2, 3, 8, 12, 1, 1, 64),
+           5: (4, 3, 8, 12, 1, 1, 64), 6: (4, 3, 8, 12, 1, 2, 64)}
+    if tile >= 6000000:
+        v = tile - 6000000
+        cin, taps = v // 1000, v % 1000
+        return (f"conv_direct_kernel<{cin}", f"conv_direct_kernel<CIN={cin}> ({taps} taps; input halo tile in LDS, weights in MFMA-fragment order straight from L2)")
+    if 5100000 <= tile < 5200000:
+        return ("conv1x1_small_kernel", "conv1x1_small_kernel (64 pixels x all input channels in LDS, fragment-ordered weights from L2)")
+    if tile >= 5000000:
+        return ("conv3x3_direct_kernel<128,", "conv3x3_direct_kernel<CIN=128> (64 cout x 16x12 px tile, input halo tile in LDS, weights in MFMA-fragment order straight from L2)")
+    if tile >= 4000000:
+        key = "sepconv_kernel<%d,%d,%d,%d,%d,%d,%d" % sep.get(tile - 4000000, (0,) * 7)
+        return (key, key + "> (fused depthwise 3x3 + pointwise 1x1)")
+    if tile >= 3000000:
+        bm, th, tw = halo.get(tile, (0, 0, 0))
+        return (f"conv3x3_halo_kernel<128,{bm},{th},{tw},", f"conv3x3_halo_kernel<CIN=128> ({bm} cout x {th}x{tw} px tile, input halo tile resident in LDS)")
+    return (f"conv_mfma_kernel<{tile // 1000},{tile % 1000},", f"conv_mfma_kernel<BM={tile // 1000},BN={tile % 1000}> (implicit GEMM, A and B staged through LDS)")
+
+
+def pmc_traffic(symbol_key: str, tag: str):
+    """HBM bytes per launch of the kernel from the committed rocprofv3 PMC passes (profiles/<round>_pmc_traffic*.json):
+    newest round first; kernel names compared with blanks removed."""
+    import glob
+    want = symbol_key.replace(" ", "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{tag}.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))["kernels"]
+        except (OSError, KeyError, ValueError):
+            continue
+        for name, d in pmc.items():
+            if want in name.replace(" ", "") and "hbm_bytes_per_launch" in d:
+                return round(d["hbm_bytes_per_launch"]), os.path.basename(path)
+    return None, None
+
+
+def roofline(pipe, batch, cfg_index):
+    """Per-launch timestamps on the engine stream with the schedule run in order (hp_engine_profile_sequence: every kernel sees the
+    cache state of a real inference, which is what rocprofv3's per-kernel averages over this bench see too).  achieved = algorithmic
+    FLOPs of the dominant kernel's launches / their summed duration.  `back_to_back_us` is the same kernel re-launched 20 times in a
+    row (weights warm in L2) for comparison."""
+    iters = 20 if cfg_index == 1 else 4
+    prof = pipe.eng.profile(batch, iters=iters, in_sequence=True)
+    warm = pipe.eng.profile(batch, iters=iters) if cfg_index == 1 else None
     mfma = [p for p in prof if p["tile"] != 0]
     by_tile = {}
     for p in mfma:
-        k = p["tile"]
-        d = by_tile.setdefault(k, {"ms": 0.0, "flops": 0.0, "n": 0})
+        d = by_tile.setdefault(p["tile"], {"ms": 0.0, "flops": 0.0, "n": 0})
         d["ms"] += p["ms"]
         d["flops"] += p["flops"]
         d["n"] += 1
@@ -185,59 +344,106 @@ def roofline(pipe):
     mfma_ms = sum(p["ms"] for p in mfma)
     mfma_fl = sum(p["flops"] for p in mfma)
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/)
-    halo = {3064192: (64, 16, 12), 3128128: (128, 8, 16)}
-    sep = {1: (1, 12, 16, 24, 1, 1, 32), 2: (1, 6, 8, 24, 2, 1, 32), 3: (2, 3, 8, 12, 2, 1, 64), 4: (2, 3, 8, 12, 1, 1, 64),
-           5: (4, 3, 8, 12, 1, 1, 64), 6: (4, 3, 8, 12, 1, 2, 64)}
-    if 5100000 <= dom_tile < 5200000:
-        key = "conv1x1_small_kernel"
-        label = "conv1x1_small_kernel (64 pixels x all input channels in LDS, fragment-ordered weights from L2)"
-    elif dom_tile >= 5000000:
-        key = "conv3x3_direct_kernel<128>"
-        label = "conv3x3_direct_kernel<CIN=128> (64 cout x 16x12 px tile, input halo tile in LDS, weights in MFMA-fragment order straight from L2)"
-    elif dom_tile >= 4000000:
-        key = "sepconv_kernel<%d, %d, %d, %d, %d, %d, %d>" % sep[dom_tile - 4000000]
-        label = key + " (fused depthwise 3x3 + pointwise 1x1)"
-    elif dom_tile >= 3000000:
-        bm, th, tw = halo[dom_tile]
-        key = f"conv3x3_halo_kernel<128, {bm}, {th}, {tw}, 1, 64, 0>"
-        label = f"conv3x3_halo_kernel<CIN=128> ({bm} cout x {th}x{tw} px tile, input halo tile resident in LDS)"
-    else:
-        key = f"conv_mfma_kernel<{dom_tile // 1000}, {dom_tile % 1000}, 64, 0>"
-        label = f"conv_mfma_kernel<BM={dom_tile // 1000},BN={dom_tile % 1000}> (implicit GEMM)"
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        for name, d in pmc.items():
-            if key in name and "hbm_bytes_per_launch" in d:
-                traffic = round(d["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        pass
-    return {
+    key, label = kernel_label(dom_tile)
+    traffic, src = pmc_traffic(key, "" if cfg_index == 1 else f"_config{cfg_index}")
+    out = {
         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+        "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
         "kernel": label,
         "launches_per_step": dom["n"], "avg_launch_us": round(dom["ms"] / dom["n"] * 1e3, 2),
-        "back_to_back_us": round(sum(p["ms"] for p in warm if p["tile"] == dom_tile) / dom["n"] * 1e3, 2),
         "flops_per_launch": round(dom["flops"] / dom["n"]),
-        "all_mfma_convs": {"achieved": round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2), "ms_per_step": round(mfma_ms, 4),
-                           "launches_per_step": len(mfma)},
+        "all_mfma_convs": {"achieved": round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2), "frac": round(mfma_fl / (mfma_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+                           "ms_per_step": round(mfma_ms, 4), "launches_per_step": len(mfma)},
         "serial_layer_ms_per_step": round(tot_ms, 4),
         "non_mfma_ms_per_step": round(tot_ms - mfma_ms, 4),
     }
+    if warm is not None:
+        out["back_to_back_us"] = round(sum(p["ms"] for p in warm if p["tile"] == dom_tile) / dom["n"] * 1e3, 2)
+    return out
+
+
+def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline):
+    """Time one BASELINE configuration; returns the dict of its numbers (identical on every rank where it matters)."""
+    import torch
+    import torch.distributed as dist
+
+    from hyperpose_amd import _lib
+    from hyperpose_amd import dist as hd
+    from hyperpose_amd.engine import Model
+
+    cfg = CONFIGS[cfg_index]
+    batch, global_batch = rank_plan(cfg["batch"], scaling, rank, world)
+    model = Model(cfg["arch"], cfg["w"], cfg["h"])
+    # one-time weight broadcast from rank 0 over RCCL/xGMI (the only collective of the whole job)
+    w_host = hd.broadcast_weights(model.init_weights(cfg["seed"]) if rank == 0 else None, model.n_weights, rank, world, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_pipes = args.pipes if args.pipes > 0 else cfg["pipes"]
+    res = {"workload": cfg["label"], "frames_per_gpu_per_step": batch, "global_batch": global_batch, "scaling": scaling,
+           "pipes_per_gpu": n_pipes, "gflop_per_frame": round(model.flops_per_frame / 1e9, 2)}
+    if batch == 0:  # strong scaling with more ranks than frames: this rank idles but still takes part in the barriers
+        pipes, frames_dev, maps = [], None, None
+    else:
+        frames, maps = synth_inputs(cfg, batch, rank)
+        frames_dev = _lib.DevBuf.from_numpy(frames)
+        inj = [_lib.DevBuf.from_numpy(m) for m in maps]
+        pipes = [Pipe(cfg, model, w_host, inj, batch) for _ in range(max(1, n_pipes))]
+
+    def timed(injected):
+        if pipes:
+            run_loop(pipes, frames_dev, warmup, injected)
+            # the GPU's clocks take a few hundred ms of load to settle (100 steps right after a short warm-up measure
+            # ~12 % low): keep the same loop running, untimed, until 0.3 s have passed since the warm-up began
+            t_ramp = time.perf_counter()
+            while time.perf_counter() - t_ramp < 0.3:
+                run_loop(pipes, frames_dev, len(pipes), injected)
+        barrier()
+        t0 = time.perf_counter()
+        nh = run_loop(pipes, frames_dev, steps, injected) if pipes else 0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        dt = hd.max_over_ranks(dt, world, device=dev)
+        barrier()
+        return dt, nh
+
+    dt, n_humans = timed(True)
+    dt_dnn = None if (args.no_dnn_output or not headline) else timed(False)[0]
+    total_frames = global_batch * steps
+    fps = total_frames / dt
+    res.update({"value": round(fps, 1), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+                "humans_per_step": n_humans / max(1, steps),
+                "fps_dnn_output": round(total_frames / dt_dnn, 1) if dt_dnn else None,
+                "conv_tflops_end_to_end": round(fps * model.flops_per_frame / 1e12, 2),
+                "conv_frac_of_mfma_peak_end_to_end": round(fps * model.flops_per_frame / 1e12 / PEAK_F16_TFLOPS / world, 4)})
+    if rank == 0 and pipes:
+        if not args.no_roofline:
+            res["roofline"] = roofline(pipes[0], batch, cfg_index)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, maps)
+        if world == 1 and not args.no_from_host:
+            del pipes[:]
+            res["h2d_inclusive"] = h2d_inclusive(model, w_host, cfg, batch, n_pipes, max(8, steps // 2))
+            if headline:
+                res["from_host"] = from_host(model, w_host, cfg, batch, n_pipes)
+    del pipes
+    return res, model
 
 
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(respawn(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
 
-    from hyperpose_amd import _lib, synth
-    from hyperpose_amd.engine import Model
-
+    from hyperpose_amd import _lib
     from hyperpose_amd import dist as hd
 
     torch.cuda.set_device(local_rank)
@@ -246,66 +452,44 @@ def main():
     if world > 1:
         hd.init("nccl", device=dev)
 
-    model = Model(ARCH, IN_W, IN_H)
-    # one-time weight broadcast from rank 0 over RCCL/xGMI (the only collective of the whole job)
-    w_host = hd.broadcast_weights(model.init_weights(20241) if rank == 0 else None, model.n_weights, rank, world, device=dev)
-
-    # per-rank synthetic inputs, resident in HBM before the timed region
-    rng = synth.rng_for(1, salt=rank)
-    frames = synth.images_u8(rng, BATCH, IN_H, IN_W)
-    conf, paf, _ = synth.paf_maps(rng, BATCH, IN_H // 8, IN_W // 8, people=(1, 2, 4, 8, 16, 3, 5, 6))
-    frames_dev = _lib.DevBuf.from_numpy(frames)
-    conf_dev, paf_dev = _lib.DevBuf.from_numpy(conf), _lib.DevBuf.from_numpy(paf)
-    pipes = [Pipe(model, w_host, conf_dev, paf_dev) for _ in range(max(1, args.pipes))]
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(injected):
-        run_loop(pipes, frames_dev, args.warmup, injected)
-        # the GPU's clocks take a few hundred ms of load to settle (100 steps right after a short warm-up measure
-        # ~12 % low): keep the same loop running, untimed, until 0.3 s have passed since the warm-up began
-        t_ramp = time.perf_counter()
-        while time.perf_counter() - t_ramp < 0.3:
-            run_loop(pipes, frames_dev, 4 * len(pipes), injected)
-        barrier()
-        t0 = time.perf_counter()
-        nh = run_loop(pipes, frames_dev, args.steps, injected)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        dt = hd.max_over_ranks(dt, world, device=dev)
-        barrier()
-        return dt, nh
-
-    dt, n_humans = timed(True)
-    dt_dnn, n_humans_dnn = (None, 0) if args.no_dnn_output else timed(False)
-
-    total_frames = BATCH * args.steps * world
-    fps = total_frames / dt
+    cfg = CONFIGS[args.config]
+    steps = args.steps if args.steps is not None else cfg["steps"]
+    head, model = measure(args.config, args, rank, world, dev, args.scaling, steps, args.warmup, True)
     out = {
-        "metric": "end-to-end FPS (preproc+DNN+PAF parse) @ 368x432",
-        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f16 (fp32 accumulate; parser fp32)", "data": "synthetic",
-        "config": {"workload": "configs[1]: Lightweight-OpenPose (MobilenetDilated) + PAF parser, batch 8 @ 368x432 per GPU, "
-                               "frames u8 HWC resident in HBM, humans written to pinned host memory",
-                   "global_batch": BATCH * world, "parallelism": f"frame-sharded x{world}, no steady-state collective",
-                   "pipes_per_gpu": len(pipes), "parser_input": "injected synthetic heat-maps (1-16 people/frame); full conv stack also runs",
-                   "humans_per_step": n_humans / max(1, args.steps),
-                   "gflop_per_frame": round(model.flops_per_frame / 1e9, 2)},
-        "fps_dnn_output": round(total_frames / dt_dnn, 1) if dt_dnn else None,
-        "conv_tflops_end_to_end": round(fps * model.flops_per_frame / 1e12, 2),
+        "metric": "end-to-end FPS (preproc+DNN+PAF parse) @ 368x432" if args.config == 1 else f"end-to-end FPS (preproc+DNN+parse), {cfg['label']}",
+        "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f16 (fp32 accumulate; parsers fp32)", "data": "synthetic",
+        "config": {"workload": cfg["label"] + " per GPU, frames u8 HWC resident in HBM, humans written to pinned host memory",
+                   "global_batch": head["global_batch"], "frames_per_gpu_per_step": head["frames_per_gpu_per_step"],
+                   "parallelism": f"frame-sharded x{world}, no steady-state collective",
+                   "pipes_per_gpu": head["pipes_per_gpu"], "frames_in_flight_per_gpu": head["pipes_per_gpu"] * head["frames_per_gpu_per_step"],
+                   "parser_input": "injected synthetic heat-maps (several people per frame); the full conv stack also runs",
+                   "humans_per_step": head["humans_per_step"], "gflop_per_frame": head["gflop_per_frame"]},
+        "fps_dnn_output": head["fps_dnn_output"],
+        "conv_tflops_end_to_end": head["conv_tflops_end_to_end"],
     }
+    for k in ("roofline", "cpu_baseline", "h2d_inclusive", "from_host"):
+        if k in head:
+            out[k] = head[k]
+    extra = args.extra
+    if extra is None:
+        extra = "2,3,4" if world == 1 else "3,4"
+        if args.config != 1:
+            extra = ""
+    workloads = {}
+    for tok in [t for t in extra.split(",") if t.strip()]:
+        k = int(tok)
+        if k == args.config or k not in CONFIGS:
+            continue
+        c = CONFIGS[k]
+        scal = "strong" if world > 1 else "weak"
+        r, _ = measure(k, args, rank, world, dev, scal, c["steps"], max(2, min(args.warmup, c["steps"] // 4)), False)
+        r["n_gpus"] = world
+        workloads[f"configs[{k}]"] = r
+    if workloads:
+        out["workloads"] = workloads
     if rank == 0:
-        if not args.no_roofline:
-            out["roofline"] = roofline(pipes[0])
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(conf, paf)
-        if world == 1 and not args.no_from_host:
-            del pipes[:]
-            out["from_host"] = from_host(model, w_host)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -931,6 +931,234 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(const conv_param
     conv_epilogue_staged<1, K0>(p, mine, m0 + wm * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same barrier-free design for ANY square kernel (KS = 3, 5, 7: the 7x7 stage convolutions are 68 % of OpenPose-VGG19's FLOPs)
+// and ANY input width that is a multiple of CK channels, with 128 output channels per block:
+//   * 8 wavefronts = 4 (32-row tiles of the 128 output channels) x 2 (halves of every tap's CK channels); two wavefronts per SIMD,
+//     so one's LDS / L2 round trips sit under the other's MFMAs.  Per wavefront and k16 step: ONE A fragment (coalesced 1 KB
+//     straight from L2, fragment order, requested two taps ahead) feeds SIX MFMAs whose B fragments come from the halo tile.
+//   * the input is consumed in chunks of CK channels; a chunk's halo tile ((TH + KS - 1) x (12 + KS - 1) pixels x CK) is staged in
+//     LDS once and serves all KS*KS taps (49 at 7x7: 2.6 halo pixels loaded per output pixel, against 49 in an im2col GEMM).
+//     NBUF = 2: the next chunk is requested into registers when a chunk starts and written to the other LDS buffer when it
+//     ends - one LDS-only barrier per chunk, no global round trip on the critical path; NBUF = 1 (a 7x7 tile of 128 channels
+//     fills 101 KB): single chunk only.
+//   * weights never touch LDS; nothing synchronises the wavefronts inside a chunk; the K-halves meet once through LDS.
+template <int KS, int CK, int TH, int NBUF>
+__global__ __launch_bounds__(512) void conv_direct_kernel(const conv_params p, int tiles_x, int tiles_y, int nchunks)
+{
+    constexpr int TW = 12, HPH = TH + KS - 1, HPW = TW + KS - 1, NT = TH * TW / 32, PAD = KS / 2, TAPS = KS * KS;
+    constexpr int K0 = (NT + 1) / 2, K1 = NT / 2;
+    constexpr int CHP = CK / 8;   // 16-byte chunks per halo pixel
+    constexpr int KQC = CK / 16;  // k16 steps per tap and chunk
+    constexpr int NS = KQC / 2;   // ... per tap, chunk and K-half
+    constexpr int HALO_BYTES = HPH * HPW * CK * 2;
+    constexpr int RED_BYTES = 8 * K0 * 16 * 64 * 4; // each wave parks up to K0 accumulator tiles
+    constexpr int EPI_BYTES = 8 * stage_geom<1>::SLAB;
+    constexpr int LDS_BYTES = NBUF * HALO_BYTES > RED_BYTES + EPI_BYTES ? NBUF * HALO_BYTES : RED_BYTES + EPI_BYTES;
+    constexpr int NIT = (HPH * HPW * CHP + 511) / 512;
+    static_assert(HPW % 2 == 0 && (CHP == 16 || CHP == 8) && NT * 32 == TH * TW, "tile geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    auto hkey = [](int hy, int hx) { return CHP == 16 ? ((hy * TW + hx) & 15) : (((hy * TW + hx) >> 1) & 7); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 3, kg = wave >> 2;
+    const int m0 = blockIdx.y * 128;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int KQ = p.Cin / 16; // k16 steps per tap over all chunks
+    const int total = nchunks * TAPS;
+
+    // ---- A fragments of steps 0 and 1 (step q = chunk * TAPS + tap): 2 x NS loads in flight from the start
+    const long tap_stride = (long)(p.Cout_pad / 32) * KQ * 512; // halves per tap
+    const __half* wfrag = p.w + ((size_t)((m0 / 32 + wm) * KQ + kg * NS) * 64 + lane) * 8;
+    auto a_off = [&](int q) -> long { // element offset of step q's first A fragment of this wave
+        const int ch = q / TAPS, tp = q - ch * TAPS;
+        return (long)tp * tap_stride + (long)ch * (KQC * 512);
+    };
+    u32x4 a0[NS], a1[NS];
+    {
+        const long o1 = a_off(min(1, total - 1));
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            a0[ks] = *reinterpret_cast<const u32x4*>(wfrag + (size_t)ks * 512);
+            a1[ks] = *reinterpret_cast<const u32x4*>(wfrag + o1 + (size_t)ks * 512);
+        }
+    }
+
+    // ---- halo tile of one chunk: global -> registers (one L2 round trip per pass of <= 8 loads per thread) -> LDS
+    constexpr int NPASS = NBUF == 2 ? 1 : (NIT + 7) / 8, PIT = (NIT + NPASS - 1) / NPASS;
+    static_assert(NBUF == 1 || NIT <= 8, "the prefetched chunk lives in registers across a whole chunk");
+    u32x4 hv[PIT];
+    auto halo_load = [&](int chunk, int pass) {
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int i = tid + (pass * PIT + it) * 512;
+            const int hp = min(i, HPH * HPW * CHP - 1) / CHP, c = i % CHP;
+            const int hy = hp / HPW, hx = hp - hy * HPW;
+            const int y = y0 + hy - PAD, x = x0 + hx - PAD;
+            // y, x >= -PAD always; rows / columns up to H + PAD - 1 lie in the zero halo of the HBM tensor, beyond that clamp + zero
+            const bool ok = y < p.H + PAD && x < p.W + PAD;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(
+                p.in.p + tv_off(p.in, b, min(y, p.H + PAD - 1), min(x, p.W + PAD - 1)) + chunk * CK + c * 8);
+            hv[it] = v & (ok ? 0xffffffffu : 0u);
+        }
+    };
+    auto halo_store = [&](int buf, int pass) {
+        unsigned char* dst = lds + buf * HALO_BYTES;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int i = tid + (pass * PIT + it) * 512;
+            if (i < HPH * HPW * CHP) {
+                const int hp = i / CHP, c = i - hp * CHP;
+                const int hy = hp / HPW, hx = hp - hy * HPW;
+                *reinterpret_cast<u32x4*>(dst + hp * (CK * 2) + ((c ^ hkey(hy, hx)) << 4)) = hv[it];
+            }
+        }
+    };
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        halo_load(0, pass);
+        halo_store(0, pass);
+    }
+    if (NBUF == 2 && nchunks > 1)
+        halo_load(1, 0);
+
+    floatx16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[j][r] = 0.f;
+
+    const int fk = lane >> 5;
+    int hpo0[NT], key0[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + (lane & 31);
+        const int br = n / TW, bc = n - br * TW;
+        hpo0[j] = (br * HPW + bc) * (CK * 2);
+        key0[j] = br * TW + bc;
+    }
+    lds_barrier(); // chunk 0 is complete
+    const int cb16 = ((kg * NS) * 2 + fk) << 4;
+
+    // one step = one tap of one chunk: NS k16 steps of NT MFMAs.  The B fragments are read ONE WHOLE k16 STEP (NT MFMAs = 192
+    // matrix-pipe cycles) before their use - across the step boundary too: the last k16 step of a step reads the first fragments
+    // of the next one - and the A fragments of step q + 2 are requested as soon as this step's are consumed.  The
+    // sched_group_barriers pin that order (hipcc otherwise sinks every read to just before its MFMA, one LDS latency each).
+    auto step_geom = [&](int q, const unsigned char*& hb, int (&base)[NT], int (&k16)[NT]) {
+        const int ch = q / TAPS, tap = q - ch * TAPS;
+        hb = lds + (NBUF == 2 ? (ch & 1) * HALO_BYTES : 0);
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int toff = (ky * HPW + kx) * (CK * 2), tkey = ky * TW + kx; // uniform
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            base[j] = hpo0[j] + toff;
+            k16[j] = (CHP == 16 ? ((key0[j] + tkey) & 15) : (((key0[j] + tkey) >> 1) & 7)) << 4;
+        }
+    };
+    half8 fb[2][NT];
+    {
+        const unsigned char* hb;
+        int base[NT], k16[NT];
+        step_geom(0, hb, base, k16);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            fb[0][j] = *reinterpret_cast<const half8*>(hb + base[j] + (cb16 ^ k16[j]));
+    }
+#define HP_STEP(A, Q)                                                                                             \
+    {                                                                                                             \
+        const int q_ = (Q);                                                                                       \
+        const int ch_ = q_ / TAPS, tap_ = q_ - ch_ * TAPS;                                                        \
+        const unsigned char* hb_;                                                                                 \
+        int base_[NT], k16_[NT];                                                                                  \
+        step_geom(q_, hb_, base_, k16_);                                                                          \
+        if (NBUF == 2 && tap_ == 0 && ch_ > 0) { /* uniform: chunk boundary (NBUF == 1 is only ever launched with one chunk) */ \
+            halo_store(ch_ & 1, 0); /* its last readers passed the previous boundary's barrier */                 \
+            lds_barrier();                                                                                        \
+            if (ch_ + 1 < nchunks)                                                                                \
+                halo_load(ch_ + 1, 0);                                                                            \
+            /* what the previous step pre-read from this buffer was the chunk before last: read again */          \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                        \
+                fb[0][j] = *reinterpret_cast<const half8*>(hb_ + base_[j] + (cb16 ^ k16_[j]));                    \
+        }                                                                                                         \
+        const long nxt_ = a_off(min(q_ + 2, total - 1));                                                          \
+        _Pragma("unroll") for (int ks = 0; ks < NS; ++ks)                                                         \
+        {                                                                                                         \
+            if (ks + 1 < NS) {                                                                                    \
+                _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
+                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(hb_ + base_[j] + ((cb16 + (ks + 1) * 32) ^ k16_[j])); \
+            } else {                                                                                              \
+                const unsigned char* hbn_;                                                                        \
+                int basen_[NT], k16n_[NT];                                                                        \
+                step_geom(min(q_ + 1, total - 1), hbn_, basen_, k16n_);                                           \
+                _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
+                    fb[0][j] = *reinterpret_cast<const half8*>(hbn_ + basen_[j] + (cb16 ^ k16n_[j]));             \
+            }                                                                                                     \
+            half8 fa;                                                                                             \
+            __builtin_memcpy(&fa, &A[ks], 16);                                                                    \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                        \
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[j], 0, 0, 0);              \
+            A[ks] = *reinterpret_cast<const u32x4*>(wfrag + nxt_ + (size_t)ks * 512);                             \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                        \
+            {                                                                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                    \
+        }                                                                                                         \
+    }
+#pragma unroll 1
+    for (int q = 0; q + 1 < total; q += 2) {
+        HP_STEP(a0, q);
+        HP_STEP(a1, q + 1);
+    }
+    if (total & 1)
+        HP_STEP(a0, total - 1);
+#undef HP_STEP
+
+    // ---- the K-halves meet: wave (wm, 0) finishes column tiles 0 .. K0-1, wave (wm, 1) tiles K0 .. NT-1; each parks the
+    // tiles the other one finishes (slot j of a wave's parking area = the j-th tile of its partner)
+    __syncthreads(); // every wave is done with the halo tiles
+    float4* const park = reinterpret_cast<float4*>(lds) + (size_t)wave * (K0 * 4 * 64) + lane;
+    const float4* const take = reinterpret_cast<const float4*>(lds) + (size_t)(wave ^ 4) * (K0 * 4 * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < K0; ++j) {
+        const floatx16& give = kg ? acc[j] : acc[K0 + j < NT ? K0 + j : NT - 1];
+        if (kg || j < K1) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                park[(j * 4 + g4) * 64] = make_float4(give[4 * g4], give[4 * g4 + 1], give[4 * g4 + 2], give[4 * g4 + 3]);
+        }
+    }
+    __syncthreads();
+    floatx16 mine[1][K0];
+    int pb[K0], py[K0], px[K0];
+    bool pv[K0];
+#pragma unroll
+    for (int j = 0; j < K0; ++j) {
+        const int jt = K0 + j < NT ? K0 + j : NT - 1; // (kg = 1 has no K0-th tile when NT is odd: masked below)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 o = take[(j * 4 + g4) * 64];
+            const floatx16& keep = kg ? acc[jt] : acc[j];
+            mine[0][j][4 * g4] = keep[4 * g4] + o.x, mine[0][j][4 * g4 + 1] = keep[4 * g4 + 1] + o.y;
+            mine[0][j][4 * g4 + 2] = keep[4 * g4 + 2] + o.z, mine[0][j][4 * g4 + 3] = keep[4 * g4 + 3] + o.w;
+        }
+        const int n = (kg ? jt : j) * 32 + (lane & 31);
+        const int br = n / TW, bc = n - br * TW;
+        pb[j] = b;
+        py[j] = y0 + br;
+        px[j] = x0 + bc;
+        pv[j] = py[j] < p.OH && px[j] < p.OW && (!kg || j < K1);
+    }
+    // the slabs live behind the parking area: no wave can still be reading what another overwrites
+    conv_epilogue_staged<1, K0>(p, mine, m0 + wm * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+}
+
 // fast epilogue (aligned fp16 NHWC vectors) when every 8-channel chunk is whole and 16-byte aligned
 static bool fast_epilogue(const conv_params& p)
 {
@@ -942,11 +1170,31 @@ static bool use_halo(const conv_params& p);
 static bool use_small1x1(const conv_params& p);
 static bool fast_epilogue(const conv_params& p);
 static int halo_variant(const conv_params& p);
-// 1: the weights of this convolution are to be packed in MFMA-fragment order for conv3x3_direct_kernel
+// conv_direct_kernel (8 wavefronts, 128 output channels x 16x12 pixels per block, any square kernel / chunked Cin) serves this layer:
+// 0 = no, otherwise the channel chunk CK (128 or 64).  HP_GDIRECT=0 switches it off, HP_GDIRECT=2 also sends the 3x3 layers with
+// 64 / 128 input channels to it (default: they stay with conv3x3_direct_kernel, whose half-size blocks share a CU at batch 8).
+static int use_gdirect(const conv_params& p)
+{
+    const char* env = getenv("HP_GDIRECT"); // read per call: an engine must be created and run under the same setting
+    const int mode = env ? atoi(env) : 1;
+    if (!mode || p.KH != p.KW || (p.KH != 3 && p.KH != 5 && p.KH != 7) || p.stride != 1 || p.dil != 1 || p.pad_t != p.KH / 2
+        || p.pad_l != p.KH / 2 || p.OH != p.H || p.OW != p.W || p.Cin % 64 || p.Cout_pad % 128 || p.in.coff % 8 || !fast_epilogue(p))
+        return 0;
+    if (p.KH == 3 && p.Cin <= 128 && mode < 2)
+        return 0;
+    if ((long)p.OH * p.OW < 256 && mode < 3) // maps smaller than two tiles: the generic implicit GEMM packs pixels of several images
+        return 0;
+    // 128-channel chunks only where ONE chunk is the whole input (7x7 / 5x5 x 128: a 101 / 82 KB tile, single-buffered); everything
+    // else runs on double-buffered 64-channel chunks (the 128-channel form of that pipeline needs more than 256 registers)
+    return p.KH >= 5 && p.Cin == 128 ? 128 : 64;
+}
+// 1: the weights of this convolution are to be packed in MFMA-fragment order for conv3x3_direct_kernel / conv_direct_kernel
 int conv_weight_layout(const conv_params& p)
 {
     static const int off = getenv("HP_HALO_DIRECT") ? !atoi(getenv("HP_HALO_DIRECT")) : 0;
     if (use_small1x1(p) && fast_epilogue(p))
+        return 1;
+    if (use_gdirect(p))
         return 1;
     return !off && use_halo(p) && fast_epilogue(p) && halo_variant(p) == 1 ? 1 : 0;
 }
@@ -1103,6 +1351,8 @@ int conv_mfma_tile(const conv_params& p)
 {
     if (p.w_layout == 1 && p.KH == 1)
         return 5100000 + p.Cin; // conv1x1_small_kernel
+    if (p.w_layout == 1 && use_gdirect(p))
+        return 6000000 + p.Cin * 1000 + p.KH * p.KW; // conv_direct_kernel
     if (p.w_layout == 1)
         return 5000000 + 64 * 1000 + 192;
     if (use_halo(p))
@@ -1134,6 +1384,24 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
         case 192: HP_LAUNCH((conv1x1_small_kernel<192>), grid, dim3(256), 0, s, p); break;
         default: HP_LAUNCH((conv1x1_small_kernel<256>), grid, dim3(256), 0, s, p); break;
         }
+        return hipGetLastError();
+    }
+    if (p.w_layout == 1 && use_gdirect(p)) {
+        const int ck = use_gdirect(p), nchunks = p.Cin / ck;
+        const int tiles_x = (p.OW + 11) / 12, tiles_y = (p.OH + 15) / 16;
+        const dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / 128);
+#define HP_GD(KS, CK, NBUF) HP_LAUNCH((conv_direct_kernel<KS, CK, 16, NBUF>), grid, dim3(512), 0, s, p, tiles_x, tiles_y, nchunks)
+        if (p.KH == 7 && ck == 128)
+            HP_GD(7, 128, 1);
+        else if (p.KH == 7)
+            HP_GD(7, 64, 2);
+        else if (p.KH == 5 && ck == 128)
+            HP_GD(5, 128, 1);
+        else if (p.KH == 5)
+            HP_GD(5, 64, 2);
+        else
+            HP_GD(3, 64, 2);
+#undef HP_GD
         return hipGetLastError();
     }
     if (p.w_layout == 1) {

@@ -146,6 +146,22 @@ int hp_engine::build(const hp_engine_desc* d)
         HP_REQUIRE(L.cin > 0 && L.cout > 0 && L.cin <= (1 << 16) && L.cout <= (1 << 16) && L.kh >= 0 && L.kh <= 31 && L.kw >= 0 && L.kw <= 31
                 && L.stride >= 1 && L.stride <= 64 && L.dil >= 0 && L.dil <= 64,
             HP_ERR_INVALID, "layer %zu: implausible channel count / geometry", i);
+        // channel offsets index device buffers: a negative one walks out of the front of the tensor
+        HP_REQUIRE(L.in_coff >= 0 && L.in_coff <= (1 << 16) && L.out_coff >= 0 && L.out_coff + L.cout <= (1 << 16), HP_ERR_INVALID,
+            "layer %zu: channel offsets in %d / out %d outside [0, 65536)", i, L.in_coff, L.out_coff);
+        HP_REQUIRE(L.res >= -1 && L.res_before_act >= 0 && L.res_before_act <= 1, HP_ERR_INVALID, "layer %zu: bad residual fields", i);
+        if (L.pad_explicit)
+            for (int k = 0; k < 4; ++k)
+                HP_REQUIRE(L.pad[k] >= 0 && L.pad[k] <= 64, HP_ERR_INVALID, "layer %zu: pad[%d] = %d outside [0, 64]", i, k, L.pad[k]);
+        // a layer may read one channel slice of a concat buffer and write another, but never the channels it reads (the
+        // blocks of one launch would race) - neither through its input nor through its residual
+        if (L.in == L.out)
+            HP_REQUIRE(L.in_coff + L.cin <= L.out_coff || L.out_coff + L.cout <= L.in_coff, HP_ERR_INVALID,
+                "layer %zu reads channels [%d,%d) and writes [%d,%d) of the same tensor %d", i, L.in_coff, L.in_coff + L.cin, L.out_coff,
+                L.out_coff + L.cout, L.out);
+        if (L.res >= 0 && L.res == L.out)
+            HP_REQUIRE(L.cout <= L.out_coff, HP_ERR_INVALID, "layer %zu adds channels [0,%d) of tensor %d while writing [%d,%d) of it", i, L.cout, L.res,
+                L.out_coff, L.out_coff + L.cout);
     }
     tensors.resize(max_id + 1);
     for (auto& t : tensors)
@@ -214,6 +230,15 @@ int hp_engine::build(const hp_engine_desc* d)
                 continue; // the fused kernel evaluates the depthwise activation as one clamp
             if (tensors[A.out]->C != A.cout)
                 continue;
+            {   // the fused kernel is configured for TF-SAME geometry: explicit pads must reproduce it, the 1x1 half must not pad at all
+                int oh, ow, pt, pl;
+                same_pad(tensors[A.in]->H, 3, A.stride, A.dil, oh, pt);
+                same_pad(tensors[A.in]->W, 3, A.stride, A.dil, ow, pl);
+                if (geos[i].OH != oh || geos[i].OW != ow || geos[i].pt != pt || geos[i].pl != pl)
+                    continue;
+                if (geos[i + 1].OH != oh || geos[i + 1].OW != ow || geos[i + 1].pt != 0 || geos[i + 1].pl != 0)
+                    continue;
+            }
             bool sole = true;
             for (size_t j = 0; j < layers.size(); ++j)
                 if (j != i + 1 && (layers[j].in == A.out || layers[j].res == A.out || (j != i && layers[j].out == A.out)))
@@ -244,6 +269,9 @@ int hp_engine::build(const hp_engine_desc* d)
                 continue;
             if (tensors[A.out]->C != A.cout || !hp::mlp_head_variant(A.cin, A.cout, Bn.cout))
                 continue;
+            if (geos[i].OH != tensors[A.in]->H || geos[i].OW != tensors[A.in]->W || geos[i].pt || geos[i].pl || geos[i + 1].OH != geos[i].OH
+                || geos[i + 1].OW != geos[i].OW || geos[i + 1].pt || geos[i + 1].pl)
+                continue; // a padded 1x1 (ONNX pads) changes the map size: the fused head assumes it does not
             if (i > 0 && fuse_with_next[i - 1])
                 continue; // already the pointwise half of a separable block
             bool sole = true;
@@ -282,6 +310,14 @@ int hp_engine::build(const hp_engine_desc* d)
         oi.x.C = o.channels, oi.x.act = o.act, oi.x.shuffle = o.shuffle == 2 ? 2 : 1, oi.x.group = o.group;
         oi.x.sigmoid_mask = o.sigmoid_mask, oi.x.softplus_mask = o.softplus_mask;
         HP_REQUIRE(o.shuffle == 0 || o.shuffle == 1 || o.shuffle == 2, HP_ERR_INVALID, "output %d: shuffle must be 0, 1 or 2", i);
+        HP_REQUIRE(o.group >= 0 && o.group <= 32 && (o.group == 0 || (o.channels / (oi.x.shuffle * oi.x.shuffle)) % o.group == 0), HP_ERR_INVALID,
+            "output %d: group %d must be 0 or divide the channel count (<= 32 components)", i, o.group);
+        HP_REQUIRE(o.grid >= 0 && o.grid <= 2 && (o.act == HP_ACT_NONE || o.act == HP_ACT_SIGMOID || o.act == HP_ACT_SOFTPLUS) && o.out_h >= 0
+                && o.out_w >= 0 && std::isfinite(o.scale),
+            HP_ERR_INVALID, "output %d: bad grid / act / crop / scale", i);
+        if (o.group > 0 && o.group < 32)
+            HP_REQUIRE((o.sigmoid_mask >> o.group) == 0 && (o.softplus_mask >> o.group) == 0, HP_ERR_INVALID,
+                "output %d: sigmoid / softplus masks name components beyond group %d", i, o.group);
         HP_REQUIRE(oi.x.C % (oi.x.shuffle * oi.x.shuffle) == 0, HP_ERR_INVALID, "output %d: channels not divisible by shuffle^2", i);
         oi.x.out_h = o.out_h > 0 ? o.out_h : ti.H * oi.x.shuffle, oi.x.out_w = o.out_w > 0 ? o.out_w : ti.W * oi.x.shuffle;
         HP_REQUIRE(oi.x.out_h <= ti.H * oi.x.shuffle && oi.x.out_w <= ti.W * oi.x.shuffle, HP_ERR_INVALID, "output %d: crop larger than the map", i);
@@ -853,6 +889,8 @@ static int infer_common(hp_engine* e, const void* input, size_t frame_bytes, int
         (void)hipGraphDestroy(graph);
         HP_HIP_TRY(ie);
         if (e->graphs.size() > 64) { // bound the cache for callers that pass a fresh pointer every time
+            (void)hipStreamSynchronize(s); // earlier launches of these executables may still be running on this stream ...
+            (void)hipStreamSynchronize(e->stream); // ... or on the engine's own
             for (auto& g : e->graphs)
                 (void)hipGraphExecDestroy(g.second);
             e->graphs.clear();

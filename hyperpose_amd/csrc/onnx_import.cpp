@@ -141,11 +141,17 @@ struct o_tensor {
     std::vector<float> f;   // every numeric type, as float
     std::vector<int64_t> i; // integer types, exact
     bool external = false;
+    // number of elements; SIZE_MAX when a dimension is negative or the product does not fit (never equal to a real payload size)
     size_t count() const
     {
         size_t n = 1;
-        for (int64_t d : dims)
+        for (int64_t d : dims) {
+            if (d < 0)
+                return SIZE_MAX;
+            if (d != 0 && n > (SIZE_MAX >> 1) / (size_t)d)
+                return SIZE_MAX;
             n *= (size_t)d;
+        }
         return n;
     }
 };
@@ -261,9 +267,17 @@ bool parse_tensor(pb r, o_tensor& t)
     }
     if (!r.ok)
         return false;
+    // the file is untrusted input: dimensions are bounded before anything is sized or indexed by them
+    if (t.dims.size() > 8)
+        return false;
+    for (int64_t d : t.dims)
+        if (d < 0 || d > 0x7fffffff)
+            return false;
     const size_t n = t.count();
+    if (n == SIZE_MAX)
+        return false;
     auto from_raw = [&](size_t esize, auto conv) {
-        if (raw.size() != n * esize)
+        if (raw.size() % esize != 0 || raw.size() / esize != n) // (not n * esize: that product can wrap)
             return false;
         for (size_t k = 0; k < n; ++k)
             conv(raw.data() + k * esize);
@@ -762,6 +776,11 @@ struct lowering {
         if (x.kind != val::IMAGE)
             need_map(n, x);
         const o_tensor& wt = *w.c;
+        for (int k = 0; k < 4; ++k)
+            if (wt.dims[k] < 1 || wt.dims[k] > (k < 2 ? 65536 : 31))
+                fail(&n, "weight dimension " + std::to_string(k) + " = " + std::to_string(wt.dims[k]) + " is outside the supported range");
+        if (wt.f.size() != wt.count())
+            fail(&n, "weight initializer carries no data");
         const int cout = (int)wt.dims[0], cin_g = (int)wt.dims[1], kh = (int)wt.dims[2], kw = (int)wt.dims[3];
         const int group = (int)n.geti("group", 1);
         hp_layer L;

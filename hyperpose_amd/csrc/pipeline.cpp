@@ -141,7 +141,7 @@ int hp_pipeline_submit(hp_pipeline* pl, const uint8_t* const* frames, const int*
                 ++run;
         HP_HIP_TRY(hipMemcpyAsync(dst, src, bytes * run, hipMemcpyHostToDevice, p.s));
         for (int r = 0; r < run; ++r) {
-            direct[i + r] = 1;
+            direct[i + r] = direct[i];
             offs[i + r] = off;
             p.w[i + r] = widths[i + r], p.h[i + r] = heights[i + r];
         }

@@ -56,3 +56,65 @@ def test_shard_covers_everything():
             for s, c in spans:
                 assert s == pos
                 pos += c
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    from hyperpose_amd import dist as hd
+    d = hd.init("gloo")
+    out = {}
+    for k, cfg in bench.CONFIGS.items():
+        for scaling in ("weak", "strong"):
+            mine, glob = bench.rank_plan(cfg["batch"], scaling, rank, world)
+            # what bench.measure reports: value = global frames per step * steps / MAX-over-ranks time
+            total = hd.sum_over_ranks(mine, world)
+            out[(k, scaling)] = (mine, glob, total)
+    q.put((rank, out))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_bench_rank_plan_world2():
+    """bench.py's per-rank work split: weak = every rank its own full batch (global = batch * world), strong = the
+    configuration's batch sharded contiguously; the per-rank counts add up to the global batch the JSON line reports."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    import bench
+    for k, cfg in bench.CONFIGS.items():
+        b = cfg["batch"]
+        for r in (0, 1):
+            assert res[r][(k, "weak")] == (b, 2 * b, 2.0 * b)
+            mine, glob, total = res[r][(k, "strong")]
+            assert glob == b and total == float(b) and mine == b // 2
+    assert res[0][(3, "strong")][0] == 16 and res[0][(4, "strong")][0] == 32
+
+
+def test_bench_gpus_flag_is_honoured(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (or fail loudly), never run one rank and
+    print n_gpus = 1: on this GPU-less box the device check refuses with exit code 2."""
+    import bench
+    from hyperpose_amd import _lib
+    assert bench.parse_args(["--gpus", "8"]).gpus == 8
+    if _lib.lib().hp_device_count() >= 2:
+        return  # a multi-GPU box would really launch; covered by the driver's SCALE runs
+    assert bench.respawn(2) == 2
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    try:
+        bench.main()
+        raise AssertionError("bench.main() returned instead of re-launching / failing")
+    except SystemExit as e:
+        assert e.code == 2

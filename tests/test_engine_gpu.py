@@ -504,3 +504,130 @@ def test_corrupted_engine_files_are_rejected_not_crashed(hp, tmp_path):
         except hp.HpError:
             bad += 1
     assert bad >= 20
+
+
+def test_hostile_layer_fields_are_rejected(hp):
+    """hp_engine_create / hp_engine_load take untrusted descriptions: fields that index device memory (channel offsets, pads), and
+    layers whose read and write channel ranges overlap inside one launch, must be refused, not turned into out-of-bounds device
+    writes or races."""
+    def build(mut):
+        m = E.Model("lw_openpose_vggtiny", 64, 48)
+        w = m.init_weights(1)
+        layers = list(m.layers)
+        mut(layers)
+        return E.Engine(layers, m.outputs, w, 64, 48, max_batch=1)
+
+    build(lambda L: None).close()
+
+    def neg_out_coff(L):
+        L[3].out_coff = -8
+    def huge_out_coff(L):
+        L[3].out_coff = 1 << 20
+    def neg_in_coff(L):
+        L[3].in_coff = -8
+    def huge_pad(L):
+        L[3].pad_explicit = 1
+        L[3].pad[:] = [1 << 30, 1, 1, 1]
+    def neg_pad(L):
+        L[3].pad_explicit = 1
+        L[3].pad[:] = [1, -3, 1, 1]
+    def in_place(L):       # reads and writes the same channels of one tensor
+        L[3].out = L[3].in_
+    def res_in_place(L):   # residual = the tensor being written, same channels
+        k = next(i for i, l in enumerate(L) if l.res >= 0)
+        L[k].res = L[k].out
+    def bad_res_flag(L):
+        L[3].res_before_act = 7
+    for mut in (neg_out_coff, huge_out_coff, neg_in_coff, huge_pad, neg_pad, in_place, res_in_place, bad_res_flag):
+        with pytest.raises(hp.HpError):
+            build(mut)
+
+    # the same through the serialized-engine loader: every 32-bit word of the first layer records set to hostile values
+    import struct as S
+    m = E.Model("lw_openpose_vggtiny", 64, 48)
+    eng = E.Engine.from_model(m, m.init_weights(1), max_batch=1)
+    import tempfile, os
+    d = tempfile.mkdtemp()
+    path = os.path.join(d, "e.hpeng")
+    eng.save(path)
+    raw = bytearray(open(path, "rb").read())
+    rejected = 0
+    for word in range(8, 8 + 4 * 26):  # the header and the first four hp_layer records (26 words each)
+        for val in (-8, -1, 1 << 30, 0x7fffffff):
+            mut = bytearray(raw)
+            mut[word * 4:word * 4 + 4] = S.pack("<i", val)
+            p2 = os.path.join(d, "m.hpeng")
+            open(p2, "wb").write(bytes(mut))
+            try:
+                e2 = E.Engine.load(p2)
+                fr = np.zeros((1, 48, 64, 3), np.uint8)
+                e2.inference(fr)   # whatever still loads must also run without faulting
+                e2.close()
+            except (hp.HpError, ValueError):
+                rejected += 1
+    assert rejected > 100
+
+
+def test_onnx_pads_block_the_fused_kernels(hp):
+    """A 1x1 convolution with ONNX pads (its output is larger than its input) must not be folded into the fused two-layer head or
+    the fused separable block, which assume an unpadded 1x1: result == the unfused evaluation by the torch oracle."""
+    from oracle import ref_net
+    L = [E.make_layer(E.OP_CONV, 0, 1, 3, 128, k=3, act=E.ACT_RELU, w_off=0, b_off=3456),
+         E.make_layer(E.OP_CONV, 1, 2, 128, 512, k=1, act=E.ACT_RELU, w_off=3584, b_off=3584 + 65536, pads=(1, 1, 1, 1)),
+         E.make_layer(E.OP_CONV, 2, 3, 512, 19, k=1, w_off=3584 + 65536 + 512, b_off=3584 + 65536 + 512 + 9728)]
+    n_w = 3584 + 65536 + 512 + 9728 + 19
+    rng = np.random.default_rng(3)
+    w = (rng.standard_normal(n_w) * 0.05).astype(np.float32)
+    o = E.OutputDesc()
+    o.name, o.tensor, o.coff, o.channels = b"y", 3, 0, 19
+    eng = E.Engine(L, [o], w, 32, 24, max_batch=1)
+    fr = rng.integers(0, 256, (1, 24, 32, 3), dtype=np.uint8)
+    got = eng.inference(fr)[0][0][1]
+    ref = ref_net.run(L, [o], w, frames_u8=fr, match_fp16=True)["y"][0]
+    assert got.shape == ref.shape == (19, 26, 34)
+    assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 2e-3
+
+
+@pytest.mark.parametrize("k,cin,cout,h,w", [
+    (7, 128, 128, 23, 29), (7, 185, 128, 23, 29), (7, 128, 256, 37, 50), (3, 256, 256, 23, 29), (3, 512, 128, 33, 25),
+    (3, 192, 384, 19, 40), (5, 128, 128, 23, 29), (5, 320, 128, 17, 31),
+])
+def test_direct_conv_any_kernel_and_width(hp, k, cin, cout, h, w):
+    """conv_direct_kernel (8 wavefronts, halo tile of a channel chunk in LDS for all k*k taps, fragment-ordered weights from L2,
+    double-buffered 64-channel chunks) against the torch oracle: 7x7 / 5x5 / 3x3, one chunk and several, a 185-channel concat
+    slice (padded to 192), PReLU, residual after and before the activation, tiles hanging over the right / bottom edge."""
+    net = Net(k * 1000 + cin)
+    cat = net.new_tensor()
+    c0 = min(cin, 128)
+    net.conv(0, 3, c0, 3, 1, out=cat, out_coff=0)
+    if cin > c0:
+        net.conv(0, 3, cin - c0, 3, 1, act=E.ACT_LEAKY, act_param=0.2, out=cat, out_coff=c0)
+    u = net.conv(cat, cin, cout, k, act=E.ACT_PRELU)
+    v = net.conv(u, cout, cout, k, act=E.ACT_RELU, res=u, res_before_act=0)
+    r = net.conv(v, cout, cout, k, act=E.ACT_RELU, res=u, res_before_act=1)
+    y = net.conv(r, cout, 19, 1, act=E.ACT_NONE)
+    fr = _frames(3, h, w, seed=k + cin)
+    eng, got, ref = _run_both(net, [Out("y", y, 0, 19), Out("z_mid", v, 0, cout)], fr, h, w)
+    _check(got, ref, 3)
+    prof = eng.profile(3, 1)
+    assert sum(1 for p in prof if p["tile"] >= 6000000) == 3, [p["tile"] for p in prof]  # the three k x k layers really ran on conv_direct_kernel
+
+
+def test_direct_conv_matches_generic_kernel_bit_for_bit_inputs(hp, monkeypatch):
+    """Same network through conv_direct_kernel and (HP_GDIRECT=0) the LDS-staged implicit GEMM: both within tolerance of the oracle and
+    of each other; HP_GDIRECT=2 also routes the 3x3 x 128 layers of the LW-OpenPose head to the 8-wavefront kernel."""
+    m = E.Model("openpose_vgg19", 96, 64)
+    w = m.init_weights(9)
+    fr = _frames(2, 64, 96, seed=3)
+    res = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("HP_GDIRECT", mode)
+        eng = E.Engine.from_model(m, w, max_batch=2)  # (the variable is read per call: created and run under the same setting)
+        res[mode] = eng.inference(fr)
+        tiles = [p["tile"] for p in eng.profile(2, 1)]
+        n_direct = sum(1 for t in tiles if t >= 6000000)
+        assert (n_direct == 0) if mode == "0" else (n_direct >= 20), (mode, n_direct)
+        eng.close()
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True, mean=m.mean, inv_std=m.inv_std)
+    for mode in res:
+        _check(res[mode], ref, 2, rel=4e-3, abs_=2e-3)

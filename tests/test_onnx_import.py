@@ -3,6 +3,7 @@ is host code.  The lowered layer list is evaluated by the fp32 torch oracle (ora
 outputs PyTorch computed for the very module the file was exported from (tests/golden/onnx/*.npz), to fp32 round-off:
 |err| <= 1e-4 * max|ref|."""
 import os
+import struct
 
 import numpy as np
 import pytest
@@ -192,3 +193,22 @@ def test_corrupted_files_never_crash_the_importer():
             except HpError:
                 bad += 1
     assert ok + bad == 400 and bad > 50
+
+
+def test_hostile_tensor_dims_are_rejected():
+    """TensorProto dims are untrusted: a huge / negative dimension with an empty (or short) raw_data must be an error, not 2^62 reads
+    past the buffer (the element-count product used to wrap around the size check)."""
+    ow = W
+
+    def conv_model(w_dims, payload):
+        t = b"".join(ow._int(1, d) for d in w_dims) + ow._int(2, 1) + ow._len(9, payload) + ow._str(8, "w")
+        n = ow.node("Conv", ["x", "w"], ["y"], [ow.attr_ints("kernel_shape", [1, 1])])
+        return ow.model([n], [t], [ow.value_info("x", [1, 3, 8, 8])], [ow.value_info("y", [1, 4, 8, 8])])
+
+    good = conv_model([4, 3, 1, 1], struct.pack("<12f", *range(12)))
+    assert E.Model.from_onnx(good).layers[0].cout == 4
+    for dims, payload in (([1 << 62], b""), ([1 << 62, 4], b""), ([1 << 32, 1 << 32], b""), ([-4, 3, 1, 1], struct.pack("<12f", *range(12))),
+                          ([1 << 31, 3, 1, 1], b""), ([4, 3, 1, 1], struct.pack("<11f", *range(11))), ([4, 3, 1 << 40, 1], b""),
+                          ([0, 3, 1, 1], b""), ([4, 3, 1, 64], struct.pack("<768f", *([0.0] * 768)))):
+        with pytest.raises(HpError):
+            E.Model.from_onnx(conv_model(dims, payload))

@@ -75,3 +75,29 @@ def test_gpu_threshold_variants(hp):
         got = p.process_batch(paf, pif)
         for b in range(2):
             assert _same(got[b], loader.ref_pifpaf_process(paf[b], pif[b], 385, 385, thr))
+
+
+@pytest.mark.gpu
+def test_gpu_async_enqueue_collect(hp):
+    """hp_pifpaf_enqueue / hp_pifpaf_collect == the blocking call == the reference's own decoder, batch of 24 decoded on the host
+    worker pool (frames in any order across the threads, results in frame order)."""
+    from hyperpose_amd.parser import PifPaf
+    if loader.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    B = 24
+    p = PifPaf(385, 385, max_batch=B)
+    for salt in (3, 4):
+        paf, pif = synth.pifpaf_maps(synth.rng_for(4, salt=salt), B, people=(3, 0, 1, 5, 2))
+        dp, di = hp.DevBuf.from_numpy(paf), hp.DevBuf.from_numpy(pif)
+        p.enqueue(dp, di, B, 49, 49)
+        with pytest.raises(Exception):
+            p.enqueue(dp, di, B, 49, 49)
+        got = p.collect()
+        total = 0
+        for b in range(B):
+            ref = loader.ref_pifpaf_process(paf[b], pif[b])
+            assert got[b].tobytes() == ref.tobytes(), (salt, b, len(got[b]), len(ref))
+            total += len(ref)
+        assert total >= 20
+    with pytest.raises(Exception):
+        p.collect()

@@ -64,3 +64,45 @@ def test_pipeline_equals_stages_by_hand(hp, keep_ratio):
             assert hg.tobytes() == hr.tobytes()
             total += len(hg)
     assert total > 0  # the loose thresholds make the random-weight maps produce humans: the comparison is not vacuous
+
+
+@pytest.mark.parametrize("kind", ["ppn", "pifpaf"])
+def test_pipeline_other_parsers_equal_stages_by_hand(hp, kind):
+    """hp_pipeline_create_ex with the PoseProposal / PifPaf parser == resize on the host -> engine -> the blocking parser call."""
+    from hyperpose_amd.parser import PifPaf, PoseProposal
+    if kind == "ppn":
+        in_w = in_h = 192
+        m = E.Model("pose_proposal_resnet50", in_w, in_h)
+    else:
+        in_w = in_h = 129
+        m = E.Model("pifpaf_resnet50", in_w, in_h)
+    w = m.init_weights(5)
+    pl = Pipeline(m, w, max_batch=3, n_pipes=2, keep_ratio=False, max_frame_wh=(1280, 720), parser=kind,
+                  thresholds=(0.02, 0.01, 0.3) if kind == "ppn" else (0.1,))
+    eng = E.Engine.from_model(m, w, max_batch=3)
+    rng = np.random.default_rng(9)
+    batches = [_frames(rng, n, k) for n, k in ((3, 0), (2, 3), (3, 1))]
+    batches[1][0] = rng.integers(0, 256, (in_h, in_w, 3), dtype=np.uint8)  # a network-sized frame: direct H2D, no resize kernel
+    got = []
+    for b in batches:
+        if pl.in_flight == pl.n_pipes:
+            got.append(pl.collect())
+        pl.submit(b)
+    while pl.in_flight:
+        got.append(pl.collect())
+    for b, g in zip(batches, got):
+        net = np.stack([loader.resize_linear_u8(f, in_w, in_h) for f in b])
+        maps = eng.inference(net)
+        if kind == "ppn":
+            par = PoseProposal((in_w, in_h), 0.02, 0.01, 0.3, max_batch=3)
+            g6 = in_w // 32
+            tens = [np.stack([fm[i][1] for fm in maps]) for i in range(6)] + [np.stack([fm[6][1] for fm in maps]).reshape(len(b), 17, 9, 9, g6, g6)]
+            ref = par.process_batch(tens)
+        else:
+            par = PifPaf(in_h, in_w, 0.1, max_batch=3)
+            fh = maps[0][1][1].shape[-1]
+            ref = par.process_batch(np.stack([fm[0][1] for fm in maps]).reshape(len(b), 19, 9, fh, fh),
+                                    np.stack([fm[1][1] for fm in maps]).reshape(len(b), 17, 5, fh, fh))
+        assert len(g) == len(b)
+        for hg, hr in zip(g, ref):
+            assert hg.tobytes() == hr.tobytes()

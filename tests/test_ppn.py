@@ -79,3 +79,25 @@ def test_gpu_thresholds_and_other_resolution(hp):
     got = p.process_batch(t)
     for b in range(4):
         assert _same(got[b], loader.ref_ppn_process([a[b] for a in t], 384, 384, 0.05, 0.036, 0.1))
+
+
+@pytest.mark.gpu
+def test_gpu_async_enqueue_collect(hp):
+    """hp_ppn_enqueue / hp_ppn_collect (lists written straight to pinned memory, tails on the worker pool) == the blocking call ==
+    the reference; a second enqueue before collect is refused; repeated batches do not leak state between frames."""
+    from hyperpose_amd.parser import PoseProposal
+    if loader.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    B = 16
+    p = PoseProposal((384, 384), max_batch=B)
+    for salt in (1, 2):
+        t = synth.ppn_maps(synth.rng_for(3, salt=salt), B, people=(4, 0, 2, 7), spurious=0.03)
+        dev = [hp.DevBuf.from_numpy(a) for a in t]
+        p.enqueue(dev, B, t[0].shape[1:], t[6].shape[1:])
+        with pytest.raises(Exception):
+            p.enqueue(dev, B, t[0].shape[1:], t[6].shape[1:])
+        got = p.collect()
+        for b in range(B):
+            assert _same(got[b], loader.ref_ppn_process([a[b] for a in t])), (salt, b)
+    with pytest.raises(Exception):
+        p.collect()  # nothing in flight

@@ -1,20 +1,25 @@
 #!/bin/bash
-# tools/collect_profiles.sh <tag> — run ON THE GPU BOX (gpurun): rocprofv3 kernel stats + PMC traffic of the bench, one pipe so
+# tools/collect_profiles.sh <tag> [config] — run ON THE GPU BOX (gpurun): rocprofv3 kernel stats + PMC traffic of the bench, one pipe so
 # that kernels do not overlap (the per-launch durations then compare with hp_engine_profile / bench.py's roofline).
 # Outputs (merged back by gpurun): gpurun_out/<tag>_kernel_stats.csv, gpurun_out/<tag>_pmc_traffic.json
 set -u
 tag=${1:-r01}
+cfg=${2:-1}
+sfx=""
+[ "$cfg" != "1" ] && sfx="_config$cfg"
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python $repo/bench.py --steps 12 --warmup 3 --pipes 1 --no-cpu-baseline --no-roofline --no-from-host --no-dnn-output"
+steps=12
+[ "$cfg" != "1" ] && steps=3
+cmd="python $repo/bench.py --config $cfg --extra= --steps $steps --warmup 2 --pipes 1 --no-cpu-baseline --no-roofline --no-from-host --no-dnn-output"
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- $cmd > /dev/null 2>&1
-cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
+cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats${sfx}.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -- $cmd > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -- $cmd > /dev/null 2>&1
-python - "$out/${tag}_pmc_traffic.json" $(find /tmp/prof_f -name "*counter_collection.csv" | head -1) $(find /tmp/prof_w -name "*counter_collection.csv" | head -1) <<'PY'
+python - "$out/${tag}_pmc_traffic${sfx}.json" $(find /tmp/prof_f -name "*counter_collection.csv" | head -1) $(find /tmp/prof_w -name "*counter_collection.csv" | head -1) <<'PY'
 import csv, json, sys
 out, ff, fw = sys.argv[1:4]
 agg = {}
@@ -43,7 +48,7 @@ PY
 # third counter pass: where the wave cycles go (SQ) and how busy the matrix pipe is
 rm -rf /tmp/prof_sq
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_sq -- $cmd > /dev/null 2>&1
-python - "$out/${tag}_pmc_sq.json" $(find /tmp/prof_sq -name "*counter_collection.csv" | head -1) "$out/${tag}_kernel_stats.csv" <<'PY'
+python - "$out/${tag}_pmc_sq${sfx}.json" $(find /tmp/prof_sq -name "*counter_collection.csv" | head -1) "$out/${tag}_kernel_stats${sfx}.csv" <<'PY'
 import csv, json, sys
 out, path, stats = sys.argv[1:4]
 dur = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(stats))}
@@ -73,4 +78,4 @@ json.dump({"note": "rocprofv3 --pmc (one pass, SQ + GRBM) over `python bench.py 
            "kernels": res}, open(out, "w"), indent=1)
 print("sq kernels:", len(res))
 PY
-head -12 $out/${tag}_kernel_stats.csv | cut -c1-150
+head -12 $out/${tag}_kernel_stats${sfx}.csv | cut -c1-150
