@@ -944,30 +944,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(const conv_param
 //     fills 101 KB): single chunk only.
 //   * weights never touch LDS; nothing synchronises the wavefronts inside a chunk; the K-halves meet once through LDS.
 template <int KS, int CK, int TH, int NBUF>
-__global__ __launch_bounds__(512) void conv_direct_kernel(const conv_params p, int tiles_x, int tiles_y, int nchunks)
+struct direct_geom {
+    static constexpr int TW = 12, HPH = TH + KS - 1, HPW = TW + KS - 1, NT = TH * TW / 32;
+    static constexpr int K0 = (NT + 1) / 2;
+    static constexpr int HALO_BYTES = HPH * HPW * CK * 2;
+    static constexpr int RED_BYTES = 8 * K0 * 16 * 64 * 4; // each wave parks up to K0 accumulator tiles
+    static constexpr int EPI_BYTES = 8 * stage_geom<1>::SLAB;
+    static constexpr int LDS_BYTES = NBUF * HALO_BYTES > RED_BYTES + EPI_BYTES ? NBUF * HALO_BYTES : RED_BYTES + EPI_BYTES;
+};
+
+// one block's work on the TH x 12 pixel tile at (b, y0, x0); TH = 16 is the full tile, TH = 8 serves tile rows of which at most 8 rows
+// exist (the last tile row of a 54-row map has 6): half the MFMAs and halo rows instead of multiplying rows that are thrown away
+template <int KS, int CK, int TH, int NBUF>
+__device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned char* lds, int b, int y0, int x0, int nchunks)
 {
-    constexpr int TW = 12, HPH = TH + KS - 1, HPW = TW + KS - 1, NT = TH * TW / 32, PAD = KS / 2, TAPS = KS * KS;
+    using G = direct_geom<KS, CK, TH, NBUF>;
+    constexpr int TW = 12, HPH = G::HPH, HPW = G::HPW, NT = G::NT, PAD = KS / 2, TAPS = KS * KS;
     constexpr int K0 = (NT + 1) / 2, K1 = NT / 2;
     constexpr int CHP = CK / 8;   // 16-byte chunks per halo pixel
     constexpr int KQC = CK / 16;  // k16 steps per tap and chunk
     constexpr int NS = KQC / 2;   // ... per tap, chunk and K-half
-    constexpr int HALO_BYTES = HPH * HPW * CK * 2;
-    constexpr int RED_BYTES = 8 * K0 * 16 * 64 * 4; // each wave parks up to K0 accumulator tiles
-    constexpr int EPI_BYTES = 8 * stage_geom<1>::SLAB;
-    constexpr int LDS_BYTES = NBUF * HALO_BYTES > RED_BYTES + EPI_BYTES ? NBUF * HALO_BYTES : RED_BYTES + EPI_BYTES;
+    constexpr int HALO_BYTES = G::HALO_BYTES, RED_BYTES = G::RED_BYTES;
     constexpr int NIT = (HPH * HPW * CHP + 511) / 512;
     static_assert(HPW % 2 == 0 && (CHP == 16 || CHP == 8) && NT * 32 == TH * TW, "tile geometry");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     auto hkey = [](int hy, int hx) { return CHP == 16 ? ((hy * TW + hx) & 15) : (((hy * TW + hx) >> 1) & 7); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 3, kg = wave >> 2;
     const int m0 = blockIdx.y * 128;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y, b = t / tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
     const int KQ = p.Cin / 16; // k16 steps per tap over all chunks
     const int total = nchunks * TAPS;
 
@@ -1157,6 +1161,32 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(const conv_params p, i
     }
     // the slabs live behind the parking area: no wave can still be reading what another overwrites
     conv_epilogue_staged<1, K0>(p, mine, m0 + wm * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+}
+
+template <int KS, int CK, int NBUF>
+__global__ __launch_bounds__(512) void conv_direct_kernel(const conv_params p, int tiles_x, int tiles_y, int nchunks)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[direct_geom<KS, CK, 16, NBUF>::LDS_BYTES];
+    // block -> tile: the tiles of the last tile row come LAST in dispatch order - when that row is a half tile they are the short
+    // blocks, and short jobs at the end even out the CUs' finishing times
+    int tx, ty, b;
+    {
+        const int t = blockIdx.x, per_full = tiles_x * (tiles_y - 1), full = per_full * p.B;
+        if (t < full) {
+            b = t / per_full;
+            const int r = t - b * per_full;
+            ty = r / tiles_x, tx = r - ty * tiles_x;
+        } else {
+            const int r = t - full;
+            b = r / tiles_x, tx = r - b * tiles_x, ty = tiles_y - 1;
+        }
+    }
+    const int y0 = ty * 16, x0 = tx * 12;
+    // (the two-path form of the chunk-pipelined kernels needs more than 256 registers: they always take the full tile)
+    if (NBUF == 1 && p.OH - y0 <= 8) // uniform
+        conv_direct_body<KS, CK, 8, NBUF>(p, lds, b, y0, x0, nchunks);
+    else
+        conv_direct_body<KS, CK, 16, NBUF>(p, lds, b, y0, x0, nchunks);
 }
 
 // fast epilogue (aligned fp16 NHWC vectors) when every 8-channel chunk is whole and 16-byte aligned
@@ -1390,7 +1420,7 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
         const int ck = use_gdirect(p), nchunks = p.Cin / ck;
         const int tiles_x = (p.OW + 11) / 12, tiles_y = (p.OH + 15) / 16;
         const dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / 128);
-#define HP_GD(KS, CK, NBUF) HP_LAUNCH((conv_direct_kernel<KS, CK, 16, NBUF>), grid, dim3(512), 0, s, p, tiles_x, tiles_y, nchunks)
+#define HP_GD(KS, CK, NBUF) HP_LAUNCH((conv_direct_kernel<KS, CK, NBUF>), grid, dim3(512), 0, s, p, tiles_x, tiles_y, nchunks)
         if (p.KH == 7 && ck == 128)
             HP_GD(7, 128, 1);
         else if (p.KH == 7)

@@ -55,8 +55,9 @@ def build(ref: bool = True) -> None:
 _libs = {}
 
 
-def lib(fast: bool = False):
-    name = "liboracle_fast.so" if fast else "liboracle.so"
+def lib(fast: bool = False, variant: int = 0):
+    """variant 1 / 2: the two OpenCV restatements rounded as an FMA build may round them (paf_oracle.cpp, HP_ORACLE_VARIANT)."""
+    name = f"liboracle_v{variant}.so" if variant else ("liboracle_fast.so" if fast else "liboracle.so")
     if name not in _libs:
         path = os.path.join(HERE, "_build", name)
         if not os.path.exists(path):
@@ -120,7 +121,7 @@ def gaussian_kernel(ksize: int = 17, sigma: float = 3.0) -> np.ndarray:
 
 def paf_process(conf: np.ndarray, paf: np.ndarray, conf_thresh: float = 0.05, paf_thresh: float = 0.05,
                 res_w: int = -1, res_h: int = -1, cap_humans: int = 128, cap_peaks: int = 8192,
-                cap_conns: int = 8192, fast: bool = False):
+                cap_conns: int = 8192, fast: bool = False, variant: int = 0):
     """One frame through the restated parser::paf::process; returns (humans, peaks, conns) numpy records."""
     conf = np.ascontiguousarray(conf, np.float32)
     paf = np.ascontiguousarray(paf, np.float32)
@@ -129,7 +130,7 @@ def paf_process(conf: np.ndarray, paf: np.ndarray, conf_thresh: float = 0.05, pa
     peaks = (OPeak * cap_peaks)()
     conns = (OConn * cap_conns)()
     n_peaks, n_conns = C.c_int(0), C.c_int(0)
-    n = lib(fast).oracle_paf_process(_fp(conf), j, rows, cols, _fp(paf), paf.shape[0],
+    n = lib(fast, variant).oracle_paf_process(_fp(conf), j, rows, cols, _fp(paf), paf.shape[0],
                                      C.c_float(conf_thresh), C.c_float(paf_thresh), res_w, res_h,
                                      humans, cap_humans, peaks, cap_peaks, C.byref(n_peaks),
                                      conns, cap_conns, C.byref(n_conns))

@@ -34,7 +34,28 @@
 #include <utility>
 #include <vector>
 
+/* HP_ORACLE_VARIANT: how a real OpenCV 4.4.0 binary may round the same published algorithm (tests/test_paf_envelope.py):
+ *   0  scalar, non-fused: a*b + c*d, s += k*x                                (the parity oracle; -ffp-contract=off)
+ *   1  OpenCV's universal-intrinsic forms on an FMA target (AVX2 dispatch): VResizeLinearVec_32f = v_muladd(S0, b0, S1*b1),
+ *      RowVec_32f / SymmColumnVec_32f = v_muladd(x, k, s), HResizeLinear (plain C++) contracted by the compiler the same way
+ *   2  the other association a compiler may pick when contracting a*b + c*d: fma(c, d, a*b)
+ * Variants 1 and 2 are compiled with -mfma; nothing but the two OpenCV restatements depends on the variant. */
+#ifndef HP_ORACLE_VARIANT
+#define HP_ORACLE_VARIANT 0
+#endif
+
 namespace {
+
+#if HP_ORACLE_VARIANT == 0
+inline float madd2(float a, float b, float c, float d) { return a * b + c * d; }
+inline float macc(float k, float x, float s) { return s + k * x; }
+#elif HP_ORACLE_VARIANT == 1
+inline float madd2(float a, float b, float c, float d) { return std::fma(a, b, c * d); }
+inline float macc(float k, float x, float s) { return std::fma(k, x, s); }
+#else
+inline float madd2(float a, float b, float c, float d) { return std::fma(c, d, a * b); }
+inline float macc(float k, float x, float s) { return std::fma(k, x, s); }
+#endif
 
 /* src/coco.hpp:10-30 */
 const int COCOPAIRS_NET[19][2] = {
@@ -114,7 +135,7 @@ bool resize_area_1ch(const float* src, int sh, int sw, float* dst, int dh, int d
         int dx = 0;
         for (; dx < tx.vmax; ++dx) {
             const int sx = tx.ofs[dx];
-            D[dx] = S[sx] * tx.c0[dx] + S[sx + 1] * tx.c1[dx];
+            D[dx] = madd2(S[sx], tx.c0[dx], S[sx + 1], tx.c1[dx]);
         }
         for (; dx < dw; ++dx)
             D[dx] = S[tx.ofs[dx]] * 1.f;
@@ -127,7 +148,7 @@ bool resize_area_1ch(const float* src, int sh, int sw, float* dst, int dh, int d
         const float* S1 = rows.data() + (size_t)sy1 * dw;
         float* D = dst + (size_t)dy * dw;
         for (int x = 0; x < dw; ++x)
-            D[x] = S0[x] * b0 + S1[x] * b1;
+            D[x] = madd2(S0[x], b0, S1[x], b1);
     }
     return true;
 }
@@ -178,7 +199,7 @@ void gaussian_blur_1ch(const float* src, int h, int w, int ksize, const float* k
         for (int x = 0; x < w; ++x) {
             float s = kern[0] * S[reflect101(x - r, w)];
             for (int k = 1; k < ksize; ++k)
-                s += kern[k] * S[reflect101(x - r + k, w)];
+                s = macc(kern[k], S[reflect101(x - r + k, w)], s);
             D[x] = s;
         }
     }
@@ -187,11 +208,11 @@ void gaussian_blur_1ch(const float* src, int h, int w, int ksize, const float* k
         float* D = dst + (size_t)y * w;
         const float* C = rowf.data() + (size_t)y * w;
         for (int x = 0; x < w; ++x) {
-            float s = ky[0] * C[x] + 0.f;
+            float s = macc(ky[0], C[x], 0.f);
             for (int k = 1; k <= r; ++k) {
                 const float* S = rowf.data() + (size_t)reflect101(y + k, h) * w;
                 const float* S2 = rowf.data() + (size_t)reflect101(y - k, h) * w;
-                s += ky[k] * (S[x] + S2[x]);
+                s = macc(ky[k], S[x] + S2[x], s);
             }
             D[x] = s;
         }

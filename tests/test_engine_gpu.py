@@ -610,23 +610,24 @@ def test_direct_conv_any_kernel_and_width(hp, k, cin, cout, h, w):
     eng, got, ref = _run_both(net, [Out("y", y, 0, 19), Out("z_mid", v, 0, cout)], fr, h, w)
     _check(got, ref, 3)
     prof = eng.profile(3, 1)
-    assert sum(1 for p in prof if p["tile"] >= 6000000) == 3, [p["tile"] for p in prof]  # the three k x k layers really ran on conv_direct_kernel
+    # the k x k layers whose output stays fp16 NHWC really ran on conv_direct_kernel (z_mid is also a network output: generic epilogue)
+    assert sum(1 for p in prof if p["tile"] >= 6000000) == 2, [p["tile"] for p in prof]
 
 
 def test_direct_conv_matches_generic_kernel_bit_for_bit_inputs(hp, monkeypatch):
     """Same network through conv_direct_kernel and (HP_GDIRECT=0) the LDS-staged implicit GEMM: both within tolerance of the oracle and
-    of each other; HP_GDIRECT=2 also routes the 3x3 x 128 layers of the LW-OpenPose head to the 8-wavefront kernel."""
+    of each other; HP_GDIRECT=3 routes every eligible layer (3x3 x 64 / 128 channels, small maps) to the 8-wavefront kernel."""
     m = E.Model("openpose_vgg19", 96, 64)
     w = m.init_weights(9)
     fr = _frames(2, 64, 96, seed=3)
     res = {}
-    for mode in ("0", "1", "2"):
+    for mode in ("0", "1", "3"):  # 3: also the 3x3 layers with <= 128 input channels and the maps smaller than two tiles
         monkeypatch.setenv("HP_GDIRECT", mode)
         eng = E.Engine.from_model(m, w, max_batch=2)  # (the variable is read per call: created and run under the same setting)
         res[mode] = eng.inference(fr)
         tiles = [p["tile"] for p in eng.profile(2, 1)]
         n_direct = sum(1 for t in tiles if t >= 6000000)
-        assert (n_direct == 0) if mode == "0" else (n_direct >= 20), (mode, n_direct)
+        assert n_direct == 0 if mode == "0" else n_direct >= (3 if mode == "1" else 60), (mode, n_direct)
         eng.close()
     ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True, mean=m.mean, inv_std=m.inv_std)
     for mode in res:
