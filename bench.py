@@ -294,7 +294,11 @@ def kernel_label(tile: int):
     if tile >= 6000000:
         v = tile - 6000000
         cin, taps = v // 1000, v % 1000
-        return (f"conv_direct_kernel<{cin}", f"conv_direct_kernel<CIN={cin}> ({taps} taps; input halo tile in LDS, weights in MFMA-fragment order straight from L2)")
+        ks = int(round(taps ** 0.5))
+        ck, nbuf = (128, 1) if cin == 128 else (64, 1 if cin == 64 else 2)
+        return (f"conv_direct_kernel<{ks},{ck},{nbuf}>",
+                f"conv_direct_kernel<KS={ks},CK={ck},NBUF={nbuf}> ({ks}x{ks} taps, {cin} input channels in {cin // ck} chunk(s); 8 wavefronts, 128 cout x 16x12 px "
+                "per block, halo tile of a chunk in LDS for all taps, weights in MFMA-fragment order straight from L2)")
     if 5100000 <= tile < 5200000:
         return ("conv1x1_small_kernel", "conv1x1_small_kernel (64 pixels x all input channels in LDS, fragment-ordered weights from L2)")
     if tile >= 5000000:

@@ -974,6 +974,11 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
     const int m0 = blockIdx.y * 128;
     const int KQ = p.Cin / 16; // k16 steps per tap over all chunks
     const int total = nchunks * TAPS;
+    int dbg_i = 0; // tools/direct_timeline.hip: s_memtime stamps of block (0, 0) / wave 0 and of the last wave
+#define HP_DSTAMP()                                                                                               \
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && (tid == 0 || tid == 448))                                  \
+        p.dbg[(tid ? 32 : 0) + (dbg_i++)] = __builtin_amdgcn_s_memtime();
+    HP_DSTAMP();
 
     // ---- A fragments of steps 0 and 1 (step q = chunk * TAPS + tap): 2 x NS loads in flight from the start
     const long tap_stride = (long)(p.Cout_pad / 32) * KQ * 512; // halves per tap
@@ -1046,7 +1051,12 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
         hpo0[j] = (br * HPW + bc) * (CK * 2);
         key0[j] = br * TW + bc;
     }
+    HP_DSTAMP();
     lds_barrier(); // chunk 0 is complete
+    HP_DSTAMP();
+    const int prio_mode = p.dbg_flags;
+    if (prio_mode == 2 && kg) // static: the younger half of the block (waves 4-7) is favoured
+        __builtin_amdgcn_s_setprio(1);
     const int cb16 = ((kg * NS) * 2 + fk) << 4;
 
     // one step = one tap of one chunk: NS k16 steps of NT MFMAs.  The B fragments are read ONE WHOLE k16 STEP (NT MFMAs = 192
@@ -1090,6 +1100,12 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
                 fb[0][j] = *reinterpret_cast<const half8*>(hb_ + base_[j] + (cb16 ^ k16_[j]));                    \
         }                                                                                                         \
         const long nxt_ = a_off(min(q_ + 2, total - 1));                                                          \
+        if (prio_mode == 1) { /* the two waves of a SIMD take turns being the favoured one, tap by tap */         \
+            if (((q_ >> 2) ^ kg) & 1)                                                                             \
+                __builtin_amdgcn_s_setprio(1);                                                                    \
+            else                                                                                                  \
+                __builtin_amdgcn_s_setprio(0);                                                                    \
+        }                                                                                                         \
         _Pragma("unroll") for (int ks = 0; ks < NS; ++ks)                                                         \
         {                                                                                                         \
             if (ks + 1 < NS) {                                                                                    \
@@ -1119,9 +1135,12 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
     for (int q = 0; q + 1 < total; q += 2) {
         HP_STEP(a0, q);
         HP_STEP(a1, q + 1);
+        if (p.dbg && q % 12 == 10)
+            HP_DSTAMP();
     }
     if (total & 1)
         HP_STEP(a0, total - 1);
+    HP_DSTAMP();
 #undef HP_STEP
 
     // ---- the K-halves meet: wave (wm, 0) finishes column tiles 0 .. K0-1, wave (wm, 1) tiles K0 .. NT-1; each parks the
@@ -1159,8 +1178,11 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
         px[j] = x0 + bc;
         pv[j] = py[j] < p.OH && px[j] < p.OW && (!kg || j < K1);
     }
+    HP_DSTAMP();
     // the slabs live behind the parking area: no wave can still be reading what another overwrites
     conv_epilogue_staged<1, K0>(p, mine, m0 + wm * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+    HP_DSTAMP();
+#undef HP_DSTAMP
 }
 
 template <int KS, int CK, int NBUF>
@@ -1216,7 +1238,9 @@ static int use_gdirect(const conv_params& p)
         return 0;
     // 128-channel chunks only where ONE chunk is the whole input (7x7 / 5x5 x 128: a 101 / 82 KB tile, single-buffered); everything
     // else runs on double-buffered 64-channel chunks (the 128-channel form of that pipeline needs more than 256 registers)
-    return p.KH >= 5 && p.Cin == 128 ? 128 : 64;
+    // (measured: 7x7 x 128 as two pipelined 64-channel chunks is 10 % slower than as one 128-channel chunk - the chunk barrier waits for
+    // the wavefronts that lose the matrix-pipe arbitration)
+    return p.Cin == 128 ? 128 : 64;
 }
 // 1: the weights of this convolution are to be packed in MFMA-fragment order for conv3x3_direct_kernel / conv_direct_kernel
 int conv_weight_layout(const conv_params& p)
@@ -1232,7 +1256,7 @@ int conv_weight_layout(const conv_params& p)
 static bool use_halo(const conv_params& p)
 {
     return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil == 1 && p.pad_t == 1 && p.pad_l == 1 && (p.Cin == 128 || p.Cin == 64)
-        && p.Cout_pad % 128 == 0 && p.in.coff % 8 == 0;
+        && p.Cout_pad % 64 == 0 && p.in.coff % 8 == 0; // (64 output channels: only the 64-row direct variant, see halo_variant)
 }
 
 template <int BM, int BN, int BK>
@@ -1260,6 +1284,8 @@ static int g_force_halo_variant = -1;
 void debug_force_halo_variant(int v) { g_force_halo_variant = v; }
 static int halo_variant(const conv_params& p)
 {
+    if (p.Cout_pad % 128)
+        return 1; // VGG19's 64 -> 64 layer: 64-row blocks only
     if (g_force_halo_variant >= 0)
         return g_force_halo_variant;
     static const int env_v = getenv("HP_HALO_VARIANT") ? atoi(getenv("HP_HALO_VARIANT")) : -1;
@@ -1429,6 +1455,10 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
             HP_GD(5, 128, 1);
         else if (p.KH == 5)
             HP_GD(5, 64, 2);
+        else if (ck == 128)
+            HP_GD(3, 128, 1);
+        else if (nchunks == 1)
+            HP_GD(3, 64, 1);
         else
             HP_GD(3, 64, 2);
 #undef HP_GD

@@ -52,6 +52,7 @@ struct conv_params {
     float* out_f32; // fp32 NCHW [B][Cout][OH][OW]
     int npix;       // B*OH*OW
     unsigned long long* dbg; // optional s_memtime timeline of block 0 / wave 0 (tools/microbench), nullptr in production
+    int dbg_flags;           // scheduling experiments of conv_direct_kernel (HP_GDIRECT_PRIO), 0 in production
 };
 
 // fills act_slope / act_hi from act / act_param; false for activations the MFMA epilogue does not fuse

@@ -515,6 +515,7 @@ int hp_engine::build(const hp_engine_desc* d)
             p.out = to.view(L.out_coff);
             p.out_f32 = nullptr;
             p.dbg = nullptr;
+            p.dbg_flags = getenv("HP_GDIRECT_PRIO") ? atoi(getenv("HP_GDIRECT_PRIO")) : 0;
             for (auto& o : outputs)
                 if (o.fused_layer == (int)i)
                     p.out_f32 = o.buf->as<float>();
@@ -842,6 +843,18 @@ void hp_engine_destroy(hp_engine* e)
 }
 
 int hp_engine_max_batch(const hp_engine* e) { return e ? e->max_batch : HP_ERR_INVALID; }
+
+int hp_engine_describe(const hp_engine* e, hp_engine_desc* d)
+{
+    HP_REQUIRE(e && d, HP_ERR_INVALID, "hp_engine_describe: null argument");
+    d->in_w = e->in_w, d->in_h = e->in_h, d->max_batch = e->max_batch, d->factor = e->factor, d->flip_rb = e->flip_rb;
+    for (int c = 0; c < 3; ++c)
+        d->mean[c] = e->mean[c], d->inv_std[c] = e->inv_std[c];
+    d->layers = e->layers.data(), d->n_layers = (int32_t)e->layers.size();
+    d->outputs = e->out_descs.data(), d->n_outputs = (int32_t)e->out_descs.size();
+    d->weights = e->weights_blob.data(), d->n_weights = e->weights_blob.size();
+    return HP_OK;
+}
 
 int hp_engine_input_size(const hp_engine* e, int* w, int* h)
 {

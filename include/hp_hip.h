@@ -230,6 +230,10 @@ typedef struct hp_engine hp_engine;
 int hp_engine_create(hp_engine** out, const hp_engine_desc* desc);
 void hp_engine_destroy(hp_engine* e);
 int hp_engine_max_batch(const hp_engine* e);                  /* tensorrt::max_batch_size() */
+/* The description the engine was created from (topology, outputs, pre-processing, fp32 weights), as pointers INTO the engine, valid
+ * while it lives: lets a stream (hp_pipeline_create_ex) replicate an engine that came from a file (ONNX, serialized) - the reference's
+ * stream shares ONE engine between its stages (include/hyperpose/stream/stream.hpp:136), the GPU pipeline keeps one per batch in flight. */
+int hp_engine_describe(const hp_engine* e, hp_engine_desc* out);
 int hp_engine_input_size(const hp_engine* e, int* w, int* h); /* tensorrt::input_size() */
 
 /* tensorrt::inference(std::vector<cv::Mat>) with network-sized frames (src/tensorrt.cpp:436-461): n u8 HWC BGR

@@ -44,6 +44,16 @@ namespace parser {
             return run(n, dev_conf, conf_shape, dev_paf, paf_shape, 1);
         }
 
+        // the constructor arguments in the form the GPU stream operator takes (hp_pipeline_create_ex)
+        hp_parser_desc stream_desc() const
+        {
+            hp_parser_desc d{};
+            d.kind = HP_PARSER_PAF;
+            d.thresh[0] = m_conf_thresh, d.thresh[1] = m_paf_thresh;
+            d.res_w = m_resolution_size.width, d.res_h = m_resolution_size.height;
+            return d;
+        }
+
         void set_paf_thresh(float thresh)
         {
             m_paf_thresh = thresh;

@@ -18,6 +18,14 @@ public:
     pifpaf(const pifpaf& p)
         : m_net_h(p.m_net_h), m_net_w(p.m_net_w), m_keypoint_thresh(p.m_keypoint_thresh) {}
     ~pifpaf() { hp_pifpaf_destroy(m_h); }
+    hp_parser_desc stream_desc() const
+    {
+        hp_parser_desc d{};
+        d.kind = HP_PARSER_PIFPAF;
+        d.thresh[0] = m_keypoint_thresh;
+        d.res_w = d.res_h = -1;
+        return d;
+    }
 
     std::vector<human_t> process(const feature_map_t& paf, const feature_map_t& pif)
     {

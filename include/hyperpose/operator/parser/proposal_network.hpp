@@ -55,6 +55,14 @@ namespace parser {
             assert(l.size() == 7);
             return this->process(l.at(0), l.at(1), l.at(2), l.at(3), l.at(4), l.at(5), l.at(6));
         }
+        hp_parser_desc stream_desc() const
+        {
+            hp_parser_desc d{};
+            d.kind = HP_PARSER_PPN;
+            d.thresh[0] = m_point_thresh, d.thresh[1] = m_limb_thresh, d.thresh[2] = m_nms_thresh;
+            d.res_w = d.res_h = -1;
+            return d;
+        }
         void set_point_thresh(float thresh) { m_point_thresh = thresh, push(); }
         void set_limb_thresh(float thresh) { m_limb_thresh = thresh, push(); }
         void set_nms_thresh(float thresh) { m_nms_thresh = thresh, push(); }

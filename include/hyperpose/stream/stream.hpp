@@ -1,21 +1,53 @@
-// hyperpose::hip_stream — the GPU form of the reference's stream operator
-// (include/hyperpose/stream/stream.hpp:119-145: `make_stream(engine, parser)`, `stream.async() << frames`,
-// `stream.sync() >> writer`).  The reference wires four CPU threads and three queues (resize -> inference -> parse ->
-// write); here a batch of frames of any size is handed to `hp_pipeline_submit` and stays on the device from the H2D copy
-// to the parsed humans (cv::resize / non_scaling_resize, conv stack, PAF parser on one HIP stream per in-flight batch).
-// push() = `async() << frames` for one batch, pop() = the oldest batch's pose set in submission order, with
-// resume_ratio already applied when keep_ratio is set (src/stream.cpp:120-124).
+// hyperpose::stream / hyperpose::make_stream on the GPU — the surface of the reference's stream operator
+// (include/hyperpose/stream/stream.hpp:121-319):
+//     auto stream = hyperpose::make_stream(engine, parser [, use_original_resolution, keep_ratio, parser_cnt, queue_max_size]);
+//     stream.async() << frames;        // std::vector<cv::Mat>, one cv::Mat, (with OpenCV) a cv::VideoCapture
+//     stream.sync() >> sink;           // blocks until every ingested frame has come out, in input order
+// for all three parsers (paf, pose_proposal, pifpaf).  The reference wires four CPU threads and three mutex-guarded queues
+// (resize -> inference -> parse -> write, stream.hpp:326-385, src/stream.cpp) with a host round trip between each; here ONE feeder thread
+// cuts the input into batches and hands them to hp_pipeline_* (include/hp_hip.h): the frames stay on the device from the H2D copy to
+// the parsed humans (cv::resize / non_scaling_resize, conv stack and parser kernels on one HIP stream per batch, several batches in
+// flight), and resume_ratio is applied on the way out when keep_ratio is set (src/stream.cpp:120-124).
+// Sinks: with OpenCV (HYPERPOSE_USE_OPENCV) a cv::VideoWriter or a name generator `std::string()` exactly as in the reference
+// (draw_human + write / imwrite); in any build a `std::vector<std::vector<human_t>>` (one pose set per frame, appended in order) or a
+// callable `void(size_t index, const cv::Mat& frame, const std::vector<human_t>& poses)`.
+// `hip_stream` (push / pop of whole batches) is the thin form underneath.
 #pragma once
 #include "../../hp_hip.h"
-#include "../operator/dnn/hip_engine.hpp"
+#include "../operator/dnn/tensorrt.hpp"
+#include "../operator/parser/paf.hpp"
 #include "../utility/cv_min.hpp"
 #include "../utility/human.hpp"
 
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <stdexcept>
+#include <string>
+#include <thread>
+#include <type_traits>
 #include <vector>
 
 namespace hyperpose {
 
+namespace detail {
+    inline void hp_check(int rc)
+    {
+        if (rc != HP_OK)
+            throw std::runtime_error(hp_last_error());
+    }
+    inline human_t to_human(const hp_human& h)
+    {
+        human_t r;
+        r.score = h.score;
+        for (int k = 0; k < COCO_N_PARTS; ++k)
+            r.parts[k] = body_part_t{ h.parts[k].has_value != 0, h.parts[k].x, h.parts[k].y, h.parts[k].score };
+        return r;
+    }
+} // namespace detail
+
+// Whole batches in, whole batches out (submission order); at most n_pipes batches in flight.
 class hip_stream {
 public:
     using pose_set = std::vector<human_t>; // one frame
@@ -25,65 +57,333 @@ public:
         double factor = 1. / 255, bool flip_rgb = true)
         : m_max_batch(max_batch_size)
     {
-        hp_model* m = nullptr;
-        check(hp_model_build(&m, model.arch.c_str(), input_size.width, input_size.height));
-        std::vector<float> w = model.weights;
-        if (w.empty()) {
-            w.resize(hp_model_num_weights(m));
-            check(hp_model_init_weights(m, model.seed, w.data(), w.size()));
-        }
-        hp_engine_desc d{};
-        const hp_layer* layers = nullptr;
-        const hp_output_desc* outs = nullptr;
-        int nl = 0, no = 0;
-        check(hp_model_layers(m, &layers, &nl));
-        check(hp_model_outputs(m, &outs, &no));
-        check(hp_model_preproc(m, d.mean, d.inv_std));
-        d.in_w = input_size.width, d.in_h = input_size.height, d.max_batch = max_batch_size, d.factor = factor, d.flip_rb = flip_rgb ? 1 : 0;
-        d.layers = layers, d.n_layers = nl, d.outputs = outs, d.n_outputs = no, d.weights = w.data(), d.n_weights = w.size();
-        const int rc = hp_pipeline_create(&m_pl, &d, n_pipes, keep_ratio ? 1 : 0, conf_thresh, paf_thresh, (size_t)max_frame.area() * 3);
-        hp_model_destroy(m);
-        check(rc);
-        m_out.resize((size_t)max_batch_size * CAP);
-        m_n.resize(max_batch_size);
+        dnn::tensorrt engine(model, input_size, max_batch_size, keep_ratio, factor, flip_rgb);
+        hp_parser_desc pd{};
+        pd.kind = HP_PARSER_PAF, pd.thresh[0] = conf_thresh, pd.thresh[1] = paf_thresh, pd.res_w = pd.res_h = -1;
+        init(engine.handle(), pd, max_batch_size, keep_ratio, n_pipes, max_frame);
+    }
+    // replicate an existing engine (any model source) behind any of the three parsers
+    hip_stream(hp_engine* engine, const hp_parser_desc& parser, int max_batch_size, bool keep_ratio, int n_pipes = 4,
+        cv::Size max_frame = cv::Size(1920, 1080))
+        : m_max_batch(max_batch_size)
+    {
+        init(engine, parser, max_batch_size, keep_ratio, n_pipes, max_frame);
     }
     hip_stream(const hip_stream&) = delete;
     ~hip_stream() { hp_pipeline_destroy(m_pl); }
 
     size_t in_flight() const { return (size_t)hp_pipeline_in_flight(m_pl); }
+    int n_pipes() const { return m_pipes; }
+    int max_batch() const { return m_max_batch; }
 
-    // `stream.async() << frames`: one batch (<= max_batch_size frames, any sizes); throws when every pipe is busy
+    // one batch (<= max_batch_size frames, any sizes); throws when every pipe is busy
     void push(const std::vector<cv::Mat>& frames)
     {
         std::vector<const uint8_t*> ptrs;
         std::vector<int> ws, hs;
-        for (const auto& f : frames)
-            ptrs.push_back(f.data()), ws.push_back(f.cols), hs.push_back(f.rows);
-        check(hp_pipeline_submit(m_pl, ptrs.data(), ws.data(), hs.data(), (int)frames.size()));
+        m_scratch.resize(frames.size());
+        for (size_t i = 0; i < frames.size(); ++i) {
+            ptrs.push_back(detail::mat_bytes(frames[i], m_scratch[i]));
+            ws.push_back(frames[i].cols), hs.push_back(frames[i].rows);
+        }
+        detail::hp_check(hp_pipeline_submit(m_pl, ptrs.data(), ws.data(), hs.data(), (int)frames.size()));
     }
 
     // the oldest batch's humans, one pose_set per frame
     std::vector<pose_set> pop()
     {
         int nf = 0;
-        check(hp_pipeline_collect(m_pl, reinterpret_cast<hp_human*>(m_out.data()), CAP, m_n.data(), &nf));
+        detail::hp_check(hp_pipeline_collect(m_pl, m_out.data(), CAP, m_n.data(), &nf));
         std::vector<pose_set> r(nf);
         for (int i = 0; i < nf; ++i)
-            r[i].assign(m_out.begin() + (size_t)i * CAP, m_out.begin() + (size_t)i * CAP + m_n[i]);
+            for (int k = 0; k < m_n[i] && k < CAP; ++k)
+                r[i].push_back(detail::to_human(m_out[(size_t)i * CAP + k]));
         return r;
     }
 
 private:
     static constexpr int CAP = 128;
-    static void check(int rc)
+    void init(hp_engine* engine, const hp_parser_desc& parser, int max_batch_size, bool keep_ratio, int n_pipes, cv::Size max_frame)
     {
-        if (rc != HP_OK)
-            throw std::runtime_error(hp_last_error());
+        hp_engine_desc d{};
+        detail::hp_check(hp_engine_describe(engine, &d));
+        d.max_batch = max_batch_size;
+        detail::hp_check(hp_pipeline_create_ex(&m_pl, &d, &parser, n_pipes, keep_ratio ? 1 : 0, (size_t)max_frame.area() * 3));
+        m_pipes = n_pipes;
+        m_out.resize((size_t)max_batch_size * CAP);
+        m_n.resize(max_batch_size);
     }
     hp_pipeline* m_pl = nullptr;
-    int m_max_batch;
-    std::vector<human_t> m_out;
+    int m_max_batch, m_pipes = 0;
+    std::vector<hp_human> m_out;
     std::vector<int> m_n;
+    std::vector<std::vector<uint8_t>> m_scratch;
 };
+
+template <typename DNNEngine, typename Parser>
+class stream {
+public:
+    using pose_set = std::vector<human_t>;
+
+    /// Same parameters as the reference (stream.hpp:136): `parser_cnt` (CPU parser replicas there) is the number of batches kept in
+    /// flight here (0: 4), `queue_max_size` bounds the frames waiting for a batch slot.
+    explicit stream(DNNEngine& engine, Parser& parser, bool use_original_resolution = false, bool keep_ratio = false, size_t parser_cnt = 0,
+        size_t queue_max_size = 128)
+        : m_engine_ref(engine), m_main_parser_ref(parser), m_use_original_resolution(use_original_resolution), m_keep_ratio(keep_ratio)
+        , m_queue_max(queue_max_size ? queue_max_size : 1)
+        , m_gpu(engine.handle(), parser.stream_desc(), engine.max_batch_size(), keep_ratio, parser_cnt == 0 ? 4 : (int)std::min<size_t>(parser_cnt, 16))
+    {
+        m_worker = std::thread([this] { run(); });
+    }
+    stream(const stream&) = delete;
+    ~stream()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_mu);
+            m_shutdown = true;
+        }
+        m_cv_in.notify_all();
+        m_cv_out.notify_all();
+        if (m_worker.joinable())
+            m_worker.join();
+    }
+
+    class async_handler {
+        stream& m_stream;
+
+    public:
+        async_handler(stream& s)
+            : m_stream(s)
+        {
+        }
+        template <typename S>
+        async_handler& operator<<(S&& source)
+        {
+            m_stream.add_input_stream(std::forward<S>(source));
+            return *this;
+        }
+        // (asynchronous output as in the reference: the sink is drained on another thread; it must outlive the stream or be awaited
+        // through a later sync() call)
+        template <typename S>
+        async_handler& operator>>(S&& sink)
+        {
+            m_stream.m_async_sinks.emplace_back([&s = m_stream, &sink] { s.write_to(sink); });
+            return *this;
+        }
+    };
+    class sync_handler {
+        stream& m_stream;
+
+    public:
+        sync_handler(stream& s)
+            : m_stream(s)
+        {
+        }
+        template <typename S>
+        sync_handler& operator<<(S&& source)
+        {
+            m_stream.add_input_stream(std::forward<S>(source));
+            return *this;
+        }
+        template <typename S>
+        sync_handler& operator>>(S&& sink)
+        {
+            m_stream.write_to(sink);
+            return *this;
+        }
+    };
+    async_handler async() { return *this; }
+    sync_handler sync() { return *this; }
+
+    /// (the reference prints queue lengths periodically, src/stream.cpp add_queue_monitor; kept as a no-op hook)
+    void add_monitor(size_t) {}
+    size_t processed_num() const noexcept { return m_ingest.load(); }
+
+private:
+    struct item {
+        cv::Mat frame;
+        pose_set poses;
+    };
+
+    // ---- input side: src/stream.cpp:18-66
+    void add_input_stream(const std::vector<cv::Mat>& frames)
+    {
+        for (const auto& f : frames)
+            enqueue(f);
+    }
+    void add_input_stream(std::vector<cv::Mat>& frames) { add_input_stream(static_cast<const std::vector<cv::Mat>&>(frames)); }
+    void add_input_stream(std::vector<cv::Mat>&& frames) { add_input_stream(static_cast<const std::vector<cv::Mat>&>(frames)); }
+    void add_input_stream(const cv::Mat& f) { enqueue(f); }
+    void add_input_stream(cv::Mat& f) { enqueue(f); }
+    void add_input_stream(cv::Mat&& f) { enqueue(f); }
+#ifdef HYPERPOSE_USE_OPENCV
+    void add_input_stream(cv::VideoCapture& cap)
+    {
+        while (cap.isOpened()) {
+            cv::Mat mat;
+            cap >> mat;
+            if (mat.empty())
+                break;
+            enqueue(mat);
+        }
+    }
+#endif
+    void enqueue(const cv::Mat& f)
+    {
+        if (f.empty())
+            return;
+        std::unique_lock<std::mutex> lk(m_mu);
+        m_cv_space.wait(lk, [this] { return m_in.size() < m_queue_max || m_shutdown; });
+        m_in.push_back(f);
+        ++m_remaining;
+        ++m_ingest;
+        m_cv_in.notify_one();
+    }
+
+    // ---- feeder: batches -> hp_pipeline -> ordered results (the reference's resize / inference / parse stages, stream.hpp:326-385)
+    void run()
+    {
+        std::deque<std::vector<cv::Mat>> inflight;
+        for (;;) {
+            std::vector<cv::Mat> batch;
+            {
+                std::unique_lock<std::mutex> lk(m_mu);
+                if (inflight.empty())
+                    m_cv_in.wait(lk, [this] { return !m_in.empty() || m_shutdown; });
+                if (m_shutdown && m_in.empty() && inflight.empty())
+                    return;
+                while (!m_in.empty() && (int)batch.size() < m_gpu.max_batch()) {
+                    batch.push_back(std::move(m_in.front()));
+                    m_in.pop_front();
+                }
+                m_cv_space.notify_all();
+            }
+            try {
+                if (!batch.empty()) {
+                    if ((int)m_gpu.in_flight() == m_gpu.n_pipes())
+                        deliver(inflight);
+                    m_gpu.push(batch);
+                    inflight.push_back(std::move(batch));
+                } else if (!inflight.empty())
+                    deliver(inflight);
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> lk(m_mu);
+                m_error = e.what();
+                m_shutdown = true;
+                m_cv_out.notify_all();
+                return;
+            }
+        }
+    }
+    void deliver(std::deque<std::vector<cv::Mat>>& inflight)
+    {
+        auto poses = m_gpu.pop();
+        std::vector<cv::Mat> frames = std::move(inflight.front());
+        inflight.pop_front();
+        std::lock_guard<std::mutex> lk(m_mu);
+        for (size_t i = 0; i < frames.size(); ++i)
+            m_out.push_back(item{ std::move(frames[i]), i < poses.size() ? std::move(poses[i]) : pose_set{} });
+        m_cv_out.notify_all();
+    }
+
+    // ---- output side: blocks until everything ingested so far has been written (src/stream.cpp:114-147)
+    template <typename F>
+    void drain(F&& emit)
+    {
+        for (;;) {
+            item it;
+            {
+                std::unique_lock<std::mutex> lk(m_mu);
+                m_cv_out.wait(lk, [this] { return !m_out.empty() || m_remaining == 0 || m_shutdown; });
+                if (!m_error.empty())
+                    throw std::runtime_error(m_error);
+                if (m_out.empty()) {
+                    if (m_remaining == 0 || m_shutdown)
+                        return;
+                    continue;
+                }
+                it = std::move(m_out.front());
+                m_out.pop_front();
+                --m_remaining;
+            }
+            emit(m_written++, it);
+        }
+    }
+    void write_to(std::vector<pose_set>& sink)
+    {
+        drain([&](size_t, item& it) { sink.push_back(std::move(it.poses)); });
+    }
+    template <typename F>
+    auto write_to(F& fn) -> decltype(fn(size_t(0), std::declval<const cv::Mat&>(), std::declval<const pose_set&>()), void())
+    {
+        drain([&](size_t idx, item& it) { fn(idx, static_cast<const cv::Mat&>(it.frame), static_cast<const pose_set&>(it.poses)); });
+    }
+#ifdef HYPERPOSE_USE_OPENCV
+    cv::Mat rendered(item& it)
+    {
+        cv::Mat img = it.frame;
+        if (!m_use_original_resolution) {
+            cv::Mat r;
+            if (m_keep_ratio)
+                r = non_scaling_resize(img, m_engine_ref.input_size());
+            else
+                cv::resize(img, r, m_engine_ref.input_size());
+            img = r;
+            // (poses are already in original-frame coordinates when keep_ratio is set; on the letter-boxed image they are re-applied)
+        }
+        for (auto&& pose : it.poses)
+            draw_human(img, pose);
+        return img;
+    }
+    void write_to(cv::VideoWriter& writer)
+    {
+        drain([&](size_t, item& it) { writer << rendered(it); });
+    }
+    template <typename NameGetter>
+    auto write_to(NameGetter& name_getter) -> std::enable_if_t<std::is_convertible_v<decltype(name_getter()), std::string>>
+    {
+        drain([&](size_t, item& it) { cv::imwrite(name_getter(), rendered(it)); });
+    }
+#endif
+
+    DNNEngine& m_engine_ref;
+    Parser& m_main_parser_ref;
+    const bool m_use_original_resolution, m_keep_ratio;
+    const size_t m_queue_max;
+    hip_stream m_gpu;
+
+    std::mutex m_mu;
+    std::condition_variable m_cv_in, m_cv_out, m_cv_space;
+    std::deque<cv::Mat> m_in;
+    std::deque<item> m_out;
+    size_t m_remaining = 0, m_written = 0;
+    std::atomic<size_t> m_ingest{ 0 };
+    bool m_shutdown = false;
+    std::string m_error;
+    std::thread m_worker;
+    struct joining_thread {
+        std::thread t;
+        template <typename F>
+        explicit joining_thread(F&& f)
+            : t(std::forward<F>(f))
+        {
+        }
+        joining_thread(joining_thread&&) = default;
+        ~joining_thread()
+        {
+            if (t.joinable())
+                t.join();
+        }
+    };
+    std::vector<joining_thread> m_async_sinks;
+};
+
+/// include/hyperpose/stream/stream.hpp:307-315
+template <typename DNNEngine, typename Parser, typename... Others>
+auto make_stream(DNNEngine&& engine, Parser&& parser, Others&&... others)
+{
+    return stream<std::remove_reference_t<DNNEngine>, std::remove_reference_t<Parser>>(
+        std::forward<DNNEngine>(engine), std::forward<Parser>(parser), std::forward<Others>(others)...);
+}
 
 } // namespace hyperpose

@@ -10,10 +10,14 @@ SRC = os.path.join(ROOT, "tests", "cpp", "operator_api_paf.cpp")
 BIN = os.path.join(ROOT, "tests", "cpp", "operator_api_paf.bin")
 
 
-def _build():
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), SRC,
-                           "-L" + os.path.join(ROOT, "hyperpose_amd"), "-lhp_hip",
-                           "-Wl,-rpath," + os.path.join(ROOT, "hyperpose_amd"), "-o", BIN])
+SRC2 = os.path.join(ROOT, "tests", "cpp", "reference_call_sites.cpp")
+BIN2 = os.path.join(ROOT, "tests", "cpp", "reference_call_sites.bin")
+
+
+def _build(src=SRC, out=BIN):
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), src,
+                           "-L" + os.path.join(ROOT, "hyperpose_amd"), "-lhp_hip", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "hyperpose_amd"), "-o", out])
 
 
 def test_mirror_headers_compile():
@@ -28,3 +32,19 @@ def test_operator_api_flow_runs():
     assert out.returncode == 0, out.stdout + out.stderr
     tag, n_packets, humans, threw = out.stdout.split()[-4:]
     assert tag == "OK" and int(n_packets) == 3 and int(threw) == 1
+
+
+def test_reference_call_sites_compile():
+    """The reference's own engine-construction / inference / make_stream lines (examples/operator_api_batched_images_paf.example.cpp:36-74,
+    examples/stream_api_video_paf.example.cpp:74-88), pasted verbatim into tests/cpp/reference_call_sites.cpp, compile against the mirror."""
+    _build(SRC2, BIN2)
+    assert os.path.exists(BIN2)
+
+
+@pytest.mark.gpu
+def test_reference_call_sites_run():
+    _build(SRC2, BIN2)
+    out = subprocess.run([BIN2, os.path.join(ROOT, "tests", "golden", "onnx", "mobile_paf.onnx")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    tag, humans, frames, stream_humans, threw = out.stdout.split()[-5:]
+    assert tag == "OK" and int(frames) == 11 and int(threw) == 1

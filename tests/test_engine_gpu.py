@@ -142,7 +142,7 @@ def test_first_conv_matrix_pipe_shapes(hp, monkeypatch, stride, cout, act, h, w,
 @pytest.mark.parametrize("cin,cout,k,stride,dil", [
     (32, 64, 1, 1, 1), (64, 128, 1, 1, 1), (128, 128, 3, 1, 1), (128, 512, 1, 1, 1), (512, 19, 1, 1, 1),
     (512, 38, 1, 1, 1), (64, 64, 3, 2, 1), (96, 128, 3, 1, 2), (128, 128, 7, 1, 1), (256, 200, 3, 1, 1),
-    (64, 256, 1, 2, 1),
+    (64, 256, 1, 2, 1), (64, 64, 3, 1, 1), (128, 64, 3, 1, 1),
 ])
 def test_mfma_conv_shapes(hp, cin, cout, k, stride, dil):
     net = Net(cin * 7 + cout)
@@ -611,7 +611,8 @@ def test_direct_conv_any_kernel_and_width(hp, k, cin, cout, h, w):
     _check(got, ref, 3)
     prof = eng.profile(3, 1)
     # the k x k layers whose output stays fp16 NHWC really ran on conv_direct_kernel (z_mid is also a network output: generic epilogue)
-    assert sum(1 for p in prof if p["tile"] >= 6000000) == 2, [p["tile"] for p in prof]
+    want = 2 if (k > 3 or cout > 128) else 1  # (3x3 layers with 128 input channels stay on conv3x3_direct_kernel)
+    assert sum(1 for p in prof if p["tile"] >= 6000000) == want, [p["tile"] for p in prof]
 
 
 def test_direct_conv_matches_generic_kernel_bit_for_bit_inputs(hp, monkeypatch):
@@ -632,3 +633,19 @@ def test_direct_conv_matches_generic_kernel_bit_for_bit_inputs(hp, monkeypatch):
     ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True, mean=m.mean, inv_std=m.inv_std)
     for mode in res:
         _check(res[mode], ref, 2, rel=4e-3, abs_=2e-3)
+
+
+def test_vgg_64_channel_layers_on_the_direct_kernel(hp):
+    """3x3 64 -> 64 (VGG19's second layer: 64 output channels = ONE 64-row block column) and 128 -> 64 through conv3x3_direct_kernel,
+    feeding further layers (fp16 NHWC epilogue), against the oracle."""
+    net = Net(77)
+    a = net.conv(0, 3, 64, 3, 1)
+    b = net.conv(a, 64, 64, 3, 1)
+    c = net.conv(b, 64, 128, 3, 1)
+    d = net.conv(c, 128, 64, 3, 1, act=E.ACT_PRELU)
+    y = net.conv(d, 64, 19, 1, act=E.ACT_NONE)
+    fr = _frames(2, 37, 41, seed=4)
+    eng, got, ref = _run_both(net, [Out("y", y, 0, 19)], fr, 37, 41)
+    _check(got, ref, 2)
+    tiles = [p["tile"] for p in eng.profile(2, 1)]
+    assert tiles[1] // 1000000 == 5 and tiles[3] // 1000000 == 5, tiles
