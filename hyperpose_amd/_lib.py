@@ -50,7 +50,7 @@ _lib = None
 # every symbol include/hp_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "hp_init", "hp_device_count", "hp_last_error", "hp_version", "hp_malloc", "hp_free", "hp_malloc_host",
-    "hp_free_host", "hp_memcpy_h2d", "hp_memcpy_d2h", "hp_device_synchronize", "hp_stream_wait_stream", "hp_preproc_u8hwc_to_f32nchw", "hp_resize_u8c3", "hp_letterbox_u8c3", "hp_letterbox_inner", "hp_resume_ratio",
+    "hp_free_host", "hp_memcpy_h2d", "hp_memcpy_d2h", "hp_device_synchronize", "hp_stream_wait_stream", "hp_dist_unique_id", "hp_dist_init", "hp_dist_destroy", "hp_dist_broadcast_weights", "hp_dist_shard", "hp_preproc_u8hwc_to_f32nchw", "hp_resize_u8c3", "hp_letterbox_u8c3", "hp_letterbox_inner", "hp_resume_ratio",
     "hp_paf_create", "hp_paf_stream", "hp_paf_destroy", "hp_paf_set_conf_thresh", "hp_paf_set_paf_thresh", "hp_paf_process_batch",
     "hp_paf_enqueue", "hp_paf_collect", "hp_paf_debug_peaks", "hp_paf_debug_conns", "hp_paf_debug_maps",
     "hp_pifpaf_create", "hp_pifpaf_destroy", "hp_pifpaf_process_batch", "hp_pifpaf_stream", "hp_pifpaf_enqueue", "hp_pifpaf_collect",

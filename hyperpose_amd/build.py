@@ -34,6 +34,7 @@ UNITS = [
     ("models.cpp", []),
     ("onnx_import.cpp", []),
     ("pipeline.cpp", []),
+    ("dist.cpp", []),
 ]
 
 
@@ -66,7 +67,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     if changed or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"]
         if verbose:
             print("[hyperpose_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

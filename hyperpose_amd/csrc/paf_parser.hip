@@ -34,7 +34,7 @@ namespace {
 constexpr int KSIZE = 17; // paf.cpp:331 (peak_finder ksize)
 constexpr int KR = KSIZE / 2;
 constexpr int PEAK_THREADS = 256;
-constexpr int MAXH = 256;          // humans in flight per frame in the assembly kernel
+constexpr int MAXH = 512;          // humans in flight per frame in the assembly kernel
 constexpr int THRESH_VECTOR_CNT1 = 8; // paf.cpp:57
 constexpr int THRESH_PART_CNT = 4;    // paf.cpp:58
 constexpr float THRESH_HUMAN_SCORE = 0.4; // paf.cpp:59
@@ -313,6 +313,110 @@ struct cand_t {
     int seq; // a * n2 + b: generation order (tie-break for equal scores)
 };
 
+// libstdc++'s std::sort (bits/stl_algo.h: __introsort_loop with median-of-three __unguarded_partition_pivot down to 16 elements, then
+// __final_insertion_sort) restated on an index array, comparator std::greater<connection_candidate> = by score (src/paf.cpp:47-50).  The
+// standard leaves the order of equal elements open; the reference's results depend on this implementation's choice, so it is
+// reproduced step by step (the sequence of comparisons and swaps is a pure function of the scores).  Returns false if the depth limit
+// (2 * floor(log2 n)) is exhausted, where libstdc++ switches to heap sort (not restated; never reached by partition-friendly data).
+__device__ bool libstdcxx_sort_greater(int* v, int n, const cand_t* c)
+{
+#define HP_GT(i, j) (c[v[i]].score > c[v[j]].score)
+#define HP_SWAP(i, j)                                                                                             \
+    {                                                                                                             \
+        const int t_ = v[i];                                                                                      \
+        v[i] = v[j];                                                                                              \
+        v[j] = t_;                                                                                                \
+    }
+    if (n <= 1)
+        return true;
+    bool ok = true;
+    int lg = 0;
+    while ((2 << lg) <= n)
+        ++lg;
+    // __introsort_loop(first, last, depth): `while (last - first > 16) { ...; __introsort_loop(cut, last, depth); last = cut; }` with
+    // the recursion on the RIGHT part first: an explicit stack of (first, last, depth) reproduces the same sequence of partitions
+    int stk_f[64], stk_l[64], stk_d[64], sp = 0;
+    stk_f[0] = 0, stk_l[0] = n, stk_d[0] = 2 * lg, sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stk_f[sp], last = stk_l[sp], depth = stk_d[sp];
+        // iterative form of the loop: every partition pushes the LEFT remainder to be continued after the right recursion returns
+        while (last - first > 16) {
+            if (depth == 0) {
+                ok = false;
+                break;
+            }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            { // __move_median_to_first(result = first, a = first + 1, b = mid, c = last - 1)
+                const int a = first + 1, b = mid, cc = last - 1;
+                if (HP_GT(a, b)) {
+                    if (HP_GT(b, cc))
+                        HP_SWAP(first, b)
+                    else if (HP_GT(a, cc))
+                        HP_SWAP(first, cc)
+                    else
+                        HP_SWAP(first, a)
+                } else if (HP_GT(a, cc))
+                    HP_SWAP(first, a)
+                else if (HP_GT(b, cc))
+                    HP_SWAP(first, cc)
+                else
+                    HP_SWAP(first, b)
+            }
+            int lo = first + 1, hi = last; // __unguarded_partition(first + 1, last, pivot = first)
+            for (;;) {
+                while (HP_GT(lo, first))
+                    ++lo;
+                --hi;
+                while (HP_GT(first, hi))
+                    --hi;
+                if (!(lo < hi))
+                    break;
+                HP_SWAP(lo, hi)
+                ++lo;
+            }
+            const int cut = lo;
+            // recursion on [cut, last) happens NOW in libstdc++, the loop then continues with [first, cut): push the continuation
+            // first (it is popped after the right part and everything below it is done), then descend into the right part
+            if (sp < 63) {
+                stk_f[sp] = first, stk_l[sp] = cut, stk_d[sp] = depth, ++sp;
+            } else
+                ok = false;
+            first = cut;
+        }
+    }
+    // __final_insertion_sort: guarded insertion sort of the first 16, unguarded linear inserts for the rest
+    const int head = n > 16 ? 16 : n;
+    for (int i = 1; i < head; ++i) {
+        const int val = v[i];
+        if (c[val].score > c[v[0]].score) {
+            for (int k = i; k > 0; --k)
+                v[k] = v[k - 1];
+            v[0] = val;
+        } else {
+            int k = i;
+            while (c[val].score > c[v[k - 1]].score) {
+                v[k] = v[k - 1];
+                --k;
+            }
+            v[k] = val;
+        }
+    }
+    for (int i = head; i < n; ++i) {
+        const int val = v[i];
+        int k = i;
+        while (k > 0 && c[val].score > c[v[k - 1]].score) { // (k > 0 never decides after a completed introsort loop; kept as a guard)
+            v[k] = v[k - 1];
+            --k;
+        }
+        v[k] = val;
+    }
+#undef HP_GT
+#undef HP_SWAP
+    return ok;
+}
+
 __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict__ paf, geom_t g, float paf_thresh,
     const dpeak* __restrict__ sorted, const int* __restrict__ pcount, int peak_cap, int cand_cap,
     dconn* __restrict__ conns, int* __restrict__ conn_count, int* __restrict__ flags)
@@ -398,7 +502,15 @@ __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict_
         n = cand_cap;
     }
 
-    // std::sort(..., std::greater) (paf.cpp:249): rank by (score desc, generation order asc)
+    // std::sort(..., std::greater) (paf.cpp:249): rank by (score desc, generation order asc).  Without equal scores that IS the
+    // result of any correct sort.  With equal scores the reference's order is whatever libstdc++'s std::sort leaves: up to 16
+    // candidates it is a plain insertion sort (stable = generation order, what the ranks give); beyond that introsort's
+    // partitioning decides, and the limb is re-sorted below by the same algorithm on one lane.
+    __shared__ int s_ties;
+    if (tid == 0)
+        s_ties = 0;
+    __syncthreads();
+    bool tie = false;
     for (int i = tid; i < n; i += blockDim.x) {
         const float sc = s_cand[i].score;
         const int sq = s_cand[i].seq;
@@ -406,10 +518,27 @@ __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict_
         for (int j = 0; j < n; ++j) {
             const float sj = s_cand[j].score;
             rank += (sj > sc) || (sj == sc && s_cand[j].seq < sq);
+            tie |= sj == sc && j != i;
         }
         s_order[rank] = i;
     }
+    if (tie)
+        s_ties = 1;
     __syncthreads();
+    if (s_ties && n > 16) {
+        // generation order first (the vector std::sort receives, paf.cpp:108-141), then libstdc++'s algorithm on it
+        for (int i = tid; i < n; i += blockDim.x) {
+            const int sq = s_cand[i].seq;
+            int rank = 0;
+            for (int j = 0; j < n; ++j)
+                rank += s_cand[j].seq < sq;
+            s_order[rank] = i;
+        }
+        __syncthreads();
+        if (tid == 0 && !libstdcxx_sort_greater(s_order, n, s_cand))
+            atomicOr(flags + f, 8); // introsort's depth limit ran out (heap-sort fallback not restated): order = generation order of ties
+        __syncthreads();
+    }
 
     // greedy assignment (paf.cpp:252-270) by wavefront 0: "used" bitmaps live in registers, one 32-bit word
     // per lane (covers 2048 peaks per part); conflicts inside a 64-candidate chunk are resolved leader by leader.
@@ -729,9 +858,31 @@ struct hp_paf {
     hp::host_buf h_humans, h_counts; // h_counts: [n_humans(max_batch) | flags(max_batch)], written by the assemble kernel
     int pending = 0; // frames of the enqueued, not yet collected batch
     int last_n = 0;  // frames of the last completed batch (debug taps)
+    const float *last_conf = nullptr, *last_paf = nullptr; // inputs of the batch in flight (re-parsed with larger lists on overflow)
 
     int shape(const int conf_shape[3], const int paf_shape[3]);
+    int alloc_lists();
+    int launch(int n, const float* dev_conf, const float* dev_paf, hipStream_t s);
 };
+
+// The reference's lists are std::vectors (src/post_process.hpp:171-193, src/paf.cpp:108-141): they grow.  Here they start at sizes
+// that fit every realistic frame (512 peaks per part, 2048 candidates per limb, 128 humans) and hp_paf_collect re-parses a batch
+// with doubled lists when a frame overflowed one.  Hard limits (reported as HP_ERR_CAPACITY, results truncated): 2048 peaks per
+// part (the greedy pass keeps its "used" sets in 64 x 32-bit lane registers), the candidates that fit the CU's LDS next to the two PAF
+// planes (~8000 at 46x54), 512 skeleton fragments alive or merged per frame (MAXH), 1024 humans returned.
+constexpr int PEAK_CAP_MAX = 2048, HUMAN_CAP_MAX = 1024;
+int hp_paf::alloc_lists()
+{
+    limbs_lds = (size_t)4 * 2 * g.R * g.Cc + (size_t)cand_cap * (sizeof(cand_t) + sizeof(int));
+    HP_REQUIRE(limbs_lds <= 160 * 1024, HP_ERR_INVALID, "paf: feature map too large for LDS tiling");
+    HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limbs_lds));
+    const size_t B = max_batch;
+    HP_TRY(plist.alloc(B * HP_COCO_N_PARTS * peak_cap * sizeof(dpeak)));
+    HP_TRY(sorted.alloc(B * HP_COCO_N_PARTS * peak_cap * sizeof(dpeak)));
+    HP_TRY(conns.alloc(B * HP_COCO_N_PAIRS * peak_cap * sizeof(dconn)));
+    HP_TRY(h_humans.alloc(B * human_cap * sizeof(hp_human)));
+    return HP_OK;
+}
 
 int hp_paf::shape(const int cs[3], const int ps[3])
 {
@@ -784,21 +935,16 @@ int hp_paf::shape(const int cs[3], const int ps[3])
     bands = hp::ceil_div(g.UH, BH);
     src_rows_cap = std::min(g.R, (int)std::ceil((BH + 2 * (KR + 1)) * (double)g.R / g.UH) + 3);
     peaks_lds = (size_t)4 * ((size_t)src_rows_cap * g.Cc + 2 + 4 * KR + 2 + (2 * 2 + 8) * PEAK_THREADS + 4 * (BH + 2 * (KR + 1) + 6));
-    limbs_lds = (size_t)4 * 2 * g.R * g.Cc + (size_t)cand_cap * (sizeof(cand_t) + sizeof(int));
-    HP_REQUIRE(peaks_lds <= 160 * 1024 && limbs_lds <= 160 * 1024, HP_ERR_INVALID, "paf: feature map too large for LDS tiling");
+    HP_REQUIRE(peaks_lds <= 160 * 1024, HP_ERR_INVALID, "paf: feature map too large for LDS tiling");
     HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_peaks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)peaks_lds));
     HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_peaks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)peaks_lds));
-    HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limbs_lds));
+    HP_TRY(alloc_lists());
 
     const size_t B = max_batch;
-    HP_TRY(plist.alloc(B * HP_COCO_N_PARTS * peak_cap * sizeof(dpeak)));
-    HP_TRY(sorted.alloc(B * HP_COCO_N_PARTS * peak_cap * sizeof(dpeak)));
     HP_TRY(pcount.alloc(B * HP_COCO_N_PARTS * sizeof(int)));
     HP_TRY(pcount_last.alloc(B * HP_COCO_N_PARTS * sizeof(int)));
-    HP_TRY(conns.alloc(B * HP_COCO_N_PAIRS * peak_cap * sizeof(dconn)));
     HP_TRY(conn_count.alloc(B * HP_COCO_N_PAIRS * sizeof(int)));
     HP_TRY(flags.alloc(B * sizeof(int)));
-    HP_TRY(h_humans.alloc(B * human_cap * sizeof(hp_human)));
     HP_TRY(h_counts.alloc(2 * B * sizeof(int)));
     // invariant between batches: peak counters and overflow flags are zero (the assemble kernel restores it)
     HP_HIP_TRY(hipMemset(pcount.p, 0, B * HP_COCO_N_PARTS * sizeof(int)));
@@ -870,15 +1016,11 @@ static int launch_peaks(hp_paf* p, int n, const float* dev_conf, hipStream_t s, 
     return HP_OK;
 }
 
-int hp_paf_enqueue(hp_paf* p, int n, const float* dev_conf, const int conf_shape[3], const float* dev_paf,
-    const int paf_shape[3], void* stream)
-{
-    HP_REQUIRE(p && dev_conf && dev_paf, HP_ERR_INVALID, "hp_paf_enqueue: null argument");
-    HP_REQUIRE(n >= 1 && n <= p->max_batch, HP_ERR_CAPACITY, "hp_paf_enqueue: batch %d > max_batch %d", n, p->max_batch);
-    HP_REQUIRE(p->pending == 0, HP_ERR_STATE, "hp_paf_enqueue: previous batch not collected");
-    HP_TRY(p->shape(conf_shape, paf_shape));
-    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+} // extern "C"
 
+int hp_paf::launch(int n, const float* dev_conf, const float* dev_paf, hipStream_t s)
+{
+    hp_paf* p = this;
     // (pcount / flags are zero here: zeroed at creation and re-zeroed by every assemble launch)
     HP_TRY(launch_peaks(p, n, dev_conf, s, nullptr, nullptr, HP_COCO_N_PARTS));
     hipLaunchKernelGGL(paf_sort_kernel, dim3(HP_COCO_N_PARTS, n), dim3(256), p->peak_cap * sizeof(int), s,
@@ -891,6 +1033,20 @@ int hp_paf_enqueue(hp_paf* p, int n, const float* dev_conf, const int conf_shape
         p->human_cap, p->flags.as<int>(), p->h_counts.as<int>() + p->max_batch, p->pcount_last.as<int>());
     HP_HIP_TRY(hipGetLastError());
     HP_HIP_TRY(hipEventRecord(p->done, s));
+    return HP_OK;
+}
+
+extern "C" {
+
+int hp_paf_enqueue(hp_paf* p, int n, const float* dev_conf, const int conf_shape[3], const float* dev_paf,
+    const int paf_shape[3], void* stream)
+{
+    HP_REQUIRE(p && dev_conf && dev_paf, HP_ERR_INVALID, "hp_paf_enqueue: null argument");
+    HP_REQUIRE(n >= 1 && n <= p->max_batch, HP_ERR_CAPACITY, "hp_paf_enqueue: batch %d > max_batch %d", n, p->max_batch);
+    HP_REQUIRE(p->pending == 0, HP_ERR_STATE, "hp_paf_enqueue: previous batch not collected");
+    HP_TRY(p->shape(conf_shape, paf_shape));
+    HP_TRY(p->launch(n, dev_conf, dev_paf, stream ? (hipStream_t)stream : p->stream));
+    p->last_conf = dev_conf, p->last_paf = dev_paf; // must stay valid until hp_paf_collect (a frame that overflows a list is re-parsed)
     p->pending = n;
     return HP_OK;
 }
@@ -903,15 +1059,42 @@ int hp_paf_collect(hp_paf* p, hp_human* out, int cap_per_frame, int* n_out)
     const int n = p->pending;
     p->pending = 0;
     p->last_n = n;
-    int fl = 0;
-    for (int f = 0; f < n; ++f)
-        fl |= p->h_counts.as<int>()[p->max_batch + f];
-    HP_REQUIRE(fl == 0, HP_ERR_CAPACITY, "paf: device list overflow (flags=%d: 1=peaks/part>%d, 2=candidates/limb>%d, 4=humans>%d)",
-        fl, p->peak_cap, p->cand_cap, MAXH);
+    int fl = 0, max_h = 0;
+    for (int round = 0;; ++round) {
+        fl = 0, max_h = 0;
+        for (int f = 0; f < n; ++f) {
+            fl |= p->h_counts.as<int>()[p->max_batch + f];
+            max_h = std::max(max_h, p->h_counts.as<int>()[f]);
+        }
+        // a list overflowed somewhere in the batch: grow what can grow and parse the batch again (the reference's vectors just grow)
+        const size_t planes = (size_t)4 * 2 * p->g.R * p->g.Cc, per_cand = sizeof(cand_t) + sizeof(int);
+        const int cand_max = (int)((156 * 1024 - planes) / per_cand);
+        bool grown = false;
+        if ((fl & 1) && p->peak_cap < PEAK_CAP_MAX)
+            p->peak_cap = std::min(p->peak_cap * 2, PEAK_CAP_MAX), grown = true;
+        if ((fl & 2) && p->cand_cap < cand_max)
+            p->cand_cap = std::min(p->cand_cap * 2, cand_max), grown = true;
+        if (max_h > p->human_cap && p->human_cap < HUMAN_CAP_MAX) {
+            while (p->human_cap < max_h && p->human_cap < HUMAN_CAP_MAX)
+                p->human_cap *= 2;
+            grown = true;
+        }
+        if (!grown || round >= 6)
+            break;
+        HP_TRY(p->alloc_lists());
+        HP_TRY(p->launch(n, p->last_conf, p->last_paf, p->stream));
+        HP_HIP_TRY(hipEventSynchronize(p->done));
+    }
     int rc = HP_OK;
     for (int f = 0; f < n; ++f) {
         const int nh = p->h_counts.as<int>()[f];
+        const int ff = p->h_counts.as<int>()[p->max_batch + f] & 7;
         n_out[f] = nh;
+        if (ff) { // per-frame status: the other frames of the batch are complete, this one is truncated at a hard limit
+            hp::set_error("paf: frame %d exceeds a hard list limit (flags=%d: 1=peaks/part>%d, 2=candidates/limb>%d, 4=skeleton fragments>%d); its result is truncated",
+                f, ff, p->peak_cap, p->cand_cap, MAXH);
+            rc = HP_ERR_CAPACITY;
+        }
         if (nh > cap_per_frame || nh > p->human_cap) {
             hp::set_error("paf: frame %d has %d humans, capacity %d", f, nh, std::min(cap_per_frame, p->human_cap));
             rc = HP_ERR_CAPACITY;

@@ -79,6 +79,20 @@ int hp_device_synchronize(void);
  * reference's stream pipeline hands a batch from its inference thread to its parser thread (stream.hpp:139-190). */
 int hp_stream_wait_stream(void* waiter, void* signaler);
 
+/* ---- multi-GPU: frames shard over the GPUs of a node, one process per GPU, no steady-state collective.  The one
+ * collective is the start-up broadcast of the weight blob over RCCL / xGMI.  Rendezvous: rank 0 calls hp_dist_unique_id and hands the
+ * 128 bytes to the other ranks by whatever channel launched them (a file, an environment variable, MPI, a TCP store);
+ * every rank then calls hp_dist_init after hp_init(device).  librccl.so is loaded on first use. */
+#define HP_DIST_ID_BYTES 128
+typedef struct hp_comm hp_comm;
+int hp_dist_unique_id(char id[HP_DIST_ID_BYTES]);
+int hp_dist_init(hp_comm** out, int rank, int world, const char id[HP_DIST_ID_BYTES]);
+void hp_dist_destroy(hp_comm* c);
+/* host_weights [n]: read on `root`, overwritten on every other rank (ncclBroadcast through a device buffer) */
+int hp_dist_broadcast_weights(hp_comm* c, float* host_weights, size_t n, int root);
+/* contiguous split of a global batch over the ranks: rank r processes frames [start, start + count) */
+void hp_dist_shard(int total_frames, int rank, int world, int* start, int* count);
+
 /* ---- pre-processing: replaces hyperpose::nhwc_images_append_nchw_batch (src/data.cpp:21-51) -------
  * u8 HWC (BGR) frames [n,h,w,3] -> f32 CHW [n,3,h,w], value = (float)((double)u8 * factor), channel
  * order {2,1,0} when flip_rb.  Both pointers are device pointers; `stream` is a hipStream_t (NULL = default). */

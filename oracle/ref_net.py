@@ -48,15 +48,22 @@ def _q(x, on):
 
 
 def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, frames_f32: np.ndarray = None,
-        factor=1.0 / 255, flip_rb=True, mean=(0, 0, 0), inv_std=(1, 1, 1), match_fp16=True, return_tensors=False):
-    """Returns {name: [n,C,H,W] float32} (and the dict of internal tensors when return_tensors)."""
+        factor=1.0 / 255, flip_rb=True, mean=(0, 0, 0), inv_std=(1, 1, 1), match_fp16=True, return_tensors=False, device="cpu"):
+    """Returns {name: [n,C,H,W] float32} (and the dict of internal tensors when return_tensors).  ``device="cuda"`` evaluates the
+    same fp32 definition with PyTorch's own GPU kernels (MIOpen / rocBLAS - an implementation independent of libhp_hip.so) so that
+    the full-size BASELINE configurations can be checked in seconds; TF32-style shortcuts are switched off."""
     torch.set_num_threads(max(1, torch.get_num_threads()))
-    w = torch.from_numpy(np.ascontiguousarray(weights, np.float32))
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.backends.cudnn.allow_tf32 = False
+        torch.backends.cuda.matmul.allow_tf32 = False
+    w = torch.from_numpy(np.ascontiguousarray(weights, np.float32)).to(dev)
     if frames_u8 is not None:
         x0 = torch.from_numpy(loader.nhwc_u8_to_nchw_f32(frames_u8, factor, flip_rb))
     else:
         x0 = torch.from_numpy(np.ascontiguousarray(frames_f32, np.float32))
-    x0 = (x0 - torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)) * torch.tensor(inv_std, dtype=torch.float32).view(1, 3, 1, 1)
+    x0 = x0.to(dev)
+    x0 = (x0 - torch.tensor(mean, dtype=torch.float32, device=dev).view(1, 3, 1, 1)) * torch.tensor(inv_std, dtype=torch.float32, device=dev).view(1, 3, 1, 1)
     tensors = {0: x0}
     for L in layers:
         x = tensors[L.in_][:, L.in_coff:L.in_coff + L.cin]
@@ -99,9 +106,9 @@ def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, fram
         full = tensors.get(L.out)
         need = L.out_coff + L.cout
         if full is None:
-            full = torch.zeros(y.shape[0], need, oh, ow)
+            full = torch.zeros(y.shape[0], need, oh, ow, device=dev)
         elif full.shape[1] < need:
-            full = torch.cat([full, torch.zeros(y.shape[0], need - full.shape[1], oh, ow)], 1)
+            full = torch.cat([full, torch.zeros(y.shape[0], need - full.shape[1], oh, ow, device=dev)], 1)
         full = full.clone()
         full[:, L.out_coff:need] = y  # un-rounded copy kept for fused fp32 outputs
         tensors[L.out] = full
@@ -136,11 +143,11 @@ def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, fram
             else:
                 v = _act(v, o.act, 0.0, None)
             if grid == 1:
-                v = v + torch.arange(v.shape[3], dtype=torch.float32).view(1, 1, 1, -1)
+                v = v + torch.arange(v.shape[3], dtype=torch.float32, device=dev).view(1, 1, 1, -1)
             elif grid == 2:
-                v = v + torch.arange(v.shape[2], dtype=torch.float32).view(1, 1, -1, 1)
+                v = v + torch.arange(v.shape[2], dtype=torch.float32, device=dev).view(1, 1, -1, 1)
             v = v * scale
-        result[name] = v.numpy()
+        result[name] = v.cpu().numpy()
     if return_tensors:
-        return result, {k: v.numpy() for k, v in tensors.items() if isinstance(k, int)}
+        return result, {k: v.cpu().numpy() for k, v in tensors.items() if isinstance(k, int)}
     return result

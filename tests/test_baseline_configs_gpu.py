@@ -1,5 +1,6 @@
-"""GPU: the BASELINE.json configurations at their FULL sizes, through size-independent properties (the torch CPU oracle
-would need minutes per frame at these sizes; small-size parity against it is in test_engine_gpu.py):
+"""GPU: the BASELINE.json configurations at their FULL sizes: oracle parity of probed frames against oracle/ref_net.py evaluated by
+PyTorch's own fp32 GPU kernels (the CPU evaluation needs minutes per frame; small-size parity against it is in test_engine_gpu.py),
+plus size-independent properties:
   * batch invariance — frame i of a full batch == the same frame run alone (bit for bit: every output pixel
     accumulates in the same order wherever its tile falls),
   * duplicated frames in one batch give identical maps, different frames do not,
@@ -11,7 +12,7 @@ import pytest
 
 from hyperpose_amd import engine as E
 from hyperpose_amd import synth
-from oracle import loader
+from oracle import loader, ref_net
 
 pytestmark = pytest.mark.gpu
 
@@ -19,6 +20,24 @@ pytestmark = pytest.mark.gpu
 def _maps(eng, frames):
     got = eng.inference(frames)
     return [[a for _, a in g] for g in got]
+
+
+def _check_full_size_against_torch_gpu(m, w, frames, full, probe, rel, abs_):
+    """Oracle parity AT FULL SIZE: the probed frames of the batch against oracle/ref_net.py evaluated in fp32 by PyTorch's own GPU
+    kernels (MIOpen / rocBLAS: an implementation independent of libhp_hip.so; the CPU evaluation would take minutes per frame).
+    fp16 storage points matched, so what remains is fp32 summation order: |err| <= rel * max|ref| + abs."""
+    import torch
+    assert torch.cuda.is_available()
+    for i in probe:
+        ref = ref_net.run(m.layers, m.outputs, w, frames_u8=frames[i:i + 1], match_fp16=True, mean=m.mean, inv_std=m.inv_std, device="cuda")
+        names = sorted(ref)
+        assert len(names) == len(full[i])
+        for k, nm in enumerate(names):
+            r, g = ref[nm][0], full[i][k]
+            assert r.shape == g.shape, (nm, r.shape, g.shape)
+            err, scale = float(np.abs(g - r).max()), float(np.abs(r).max())
+            assert err <= rel * scale + abs_, f"frame {i} output {nm}: max err {err:.4g} vs scale {scale:.4g}"
+    torch.cuda.empty_cache()
 
 
 def _check_invariance(eng, frames, probe=(0, 5)):
@@ -38,6 +57,7 @@ def test_config1_lw_openpose_b8_368x432(hp):
     fr = synth.images_u8(synth.rng_for(1), 8, 368, 432)
     fr[3] = fr[1]
     full = _check_invariance(eng, fr)
+    _check_full_size_against_torch_gpu(m, m.init_weights(20241), fr, full, (0, 7), 1e-2, 2e-3)
     assert np.array_equal(full[3][0], full[1][0]) and not np.array_equal(full[2][0], full[1][0])
     # parser on the device-resident DNN output == oracle on the same maps
     eng.inference(fr)
@@ -64,6 +84,7 @@ def test_config2_openpose_vgg19_b16_432x768(hp):
     fr = synth.images_u8(synth.rng_for(2), 16, 432, 768)
     full = _check_invariance(eng, fr, probe=(0, 9))
     assert full[0][0].shape == (19, 54, 96) and full[0][1].shape == (38, 54, 96)
+    _check_full_size_against_torch_gpu(m, m.init_weights(20242), fr, full, (0, 15), 1e-2, 2e-3)
     eng.inference(fr)
     p = Paf(max_batch=16)
     (_, cs, cp), (_, ps, pp) = eng.outputs
@@ -89,6 +110,7 @@ def test_config3_pose_proposal_resnet50_b32_384(hp):
     fr = synth.images_u8(synth.rng_for(3), 32, 384, 384)
     full = _check_invariance(eng, fr, probe=(0, 20))
     assert [a.shape for a in full[0]] == [(18, 12, 12)] * 6 + [(17 * 81, 12, 12)]
+    _check_full_size_against_torch_gpu(m, m.init_weights(20243), fr, full, (0, 31), 2e-2, 5e-3)
     eng.inference(fr)
     parser = PoseProposal((384, 384), max_batch=32)
     humans = parser.process_batch([p for _, _, p in eng.outputs], on_device=True, n=32, conf_shape=(18, 12, 12), edge_shape=(17, 9, 9, 12, 12))
@@ -105,6 +127,7 @@ def test_config4_pifpaf_resnet50_b64_385(hp):
     fr = synth.images_u8(synth.rng_for(4), 64, 385, 385)
     full = _check_invariance(eng, fr, probe=(0, 40))
     assert full[0][0].shape == (171, 49, 49) and full[0][1].shape == (85, 49, 49)
+    _check_full_size_against_torch_gpu(m, m.init_weights(20244), fr, full, (0, 63), 2e-2, 5e-3)
     eng.inference(fr)
     parser = PifPaf(385, 385, max_batch=64)
     humans = parser.process_batch(eng.outputs[0][2], eng.outputs[1][2], on_device=True, n=64, fh=49, fw=49)

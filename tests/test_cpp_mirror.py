@@ -44,7 +44,16 @@ def test_reference_call_sites_compile():
 @pytest.mark.gpu
 def test_reference_call_sites_run():
     _build(SRC2, BIN2)
-    out = subprocess.run([BIN2, os.path.join(ROOT, "tests", "golden", "onnx", "mobile_paf.onnx")], capture_output=True, text=True, timeout=600)
+    # a real Lightweight-OpenPose graph (19 conf / 38 paf channels) exported by PyTorch's ONNX serializer at the test's 48 x 64 input
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch_from_layers as T
+    from hyperpose_amd import engine as E
+    m = E.Model("lw_openpose_mobilenet", 48, 64)
+    path = os.path.join(tempfile.mkdtemp(), "lw_openpose.onnx")
+    T.export(m.layers, m.outputs, m.init_weights(3), 64, 48, path, m.mean, m.inv_std)
+    out = subprocess.run([BIN2, path], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     tag, humans, frames, stream_humans, threw = out.stdout.split()[-5:]
     assert tag == "OK" and int(frames) == 11 and int(threw) == 1

@@ -118,3 +118,17 @@ def test_bench_gpus_flag_is_honoured(monkeypatch):
         raise AssertionError("bench.main() returned instead of re-launching / failing")
     except SystemExit as e:
         assert e.code == 2
+
+
+def test_c_abi_shard_matches_python():
+    """hp_dist_shard (the C ABI's frame split for C++ hosts) == hyperpose_amd.dist.shard."""
+    import ctypes as C
+    from hyperpose_amd import _lib
+    from hyperpose_amd import dist as hd
+    L = _lib.lib()
+    for total in (0, 1, 8, 13, 32, 64):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                s, c = C.c_int(-1), C.c_int(-1)
+                L.hp_dist_shard(total, r, world, C.byref(s), C.byref(c))
+                assert (s.value, c.value) == hd.shard(total, r, world)

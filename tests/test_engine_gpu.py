@@ -649,3 +649,21 @@ def test_vgg_64_channel_layers_on_the_direct_kernel(hp):
     _check(got, ref, 2)
     tiles = [p["tile"] for p in eng.profile(2, 1)]
     assert tiles[1] // 1000000 == 5 and tiles[3] // 1000000 == 5, tiles
+
+
+def test_c_abi_rccl_communicator_single_rank(hp):
+    """hp_dist_* (RCCL bound at run time): unique id, communicator on this device, broadcast of a weight blob.  One GPU here, so
+    world = 1 (the N-rank path is the same three calls; the driver's multi-GPU bench exercises RCCL through torch.distributed)."""
+    import ctypes as C
+    L = hp.lib()
+    uid = (C.c_char * 128)()
+    hp.check(L.hp_dist_unique_id(uid))
+    assert any(b != 0 for b in bytes(uid))
+    comm = C.c_void_p()
+    hp.check(L.hp_dist_init(C.byref(comm), 0, 1, uid))
+    w = np.arange(1000, dtype=np.float32)
+    hp.check(L.hp_dist_broadcast_weights(comm, w.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(w.size), 0))
+    assert np.array_equal(w, np.arange(1000, dtype=np.float32))
+    with pytest.raises(hp.HpError):
+        hp.check(L.hp_dist_broadcast_weights(comm, w.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(w.size), 3))
+    L.hp_dist_destroy(comm)
