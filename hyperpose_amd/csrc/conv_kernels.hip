@@ -853,29 +853,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(const conv_param
         key0[j] = brow[j] * TW + bcol[j];
     }
     const int cb16 = ((kg * NS) * 2 + fk) << 4;
+    // (B fragments are read one whole k16 step = NT MFMAs ahead of their use, across tap boundaries too, and the order is pinned:
+    // hipcc otherwise sinks every ds_read to just before its MFMA and the wavefront eats one LDS latency per MFMA)
+    auto tap_geom = [&](int tap, int (&base)[NT], int (&k16)[NT]) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int toff = (ky * HPW + kx) * (CIN * 2), tkey = ky * TW + kx; // uniform
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            base[j] = hpo0[j] + toff;
+            k16[j] = (CHP == 16 ? ((key0[j] + tkey) & 15) : (((key0[j] + tkey) >> 1) & 7)) << 4;
+        }
+    };
+    half8 fb[2][NT];
+    {
+        int base[NT], k16[NT];
+        tap_geom(0, base, k16);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            fb[0][j] = *reinterpret_cast<const half8*>(lds + base[j] + (cb16 ^ k16[j]));
+    }
 #define HP_TAP(A, TAP)                                                                                            \
     {                                                                                                             \
-        const int ky_ = (TAP) / 3, kx_ = (TAP) - ky_ * 3;                                                         \
-        const int toff_ = (ky_ * HPW + kx_) * (CIN * 2), tkey_ = ky_ * TW + kx_; /* uniform */                    \
         int base_[NT], k16_[NT];                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
-        {                                                                                                         \
-            base_[j] = hpo0[j] + toff_;                                                                           \
-            k16_[j] = (CHP == 16 ? ((key0[j] + tkey_) & 15) : (((key0[j] + tkey_) >> 1) & 7)) << 4;               \
-        }                                                                                                         \
-        half8 fb[2][NT];                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
-            fb[0][j] = *reinterpret_cast<const half8*>(lds + base_[j] + (cb16 ^ k16_[j]));                        \
+        tap_geom((TAP), base_, k16_);                                                                             \
         _Pragma("unroll") for (int ks = 0; ks < NS; ++ks)                                                         \
         {                                                                                                         \
-            if (ks + 1 < NS)                                                                                      \
+            if (ks + 1 < NS) {                                                                                    \
                 _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
                     fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(lds + base_[j] + ((cb16 + (ks + 1) * 32) ^ k16_[j])); \
+            } else {                                                                                              \
+                int basen_[NT], k16n_[NT];                                                                        \
+                tap_geom(min((TAP) + 1, 8), basen_, k16n_);                                                       \
+                _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
+                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(lds + basen_[j] + (cb16 ^ k16n_[j]));    \
+            }                                                                                                     \
             half8 fa;                                                                                             \
             __builtin_memcpy(&fa, &A[ks], 16);                                                                    \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                        \
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[j], 0, 0, 0);              \
             A[ks] = *reinterpret_cast<const u32x4*>(wfrag + (long)min((TAP) + 2, 8) * tap_stride + (size_t)ks * 512); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                        \
+            {                                                                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                    \
         }                                                                                                         \
     }
 #pragma unroll 1

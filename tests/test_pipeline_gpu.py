@@ -106,3 +106,56 @@ def test_pipeline_other_parsers_equal_stages_by_hand(hp, kind):
         assert len(g) == len(b)
         for hg, hr in zip(g, ref):
             assert hg.tobytes() == hr.tobytes()
+
+
+def test_fp16_engine_vs_fp32_oracle_keypoint_drift(hp, capsys):
+    """The reference ships an fp32 TensorRT engine; this engine stores activations in fp16 (fp32 MFMA accumulation).  The parsers are
+    bit-exact on identical heat-maps, so what an end user could see is the drift the fp16 conv stack induces THROUGH the parser.
+    Measured here: the same frames through (a) the fp16 HIP engine + GPU parser and (b) the pure-fp32 oracle conv stack
+    (oracle/ref_net.py, match_fp16 = False) + oracle parser, on weights whose output layers are blown up so that random weights give
+    O(1) maps with real peaks and limbs.  Key-points are integer positions on the 4x up-sampled map: a drifted key-point moves by whole
+    pixels or not at all."""
+    from oracle import ref_net
+    in_w, in_h = 160, 128
+    m = E.Model("lw_openpose_mobilenet", in_w, in_h)
+    w = m.init_weights(11)
+    for L in m.layers:
+        if L.op == E.OP_CONV and L.cout in (19, 38) and L.out in [o.tensor for o in m.outputs]:
+            w[L.w_off:L.w_off + L.cout * L.cin] *= 400.0
+    rng = np.random.default_rng(21)
+    frames = rng.integers(0, 256, (4, in_h, in_w, 3), dtype=np.uint8)
+    eng = E.Engine.from_model(m, w, max_batch=4)
+    got = eng.inference(frames)
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=frames, match_fp16=False)
+    paf = Paf(conf_thresh=0.05, paf_thresh=-1e9, max_batch=4)
+    gh = paf.process_batch(np.stack([g[0][1] for g in got]), np.stack([g[1][1] for g in got]))
+    map_err = max(float(np.abs(got[b][k][1] - ref[n][b]).max() / np.abs(ref[n][b]).max()) for b in range(4) for k, n in enumerate(("conf", "paf")))
+    res_w, res_h = 4 * (in_h // 8), 4 * (in_w // 8)  # the reference's swapped naming: width = 4 * rows (src/paf.cpp:314-315)
+    n_ref = n_gpu = n_kp = n_same = n_close = 0
+    worst = 0.0
+    for b in range(4):
+        oh, _, _ = loader.paf_process(ref["conf"][b], ref["paf"][b], 0.05, -1e9)
+        n_ref += len(oh)
+        n_gpu += len(gh[b])
+        # match every oracle key-point with the nearest GPU key-point of the same part
+        for h in oh:
+            for k in range(18):
+                if not h["parts"]["has_value"][k]:
+                    continue
+                n_kp += 1
+                x, y = h["parts"]["x"][k] * res_w, h["parts"]["y"][k] * res_h
+                best = 1e9
+                for g in gh[b]:
+                    if g["parts"]["has_value"][k]:
+                        best = min(best, float(np.hypot(g["parts"]["x"][k] * res_w - x, g["parts"]["y"][k] * res_h - y)))
+                n_same += best == 0.0
+                n_close += best <= 1.0
+                if best < 1e9:
+                    worst = max(worst, best)
+    with capsys.disabled():
+        print(f"\\nfp16 engine vs fp32 oracle: heat-map max rel err {map_err:.2e}; humans {n_gpu} vs {n_ref}; key-points {n_kp}: "
+              f"{n_same} identical, {n_close} within 1 px, worst matched drift {worst:.2f} px")
+    assert map_err < 2e-2
+    assert n_ref > 0 and n_kp > 20
+    assert n_same >= 0.9 * n_kp, (n_same, n_kp)        # at least 9 of 10 key-points do not move at all
+    assert abs(n_gpu - n_ref) <= max(1, n_ref // 10)
