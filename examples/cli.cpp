@@ -1,0 +1,335 @@
+// examples/cli.cpp — `hyperpose-cli` on the MI355X engine: the flag surface and control flow of the reference's examples/cli.cpp:15-35,
+// 60-330 (model / post / w / h / max_batch_size / source / runtime / keep_ratio / alpha / saving_prefix / logging / imshow), with the
+// pieces that need gflags and OpenCV replaced by what this image has:
+//   * flags: `--name=value`, `--name value`, `--flag` / `--noflag` (gflags syntax), parsed below;
+//   * media: binary PPM (P6) images - one file, or every *.ppm of a directory - and `synthetic:<n>:<w>x<h>` (seeded frames); results are
+//     written as `<saving_prefix>_<id>.ppm` with the skeletons drawn (hp::draw_human) and blended with weight alpha.  With OpenCV
+//     (-DHYPERPOSE_USE_OPENCV) any cv::imread format works; videos / the camera need cv::VideoCapture and are refused without it.
+//   * `--model`: .onnx, a serialized engine (anything else), or `builtin:<arch>` (hp_model_archs(); synthetic weights).
+// build: g++ -std=c++17 -O2 -Iinclude examples/cli.cpp -Lhyperpose_amd -lhp_hip -lpthread -Wl,-rpath,$PWD/hyperpose_amd -o hyperpose-cli
+#include <hyperpose/hyperpose.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <dirent.h>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <string_view>
+#include <variant>
+
+#define kOPERATOR "operator"
+#define kSTREAM "stream"
+#define kPAF "paf"
+#define kPPN "ppn"
+#define kPIFPAF "pifpaf"
+
+namespace hp = hyperpose;
+
+// ---- flags (defaults of examples/cli.cpp:15-35)
+static std::string FLAGS_model = "builtin:lw_openpose_mobilenet";
+static std::string FLAGS_post = kPAF;
+static int FLAGS_w = 368, FLAGS_h = 342, FLAGS_max_batch_size = 6;
+static bool FLAGS_imshow = true;
+static std::string FLAGS_source = "synthetic:4:640x480";
+static std::string FLAGS_runtime = kOPERATOR;
+static bool FLAGS_keep_ratio = true;
+static double FLAGS_alpha = 0.5;
+static std::string FLAGS_saving_prefix = "output";
+static bool FLAGS_logging = false;
+
+static std::ostream& cli_log() { return std::cout << "[HyperPose::CLI] "; }
+
+static bool parse_flags(int argc, char** argv)
+{
+    std::map<std::string, std::string*> sflags = { { "model", &FLAGS_model }, { "post", &FLAGS_post }, { "source", &FLAGS_source },
+        { "runtime", &FLAGS_runtime }, { "saving_prefix", &FLAGS_saving_prefix } };
+    std::map<std::string, int*> iflags = { { "w", &FLAGS_w }, { "h", &FLAGS_h }, { "max_batch_size", &FLAGS_max_batch_size } };
+    std::map<std::string, bool*> bflags = { { "imshow", &FLAGS_imshow }, { "keep_ratio", &FLAGS_keep_ratio }, { "logging", &FLAGS_logging } };
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a.rfind("--", 0) != 0 && a.rfind("-", 0) == 0)
+            a = "-" + a; // gflags accepts -flag too
+        if (a.rfind("--", 0) != 0) {
+            cli_log() << "ERROR: unexpected argument " << a << "\n";
+            return false;
+        }
+        a = a.substr(2);
+        std::string name = a, value;
+        bool has_value = false;
+        if (const auto eq = a.find('='); eq != std::string::npos)
+            name = a.substr(0, eq), value = a.substr(eq + 1), has_value = true;
+        if (bflags.count(name) || (name.rfind("no", 0) == 0 && bflags.count(name.substr(2)))) {
+            const bool neg = !bflags.count(name);
+            bool v = !neg;
+            if (has_value)
+                v = (value == "true" || value == "1" || value == "yes") != neg;
+            *bflags[neg ? name.substr(2) : name] = v;
+            continue;
+        }
+        if (!has_value) {
+            if (i + 1 >= argc) {
+                cli_log() << "ERROR: flag --" << name << " needs a value\n";
+                return false;
+            }
+            value = argv[++i];
+        }
+        if (sflags.count(name))
+            *sflags[name] = value;
+        else if (iflags.count(name))
+            *iflags[name] = std::atoi(value.c_str());
+        else if (name == "alpha")
+            FLAGS_alpha = std::atof(value.c_str());
+        else {
+            cli_log() << "ERROR: unknown command line flag '" << name << "'\n";
+            return false;
+        }
+    }
+    return true;
+}
+
+// ---- media
+static bool read_ppm(const std::string& path, cv::Mat& out)
+{
+    std::ifstream f(path, std::ios::binary);
+    std::string magic;
+    int w = 0, h = 0, maxv = 0;
+    auto token = [&](auto& v) {
+        for (;;) {
+            f >> std::ws;
+            if (f.peek() == '#') {
+                std::string line;
+                std::getline(f, line);
+                continue;
+            }
+            f >> v;
+            return;
+        }
+    };
+    token(magic), token(w), token(h), token(maxv);
+    if (!f || magic != "P6" || w <= 0 || h <= 0 || maxv != 255 || (size_t)w * h > (size_t)1 << 28)
+        return false;
+    f.get(); // the single whitespace after maxval
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    f.read((char*)rgb.data(), rgb.size());
+    if (!f)
+        return false;
+    out = cv::Mat(h, w, CV_8UC3);
+    uint8_t* d = const_cast<uint8_t*>(hp::detail::mat_data(out));
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+        d[i * 3] = rgb[i * 3 + 2], d[i * 3 + 1] = rgb[i * 3 + 1], d[i * 3 + 2] = rgb[i * 3]; // RGB file -> BGR cv::Mat
+    return true;
+}
+static bool write_ppm(const std::string& path, const cv::Mat& m)
+{
+    std::ofstream f(path, std::ios::binary);
+    f << "P6\n" << m.cols << " " << m.rows << "\n255\n";
+    const uint8_t* d = hp::detail::mat_data(m);
+    std::vector<uint8_t> rgb((size_t)m.rows * m.cols * 3);
+    for (size_t i = 0; i < (size_t)m.rows * m.cols; ++i)
+        rgb[i * 3] = d[i * 3 + 2], rgb[i * 3 + 1] = d[i * 3 + 1], rgb[i * 3 + 2] = d[i * 3];
+    f.write((const char*)rgb.data(), rgb.size());
+    return (bool)f;
+}
+static cv::Mat clone(const cv::Mat& m)
+{
+    cv::Mat c(m.rows, m.cols, CV_8UC3);
+    std::memcpy(const_cast<uint8_t*>(hp::detail::mat_data(c)), hp::detail::mat_data(m), (size_t)m.rows * m.cols * 3);
+    return c;
+}
+// cv::addWeighted(mat, alpha, background, 1 - alpha, 0, mat) (examples/cli.cpp:213-215): saturate_cast<uchar>(round(a * x + b * y))
+static void add_weighted(cv::Mat& mat, double alpha, const cv::Mat& background)
+{
+    uint8_t* d = const_cast<uint8_t*>(hp::detail::mat_data(mat));
+    const uint8_t* b = hp::detail::mat_data(background);
+    for (size_t i = 0; i < (size_t)mat.rows * mat.cols * 3; ++i) {
+        const double v = std::nearbyint(d[i] * alpha + b[i] * (1 - alpha));
+        d[i] = (uint8_t)std::min(255.0, std::max(0.0, v));
+    }
+}
+static std::vector<cv::Mat> load_source()
+{
+    std::vector<cv::Mat> images;
+    auto match_suffix = [](std::string_view suffix) {
+        return FLAGS_source.size() >= suffix.size() && std::equal(suffix.crbegin(), suffix.crend(), FLAGS_source.crbegin());
+    };
+    if (FLAGS_source.rfind("synthetic:", 0) == 0) {
+        int n = 0, w = 0, h = 0;
+        if (std::sscanf(FLAGS_source.c_str(), "synthetic:%d:%dx%d", &n, &w, &h) != 3 || n <= 0 || w <= 0 || h <= 0 || n > 4096)
+            return {};
+        unsigned s = 20240;
+        for (int i = 0; i < n; ++i) {
+            cv::Mat m(h, w, CV_8UC3);
+            uint8_t* d = const_cast<uint8_t*>(hp::detail::mat_data(m));
+            for (size_t k = 0; k < (size_t)w * h * 3; ++k)
+                s = s * 1664525u + 1013904223u, d[k] = (uint8_t)(s >> 24);
+            images.push_back(m);
+        }
+        return images;
+    }
+#ifdef HYPERPOSE_USE_OPENCV
+    if (match_suffix(".jpg") || match_suffix(".jpeg") || match_suffix(".png"))
+        return { cv::imread(FLAGS_source) };
+#endif
+    if (match_suffix(".ppm")) {
+        cv::Mat m;
+        if (read_ppm(FLAGS_source, m))
+            images.push_back(m);
+        return images;
+    }
+    if (DIR* dir = opendir(FLAGS_source.c_str())) { // glob_images (examples/utils.cpp)
+        std::vector<std::string> names;
+        while (dirent* e = readdir(dir))
+            names.push_back(e->d_name);
+        closedir(dir);
+        std::sort(names.begin(), names.end());
+        for (const auto& nm : names) {
+            cv::Mat m;
+            const std::string path = FLAGS_source + "/" + nm;
+            if (nm.size() > 4 && nm.substr(nm.size() - 4) == ".ppm" && read_ppm(path, m))
+                images.push_back(m);
+#ifdef HYPERPOSE_USE_OPENCV
+            else if (!(m = cv::imread(path)).empty())
+                images.push_back(m);
+#endif
+        }
+    }
+    return images;
+}
+
+class parser_variant { // examples/cli.cpp:39-54
+public:
+    using var_t = std::variant<hp::parser::pose_proposal, hp::parser::paf, hp::parser::pifpaf>;
+    template <typename Container>
+    std::vector<hp::human_t> process(Container&& feature_map_containers)
+    {
+        return std::visit([&feature_map_containers](auto& arg) { return arg.process(feature_map_containers); }, m_parser);
+    }
+    parser_variant(var_t v)
+        : m_parser(std::move(v))
+    {
+    }
+    var_t& get() { return m_parser; }
+
+private:
+    var_t m_parser;
+};
+
+int main(int argc, char** argv)
+{
+    if (!parse_flags(argc, argv))
+        return 1;
+    if (FLAGS_logging)
+        cli_log() << "Internal LOGGING enabled.\n";
+    if (FLAGS_alpha < 0 || FLAGS_alpha > 1) {
+        const double cl = std::clamp(FLAGS_alpha, 0., 1.);
+        cli_log() << "WARNING. The flag: alpha: " << FLAGS_alpha << " out of range. Clamped to " << cl << std::endl;
+        FLAGS_alpha = cl;
+    }
+    if (hp_init(0) != HP_OK) {
+        cli_log() << "ERROR: " << hp_last_error() << "\n";
+        return 2;
+    }
+    auto images = load_source();
+    if (images.empty()) {
+        cli_log() << "ERROR: Failed to parse source: " << FLAGS_source << " (PPM files / directories and synthetic:<n>:<w>x<h> are supported"
+#ifndef HYPERPOSE_USE_OPENCV
+                  << "; videos and the camera need a build with OpenCV"
+#endif
+                  << ")" << std::endl;
+        std::exit(-1);
+    }
+    if (FLAGS_imshow) {
+        FLAGS_imshow = false;
+        cli_log() << "Imshow functionality needs a display and OpenCV's highgui; results are written to files.\n";
+    }
+
+    // Engine Config (examples/cli.cpp:118-145).
+    auto engine = [&] {
+        using namespace hp::dnn;
+        cli_log() << "Configuring the Engine:"
+                  << "\n--> MODEL: " << FLAGS_model << "\n--> MAX_BATCH_SIZE: " << FLAGS_max_batch_size << "\n--> (HxW): " << FLAGS_h << " x " << FLAGS_w << '\n';
+        constexpr std::string_view onnx_suffix = ".onnx";
+        constexpr std::string_view uff_suffix = ".uff";
+        if (FLAGS_model.rfind("builtin:", 0) == 0)
+            return tensorrt(builtin_model{ FLAGS_model.substr(8), {}, 20241 }, { FLAGS_w, FLAGS_h }, FLAGS_max_batch_size, FLAGS_keep_ratio);
+        if (FLAGS_model.size() >= 5 && std::equal(onnx_suffix.crbegin(), onnx_suffix.crend(), FLAGS_model.crbegin()))
+            return tensorrt(onnx{ FLAGS_model }, { FLAGS_w, FLAGS_h }, FLAGS_max_batch_size, FLAGS_keep_ratio);
+        if (FLAGS_model.size() >= 4 && std::equal(uff_suffix.crbegin(), uff_suffix.crend(), FLAGS_model.crbegin()))
+            return tensorrt(uff{ FLAGS_model, "image", { "outputs/conf", "outputs/paf" } }, { FLAGS_w, FLAGS_h }, FLAGS_max_batch_size, FLAGS_keep_ratio);
+        cli_log() << "Your model file's suffix is not [.onnx | .uff]. Your model file path: " << FLAGS_model << '\n';
+        cli_log() << "We assume this is a serialized engine, and we'll evaluate it in this way.\n";
+        return tensorrt(tensorrt_serialized{ FLAGS_model }, { FLAGS_w, FLAGS_h }, FLAGS_max_batch_size, FLAGS_keep_ratio);
+    }();
+    cli_log() << "DNN engine is built.\n";
+
+    auto parser = parser_variant{ [&engine]() -> parser_variant::var_t {
+        if (FLAGS_post == kPAF)
+            return hp::parser::paf{};
+        if (FLAGS_post == kPPN)
+            return hp::parser::pose_proposal(engine.input_size());
+        if (FLAGS_post == kPIFPAF)
+            return hp::parser::pifpaf(engine.input_size().height, engine.input_size().width);
+        cli_log() << "ERROR: Unknown post-processing flag: `" << FLAGS_post << "`. Use `paf`, `ppn` or `pifpaf` please.\n";
+        std::exit(-1);
+    }() };
+
+    if (FLAGS_runtime != kOPERATOR and FLAGS_runtime != kSTREAM) {
+        cli_log() << "WARNING: Unknown runtime flag: " << FLAGS_runtime << ". Changed this using `operator`.\n";
+        FLAGS_runtime = "operator";
+    }
+
+    using clk_t = std::chrono::high_resolution_clock;
+    size_t n_humans = 0, n_written = 0;
+    auto render = [&](cv::Mat& img, const std::vector<hp::human_t>& poses, bool resume) {
+        cv::Mat background;
+        if (FLAGS_alpha > 0)
+            background = clone(img);
+        for (auto pose : poses) {
+            if (resume)
+                hp::resume_ratio(pose, img.size(), engine.input_size());
+            hp::draw_human(img, pose);
+        }
+        if (FLAGS_alpha > 0)
+            add_weighted(img, FLAGS_alpha, background);
+        n_humans += poses.size();
+        n_written += write_ppm(FLAGS_saving_prefix + "_" + std::to_string(n_written) + ".ppm", img);
+    };
+
+    auto beg = clk_t::now();
+    if (FLAGS_runtime == kOPERATOR) { // examples/cli.cpp:232-275 (the image-vector branch)
+        std::vector<cv::Mat> tmp{};
+        size_t counter = 0;
+        while (counter != images.size()) {
+            auto stride = std::min((size_t)FLAGS_max_batch_size, images.size() - counter);
+            tmp.clear();
+            for (size_t j = 0; j < stride; ++j)
+                tmp.push_back(images[counter + j]);
+            auto feature_maps = engine.inference(tmp);
+            std::vector<std::vector<hp::human_t>> pose_vectors;
+            pose_vectors.reserve(feature_maps.size());
+            for (auto&& packet : feature_maps)
+                pose_vectors.push_back(parser.process(packet));
+            for (size_t i = 0; i < tmp.size(); ++i)
+                render(tmp[i], pose_vectors[i], FLAGS_keep_ratio);
+            counter += stride;
+        }
+    } else { // stream runtime (examples/cli.cpp:277-330): make_stream(engine, parser, use_original_resolution = true, keep_ratio)
+        std::visit(
+            [&](auto& p) {
+                auto stream = hp::make_stream(engine, p, true, FLAGS_keep_ratio);
+                stream.async() << images;
+                auto sink = [&](size_t, const cv::Mat& frame, const std::vector<hp::human_t>& poses) {
+                    cv::Mat img = clone(frame);
+                    render(img, poses, false); // the stream already applied resume_ratio
+                };
+                stream.sync() >> sink;
+            },
+            parser.get());
+    }
+    const auto ms = std::chrono::duration<double, std::milli>(clk_t::now() - beg).count();
+    std::cout << images.size() << " images got processed in " << ms << " ms, FPS = " << 1000. * images.size() / ms << " (" << n_humans
+              << " humans, " << n_written << " files written as " << FLAGS_saving_prefix << "_<id>.ppm)\n";
+    return n_written == images.size() ? 0 : 3;
+}

@@ -1745,6 +1745,137 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const first_conv_p
     }
 }
 
+// The same for the 7 x 7 / stride 2 first layer of the ResNet-50 backbones (hyperpose/Model/backbones.py:587-697; 27 % of the
+// PoseProposal configuration's conv time in its scalar form): K = 7*7*3 = 147 -> 74 steps of v_mfma_f32_32x32x2f32.  The weights do not
+// fit the registers any more (148 per 32-channel tile): they sit in LDS as [64 channels][149] (odd pitch: the 32 lanes of a ds_read_b32
+// group - 32 channels, one k - hit 32 different banks), the im2col operand comes from the fp32 patch as before.
+template <int MT, int S, bool CLAMP>
+__global__ __launch_bounds__(256) void first_conv7_mfma_kernel(const first_conv_params p, int tiles_x, int tiles_y, float lo, float hi)
+{
+    constexpr int KS = 7, K = KS * KS * 3, STEPS = (K + 1) / 2, WP = 149;
+    constexpr int TH = 8, TW = 32, IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS, IWC = IW * 3;
+    __shared__ float s_x[IH * IWC];
+    __shared__ float s_w[MT * 32 * WP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
+
+    for (int i = tid; i < MT * 32 * (K + 1); i += 256) { // [co][k], k = (ky * 7 + kx) * 3 + c = the blob's order; k = 147 is the zero pad
+        const int co = i / (K + 1), k = i - co * (K + 1);
+        s_w[co * WP + k] = (k < K && co < p.Cout) ? p.w[(size_t)co * K + k] : 0.f;
+    }
+    float bs[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = mt * 32 + 8 * g + 4 * hh;
+            const float4 bv = ch + 3 < p.Cout ? *reinterpret_cast<const float4*>(p.bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bs[mt][4 * g] = bv.x, bs[mt][4 * g + 1] = bv.y, bs[mt][4 * g + 2] = bv.z, bs[mt][4 * g + 3] = bv.w;
+        }
+    { // the patch: all loads first (clamped addresses, one memory round trip), then the conversions and the LDS stores
+        constexpr int NIT = (IH * IW + 255) / 256;
+        float raw[NIT][3];
+        bool ok[NIT];
+        const int c0 = p.flip_rb ? 2 : 0, c2 = p.flip_rb ? 0 : 2;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(tid + it * 256, IH * IW - 1);
+            const int py = i / IW, px = i - py * IW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            ok[it] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+            if (p.in_u8) {
+                const uint8_t* q = p.in_u8 + (((size_t)b * p.H + cy) * p.W + cx) * 3;
+                raw[it][0] = (float)q[c0], raw[it][1] = (float)q[1], raw[it][2] = (float)q[c2];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    raw[it][c] = p.in_f32[(((size_t)b * 3 + c) * p.H + cy) * p.W + cx];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < IH * IW) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float x = p.in_u8 ? (float)((double)raw[it][c] * p.factor) : raw[it][c]; // src/data.cpp:48
+                    s_x[i * 3 + c] = ok[it] ? (x - p.mean[c]) * p.inv_std[c] : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const unsigned hmask = hh ? 0xffffffffu : 0u;
+#pragma unroll 1
+    for (int rr = 0; rr < TH / 4; ++rr) {
+        const int row = wave * (TH / 4) + rr, oy = oy0 + row, ox = ox0 + col;
+        if (oy >= p.OH) // uniform per wavefront
+            break;
+        const float* xb = s_x + (row * S) * IWC + (col * S) * 3;
+        floatx16 d[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                d[mt][r] = bs[mt][r];
+        const float* wl = s_w + col * WP + hh;
+#pragma unroll
+        for (int s2 = 0; s2 < STEPS; ++s2) {
+            constexpr int ROWK = KS * 3;
+            const int k0 = 2 * s2, k1 = min(2 * s2 + 1, K - 1);
+            const int o0 = (k0 / ROWK) * IWC + k0 % ROWK, o1 = (k1 / ROWK) * IWC + k1 % ROWK; // compile-time after unrolling
+            float x = xb[hh ? o1 : o0];
+            if (2 * s2 + 1 >= K) // the pad step: the odd half multiplies the zero weight by a finite value
+                x = hh ? 0.f : x;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                d[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[mt * 32 * WP + 2 * s2], x, d[mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt * 32 >= p.Cout)
+                break;
+            unsigned mine[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v0 = d[mt][4 * g + 2 * e], v1 = d[mt][4 * g + 2 * e + 1];
+                    const _Float16 h0 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v0, lo, hi) : apply_act(v0, p.act, p.act_param, 0.f));
+                    const _Float16 h1 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v1, lo, hi) : apply_act(v1, p.act, p.act_param, 0.f));
+                    unsigned short ul, uh;
+                    __builtin_memcpy(&ul, &h0, 2), __builtin_memcpy(&uh, &h1, 2);
+                    mine[g][e] = (unsigned)ul | ((unsigned)uh << 16);
+                }
+            unsigned got[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    got[q][e] = (unsigned)__shfl_xor((int)((mine[q][e] & hmask) | (mine[2 + q][e] & ~hmask)), 32);
+            if (ox < p.OW) {
+                __half* const op = p.out.p + tv_off(p.out, b, oy, ox) + mt * 32;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = 2 * hh + q;
+                    u32x4 v;
+                    v[0] = (got[q][0] & hmask) | (mine[q][0] & ~hmask), v[1] = (got[q][1] & hmask) | (mine[q][1] & ~hmask);
+                    v[2] = (mine[2 + q][0] & hmask) | (got[q][0] & ~hmask), v[3] = (mine[2 + q][1] & hmask) | (got[q][1] & ~hmask);
+                    if (mt * 32 + 8 * g < p.Cout)
+                        *reinterpret_cast<u32x4*>(op + 8 * g) = v;
+                }
+            }
+        }
+    }
+}
+
 hipError_t launch_first_conv(const first_conv_params& p, hipStream_t s)
 {
     const bool no_mfma = getenv("HP_FIRST_MFMA") && atoi(getenv("HP_FIRST_MFMA")) == 0;
@@ -1773,6 +1904,30 @@ hipError_t launch_first_conv(const first_conv_params& p, hipStream_t s)
             HP_FC2(2, 1);
 #undef HP_FC2
 #undef HP_FC
+        return hipGetLastError();
+    }
+    if (!no_mfma && p.KH == 7 && p.KW == 7 && (p.stride == 1 || p.stride == 2) && p.Cout % 8 == 0 && p.Cout <= 64 && p.out.coff % 8 == 0
+        && p.out.cs % 8 == 0) {
+        const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
+        const dim3 grid(tiles_x * tiles_y * p.B);
+        const bool clamp = p.act == ACT_NONE || p.act == ACT_RELU || p.act == ACT_RELU6;
+        const float lo = p.act == ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = p.act == ACT_RELU6 ? 6.f : __builtin_huge_valf();
+#define HP_FC7(MT_, S_)                                                                                           \
+    do {                                                                                                          \
+        if (clamp)                                                                                                \
+            HP_LAUNCH((first_conv7_mfma_kernel<MT_, S_, true>), grid, dim3(256), 0, s, p, tiles_x, tiles_y, lo, hi);  \
+        else                                                                                                      \
+            HP_LAUNCH((first_conv7_mfma_kernel<MT_, S_, false>), grid, dim3(256), 0, s, p, tiles_x, tiles_y, lo, hi); \
+    } while (0)
+        if (p.Cout <= 32 && p.stride == 2)
+            HP_FC7(1, 2);
+        else if (p.Cout <= 32)
+            HP_FC7(1, 1);
+        else if (p.stride == 2)
+            HP_FC7(2, 2);
+        else
+            HP_FC7(2, 1);
+#undef HP_FC7
         return hipGetLastError();
     }
     const int G = (p.Cout + 7) / 8;

@@ -557,6 +557,9 @@ struct val {
     int post_act = 0;     // Sigmoid / Softplus waiting for the output conversion
     int pad[4] = { 0, 0, 0, 0 }; // a Pad node waiting for its consumer (top, left, bottom, right)
     bool nhwc = false;    // IMAGE declared as N,H,W,3 and not yet transposed
+    // post-processing views of a feature map (the PoseProposal / PifPaf exports end in Split / Reshape / Transpose nodes):
+    std::vector<int64_t> view; // non-empty: a Reshape of the SAME row-major memory, may only reach a graph output or another Reshape
+    bool nhwc_view = false;    // a MAP transposed N,C,H,W -> N,H,W,C that must be transposed back before anything reads it
     float a[3] = { 1, 1, 1 }, b[3] = { 0, 0, 0 }; // IMAGE: y = a * x + b so far
     std::shared_ptr<o_tensor> c;
 };
@@ -742,6 +745,8 @@ struct lowering {
             fail(&n, v.kind == val::IMAGE ? "cannot be applied to the network input directly" : "expects a feature map, got a constant");
         if (v.post_act)
             fail(&n, "reads the result of a Sigmoid / Softplus (supported on graph outputs only)");
+        if (!v.view.empty() || v.nhwc_view)
+            fail(&n, "reads a reshaped / transposed feature map (Reshape and Transpose are supported as output post-processing only)");
         if (v.pad[0] | v.pad[1] | v.pad[2] | v.pad[3])
             if (n.op != "Conv" && n.op != "MaxPool")
                 fail(&n, "a Pad node must feed a Conv or MaxPool");
@@ -1342,13 +1347,132 @@ struct lowering {
                 vals[n.out[0]] = get(n, 0);
             else if ((op == "Unsqueeze" || op == "Squeeze" || op == "Reshape" || op == "Cast") && get(n, 0).kind == val::CONST)
                 reshape_constant(n);
-            else if (op == "Transpose") {
+            else if (op == "Reshape" || op == "Flatten" || ((op == "Squeeze" || op == "Unsqueeze") && get(n, 0).kind == val::MAP)) {
+                // post-processing of a head (e.g. the PoseProposal edge tensor [17*9*9, 12, 12] -> [17, 9, 9, 12, 12]): the memory of a
+                // contiguous NCHW map does not change, and the parsers take shapes from their own arguments - a view that may only go on
+                // to a graph output (or another Reshape)
+                val x = get(n, 0);
+                if (x.kind != val::MAP || x.nhwc_view)
+                    fail(&n, "expects a feature map in N,C,H,W order");
+                if (x.pad[0] | x.pad[1] | x.pad[2] | x.pad[3])
+                    fail(&n, "cannot reshape a padded map");
+                std::vector<int64_t> shape;
+                if (op == "Reshape") {
+                    if (!has_in(n, 1) || get(n, 1).kind != val::CONST)
+                        fail(&n, "the target shape must be a constant");
+                    shape = get(n, 1).c->i;
+                    const int64_t per_frame = (int64_t)x.C * x.H * x.W;
+                    int64_t known = 1, infer = -1;
+                    for (size_t k = 0; k < shape.size(); ++k) {
+                        if (shape[k] == 0) // "copy from the input": only meaningful on the batch axis here
+                            shape[k] = k == 0 ? 1 : -2;
+                        if (shape[k] == -1)
+                            infer = (int64_t)k;
+                        else if (shape[k] > 0)
+                            known *= shape[k];
+                        else
+                            fail(&n, "unsupported target shape");
+                    }
+                    // the batch axis may be written as -1, 0 or 1; everything after it must account for exactly one frame
+                    if (infer >= 0 && infer != 0) {
+                        if (known <= 0 || per_frame % known)
+                            fail(&n, "target shape does not divide the feature map");
+                        shape[infer] = per_frame / known, known = per_frame;
+                    } else if (infer == 0)
+                        shape[0] = 1;
+                    int64_t total = 1;
+                    for (int64_t d : shape)
+                        total *= d;
+                    if (total != per_frame)
+                        fail(&n, "target shape holds " + std::to_string(total) + " elements per frame, the feature map " + std::to_string(per_frame));
+                } else
+                    shape = { 1, (int64_t)x.C * x.H * x.W };
+                x.view = shape;
+                x.producer = -1;
+                vals[n.out[0]] = x;
+            } else if (op == "Split" || op == "Slice") {
+                // channel ranges of a head's output (PoseProposal: pc, pi, px, py, pw, ph | pe): zero-copy views at a channel offset
+                val x = get(n, 0);
+                if (x.kind != val::MAP || !x.view.empty() || x.nhwc_view) // (a pending Sigmoid / Softplus travels with every slice)
+                    fail(&n, "expects a feature map in N,C,H,W order");
+                if (x.pad[0] | x.pad[1] | x.pad[2] | x.pad[3])
+                    fail(&n, "cannot slice a padded map");
+                auto ints_of = [&](const char* attr, size_t input) -> std::vector<int64_t> {
+                    if (const o_attr* a = n.attr(attr))
+                        return a->ints;
+                    if (has_in(n, input)) {
+                        const val& c = get(n, input);
+                        if (c.kind != val::CONST)
+                            fail(&n, std::string(attr) + " must be constant");
+                        return c.c->i;
+                    }
+                    return {};
+                };
+                if (op == "Split") {
+                    int64_t axis = n.geti("axis", 0);
+                    if (axis < 0)
+                        axis += 4;
+                    if (axis != 1)
+                        fail(&n, "only a split along the channel axis is supported");
+                    std::vector<int64_t> sizes = ints_of("split", 1);
+                    if (sizes.empty()) {
+                        if (n.out.empty() || x.C % (int)n.out.size())
+                            fail(&n, "channels do not divide evenly over the outputs");
+                        sizes.assign(n.out.size(), x.C / (int64_t)n.out.size());
+                    }
+                    if (sizes.size() != n.out.size())
+                        fail(&n, "split sizes do not match the outputs");
+                    int64_t at = 0;
+                    for (size_t k = 0; k < sizes.size(); ++k) {
+                        if (sizes[k] <= 0 || at + sizes[k] > x.C)
+                            fail(&n, "split sizes exceed the channel count");
+                        val y = x;
+                        y.coff = x.coff + (int)at, y.C = (int)sizes[k], y.producer = -1;
+                        vals[n.out[k]] = y;
+                        at += sizes[k];
+                    }
+                } else {
+                    const std::vector<int64_t> starts = ints_of("starts", 1), ends = ints_of("ends", 2);
+                    std::vector<int64_t> axes = ints_of("axes", 3), steps = ints_of("steps", 4);
+                    if (starts.size() != 1 || ends.size() != 1 || (axes.size() > 1) || (steps.size() > 1) || (!steps.empty() && steps[0] != 1))
+                        fail(&n, "only a unit-step slice of one axis is supported");
+                    int64_t axis = axes.empty() ? 0 : axes[0];
+                    if (axis < 0)
+                        axis += 4;
+                    if (axis != 1)
+                        fail(&n, "only a slice along the channel axis is supported");
+                    int64_t s0 = starts[0] < 0 ? starts[0] + x.C : starts[0], e0 = ends[0] < 0 ? ends[0] + x.C : ends[0];
+                    s0 = std::max<int64_t>(0, std::min<int64_t>(s0, x.C)), e0 = std::max<int64_t>(0, std::min<int64_t>(e0, x.C));
+                    if (e0 <= s0)
+                        fail(&n, "empty slice");
+                    val y = x;
+                    y.coff = x.coff + (int)s0, y.C = (int)(e0 - s0), y.producer = -1;
+                    vals[n.out[0]] = y;
+                }
+            } else if (op == "Transpose") {
                 val x = get(n, 0);
                 const o_attr* perm = n.attr("perm");
-                const bool to_nchw = perm && perm->ints == std::vector<int64_t>{ 0, 3, 1, 2 };
-                if (x.kind != val::IMAGE || !x.nhwc || !to_nchw)
-                    fail(&n, "only the N,H,W,3 -> N,3,H,W transpose of the input is supported");
-                x.nhwc = false;
+                const std::vector<int64_t> pv = perm ? perm->ints : std::vector<int64_t>{};
+                const bool to_nchw = pv == std::vector<int64_t>{ 0, 3, 1, 2 }, to_nhwc = pv == std::vector<int64_t>{ 0, 2, 3, 1 };
+                const bool identity = pv == std::vector<int64_t>{ 0, 1, 2, 3 };
+                if (x.kind == val::IMAGE) {
+                    if (!x.nhwc || !to_nchw)
+                        fail(&n, "only the N,H,W,3 -> N,3,H,W transpose of the input is supported");
+                    x.nhwc = false;
+                } else if (x.kind == val::MAP && x.view.empty()) {
+                    // exporters that keep TensorFlow's layout wrap operators in N,C,H,W <-> N,H,W,C pairs: a pair cancels; a map left in
+                    // N,H,W,C cannot be handed to the parsers (they index [C,H,W], include/hyperpose/utility/data.hpp:22-23)
+                    if (identity)
+                        ;
+                    else if (!x.nhwc_view && to_nhwc)
+                        x.nhwc_view = true;
+                    else if (x.nhwc_view && to_nchw)
+                        x.nhwc_view = false;
+                    else
+                        fail(&n, "unsupported permutation of a feature map (N,C,H,W <-> N,H,W,C pairs and the identity are supported)");
+                    x.producer = -1;
+                } else
+                    fail(&n, "cannot transpose this value");
                 vals[n.out[0]] = x;
             } else
                 fail(&n, "operator not supported by the importer");
@@ -1364,6 +1488,8 @@ struct lowering {
             const val& v = it->second;
             if (v.pad[0] | v.pad[1] | v.pad[2] | v.pad[3])
                 fail(nullptr, "graph output '" + o.name + "' is a padded map");
+            if (v.nhwc_view)
+                fail(nullptr, "graph output '" + o.name + "' is left in N,H,W,C order: the parsers index [C,H,W]");
             m.output(o.name.c_str(), v.tensor, v.coff, v.C, v.post_act);
         }
         if (m.layers.empty())

@@ -11,6 +11,7 @@
 #include <memory>
 #include <vector>
 
+constexpr int CV_8UC3 = 16; // (a macro at global scope in OpenCV)
 namespace cv {
 struct Size {
     int width = 0, height = 0;
@@ -20,7 +21,6 @@ struct Size {
     bool operator==(const Size& o) const { return width == o.width && height == o.height; }
     bool operator!=(const Size& o) const { return !(*this == o); }
 };
-constexpr int CV_8UC3 = 16;
 // Minimal continuous 8-bit 3-channel image (rows x cols x 3, BGR), shared ownership like cv::Mat.
 class Mat {
 public:

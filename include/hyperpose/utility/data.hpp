@@ -4,9 +4,12 @@
 #pragma once
 #include <memory>
 #include <ostream>
+#include <array>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "../../hp_hip.h"
 #include "human.hpp"
 
 namespace hyperpose {
@@ -34,5 +37,56 @@ private:
 };
 
 using internal_t = std::vector<feature_map_t>;
+
+// ---- free functions of the reference's data.hpp (:58-67), evaluated by the same device code as the engine's own pre-processing
+namespace detail {
+    struct dev_ptr { // scoped hp_malloc
+        void* p = nullptr;
+        explicit dev_ptr(size_t n) { hp_malloc(&p, n); }
+        ~dev_ptr() { hp_free(p); }
+        dev_ptr(const dev_ptr&) = delete;
+    };
+    inline const uint8_t* mat_data(const cv::Mat& m)
+    {
+#ifdef HYPERPOSE_USE_OPENCV
+        return m.data;
+#else
+        return m.data();
+#endif
+    }
+} // namespace detail
+
+/// nhwc_images_append_nchw_batch (include/hyperpose/utility/data.hpp:58-64, src/data.cpp:21-51): u8 HWC images -> f32 CHW appended to
+/// `data`, every value multiplied by `factor`, channels {2,1,0} when flip_rb.  hp_preproc_u8hwc_to_f32nchw does the arithmetic.
+inline void nhwc_images_append_nchw_batch(std::vector<float>& data, std::vector<cv::Mat> images, double factor = 1.0, bool flip_rb = false)
+{
+    for (const auto& im : images) {
+        const size_t n = (size_t)im.rows * im.cols * 3;
+        if (!n)
+            continue;
+        detail::dev_ptr din(n), dout(n * sizeof(float));
+        const size_t at = data.size();
+        data.resize(at + n);
+        if (!din.p || !dout.p || hp_memcpy_h2d(din.p, detail::mat_data(im), n) != HP_OK
+            || hp_preproc_u8hwc_to_f32nchw((const uint8_t*)din.p, 1, im.rows, im.cols, factor, flip_rb ? 1 : 0, (float*)dout.p, nullptr) != HP_OK
+            || hp_device_synchronize() != HP_OK || hp_memcpy_d2h(data.data() + at, dout.p, n * sizeof(float)) != HP_OK)
+            throw std::runtime_error(hp_last_error());
+    }
+}
+
+/// non_scaling_resize (data.hpp:67, src/data.cpp:53-69): aspect-preserving resize into the top-left corner of a `size` image filled with
+/// `bgcolor`; hp_letterbox_u8c3 does the arithmetic (bit-equal to cv::resize INTER_LINEAR on the resized region).
+inline cv::Mat non_scaling_resize(const cv::Mat& input, const cv::Size& size, const std::array<int, 3>& bgcolor = { 0, 0, 0 })
+{
+    cv::Mat out(size.height, size.width, CV_8UC3);
+    const size_t ni = (size_t)input.rows * input.cols * 3, no = (size_t)size.area() * 3;
+    detail::dev_ptr din(ni), dout(no);
+    if (!din.p || !dout.p || hp_memcpy_h2d(din.p, detail::mat_data(input), ni) != HP_OK
+        || hp_letterbox_u8c3((const uint8_t*)din.p, input.cols, input.rows, input.cols * 3, (uint8_t*)dout.p, size.width, size.height, size.width * 3,
+               bgcolor[0], bgcolor[1], bgcolor[2], nullptr) != HP_OK
+        || hp_device_synchronize() != HP_OK || hp_memcpy_d2h(const_cast<uint8_t*>(detail::mat_data(out)), dout.p, no) != HP_OK)
+        throw std::runtime_error(hp_last_error());
+    return out;
+}
 
 } // namespace hyperpose

@@ -114,18 +114,21 @@ def test_first_conv_u8_and_f32(hp):
     _check(got, ref, 2)
 
 
-@pytest.mark.parametrize("stride,cout,act,h,w,f32", [
-    (2, 32, E.ACT_RELU, 64, 96, False),   # whole 8 x 32 tiles
-    (2, 16, E.ACT_RELU6, 33, 47, False),  # ragged tiles, half a row tile of output channels
-    (1, 24, E.ACT_NONE, 19, 70, False),   # stride 1, 24 channels: three 8-channel groups
-    (1, 64, E.ACT_LEAKY, 21, 40, False),  # two row tiles, the general (non-clamp) activation path
-    (2, 40, E.ACT_RELU, 30, 34, True),    # f32 NCHW input, second row tile partly filled
+@pytest.mark.parametrize("stride,cout,act,h,w,f32,k", [
+    (2, 32, E.ACT_RELU, 64, 96, False, 3),   # whole 8 x 32 tiles
+    (2, 16, E.ACT_RELU6, 33, 47, False, 3),  # ragged tiles, half a row tile of output channels
+    (1, 24, E.ACT_NONE, 19, 70, False, 3),   # stride 1, 24 channels: three 8-channel groups
+    (1, 64, E.ACT_LEAKY, 21, 40, False, 3),  # two row tiles, the general (non-clamp) activation path
+    (2, 40, E.ACT_RELU, 30, 34, True, 3),    # f32 NCHW input, second row tile partly filled
+    (2, 64, E.ACT_RELU, 97, 129, False, 7),  # first_conv7_mfma_kernel: the ResNet-50 stem (7x7 stride 2), odd sizes
+    (2, 24, E.ACT_LEAKY, 33, 40, False, 7),  # ... one row tile partly filled, general activation
+    (1, 48, E.ACT_RELU6, 20, 37, True, 7),   # ... stride 1, f32 input
 ])
-def test_first_conv_matrix_pipe_shapes(hp, monkeypatch, stride, cout, act, h, w, f32):
-    """first_conv_mfma_kernel (3x3, stride 1 / 2, <= 64 outputs) vs the oracle and vs the scalar first_conv_kernel (HP_FIRST_MFMA=0):
-    both accumulate in fp32; they may differ in the last bit before the fp16 store."""
+def test_first_conv_matrix_pipe_shapes(hp, monkeypatch, stride, cout, act, h, w, f32, k):
+    """first_conv_mfma_kernel / first_conv7_mfma_kernel (3x3 / 7x7, stride 1 / 2, <= 64 outputs) vs the oracle and vs the scalar
+    first_conv_kernel (HP_FIRST_MFMA=0): both accumulate in fp32; they may differ in the last bit before the fp16 store."""
     net = Net(7)
-    t = net.conv(0, 3, cout, 3, stride, act=act, act_param=0.1)
+    t = net.conv(0, 3, cout, k, stride, act=act, act_param=0.1)
     z = net.conv(t, cout, 8, 1, act=E.ACT_NONE)
     outs = [Out("y", t, 0, cout), Out("z", z, 0, 8)]
     fr = np.random.default_rng(9).normal(size=(2, 3, h, w)).astype(np.float32) if f32 else _frames(2, h, w, seed=5)

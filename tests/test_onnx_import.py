@@ -212,3 +212,42 @@ def test_hostile_tensor_dims_are_rejected():
                           ([0, 3, 1, 1], b""), ([4, 3, 1, 64], struct.pack("<768f", *([0.0] * 768)))):
         with pytest.raises(HpError):
             E.Model.from_onnx(conv_model(dims, payload))
+
+
+def _post_op_model():
+    """conv 3 -> 12 (1x1) -> Sigmoid -> Split(4 | 8) -> {first: Transpose to NHWC and back; second: Reshape [N, 2, 4, H, W]}: the shape of the
+    post-processing the PoseProposal / PifPaf exports end in (split heads, 5-D edge / field tensors)."""
+    w = [0.01 * (i + 1) for i in range(36)]
+    init = [W.tensor("w", [12, 3, 1, 1], w), W.tensor("b", [12], [0.1 * i for i in range(12)]),
+            W.tensor("shape", [5], [-1, 2, 4, 6, 8], int64=True), W.tensor("split", [2], [4, 8], int64=True)]
+    nodes = [W.node("Conv", ["x", "w", "b"], ["c"], [W.attr_ints("kernel_shape", [1, 1])]),
+             W.node("Sigmoid", ["c"], ["s"]),
+             W.node("Split", ["s", "split"], ["head_a", "head_b"], [W.attr_int("axis", 1)]),
+             W.node("Transpose", ["head_a"], ["a_nhwc"], [W.attr_ints("perm", [0, 2, 3, 1])]),
+             W.node("Transpose", ["a_nhwc"], ["out_a"], [W.attr_ints("perm", [0, 3, 1, 2])]),
+             W.node("Reshape", ["head_b", "shape"], ["out_b"])]
+    return W.model(nodes, init, [W.value_info("x", ["N", 3, 6, 8])], [W.value_info("out_a", ["N", 4, 6, 8]), W.value_info("out_b", ["N", 2, 4, 6, 8])], opset=13)
+
+
+def test_post_processing_operators_of_the_exported_heads():
+    m = E.Model.from_onnx(_post_op_model())
+    assert len(m.layers) == 1 and m.layers[0].cout == 12
+    outs = {o.name: (o.coff, o.channels, o.act) for o in m.outputs}
+    assert outs == {b"out_a": (0, 4, E.ACT_SIGMOID), b"out_b": (4, 8, E.ACT_SIGMOID)}
+    # views cannot feed further layers, and a map left in N,H,W,C order cannot be an output
+    bad = W.model([W.node("Conv", ["x", "w"], ["c"], [W.attr_ints("kernel_shape", [1, 1])]),
+                   W.node("Transpose", ["c"], ["y"], [W.attr_ints("perm", [0, 2, 3, 1])])],
+                  [W.tensor("w", [4, 3, 1, 1], [0.1] * 12)], [W.value_info("x", ["N", 3, 6, 8])], [W.value_info("y", ["N", 6, 8, 4])])
+    with pytest.raises(HpError, match="N,H,W,C"):
+        E.Model.from_onnx(bad)
+    bad2 = W.model([W.node("Conv", ["x", "w"], ["c"], [W.attr_ints("kernel_shape", [1, 1])]),
+                    W.node("Reshape", ["c", "shape"], ["r"]), W.node("Relu", ["r"], ["y"])],
+                   [W.tensor("w", [4, 3, 1, 1], [0.1] * 12), W.tensor("shape", [3], [-1, 4, 48], int64=True)],
+                   [W.value_info("x", ["N", 3, 6, 8])], [W.value_info("y", ["N", 4, 48])])
+    with pytest.raises(HpError, match="reshaped"):
+        E.Model.from_onnx(bad2)
+    bad3 = W.model([W.node("Conv", ["x", "w"], ["c"], [W.attr_ints("kernel_shape", [1, 1])]), W.node("Reshape", ["c", "shape"], ["y"])],
+                   [W.tensor("w", [4, 3, 1, 1], [0.1] * 12), W.tensor("shape", [3], [-1, 5, 48], int64=True)],
+                   [W.value_info("x", ["N", 3, 6, 8])], [W.value_info("y", ["N", 5, 48])])
+    with pytest.raises(HpError):
+        E.Model.from_onnx(bad3)

@@ -65,3 +65,22 @@ def test_config1_model_from_onnx_runs_the_same_schedule(hp, tmp_path):
         for (n0, x0), (n1, x1) in zip(ga[f], gb[f]):
             assert n0 == n1 and np.array_equal(x0, x1)
     assert [(t["op"], t["tile"]) for t in a.profile(2, 1)] == [(t["op"], t["tile"]) for t in b.profile(2, 1)]
+
+
+def test_post_processing_operators_run(hp):
+    """Split / Reshape / Transpose-pair post-processing (test_onnx_import._post_op_model): values == the torch evaluation of the same graph."""
+    import torch
+    import test_onnx_import as T
+    m = E.Model.from_onnx(T._post_op_model())
+    eng = E.Engine.from_model(m, m.weights, max_batch=2, factor=1.0, flip_rgb=False)
+    rng = np.random.default_rng(1)
+    fr = rng.integers(0, 256, (2, 6, 8, 3), dtype=np.uint8)
+    got = eng.inference(fr)
+    x = torch.from_numpy(fr.astype(np.float32)).permute(0, 3, 1, 2)
+    w = torch.tensor([0.01 * (i + 1) for i in range(36)], dtype=torch.float32).view(12, 3, 1, 1)
+    b = torch.tensor([0.1 * i for i in range(12)], dtype=torch.float32)
+    y = torch.sigmoid(torch.nn.functional.conv2d(x, w, b)).numpy()
+    for f in range(2):
+        named = dict(got[f])
+        assert np.allclose(named["out_a"], y[f, :4], atol=2e-3)
+        assert np.allclose(named["out_b"], y[f, 4:], atol=2e-3)   # [8, 6, 8] = the [2, 4, 6, 8] view's memory
