@@ -1367,6 +1367,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const conv_params p)
     unsigned char* const s_slab = lds + NPX * ROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * NPX, HW = p.OH * p.OW;
+    const int groups = p.Cout_pad / 128; // 128 output channels at a time against the SAME staged pixels (ResNet's 64 -> 256, 128 -> 512 ...)
 
     u32x4 a[KQ];
 #pragma unroll
@@ -1388,23 +1389,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const conv_params p)
         }
     }
     lds_barrier();
-    floatx16 acc[1][NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            acc[0][j][r] = 0.f;
     const int frow = lane & 31, fk = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < KQ; ++ks) {
-        half8 fa;
-        __builtin_memcpy(&fa, &a[ks], 16);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const half8 fb = *reinterpret_cast<const half8*>(s_b + (j * 32 + frow) * ROW + (ks * 2 + fk) * 16);
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[0][j], 0, 0, 0);
-        }
-    }
     int pb[NT], py[NT], px[NT];
     bool pv[NT];
 #pragma unroll
@@ -1415,13 +1400,36 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const conv_params p)
         py[j] = r / p.OW, px[j] = r - py[j] * p.OW;
         pv[j] = n < p.npix;
     }
-    conv_epilogue_staged<1, NT>(p, acc, wave * 32, lane, s_slab + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+#pragma unroll 1
+    for (int mg = 0; mg < groups; ++mg) {
+        floatx16 acc[1][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[0][j][r] = 0.f;
+        const int nxt = min(mg + 1, groups - 1); // the next group's weights are requested as this group's are consumed
+#pragma unroll
+        for (int ks = 0; ks < KQ; ++ks) {
+            half8 fa;
+            __builtin_memcpy(&fa, &a[ks], 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const half8 fb = *reinterpret_cast<const half8*>(s_b + (j * 32 + frow) * ROW + (ks * 2 + fk) * 16);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[0][j], 0, 0, 0);
+            }
+            a[ks] = *reinterpret_cast<const u32x4*>(p.w + ((size_t)((nxt * 4 + wave) * KQ + ks) * 64 + lane) * 8);
+        }
+        conv_epilogue_staged<1, NT>(p, acc, mg * 128 + wave * 32, lane, s_slab + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+    }
 }
 
 static bool use_small1x1(const conv_params& p)
 {
     static const bool off = getenv("HP_NO_SMALL_1X1") != nullptr;
-    return !off && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.Cout_pad == 128 && (p.Cin == 64 || p.Cin == 128 || p.Cin == 192 || p.Cin == 256)
+    return !off && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.Cout_pad % 128 == 0 && p.Cout_pad <= 512
+        && (p.Cout_pad == 128 || p.Cin <= 128) // (wider outputs only where the layer is HBM-bound: K <= 128)
+        && (p.Cin == 64 || p.Cin == 128 || p.Cin == 192 || p.Cin == 256)
         && p.in.coff % 8 == 0 && p.in.cs - p.in.coff >= p.Cin && p.OH == p.H && p.OW == p.W;
 }
 
