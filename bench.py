@@ -143,9 +143,13 @@ class Pipe:
         self.inj = injected
         self.busy = False
 
-    def submit(self, frames_dev, injected: bool):
+    def submit(self, frames_dev, injected: bool, engine: bool = True, parser: bool = True):
         n = self.batch
-        self.eng.enqueue_u8(frames_dev, n)
+        if engine:
+            self.eng.enqueue_u8(frames_dev, n)
+        if not parser:
+            self.eng.synchronize()
+            return
         src = self.inj if injected else self.dnn
         if self.kind == "paf":
             self.par.enqueue(src[0], src[1], n, self.s0, self.s1, stream=self.stream)
@@ -423,6 +427,21 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
                 "fps_dnn_output": round(total_frames / dt_dnn, 1) if dt_dnn else None,
                 "conv_tflops_end_to_end": round(fps * model.flops_per_frame / 1e12, 2),
                 "conv_frac_of_mfma_peak_end_to_end": round(fps * model.flops_per_frame / 1e12 / PEAK_F16_TFLOPS / world, 4)})
+    if rank == 0 and pipes and not args.no_roofline:
+        # where the step's time goes: the parser alone (injected maps: GPU kernels + the host tail in collect) and the conv stack
+        # alone, each through ONE pipe, next to the end-to-end step above (in which several pipes overlap them)
+        k = max(4, min(20, steps // 4))
+        p0 = pipes[0]
+        for what, eng_on, par_on in (("parser_only_ms_per_step", False, True), ("engine_only_ms_per_step", True, False)):
+            for it in range(k + 2):
+                if it == 2:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                p0.submit(frames_dev, True, engine=eng_on, parser=par_on)
+                p0.collect()
+            torch.cuda.synchronize()
+            res[what] = round((time.perf_counter() - t0) / k * 1e3, 4)
+        res["parser_share_of_serial_step"] = round(res["parser_only_ms_per_step"] / (res["parser_only_ms_per_step"] + res["engine_only_ms_per_step"]), 4)
     if rank == 0 and pipes:
         if not args.no_roofline:
             res["roofline"] = roofline(pipes[0], batch, cfg_index)
@@ -473,7 +492,7 @@ def main():
         "fps_dnn_output": head["fps_dnn_output"],
         "conv_tflops_end_to_end": head["conv_tflops_end_to_end"],
     }
-    for k in ("roofline", "cpu_baseline", "h2d_inclusive", "from_host"):
+    for k in ("roofline", "cpu_baseline", "h2d_inclusive", "from_host", "parser_only_ms_per_step", "engine_only_ms_per_step", "parser_share_of_serial_step"):
         if k in head:
             out[k] = head[k]
     extra = args.extra

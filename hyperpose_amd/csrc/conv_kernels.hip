@@ -1019,7 +1019,7 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
         }
     }
 
-    // ---- halo tile of one chunk: global -> registers (one L2 round trip per pass of <= 8 loads per thread) -> LDS
+    // ---- halo tile of one chunk: global -> registers (one L2 round trip per pass of <= 8 loads per thread; one pass of 13 is slower: 9.0 k instead of 8.5 k cycles) -> LDS
     constexpr int NPASS = NBUF == 2 ? 1 : (NIT + 7) / 8, PIT = (NIT + NPASS - 1) / NPASS;
     static_assert(NBUF == 1 || NIT <= 8, "the prefetched chunk lives in registers across a whole chunk");
     u32x4 hv[PIT];
