@@ -1256,7 +1256,9 @@ static int use_gdirect(const conv_params& p)
         return 0;
     if (p.KH == 3 && p.Cin <= 128 && mode < 2)
         return 0;
-    if ((long)p.OH * p.OW < 256 && mode < 3) // maps smaller than two tiles: the generic implicit GEMM packs pixels of several images
+    // maps smaller than two tiles: the generic implicit GEMM packs pixels of several images into one tile - worth more than the halo
+    // re-use unless K is long (measured at 12 x 12: 512 -> 512 57 -> 45 us, 2048 -> 512 212 -> 163 us on this kernel)
+    if ((long)p.OH * p.OW < 256 && p.Cin < 256 && mode < 3)
         return 0;
     // 128-channel chunks only where ONE chunk is the whole input (7x7 / 5x5 x 128: a 101 / 82 KB tile, single-buffered); everything
     // else runs on double-buffered 64-channel chunks (the 128-channel form of that pipeline needs more than 256 registers)
