@@ -442,6 +442,7 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
             torch.cuda.synchronize()
             res[what] = round((time.perf_counter() - t0) / k * 1e3, 4)
         res["parser_share_of_serial_step"] = round(res["parser_only_ms_per_step"] / (res["parser_only_ms_per_step"] + res["engine_only_ms_per_step"]), 4)
+        del p0
     if rank == 0 and pipes:
         if not args.no_roofline:
             res["roofline"] = roofline(pipes[0], batch, cfg_index)
