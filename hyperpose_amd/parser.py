@@ -225,6 +225,13 @@ class PifPaf:
     def process(self, paf, pif):
         return self.process_batch(np.asarray(paf)[None], np.asarray(pif)[None])[0]
 
+    def decode_flags(self, n: int):
+        """Per frame of the last batch: 0 = decoded by the device kernel, -1 = host tail by configuration (HP_PIFPAF_HOST_TAIL=1),
+        > 0 = the reason the device decoder handed the frame to the host tail (include/hp_hip.h)."""
+        flags = (C.c_int * n)()
+        check(lib().hp_pifpaf_decode_flags(self._h, flags, n))
+        return list(flags)
+
     def enqueue(self, dev_paf, dev_pif, n: int, fh: int, fw: int, stream=None):
         check(lib().hp_pifpaf_enqueue(self._h, n, as_ptr(dev_paf), as_ptr(dev_pif), fh, fw, C.c_void_p(stream) if stream else None))
         self._pending = n

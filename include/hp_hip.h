@@ -169,8 +169,10 @@ int hp_ppn_collect(hp_ppn* p, hp_human* out, int cap_per_frame, int* n_out);
 
 /* ---- hyperpose::parser::pifpaf (include/hyperpose/operator/parser/pifpaf.hpp:8-26, src/pifpaf.cpp,
  * src/pifpaf_decoder/openpifpaf_postprocessor.cpp).  GPU: PIF cell compaction, seed and CAF scoring with the
- * hi-res confidence map evaluated on demand (never materialised), list packing; host: seed-ordered greedy grow,
- * occupancy, soft-NMS and the 17 -> 18 key-point remap on the compacted lists. */
+ * hi-res confidence map evaluated on demand (never materialised), and the decoder itself - seed-ordered greedy grow, occupancy,
+ * soft-NMS, the 17 -> 18 key-point remap - as one wavefront per frame (pp_decode_kernel).  A frame the device decoder cannot finish
+ * (capacity, or a score too close to a float rounding boundary to be libm-independent) is decoded by the host tail from the packed
+ * lists; HP_PIFPAF_HOST_TAIL=1 sends every frame there. */
 typedef struct hp_pifpaf hp_pifpaf;
 int hp_pifpaf_create(hp_pifpaf** out, int net_h, int net_w, float thresh, int max_batch); /* pifpaf(int h, int w, float thresh = 0.1) */
 void hp_pifpaf_destroy(hp_pifpaf* p);
@@ -182,6 +184,9 @@ int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* 
 void* hp_pifpaf_stream(hp_pifpaf* p);
 int hp_pifpaf_enqueue(hp_pifpaf* p, int n, const float* dev_paf, const float* dev_pif, int fh, int fw, void* stream);
 int hp_pifpaf_collect(hp_pifpaf* p, hp_human* out, int cap_per_frame, int* n_out);
+/* Per frame of the last collected batch: 0 = decoded on the device, -1 = host tail by configuration, > 0 = why the device decoder
+ * handed the frame to the host tail (1 annotations > 256, 2 soft-NMS extent, 4 sort depth, 8 seeds, 16 frontier, 32 rounding). */
+int hp_pifpaf_decode_flags(const hp_pifpaf* p, int* flags, int n);
 
 /* ---- hyperpose::dnn engine: replaces dnn::tensorrt (include/hyperpose/operator/dnn/tensorrt.hpp:33-141,
  * src/tensorrt.cpp).  The network is a static list of layers over numbered tensors (tensor 0 = the input

@@ -1,0 +1,84 @@
+"""PifPaf device decoder (pp_decode_kernel: seed order, grow with the reference's frontier queue, occupancy, soft-NMS, sort, remap as one
+wavefront per frame; reference src/pifpaf_decoder/openpifpaf_postprocessor.cpp:382-635, 764-851) against the reference's own decoder
+(oracle/_ref) and against the host tail (HP_PIFPAF_HOST_TAIL=1), byte for byte.  `decode_flags` says which path produced each frame, so a
+device bug cannot hide behind the fall-back."""
+import os
+
+import numpy as np
+import pytest
+
+from hyperpose_amd import synth
+from oracle import loader
+
+pytestmark = pytest.mark.gpu
+
+
+def _parser(host_tail, *a, **k):
+    from hyperpose_amd.parser import PifPaf
+    old = os.environ.get("HP_PIFPAF_HOST_TAIL")
+    os.environ["HP_PIFPAF_HOST_TAIL"] = "1" if host_tail else "0"
+    try:
+        return PifPaf(*a, **k)
+    finally:
+        if old is None:
+            del os.environ["HP_PIFPAF_HOST_TAIL"]
+        else:
+            os.environ["HP_PIFPAF_HOST_TAIL"] = old
+
+
+def test_device_decoder_matches_reference_and_host_tail(hp):
+    if loader.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    B = 24
+    dev, host = _parser(False, 385, 385, max_batch=B), _parser(True, 385, 385, max_batch=B)
+    on_device = humans = 0
+    for salt, people, noise in ((3, (3, 0, 1, 5, 2), 0.02), (11, (1, 2, 3, 4, 6, 8, 0, 5), 0.02), (12, (4, 7, 9, 12), 0.1)):
+        paf, pif = synth.pifpaf_maps(synth.rng_for(4, salt=salt), B, people=people, noise=noise)
+        got, ref_host = dev.process_batch(paf, pif), host.process_batch(paf, pif)
+        flags = dev.decode_flags(B)
+        assert host.decode_flags(B) == [-1] * B
+        for b in range(B):
+            ref = loader.ref_pifpaf_process(paf[b], pif[b])
+            assert got[b].tobytes() == ref.tobytes(), (salt, b, flags[b], len(got[b]), len(ref))
+            assert ref_host[b].tobytes() == ref.tobytes()
+            humans += len(ref)
+        on_device += sum(f == 0 for f in flags)
+        assert all(f in (0, 32) for f in flags), flags  # only the rounding guard may hand a frame of this kind to the host
+    assert on_device >= 3 * B - 3, on_device
+    assert humans >= 150
+
+
+def test_device_decoder_stress_against_host_tail(hp):
+    """Many noisy frames (dense seeds, long CAF lists, crowded occupancy): device == host tail on every frame; the frames the device
+    handed back are counted and must stay the exception."""
+    B = 64
+    dev, host = _parser(False, 385, 385, 0.05, max_batch=B, cap_per_frame=256), _parser(True, 385, 385, 0.05, max_batch=B, cap_per_frame=256)
+    fell_back = total = 0
+    for salt, noise in ((21, 0.05), (22, 0.2), (23, 0.3)):
+        paf, pif = synth.pifpaf_maps(synth.rng_for(4, salt=salt), B, people=(2, 5, 9, 14, 20, 1, 0, 30), noise=noise)
+        got, ref = dev.process_batch(paf, pif), host.process_batch(paf, pif)
+        flags = dev.decode_flags(B)
+        for b in range(B):
+            assert got[b].tobytes() == ref[b].tobytes(), (salt, b, flags[b], len(got[b]), len(ref[b]))
+            total += len(ref[b])
+        fell_back += sum(f != 0 for f in flags)
+    assert total >= 500
+    assert fell_back <= 10, fell_back
+
+
+def test_device_decoder_other_geometry_and_async(hp):
+    """Non-square fields (321x481 network), asynchronous halves, device-resident inputs."""
+    B = 8
+    fh, fw = 41, 61
+    dev, host = _parser(False, 321, 481, max_batch=B), _parser(True, 321, 481, max_batch=B)
+    paf, pif = synth.pifpaf_maps(synth.rng_for(4, salt=31), B, fh=fh, fw=fw, people=(2, 3, 5, 0))
+    dp, di = hp.DevBuf.from_numpy(paf), hp.DevBuf.from_numpy(pif)
+    dev.enqueue(dp, di, B, fh, fw)
+    got = dev.collect()
+    ref = host.process_batch(paf, pif)
+    assert sum(f == 0 for f in dev.decode_flags(B)) >= B - 1
+    for b in range(B):
+        assert got[b].tobytes() == ref[b].tobytes(), b
+        if loader.ref_lib() is not None:
+            assert got[b].tobytes() == loader.ref_pifpaf_process(paf[b], pif[b], 321, 481).tobytes()
+    assert sum(len(r) for r in ref) >= 10
