@@ -1886,8 +1886,190 @@ __global__ __launch_bounds__(256) void first_conv7_mfma_kernel(const first_conv_
     }
 }
 
+// The first layer on the fp16 matrix pipe (v_mfma_f32_32x32x16_f16, fp32 accumulation like every other layer): 16 x the rate of the
+// fp32 pipe per k.  u8 pixels are exact in fp16; the normalised value (x * factor - mean) / std and the weights are rounded to fp16 once
+// (the rounding every other layer's operands already carry).  A block owns 16 rows x 32 columns of output pixels; its input patch is
+// converted once into LDS as [row][x * 3 + c] halves, so the KS * 3 values of one kernel row of one pixel are contiguous: the im2col
+// operand of a k16 step is four ds_read_b32.  K is laid out as KS kernel rows padded to ROWP = a multiple of 8 (24 for 7 x 7, 16 for 3 x 3):
+// the pad positions read the next pixels' (finite) data against zero weights.  The weights sit in registers in fragment order
+// (first_conv_params::w16, packed by the engine: [Cout / 32][step][64 lanes][8 halves]).  Stride 1 makes odd columns start on an odd
+// half: a second copy of the patch shifted by one half keeps every read 4-byte aligned.
+template <int KS, int MT, int S, bool CLAMP>
+__global__ __launch_bounds__(256) void first_conv_f16_kernel(const first_conv_params p, int tiles_x, int tiles_y, float lo, float hi)
+{
+    constexpr int ROWP = (KS * 3 + 7) / 8 * 8, KP = KS * ROWP, STEPS = (KP + 15) / 16;
+    constexpr int TH = 16, TW = 32, IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int PITCH = ((TW - 1) * S * 3 + ROWP + 2 + 1) / 2 * 2; // every read of a row stays inside it (+2: the shifted copy)
+    constexpr int NCOPY = (S & 1) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) _Float16 s_x[NCOPY][IH * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
+
+    // this lane's weights and bias (requested first: their latency hides behind the patch conversion)
+    half8 wa[MT][STEPS];
+    float bs[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st)
+            wa[mt][st] = *reinterpret_cast<const half8*>(p.w16 + (((size_t)mt * STEPS + st) * 64 + lane) * 8);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { // accumulator registers 4g .. 4g+3 = channels mt*32 + 8g + 4hh + (0..3)
+            const int ch = mt * 32 + 8 * g + 4 * hh;
+            const float4 bv = ch + 3 < p.Cout ? *reinterpret_cast<const float4*>(p.bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bs[mt][4 * g] = bv.x, bs[mt][4 * g + 1] = bv.y, bs[mt][4 * g + 2] = bv.z, bs[mt][4 * g + 3] = bv.w;
+        }
+    }
+    // the patch: zero-fill (row pads are read against zero weights and must be finite), then all pixel loads, then the conversions
+    for (int i = tid; i < NCOPY * IH * PITCH / 2; i += 256)
+        reinterpret_cast<unsigned*>(&s_x[0][0])[i] = 0u;
+    __syncthreads();
+    {
+        constexpr int NIT = (IH * IW + 255) / 256;
+        const int c0 = p.flip_rb ? 2 : 0, c2 = p.flip_rb ? 0 : 2;
+#pragma unroll 4
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i >= IH * IW)
+                break;
+            const int py = i / IW, px = i - py * IW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W)
+                continue; // stays zero = the convolution's padding
+            float raw[3];
+            if (p.in_u8) {
+                const uint8_t* q = p.in_u8 + (((size_t)b * p.H + iy) * p.W + ix) * 3;
+                raw[0] = (float)((double)(float)q[c0] * p.factor), raw[1] = (float)((double)(float)q[1] * p.factor),
+                raw[2] = (float)((double)(float)q[c2] * p.factor); // src/data.cpp:48
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    raw[c] = p.in_f32[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const _Float16 v = (_Float16)((raw[c] - p.mean[c]) * p.inv_std[c]);
+                s_x[0][py * PITCH + px * 3 + c] = v;
+                if (NCOPY == 2 && px * 3 + c >= 1)
+                    s_x[NCOPY - 1][py * PITCH + px * 3 + c - 1] = v; // copy 1 [j] = copy 0 [j + 1]
+            }
+        }
+    }
+    __syncthreads();
+
+    const unsigned hmask = hh ? 0xffffffffu : 0u;
+    const int odd = (NCOPY == 2) ? ((col * S * 3) & 1) : 0;
+    const _Float16* const xcopy = &s_x[odd][0] + (col * S * 3 - odd);
+#pragma unroll 1
+    for (int rr = 0; rr < TH / 4; ++rr) {
+        const int row = wave * (TH / 4) + rr, oy = oy0 + row, ox = ox0 + col;
+        if (oy >= p.OH) // uniform per wavefront
+            break;
+        const _Float16* xb = xcopy + (row * S) * PITCH;
+        floatx16 d[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                d[mt][r] = bs[mt][r];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            // k' = st * 16 + hh * 8 + i  ->  kernel row k' / ROWP (clamped: the tail of the last step has zero weights), offset k' % ROWP
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int ka = st * 16, kb = st * 16 + 8;
+            const int oa = min(ka / ROWP, KS - 1) * PITCH + ka % ROWP, ob = min(kb / ROWP, KS - 1) * PITCH + kb % ROWP; // compile time
+            const unsigned* q = reinterpret_cast<const unsigned*>(xb + (hh ? ob : oa));
+            u32x4 raw;
+            raw[0] = q[0], raw[1] = q[1], raw[2] = q[2], raw[3] = q[3];
+            half8 xv;
+            __builtin_memcpy(&xv, &raw, 16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                d[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[mt][st], xv, d[mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt * 32 >= p.Cout)
+                break;
+            // d[4g + e] = channel mt*32 + 8g + 4hh + e of pixel `col`.  Half 0 keeps groups 0, 1 and half 1 groups 2, 3: each sends the
+            // other its two foreign groups and ends with 8 consecutive channels per group.
+            unsigned mine[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v0 = d[mt][4 * g + 2 * e], v1 = d[mt][4 * g + 2 * e + 1];
+                    const _Float16 h0 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v0, lo, hi) : apply_act(v0, p.act, p.act_param, 0.f));
+                    const _Float16 h1 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v1, lo, hi) : apply_act(v1, p.act, p.act_param, 0.f));
+                    unsigned short ul, uh;
+                    __builtin_memcpy(&ul, &h0, 2), __builtin_memcpy(&uh, &h1, 2);
+                    mine[g][e] = (unsigned)ul | ((unsigned)uh << 16);
+                }
+            unsigned got[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    got[q][e] = (unsigned)__shfl_xor((int)((mine[q][e] & hmask) | (mine[2 + q][e] & ~hmask)), 32);
+            if (ox < p.OW) {
+                __half* const op = p.out.p + tv_off(p.out, b, oy, ox) + mt * 32;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = 2 * hh + q;
+                    u32x4 v;
+                    v[0] = (got[q][0] & hmask) | (mine[q][0] & ~hmask), v[1] = (got[q][1] & hmask) | (mine[q][1] & ~hmask);
+                    v[2] = (mine[2 + q][0] & hmask) | (got[q][0] & ~hmask), v[3] = (mine[2 + q][1] & hmask) | (got[q][1] & ~hmask);
+                    if (mt * 32 + 8 * g < p.Cout)
+                        *reinterpret_cast<u32x4*>(op + 8 * g) = v;
+                }
+            }
+        }
+    }
+}
+
 hipError_t launch_first_conv(const first_conv_params& p, hipStream_t s)
 {
+    const bool no_f16 = getenv("HP_FIRST_F16") && atoi(getenv("HP_FIRST_F16")) == 0;
+    if (!no_f16 && p.w16 && p.KH == p.KW && (p.KH == 3 || p.KH == 7) && (p.stride == 1 || p.stride == 2) && p.Cout % 8 == 0 && p.Cout <= 64
+        && p.out.coff % 8 == 0 && p.out.cs % 8 == 0) {
+        const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 15) / 16;
+        const dim3 grid(tiles_x * tiles_y * p.B);
+        const bool clamp = p.act == ACT_NONE || p.act == ACT_RELU || p.act == ACT_RELU6;
+        const float lo = p.act == ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = p.act == ACT_RELU6 ? 6.f : __builtin_huge_valf();
+        const int mt = p.Cout <= 32 ? 1 : 2;
+#define HP_F16(KS_, MT_, S_)                                                                                          \
+    do {                                                                                                              \
+        if (clamp)                                                                                                    \
+            HP_LAUNCH((first_conv_f16_kernel<KS_, MT_, S_, true>), grid, dim3(256), 0, s, p, tiles_x, tiles_y, lo, hi);  \
+        else                                                                                                          \
+            HP_LAUNCH((first_conv_f16_kernel<KS_, MT_, S_, false>), grid, dim3(256), 0, s, p, tiles_x, tiles_y, lo, hi); \
+    } while (0)
+#define HP_F16S(KS_, MT_)      \
+    do {                       \
+        if (p.stride == 2)     \
+            HP_F16(KS_, MT_, 2); \
+        else                   \
+            HP_F16(KS_, MT_, 1); \
+    } while (0)
+        if (p.KH == 7 && mt == 2)
+            HP_F16S(7, 2);
+        else if (p.KH == 7)
+            HP_F16S(7, 1);
+        else if (mt == 2)
+            HP_F16S(3, 2);
+        else
+            HP_F16S(3, 1);
+#undef HP_F16S
+#undef HP_F16
+        return hipGetLastError();
+    }
+
     const bool no_mfma = getenv("HP_FIRST_MFMA") && atoi(getenv("HP_FIRST_MFMA")) == 0;
     if (!no_mfma && p.KH == 3 && p.KW == 3 && (p.stride == 1 || p.stride == 2) && p.Cout % 8 == 0 && p.Cout <= 64 && p.out.coff % 8 == 0
         && p.out.cs % 8 == 0) {

@@ -83,6 +83,7 @@ struct first_conv_params {
     int B, H, W, OH, OW;
     int Cout, KH, KW, stride, pad_t, pad_l;
     const float* w; // fp32 [Cout][KH][KW][3]
+    const __half* w16; // the same weights for first_conv_f16_kernel: fp16, [Cout / 32][step][64 lanes][8], k' = ky * ROWP + kx * 3 + c (or nullptr)
     const float* bias;
     int act;
     float act_param;

@@ -399,6 +399,21 @@ int hp_engine::build(const hp_engine_desc* d)
             HP_TRY(upload(w, nw * sizeof(float), &dw));
             HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
             p.w = (const float*)dw, p.bias = (const float*)db;
+            p.w16 = nullptr;
+            if (L.kh == L.kw && (L.kh == 3 || L.kh == 7) && L.cout % 8 == 0 && L.cout <= 64) {
+                // fragment order of first_conv_f16_kernel: kernel rows padded to ROWP (a multiple of 8), K' = KS * ROWP in steps of 16
+                const int KS = L.kh, ROWP = (KS * 3 + 7) / 8 * 8, KP = KS * ROWP, STEPS = (KP + 15) / 16, MT = L.cout <= 32 ? 1 : 2;
+                std::vector<__half> w16((size_t)MT * STEPS * 64 * 8, __float2half(0.f));
+                for (int co = 0; co < L.cout; ++co)
+                    for (int ky = 0; ky < KS; ++ky)
+                        for (int r = 0; r < KS * 3; ++r) {
+                            const int k = ky * ROWP + r, st = k / 16, hh = (k % 16) / 8, e = k % 8;
+                            w16[((((size_t)(co / 32) * STEPS + st) * 64) + hh * 32 + co % 32) * 8 + e] = __float2half(w[((size_t)co * KS + ky) * KS * 3 + r]);
+                        }
+                void* d16 = nullptr;
+                HP_TRY(upload(w16.data(), w16.size() * sizeof(__half), &d16));
+                p.w16 = (const __half*)d16;
+            }
             p.out = to.view(L.out_coff);
             st.flops = 2.0 * opix * L.cout * L.kh * L.kw * 3;
             st.bytes = (double)ti.H * ti.W * 3 + opix * L.cout * 2 + nw * 4;

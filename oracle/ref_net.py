@@ -93,7 +93,12 @@ def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, fram
             else:
                 wt = w[L.w_off:L.w_off + L.cin * L.kh * L.kw].view(L.cin, 1, L.kh, L.kw)
                 groups = L.cin
-            wt = _q(wt, match_fp16 and not first)  # the first layer keeps fp32 weights in the engine
+            # the first layer: on the fp16 matrix pipe (normalised input and weights rounded to fp16, first_conv_f16_kernel) for the
+            # common 3 x 3 / 7 x 7 stems with <= 64 output channels, all-fp32 otherwise
+            first_f16 = first and L.op == OP_CONV and L.kh == L.kw and L.kh in (3, 7) and L.cout % 8 == 0 and L.cout <= 64 and L.stride in (1, 2)
+            wt = _q(wt, match_fp16 and (not first or first_f16))
+            if first_f16:
+                xp = _q(xp, match_fp16)
             b = w[L.b_off:L.b_off + L.cout] if L.b_off >= 0 else None
             y = F.conv2d(xp, wt.contiguous(), b, stride=L.stride, dilation=L.dil, groups=groups)
             alpha = w[L.alpha_off:L.alpha_off + L.cout] if L.alpha_off >= 0 else None
