@@ -626,35 +626,67 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
     const int f = blockIdx.x;
     const dpeak* sorted_f = sorted + (size_t)f * HP_COCO_N_PARTS * peak_cap;
 
-    if (lane == 0) {
-        int acc = 0;
-        for (int c = 0; c < HP_COCO_N_PARTS; ++c) {
-            s_start[c] = acc;
-            const int raw = pcount[f * HP_COCO_N_PARTS + c];
+    { // prefix sums of the per-part peak counts and the per-limb connection counts: one load per lane, a wave scan
+        int np = 0, ncn = 0;
+        if (lane < HP_COCO_N_PARTS) {
+            const int raw = pcount[f * HP_COCO_N_PARTS + lane];
             if (raw > peak_cap)
                 atomicOr(flags + f, 1);
-            acc += min(raw, peak_cap);
+            np = min(raw, peak_cap);
         }
-        s_start[HP_COCO_N_PARTS] = acc;
-        int cacc = 0;
-        for (int l = 0; l < HP_COCO_N_PAIRS; ++l) {
-            s_cstart[l] = cacc;
-            cacc += conn_count[f * HP_COCO_N_PAIRS + l];
+        if (lane < HP_COCO_N_PAIRS)
+            ncn = conn_count[f * HP_COCO_N_PAIRS + lane];
+        int ip = np, ic = ncn; // inclusive scans
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const int tp = __shfl_up(ip, off), tc = __shfl_up(ic, off);
+            if (lane >= off)
+                ip += tp, ic += tc;
         }
-        s_cstart[HP_COCO_N_PAIRS] = cacc;
+        if (lane <= HP_COCO_N_PARTS)
+            s_start[lane] = ip - np; // exclusive; [N_PARTS] = the total (that lane's own count is 0)
+        if (lane <= HP_COCO_N_PAIRS)
+            s_cstart[lane] = ic - ncn;
     }
     __syncthreads();
-    // stage: connections in walk order, peak scores by id
-    for (int l = 0; l < HP_COCO_N_PAIRS; ++l) {
-        const int base = s_cstart[l], nc = s_cstart[l + 1] - base;
-        const dconn* cl = conns + ((size_t)f * HP_COCO_N_PAIRS + l) * peak_cap;
-        for (int i = lane; i < nc && base + i < ASM_CONN_CAP; i += 64)
-            s_conn[base + i] = cl[i];
-    }
-    for (int c = 0; c < HP_COCO_N_PARTS; ++c) {
-        const int base = s_start[c], np = s_start[c + 1] - base;
-        for (int i = lane; i < np && base + i < ASM_PEAK_CAP; i += 64)
-            s_pscore[base + i] = sorted_f[(size_t)c * peak_cap + i].score;
+    // stage: connections in walk order, peak scores by id.  One flat index space per table (every lane finds its limb / part from the
+    // prefix sums with 18 independent LDS reads) and four requests per lane in flight: the 19 + 18 per-list loops this replaces paid a
+    // dependent memory round trip each, more than the whole walk below.
+    {
+        const int total_c = min(s_cstart[HP_COCO_N_PAIRS], ASM_CONN_CAP);
+        for (int base = 0; base < total_c; base += 256) {
+            dconn v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(base + k * 64 + lane, total_c - 1);
+                int l = 0;
+#pragma unroll
+                for (int q = 1; q < HP_COCO_N_PAIRS; ++q)
+                    l += i >= s_cstart[q];
+                v[k] = conns[((size_t)f * HP_COCO_N_PAIRS + l) * peak_cap + (i - s_cstart[l])];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (base + k * 64 + lane < total_c)
+                    s_conn[base + k * 64 + lane] = v[k];
+        }
+        const int total_p = min(s_start[HP_COCO_N_PARTS], ASM_PEAK_CAP);
+        for (int base = 0; base < total_p; base += 256) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(base + k * 64 + lane, total_p - 1);
+                int c = 0;
+#pragma unroll
+                for (int q = 1; q < HP_COCO_N_PARTS; ++q)
+                    c += i >= s_start[q];
+                v[k] = sorted_f[(size_t)c * peak_cap + (i - s_start[c])].score;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (base + k * 64 + lane < total_p)
+                    s_pscore[base + k * 64 + lane] = v[k];
+        }
     }
     __syncthreads();
     auto peak_score = [&](int part, int id) { // all_peaks[id].score for an id of part `part`
@@ -667,69 +699,90 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
         const int p1 = c_pairs[pair_id][0], p2 = c_pairs[pair_id][1];
         const int cbase = s_cstart[pair_id], nc = s_cstart[pair_id + 1] - cbase;
         const dconn* cl = conns + ((size_t)f * HP_COCO_N_PAIRS + pair_id) * peak_cap;
-        for (int ci = 0; ci < nc; ++ci) {
-            const dconn conn = cbase + ci < ASM_CONN_CAP ? s_conn[cbase + ci] : cl[ci];
-            // which humans touch this connection (paf.cpp:164-168), lowest index first
-            int total = 0, first = -1, second = -1;
+        for (int cb = 0; cb < nc; cb += 64) {
+            // 64 connections at a time: lane i fetches connection cb + i and the scores of its two peaks, so that the serial walk
+            // below reads them with v_readlane instead of paying an LDS round trip per dependent access
+            dconn mine{ 0, 0, 0.f };
+            float my_sc1 = 0.f, my_sc2 = 0.f;
+            if (cb + lane < nc) {
+                mine = cbase + cb + lane < ASM_CONN_CAP ? s_conn[cbase + cb + lane] : cl[cb + lane];
+                my_sc1 = peak_score(p1, mine.cid1), my_sc2 = peak_score(p2, mine.cid2); // all_peaks[cid].score
+            }
+            const int nb = min(64, nc - cb);
+            for (int ci = 0; ci < nb; ++ci) {
+                dconn conn;
+                conn.cid1 = __builtin_amdgcn_readlane(mine.cid1, ci), conn.cid2 = __builtin_amdgcn_readlane(mine.cid2, ci);
+                conn.score = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.score), ci));
+                const float sc1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_sc1), ci));
+                const float sc2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_sc2), ci));
+                // which humans touch this connection (paf.cpp:164-168), lowest index first
+                int total = 0, first = -1, second = -1;
+                bool first_has_c2 = false;
 #pragma unroll
-            for (int s = 0; s < MAXH / 64; ++s) {
-                if (s * 64 >= nh) // uniform: no human lives in this slice yet
-                    break;
-                const int h = s * 64 + lane;
-                const bool t = h < nh && (s_parts[h * HP_COCO_N_PARTS + p1] == conn.cid1 || s_parts[h * HP_COCO_N_PARTS + p2] == conn.cid2);
-                unsigned long long m = __ballot(t);
-                total += __popcll(m);
-                if (m && first < 0) {
-                    first = s * 64 + __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                }
-                if (m && second < 0)
-                    second = s * 64 + __ffsll((long long)m) - 1;
-            }
-            const float sc2 = peak_score(p2, conn.cid2); // all_peaks[cid2].score
-            if (total == 1) {
-                if (lane == 0 && s_parts[first * HP_COCO_N_PARTS + p2] != conn.cid2) {
-                    s_parts[first * HP_COCO_N_PARTS + p2] = conn.cid2;
-                    ++s_n[first];
-                    s_score[first] += sc2 + conn.score;
-                }
-            } else if (total >= 2) {
-                bool both = false;
-                if (lane < HP_COCO_N_PARTS)
-                    both = s_parts[first * HP_COCO_N_PARTS + lane] > 0 && s_parts[second * HP_COCO_N_PARTS + lane] > 0; // paf.cpp:185
-                const bool membership = __ballot(both) != 0ull;
-                if (!membership) {
-                    if (lane < HP_COCO_N_PARTS) {
-                        s_parts[first * HP_COCO_N_PARTS + lane] += s_parts[second * HP_COCO_N_PARTS + lane] + 1; // paf.cpp:193
-                        s_parts[second * HP_COCO_N_PARTS + lane] = -1; // erased (paf.cpp:202): never touches again
+                for (int s = 0; s < MAXH / 64; ++s) {
+                    if (s * 64 >= nh) // uniform: no human lives in this slice yet
+                        break;
+                    const int h = s * 64 + lane;
+                    const bool in = h < nh;
+                    const bool t2 = in && s_parts[h * HP_COCO_N_PARTS + p2] == conn.cid2;
+                    const bool t = t2 || (in && s_parts[h * HP_COCO_N_PARTS + p1] == conn.cid1);
+                    unsigned long long m = __ballot(t);
+                    const unsigned long long m2 = __ballot(t2);
+                    total += __popcll(m);
+                    if (m && first < 0) {
+                        const int bit = __ffsll((long long)m) - 1;
+                        first = s * 64 + bit;
+                        first_has_c2 = (m2 >> bit) & 1ull;
+                        m &= m - 1;
                     }
-                    if (lane == 0) {
-                        s_n[first] += s_n[second];
-                        s_score[first] += s_score[second];
-                        s_score[first] += conn.score;
-                        s_n[second] = -(1 << 20); // erased: fails the n_parts filter
-                    }
-                } else if (lane == 0) {
-                    s_parts[first * HP_COCO_N_PARTS + p2] = conn.cid2;
-                    s_n[first] += 1;
-                    s_score[first] += sc2 + conn.score;
+                    if (m && second < 0)
+                        second = s * 64 + __ffsll((long long)m) - 1;
                 }
-            } else if (pair_id <= 16) { // !is_virtual_pair, coco.hpp:6
-                if (nh < MAXH) {
+                if (total == 1) {
+                    if (lane == 0 && !first_has_c2) { // humans[first].parts[p2] != cid2
+                        s_parts[first * HP_COCO_N_PARTS + p2] = conn.cid2;
+                        ++s_n[first];
+                        s_score[first] += sc2 + conn.score;
+                    }
+                } else if (total >= 2) {
+                    bool both = false;
                     if (lane < HP_COCO_N_PARTS)
-                        s_parts[nh * HP_COCO_N_PARTS + lane] = lane == p1 ? conn.cid1 : (lane == p2 ? conn.cid2 : -1);
-                    if (lane == 0) {
-                        const float sc1 = peak_score(p1, conn.cid1);
-                        s_n[nh] = 2;
-                        s_score[nh] = sc1 + sc2 + conn.score;
+                        both = s_parts[first * HP_COCO_N_PARTS + lane] > 0 && s_parts[second * HP_COCO_N_PARTS + lane] > 0; // paf.cpp:185
+                    const bool membership = __ballot(both) != 0ull;
+                    if (!membership) {
+                        if (lane < HP_COCO_N_PARTS) {
+                            s_parts[first * HP_COCO_N_PARTS + lane] += s_parts[second * HP_COCO_N_PARTS + lane] + 1; // paf.cpp:193
+                            s_parts[second * HP_COCO_N_PARTS + lane] = -1; // erased (paf.cpp:202): never touches again
+                        }
+                        if (lane == 0) {
+                            s_n[first] += s_n[second];
+                            s_score[first] += s_score[second];
+                            s_score[first] += conn.score;
+                            s_n[second] = -(1 << 20); // erased: fails the n_parts filter
+                        }
+                    } else if (lane == 0) {
+                        s_parts[first * HP_COCO_N_PARTS + p2] = conn.cid2;
+                        s_n[first] += 1;
+                        s_score[first] += sc2 + conn.score;
                     }
-                    ++nh;
-                } else
-                    overflow = true;
+                } else if (pair_id <= 16) { // !is_virtual_pair, coco.hpp:6
+                    if (nh < MAXH) {
+                        if (lane < HP_COCO_N_PARTS)
+                            s_parts[nh * HP_COCO_N_PARTS + lane] = lane == p1 ? conn.cid1 : (lane == p2 ? conn.cid2 : -1);
+                        if (lane == 0) {
+                            s_n[nh] = 2;
+                            s_score[nh] = sc1 + sc2 + conn.score;
+                        }
+                        ++nh;
+                    } else
+                        overflow = true;
+                }
+                // one wavefront, DS operations retire in order: the next connection's reads see these writes without a barrier
+                __builtin_amdgcn_wave_barrier();
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
     if (overflow && lane == 0)
         atomicOr(flags + f, 4);
 
