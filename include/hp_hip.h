@@ -180,12 +180,14 @@ void hp_pifpaf_destroy(hp_pifpaf* p);
 int hp_pifpaf_process_batch(hp_pifpaf* p, int n, const float* paf, const float* pif, int fh, int fw, int on_device,
                             hp_human* out, int cap_per_frame, int* n_out);
 /* Asynchronous halves: enqueue = the five kernels + the packed lists written into pinned host memory, on `stream` (NULL = the
- * parser's own); collect = wait + grow / soft-NMS of every frame on the host worker pool. */
+ * parser's own) and the device decoder behind them, humans written into pinned memory; collect = wait, copy out, and the host tail
+ * (worker pool) for the frames the device decoder declined. */
 void* hp_pifpaf_stream(hp_pifpaf* p);
 int hp_pifpaf_enqueue(hp_pifpaf* p, int n, const float* dev_paf, const float* dev_pif, int fh, int fw, void* stream);
 int hp_pifpaf_collect(hp_pifpaf* p, hp_human* out, int cap_per_frame, int* n_out);
 /* Per frame of the last collected batch: 0 = decoded on the device, -1 = host tail by configuration, > 0 = why the device decoder
- * handed the frame to the host tail (1 annotations > 256, 2 soft-NMS extent, 4 sort depth, 8 seeds, 16 frontier, 32 rounding). */
+ * handed the frame to the host tail (1 annotations > 256, 2 soft-NMS extent, 4 sort depth, 8 seeds, 16 frontier / more than 256 list
+ * entries inside one search box, 32 rounding). */
 int hp_pifpaf_decode_flags(const hp_pifpaf* p, int* flags, int n);
 
 /* ---- hyperpose::dnn engine: replaces dnn::tensorrt (include/hyperpose/operator/dnn/tensorrt.hpp:33-141,
