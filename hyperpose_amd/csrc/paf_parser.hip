@@ -34,6 +34,8 @@ namespace {
 constexpr int KSIZE = 17; // paf.cpp:331 (peak_finder ksize)
 constexpr int KR = KSIZE / 2;
 constexpr int PEAK_THREADS = 256;
+constexpr int PEAK_WCOLS = 46;                 // columns a wavefront of the peaks kernel owns (lanes 9 .. 54)
+constexpr int PEAK_BCOLS = 4 * PEAK_WCOLS;       // ... and a block
 constexpr int MAXH = 512;          // humans in flight per frame in the assembly kernel
 constexpr int THRESH_VECTOR_CNT1 = 8; // paf.cpp:57
 constexpr int THRESH_PART_CNT = 4;    // paf.cpp:58
@@ -112,13 +114,16 @@ __device__ __forceinline__ float up_at(const float* __restrict__ src, int row_ba
 
 // ---------------------------------------------------------------------------------------------------
 // 1. peaks: resize_area + smooth + same_max_pool_3x3 + find_peak_coords (post_process.hpp:26-195), fused.
-// One block = one (frame, part, band of BH up-sampled rows, strip of CW columns).  One thread = one column; the block
-// marches down the rows, TWO rows per step, keeping per thread the last 18 row-filtered values in registers (the
-// column filter's window), so the 216 x 184 intermediate planes never exist anywhere: per step a thread up-samples its
-// two samples, the row pair is exchanged through LDS for the 17-tap row filter, the column filter runs out of
-// registers and an 8-row ring of smoothed values in LDS feeds the 3x3 maximum test.  The two rows of a step sit in the
-// two halves of packed-fp32 registers (v_pk_mul_f32 / v_pk_add_f32: the same IEEE roundings as the scalar forms, no
-// fusion).  One barrier per step; ~17 KB of LDS per block.
+// One block = one (frame, part, band of BH up-sampled rows, strip of CW <= 184 columns).  One thread = one column; the four wavefronts of
+// a block are INDEPENDENT: wavefront w owns the 46 columns x0 + 46 w .. + 45 (lanes 9 .. 54) plus 9 halo columns on either side, marches
+// down the rows TWO at a time, and keeps everything but the source rows in registers:
+//   * the 17-tap row filter takes its neighbours' samples with v_mov_b32_dpp wave_shr:1 / wave_shl:1 (sixteen shifts of the lane's
+//     (row m, row m+1) pair) instead of an LDS exchange - the kernel used to move 224 B of LDS per thread and step and was bound by the
+//     128 B/clk of the LDS, now 64 B (the up-sampling reads of the staged source rows), and there is no barrier inside the march;
+//   * the column filter runs out of the 18-row register window of row-filtered values as before;
+//   * the last four smoothed rows stay in registers, the 3x3 maximum test reads the left / right neighbours with two more shifts.
+// The two rows of a step sit in the two halves of packed-fp32 registers (v_pk_mul_f32 / v_pk_add_f32: the same IEEE roundings as the
+// scalar forms, no fusion); every value is computed by the same expression in the same order as before - only the data movement changed.
 // BORDER_REFLECT_101 is handled by evaluating the reflected row / column itself (the same value the CPU code reads).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -135,20 +140,15 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
 
     const int y0 = band * BH, y1 = min(g.UH, y0 + BH);
     const int x0 = strip * CW, x1 = min(g.UW, x0 + CW);
-    const int cw = x1 - x0;
     // rows really touched (reflections of the rows above / below the map fall inside this range)
     const int ry_lo = max(0, y0 - KR - 1), ry_hi = min(g.UH, y1 + KR + 1);
     const int row_base = g.ofs_y0[ry_lo];
     const int nrows = g.ofs_y1[ry_hi - 1] - row_base + 1;
 
-    // LDS carve.  The hot loop below is branch-free: threads / rows outside the useful range compute on whatever the
-    // (in-bounds) LDS words hold and their results are never looked at, hence the guard words around s_U.
-    float* s_src = smem;                                                                  // [src_rows_cap][Cc]
-    f32x2* s_U = reinterpret_cast<f32x2*>(s_src + ((src_rows_cap * g.Cc + 1) & ~1)) + KR; // [2][PEAK_THREADS] row pair (+ KR guards each side)
-    float* s_S = reinterpret_cast<float*>(s_U + 2 * PEAK_THREADS + KR) + 1;               // [8][PEAK_THREADS] ring of smoothed rows (+1 guard each side)
-    // per logical row m_begin + i (reflected): source row offsets inside s_src and the two vertical coefficients
+    // LDS: the source rows of the band and, per logical row, its two source rows and vertical coefficients (read-only after staging)
+    float* s_src = smem; // [src_rows_cap][Cc]
     const int tab_n = BH + 2 * (KR + 1) + 6;
-    int* s_r0 = reinterpret_cast<int*>(s_S + 8 * PEAK_THREADS + 1);
+    int* s_r0 = reinterpret_cast<int*>(s_src + ((src_rows_cap * g.Cc + 1) & ~1));
     int* s_r1 = s_r0 + tab_n;
     float* s_cy0 = reinterpret_cast<float*>(s_r1 + tab_n);
     float* s_cy1 = s_cy0 + tab_n;
@@ -169,10 +169,12 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
             vmax = __builtin_huge_valf();
     }
 
-    // thread t owns column x0 - (KR + 1) + t of the strip's halo; columns outside the map read their reflection
-    const int ux = x0 - (KR + 1) + tid;
-    const bool interior = tid >= KR + 1 && tid < cw + KR + 1;
-    const int rc = reflect101(tid < cw + 2 * (KR + 1) ? ux : 0, g.UW);
+    // lane l of wavefront w owns column x0 + 46 w - 9 + l; columns outside the map read their reflection (far-out halo lanes of a
+    // narrow map are clamped first: their values are never used)
+    const int lane = tid & 63, wv = tid >> 6;
+    const int ux = x0 + PEAK_WCOLS * wv - (KR + 1) + lane;
+    const bool interior = lane >= KR + 1 && lane < KR + 1 + PEAK_WCOLS && ux < x1;
+    const int rc = reflect101(min(max(ux, -(g.UW - 1)), 2 * g.UW - 2), g.UW);
     const int sx = g.ofs_x[rc];
     const bool two_tap = rc < g.vmax_x;
     // single-tap columns (x >= OpenCV's xmax) multiply by 1.f and add nothing: up_row keeps that form
@@ -182,8 +184,8 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
     // weights c0 + c1 = 1 and the Gaussian taps sum to 1, each within a few ulp; ~40 roundings of 2^-24 relative), so it
     // cannot exceed max(0, max source) * (1 + 1e-5).  A band whose sources all stay below thresh / 1.001 therefore has no
     // peak (the test is `smoothed > thresh`): skip it.  Real heat-maps are empty almost everywhere.
-    const bool skip = !DUMP && __syncthreads_or(vmax * 1.001f >= thresh) == 0;
-    if (skip)
+    const int alive = __syncthreads_or(vmax * 1.001f >= thresh); // (also the barrier that makes the staged rows visible to every wavefront)
+    if (!DUMP && alive == 0)
         return;
 
     // w[j] = (R[m-16+j], R[m-15+j]): overlapping pairs of the row-filtered column, logical rows m-16 .. m+1
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < KSIZE; ++i)
         w[i] = f32x2{ 0.f, 0.f };
+    float sm0 = 0.f, sm1 = 0.f; // smoothed rows ys - 2, ys - 1 of this column (the two rows below them are this step's)
 
     auto up_row = [&](int i) { // row m_begin + i: HResizeLinear on the two source rows, then VResizeLinear
         const int r0 = s_r0[i], r1 = s_r1[i];
@@ -201,9 +204,11 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
         const float h0 = two_tap ? t0 + u0 : t0, h1 = two_tap ? t1 + u1 : t1;
         return h0 * s_cy0[i] + h1 * s_cy1[i];
     };
+    auto shr1 = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }; // lane l <- l - 1
+    auto shl1 = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }; // lane l <- l + 1
 
     const int m_begin = y0 - KR - 1;
-    const int m_end = y1 + KR + 3; // the step holding m = m_end tests row y1 - 1 at the latest
+    const int m_end = y1 + KR; // the step holding m = m_end (or m_end - 1) tests row y1 - 1 at the latest
     const bool emit = interior && k < HP_COCO_N_PARTS;
     int it = 0;
     for (int m = m_begin; m <= m_end; m += 2, ++it) {
@@ -217,32 +222,43 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
             if (m + 1 >= y0 && m + 1 < y1)
                 dump_up[(((size_t)f * g.J + k) * g.UH + m + 1) * g.UW + ux] = u[1];
         }
-        s_U[(it & 1) * PEAK_THREADS + tid] = u;
-        __syncthreads();
 
-        // ---- b. RowFilter<float,float> on both rows: s = k0*S[0]; s += kk*S[kk]
+        // ---- b. RowFilter<float,float> on both rows: s = k0*S[0]; s += kk*S[kk], S[t] = the sample of column ux - 8 + t
 #pragma unroll
         for (int i = 0; i + 2 < KSIZE; ++i)
             w[i] = w[i + 2];
         {
-            const f32x2* row = s_U + (it & 1) * PEAK_THREADS + tid - KR;
-            f32x2 s = gk.k[0] * row[0];
+            f32x2 left[KR]; // left[d - 1] = the pair of lane - d
+            f32x2 x = u;
 #pragma unroll
-            for (int t = 1; t < KSIZE; ++t)
-                s += gk.k[t] * row[t];
+            for (int d = 0; d < KR; ++d) {
+                x = f32x2{ shr1(x[0]), shr1(x[1]) };
+                left[d] = x;
+            }
+            f32x2 s = gk.k[0] * left[KR - 1];
+#pragma unroll
+            for (int t = 1; t < KR; ++t)
+                s += gk.k[t] * left[KR - 1 - t];
+            s += gk.k[KR] * u;
+            x = u;
+#pragma unroll
+            for (int d = 1; d <= KR; ++d) {
+                x = f32x2{ shl1(x[0]), shl1(x[1]) };
+                s += gk.k[KR + d] * x;
+            }
             w[KSIZE - 2] = f32x2{ w[KSIZE - 3][1], s[0] };
             w[KSIZE - 1] = s;
         }
 
         // ---- c. SymmColumnFilter<float> for rows ys = m - KR, ys + 1: s = k8*C + 0; s += kk*(S[+kk] + S[-kk])
         const int ys = m - KR;
+        f32x2 sm;
         {
             f32x2 s = gk.k[KR] * w[KR] + 0.f;
 #pragma unroll
             for (int t = 1; t <= KR; ++t)
                 s += gk.k[KR + t] * (w[KR + t] + w[KR - t]);
-            s_S[(ys & 7) * PEAK_THREADS + tid] = s[0];
-            s_S[((ys + 1) & 7) * PEAK_THREADS + tid] = s[1];
+            sm = s;
             if (DUMP && dump_smooth && interior) {
                 if (ys >= y0 && ys < y1)
                     dump_smooth[(((size_t)f * g.J + k) * g.UH + ys) * g.UW + ux] = s[0];
@@ -251,34 +267,46 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
             }
         }
 
-        // ---- d. peaks of rows m - KR - 4, m - KR - 3: their 3x3 neighbourhoods were published by earlier barriers
+        // ---- d. peaks of rows ys - 1 and ys: their 3x3 neighbourhoods are the smoothed rows ys - 2 .. ys + 1 of this column and of the
+        // two neighbouring lanes
+        {
+            const float r[4] = { sm0, sm1, sm[0], sm[1] }; // rows ys - 2 .. ys + 1
+            float rl[4], rr[4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int yn = m - KR - 4 + q;
-            const float v = s_S[(yn & 7) * PEAK_THREADS + tid];
-            if (emit && v > thresh && yn >= y0 && yn < y1) {
-                // same_max_pool_3x3_2d: max over in-range taps == v  <=>  no in-range tap exceeds v
-                bool is_max = true;
+            for (int q = 0; q < 4; ++q)
+                rl[q] = shr1(r[q]), rr[q] = shl1(r[q]);
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
+            for (int q = 0; q < 2; ++q) {
+                const int yn = ys - 1 + q;
+                const float v = r[1 + q];
+                if (emit && v > thresh && yn >= y0 && yn < y1) {
+                    // same_max_pool_3x3_2d: max over in-range taps == v  <=>  no in-range tap exceeds v
+                    bool is_max = true;
 #pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int ny = yn + dy, nx = ux + dx;
-                        if (ny >= 0 && ny < g.UH && nx >= 0 && nx < g.UW)
-                            is_max = is_max && !(s_S[(ny & 7) * PEAK_THREADS + tid + dx] > v);
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        const int ny = yn + dy;
+                        if (ny < 0 || ny >= g.UH)
+                            continue;
+                        if (ux - 1 >= 0)
+                            is_max = is_max && !(rl[1 + q + dy] > v);
+                        is_max = is_max && !(r[1 + q + dy] > v);
+                        if (ux + 1 < g.UW)
+                            is_max = is_max && !(rr[1 + q + dy] > v);
                     }
-                if (is_max) {
-                    const int pos = atomicAdd(&pcount[f * HP_COCO_N_PARTS + k], 1);
-                    if (pos < peak_cap) {
-                        dpeak p;
-                        p.x = ux;
-                        p.y = yn;
-                        p.score = up_at(s_src, row_base, g, yn, ux); // raw up-sampled value (post_process.hpp:180)
-                        p.lin = yn * g.UW + ux;
-                        plist[((size_t)f * HP_COCO_N_PARTS + k) * peak_cap + pos] = p;
+                    if (is_max) {
+                        const int pos = atomicAdd(&pcount[f * HP_COCO_N_PARTS + k], 1);
+                        if (pos < peak_cap) {
+                            dpeak p;
+                            p.x = ux;
+                            p.y = yn;
+                            p.score = up_at(s_src, row_base, g, yn, ux); // raw up-sampled value (post_process.hpp:180)
+                            p.lin = yn * g.UW + ux;
+                            plist[((size_t)f * HP_COCO_N_PARTS + k) * peak_cap + pos] = p;
+                        }
                     }
                 }
             }
+            sm0 = sm[0], sm1 = sm[1];
         }
     }
 }
@@ -979,15 +1007,15 @@ int hp_paf::shape(const int cs[3], const int ps[3])
     const int* dy = d + 3 * g.UW;
     g.ofs_y0 = dy, g.ofs_y1 = dy + g.UH, g.c0_y = (const float*)(dy + 2 * g.UH), g.c1_y = (const float*)(dy + 3 * g.UH);
 
-    // tiling of the up-sampled map for the peaks kernel: strips of <= 238 columns (one thread per column plus a
-    // 9-column halo each side), bands of ~54 rows (each band recomputes 18 halo rows)
-    strips = hp::ceil_div(g.UW, PEAK_THREADS - 2 * (KR + 1));
+    // tiling of the up-sampled map for the peaks kernel: strips of <= 184 columns (four wavefronts x 46 columns, each with its own
+    // 9-column halo), bands of ~54 rows (each band recomputes 18 halo rows)
+    strips = hp::ceil_div(g.UW, PEAK_BCOLS);
     CW = hp::ceil_div(g.UW, strips);
     bands = std::max(1, (g.UH + 27) / 54);
     BH = hp::ceil_div(g.UH, bands);
     bands = hp::ceil_div(g.UH, BH);
     src_rows_cap = std::min(g.R, (int)std::ceil((BH + 2 * (KR + 1)) * (double)g.R / g.UH) + 3);
-    peaks_lds = (size_t)4 * ((size_t)src_rows_cap * g.Cc + 2 + 4 * KR + 2 + (2 * 2 + 8) * PEAK_THREADS + 4 * (BH + 2 * (KR + 1) + 6));
+    peaks_lds = (size_t)4 * (((size_t)src_rows_cap * g.Cc + 1) / 2 * 2 + 4 * (BH + 2 * (KR + 1) + 6)); // source rows + the four row tables
     HP_REQUIRE(peaks_lds <= 160 * 1024, HP_ERR_INVALID, "paf: feature map too large for LDS tiling");
     HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_peaks_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)peaks_lds));
     HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_peaks_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)peaks_lds));
