@@ -752,8 +752,11 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
                         break;
                     const int h = s * 64 + lane;
                     const bool in = h < nh;
-                    const bool t2 = in && s_parts[h * HP_COCO_N_PARTS + p2] == conn.cid2;
-                    const bool t = t2 || (in && s_parts[h * HP_COCO_N_PARTS + p1] == conn.cid1);
+                    // both reads unconditional and together (`&&` / `||` made them two dependent, exec-masked LDS round trips)
+                    const int hs = in ? h : 0;
+                    const int part1 = s_parts[hs * HP_COCO_N_PARTS + p1], part2 = s_parts[hs * HP_COCO_N_PARTS + p2];
+                    const bool t2 = in & (part2 == conn.cid2);
+                    const bool t = t2 | (in & (part1 == conn.cid1));
                     unsigned long long m = __ballot(t);
                     const unsigned long long m2 = __ballot(t2);
                     total += __popcll(m);
@@ -769,8 +772,10 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
                 if (total == 1) {
                     if (lane == 0 && !first_has_c2) { // humans[first].parts[p2] != cid2
                         s_parts[first * HP_COCO_N_PARTS + p2] = conn.cid2;
-                        ++s_n[first];
-                        s_score[first] += sc2 + conn.score;
+                        // ds_add_u32 / ds_add_f32 without return: the same integer / IEEE single add as `+=`, but nothing waits for an
+                        // LDS read on the walk's critical path
+                        atomicAdd(&s_n[first], 1);
+                        atomicAdd(&s_score[first], sc2 + conn.score);
                     }
                 } else if (total >= 2) {
                     bool both = false;
