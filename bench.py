@@ -383,7 +383,8 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
     batch, global_batch = rank_plan(cfg["batch"], scaling, rank, world)
     model = Model(cfg["arch"], cfg["w"], cfg["h"])
     # one-time weight broadcast from rank 0 over RCCL/xGMI (the only collective of the whole job)
-    w_host = hd.broadcast_weights(model.init_weights(cfg["seed"]) if rank == 0 else None, model.n_weights, rank, world, device=dev)
+    w_host = hd.broadcast_weights(model.init_weights(cfg["seed"]) if rank == 0 else None, model.n_weights, rank, world,
+                                  device=hd.collective_device(dev))
 
     def barrier():
         if world > 1:
@@ -414,7 +415,7 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
         nh = run_loop(pipes, frames_dev, steps, injected) if pipes else 0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        dt = hd.max_over_ranks(dt, world, device=dev)
+        dt = hd.max_over_ranks(dt, world, device=hd.collective_device(dev))
         barrier()
         return dt, nh
 
@@ -474,7 +475,7 @@ def main():
     _lib.init(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        hd.init("nccl", device=dev)
+        hd.init_for_gpu(dev)  # RCCL; gloo if the GPU backend cannot be brought up (the hot path has no collective either way)
 
     cfg = CONFIGS[args.config]
     steps = args.steps if args.steps is not None else cfg["steps"]

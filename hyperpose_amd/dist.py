@@ -29,6 +29,43 @@ def init(backend: str, device=None):
     return dist
 
 
+_COLLECTIVE_DEVICE = None  # device the collectives run on: the GPU under RCCL, "cpu" after a fall-back to gloo
+
+
+def init_for_gpu(device, probe: bool = True):
+    """RCCL (`nccl`) for the start-up broadcast and the two timing reductions; if the backend cannot be brought up on this node
+    (raises at init or at the first collective) the job falls back to gloo on the host - the hot path itself has no collective, so
+    nothing measured changes.  Returns the backend name."""
+    global _COLLECTIVE_DEVICE
+    import sys
+
+    import torch
+    import torch.distributed as dist
+    try:
+        init("nccl", device=device)
+        if probe:
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t)
+            torch.cuda.synchronize(device)
+        _COLLECTIVE_DEVICE = device
+        return "nccl"
+    except Exception as e:  # noqa: BLE001 - any failure of the GPU backend takes the same way out
+        print(f"[hyperpose_amd.dist] RCCL unavailable ({type(e).__name__}: {e}); collectives fall back to gloo", file=sys.stderr, flush=True)
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 1)  # the old store may still hold the port
+        init("gloo")
+        _COLLECTIVE_DEVICE = "cpu"
+        return "gloo"
+
+
+def collective_device(default):
+    return default if _COLLECTIVE_DEVICE is None else _COLLECTIVE_DEVICE
+
+
 def broadcast_weights(blob: np.ndarray | None, n: int, rank: int, world: int, device="cpu") -> np.ndarray:
     """Rank 0 passes the fp32 blob, the others None; every rank returns the same `n` floats."""
     if world == 1:

@@ -46,6 +46,43 @@ def test_two_rank_broadcast_and_sharding():
     assert t0 == t1 == 2.0 and tot0 == tot1 == 13.0
 
 
+def _fallback_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from hyperpose_amd import dist as hd
+    backend = hd.init_for_gpu(torch.device("cuda", rank))  # no GPU here: RCCL cannot come up, the job must carry on over gloo
+    dev = hd.collective_device(torch.device("cuda", rank))
+    w = hd.broadcast_weights(np.arange(1000, dtype=np.float32) if rank == 0 else None, 1000, rank, world, device=dev)
+    t = hd.max_over_ranks(3.0 + rank, world, device=dev)
+    q.put((rank, backend, str(dev), float(w.sum()), t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_failure_falls_back_to_gloo():
+    """bench.py under torchrun on a node where the GPU backend cannot be initialised: the collectives (start-up broadcast, timing
+    reductions) move to gloo on the host instead of killing the run."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, backend, dev, wsum, t in res:
+        assert backend == "gloo" and dev == "cpu"
+        assert wsum == float(np.arange(1000, dtype=np.float32).sum()) and t == 4.0
+
+
 def test_shard_covers_everything():
     from hyperpose_amd import dist as hd
     for total in (0, 1, 8, 13, 64):
