@@ -1013,10 +1013,13 @@ int hp_paf::shape(const int cs[3], const int ps[3])
     g.ofs_y0 = dy, g.ofs_y1 = dy + g.UH, g.c0_y = (const float*)(dy + 2 * g.UH), g.c1_y = (const float*)(dy + 3 * g.UH);
 
     // tiling of the up-sampled map for the peaks kernel: strips of <= 184 columns (four wavefronts x 46 columns, each with its own
-    // 9-column halo), bands of ~54 rows (each band recomputes 18 halo rows)
+    // 9-column halo), bands of ~40 rows
     strips = hp::ceil_div(g.UW, PEAK_BCOLS);
     CW = hp::ceil_div(g.UW, strips);
-    bands = std::max(1, (g.UH + 27) / 54);
+    // (bands of ~40 rows: 18 halo rows are recomputed per band, but shorter bands are skipped more often - real maps are empty almost
+    // everywhere - and 2.8 k wavefronts balance better over the 1024 SIMDs than 2.3 k: 56.6 -> 50.4 us per batch of 8 against 54-row bands)
+    const int band_rows = getenv("HP_PEAK_BAND") ? std::max(8, atoi(getenv("HP_PEAK_BAND"))) : 40;
+    bands = std::max(1, (g.UH + band_rows / 2) / band_rows);
     BH = hp::ceil_div(g.UH, bands);
     bands = hp::ceil_div(g.UH, BH);
     src_rows_cap = std::min(g.R, (int)std::ceil((BH + 2 * (KR + 1)) * (double)g.R / g.UH) + 3);
