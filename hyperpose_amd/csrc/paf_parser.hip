@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -47,6 +48,11 @@ __constant__ int c_pairs_net[19][2] = {
     { 12, 13 }, { 20, 21 }, { 14, 15 }, { 16, 17 }, { 22, 23 }, { 24, 25 }, { 0, 1 }, { 2, 3 },
     { 4, 5 }, { 6, 7 }, { 8, 9 }, { 10, 11 }, { 28, 29 }, { 30, 31 }, { 34, 35 }, { 32, 33 },
     { 36, 37 }, { 18, 19 }, { 26, 27 },
+};
+constexpr int K_PAIRS[19][2] = { // (the same table for compile-time part indices)
+    { 1, 2 }, { 1, 5 }, { 2, 3 }, { 3, 4 }, { 5, 6 }, { 6, 7 }, { 1, 8 }, { 8, 9 }, { 9, 10 },
+    { 1, 11 }, { 11, 12 }, { 12, 13 }, { 1, 0 }, { 0, 14 }, { 14, 16 }, { 0, 15 }, { 15, 17 },
+    { 2, 16 }, { 5, 17 },
 };
 __constant__ int c_pairs[19][2] = {
     { 1, 2 }, { 1, 5 }, { 2, 3 }, { 3, 4 }, { 5, 6 }, { 6, 7 }, { 1, 8 }, { 8, 9 }, { 9, 10 },
@@ -723,7 +729,129 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
 
     int nh = 0;
     bool overflow = false;
-    for (int pair_id = 0; pair_id < HP_COCO_N_PAIRS; ++pair_id) {
+    // ---- the walk with the humans IN REGISTERS (human h = lane h: its 18 part ids, part count and score): the "which humans touch this
+    // connection" test is two compares, an update is a v_cndmask, nothing on the chain goes through LDS.  The limb loop is unrolled so that
+    // the part indices are register numbers.  Holds while at most 64 skeleton fragments are alive or merged (any real frame); a frame
+    // that needs a 65th starts over on the LDS tables below.  Same operations in the same order: the results are those of the LDS walk.
+    bool reg_done = false;
+    {
+        int parts[HP_COCO_N_PARTS];
+#pragma unroll
+        for (int r = 0; r < HP_COCO_N_PARTS; ++r)
+            parts[r] = -1;
+        int hn = 0;
+        float hscore = 0.f;
+        int rnh = 0;
+        bool too_many = false;
+        auto walk_pair = [&](auto PAIR) {
+            constexpr int pair_id = decltype(PAIR)::value, p1 = K_PAIRS[pair_id][0], p2 = K_PAIRS[pair_id][1];
+            const int cbase = s_cstart[pair_id], nc = s_cstart[pair_id + 1] - cbase;
+            const dconn* cl = conns + ((size_t)f * HP_COCO_N_PAIRS + pair_id) * peak_cap;
+            for (int cb = 0; cb < nc && !too_many; cb += 64) {
+                dconn mine{ 0, 0, 0.f };
+                float my_sc1 = 0.f, my_sc2 = 0.f;
+                if (cb + lane < nc) {
+                    mine = cbase + cb + lane < ASM_CONN_CAP ? s_conn[cbase + cb + lane] : cl[cb + lane];
+                    my_sc1 = peak_score(p1, mine.cid1), my_sc2 = peak_score(p2, mine.cid2);
+                }
+                const int nb = min(64, nc - cb);
+                int ci = 0;
+                while (ci < nb) {
+                    // fast loop: connections that exactly one human touches (the common case) as straight-line, predicated code with
+                    // nothing else merging into it - a one-wavefront walk is issue-bound, every instruction and taken branch counts
+                    for (; ci < nb; ++ci) {
+                        const int cid1 = __builtin_amdgcn_readlane(mine.cid1, ci), cid2 = __builtin_amdgcn_readlane(mine.cid2, ci);
+                        const bool in = lane < rnh;
+                        const bool t2 = in & (parts[p2] == cid2);
+                        const unsigned long long m = __ballot(t2 | (in & (parts[p1] == cid1)));
+                        if (__popcll(m) != 1)
+                            break;
+                        const unsigned long long m2 = __ballot(t2);
+                        const float add = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_sc2), ci))
+                            + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.score), ci)); // sc2 + conn.score
+                        const bool attach = (m2 == 0ull) & ((m >> lane) & 1ull); // the one human's parts[p2] != cid2 (paf.cpp:170-176)
+                        parts[p2] = attach ? cid2 : parts[p2];
+                        hn += attach ? 1 : 0;
+                        hscore = attach ? hscore + add : hscore;
+                    }
+                    if (ci >= nb)
+                        break;
+                    // slow step: no human (a new one) or several (merge / attach to the first)
+                    const int cid1 = __builtin_amdgcn_readlane(mine.cid1, ci), cid2 = __builtin_amdgcn_readlane(mine.cid2, ci);
+                    const float cscore = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.score), ci));
+                    const float sc1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_sc1), ci));
+                    const float sc2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_sc2), ci));
+                    ++ci;
+                    const bool in = lane < rnh;
+                    unsigned long long m = __ballot(in & ((parts[p2] == cid2) | (parts[p1] == cid1)));
+                    const int total = __popcll(m);
+                    if (total >= 2) {
+                        const int first = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const int second = __ffsll((long long)m) - 1;
+                        bool membership = false;
+#pragma unroll
+                        for (int r = 0; r < HP_COCO_N_PARTS; ++r)
+                            membership |= __builtin_amdgcn_readlane(parts[r], first) > 0 && __builtin_amdgcn_readlane(parts[r], second) > 0; // paf.cpp:185
+                        if (!membership) {
+#pragma unroll
+                            for (int r = 0; r < HP_COCO_N_PARTS; ++r) {
+                                const int other = __builtin_amdgcn_readlane(parts[r], second);
+                                if (lane == first)
+                                    parts[r] += other + 1; // paf.cpp:193
+                                if (lane == second)
+                                    parts[r] = -1; // erased (paf.cpp:202): never touches again
+                            }
+                            const int on = __builtin_amdgcn_readlane(hn, second);
+                            const float os = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hscore), second));
+                            if (lane == first) {
+                                hn += on;
+                                hscore += os;
+                                hscore += cscore;
+                            }
+                            if (lane == second)
+                                hn = -(1 << 20); // erased: fails the n_parts filter
+                        } else if (lane == first) {
+                            parts[p2] = cid2;
+                            hn += 1;
+                            hscore += sc2 + cscore;
+                        }
+                    } else if (total == 0 && pair_id <= 16) { // !is_virtual_pair (coco.hpp:6): a new human
+                        if (rnh < 64) {
+                            if (lane == rnh) {
+#pragma unroll
+                                for (int r = 0; r < HP_COCO_N_PARTS; ++r)
+                                    parts[r] = r == p1 ? cid1 : (r == p2 ? cid2 : -1);
+                                hn = 2;
+                                hscore = sc1 + sc2 + cscore;
+                            }
+                            ++rnh;
+                        } else {
+                            too_many = true;
+                            break;
+                        }
+                    }
+                }
+            }
+        };
+#define HP_WP(K) walk_pair(std::integral_constant<int, K>{});
+        HP_WP(0) HP_WP(1) HP_WP(2) HP_WP(3) HP_WP(4) HP_WP(5) HP_WP(6) HP_WP(7) HP_WP(8) HP_WP(9) HP_WP(10) HP_WP(11) HP_WP(12) HP_WP(13) HP_WP(14)
+        HP_WP(15) HP_WP(16) HP_WP(17) HP_WP(18)
+#undef HP_WP
+        static_assert(HP_COCO_N_PAIRS == 19, "limb list");
+        if (!too_many) { // hand the tables to the common filter / emission code
+            if (lane < rnh) {
+#pragma unroll
+                for (int r = 0; r < HP_COCO_N_PARTS; ++r)
+                    s_parts[lane * HP_COCO_N_PARTS + r] = parts[r];
+                s_n[lane] = hn;
+                s_score[lane] = hscore;
+            }
+            nh = rnh;
+            reg_done = true;
+        }
+    }
+    for (int pair_id = 0; pair_id < HP_COCO_N_PAIRS && !reg_done; ++pair_id) {
         const int p1 = c_pairs[pair_id][0], p2 = c_pairs[pair_id][1];
         const int cbase = s_cstart[pair_id], nc = s_cstart[pair_id + 1] - cbase;
         const dconn* cl = conns + ((size_t)f * HP_COCO_N_PAIRS + pair_id) * peak_cap;
