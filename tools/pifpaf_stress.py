@@ -1,0 +1,33 @@
+"""Soak test of the PifPaf device decoder against the host tail on random synthetic maps (run on the GPU box):
+    PYTHONPATH=. python tools/pifpaf_stress.py [batches]
+Prints the number of frames compared, how many the device decoder handed back to the host tail, and any mismatch."""
+import os
+import sys
+
+import numpy as np
+
+from hyperpose_amd import synth
+from hyperpose_amd.parser import PifPaf
+
+n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B = 32
+os.environ["HP_PIFPAF_HOST_TAIL"] = "0"
+dev = PifPaf(385, 385, 0.05, max_batch=B, cap_per_frame=256)
+os.environ["HP_PIFPAF_HOST_TAIL"] = "1"
+host = PifPaf(385, 385, 0.05, max_batch=B, cap_per_frame=256)
+rng = np.random.default_rng(20244)
+frames = fell = humans = bad = 0
+for it in range(n_batches):
+    people = tuple(int(v) for v in rng.integers(0, 24, 8))
+    noise = float(rng.choice([0.02, 0.1, 0.2, 0.28]))
+    paf, pif = synth.pifpaf_maps(np.random.default_rng(1000 + it), B, people=people, noise=noise)
+    a, b = dev.process_batch(paf, pif), host.process_batch(paf, pif)
+    fl = dev.decode_flags(B)
+    for f in range(B):
+        frames += 1
+        fell += fl[f] != 0
+        humans += len(b[f])
+        if a[f].tobytes() != b[f].tobytes():
+            bad += 1
+            print("MISMATCH batch", it, "frame", f, "flags", fl[f], len(a[f]), len(b[f]))
+print({"frames": frames, "humans": humans, "host_tail_frames": int(fell), "mismatches": bad})
