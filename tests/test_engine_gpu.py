@@ -125,8 +125,10 @@ def test_first_conv_u8_and_f32(hp):
     (1, 48, E.ACT_RELU6, 20, 37, True, 7),   # ... stride 1, f32 input
 ])
 def test_first_conv_matrix_pipe_shapes(hp, monkeypatch, stride, cout, act, h, w, f32, k):
-    """first_conv_mfma_kernel / first_conv7_mfma_kernel (3x3 / 7x7, stride 1 / 2, <= 64 outputs) vs the oracle and vs the scalar
-    first_conv_kernel (HP_FIRST_MFMA=0): both accumulate in fp32; they may differ in the last bit before the fp16 store."""
+    """first_conv_f16_kernel (the default: fp16 matrix pipe, normalised input and weights rounded to fp16) vs the fp16-matched oracle, and
+    the three forms of the first layer against each other: fp16 pipe, fp32 matrix pipe (HP_FIRST_F16=0: first_conv_mfma_kernel /
+    first_conv7_mfma_kernel) and the scalar first_conv_kernel (HP_FIRST_MFMA=0 as well).  The two all-fp32 forms may differ in the last
+    bit before the fp16 store; the fp16 form differs from them by the operand rounding (2^-11 relative per operand)."""
     net = Net(7)
     t = net.conv(0, 3, cout, k, stride, act=act, act_param=0.1)
     z = net.conv(t, cout, 8, 1, act=E.ACT_NONE)
@@ -135,11 +137,16 @@ def test_first_conv_matrix_pipe_shapes(hp, monkeypatch, stride, cout, act, h, w,
     kw = {} if f32 else dict(mean=(0.485, 0.456, 0.406), inv_std=(4.0, 4.5, 4.4))
     eng, got, ref = _run_both(net, outs, fr, h, w, f32=f32, **kw)
     _check(got, ref, 2)
+    monkeypatch.setenv("HP_FIRST_F16", "0")
+    _, pipe32, ref32 = _run_both(net, outs, fr, h, w, f32=f32, **kw)
+    _check(pipe32, ref32, 2)  # (the oracle follows HP_FIRST_F16)
     monkeypatch.setenv("HP_FIRST_MFMA", "0")
     _, scalar, _ = _run_both(net, outs, fr, h, w, f32=f32, **kw)
     for b in range(2):
-        for (n0, a0), (n1, a1) in zip(got[b], scalar[b]):
-            _close(a0, a1, rel=1e-3, abs_=1e-3)
+        for (n0, a0), (n1, a1), (n2, a2) in zip(got[b], scalar[b], pipe32[b]):
+            _close(a2, a1, rel=1e-3, abs_=1e-3)
+            scale = float(np.abs(a1).max()) + 1e-6
+            assert np.abs(a0 - a1).max() <= 1e-2 * scale + 1e-3, (n0, "fp16 pipe vs scalar fp32")
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,dil", [
