@@ -123,38 +123,34 @@ __device__ float pifhr_at_wave(const pp_cell* cells, int n, int yy, int xx, int 
     float val = 0.f;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        bool on = false;
-        float vv = 0.f;
-        if (i < n) {
-            const pp_cell c = cells[i];
-            if (!(xx < c.minx || xx >= c.maxx || yy < c.miny || yy >= c.maxy)) {
-                const float dx2 = ((float)xx - c.cx) * ((float)xx - c.cx);
-                const float dy2 = ((float)yy - c.cy) * ((float)yy - c.cy);
-                const float tc = c.sigma * 1.0f;
-                if (!(dx2 + dy2 > tc * tc)) {
-                    on = true;
-                    if (dx2 < 0.25 && dy2 < 0.25)
-                        vv = c.v16;
-                    else {
-                        float x = (float)(-0.5 * (double)(dx2 + dy2) / (double)(c.sigma * c.sigma));
-                        if (x > 2 || x < -2)
-                            x = 0.f;
-                        else {
-                            x = 1.f + x / 8;
-                            x *= x;
-                            x *= x;
-                            x *= x;
-                        }
-                        vv = c.v16 * x;
-                    }
-                }
-            }
-        }
+        // branch-free up to the one uniform test: the cell is read unconditionally (clamped index), the footprint and radius tests are
+        // bit operations, and the expensive part (a double division) runs only when some lane's cell covers the point
+        const pp_cell c = cells[min(i, n - 1)];
+        const bool inb = (i < n) & !((xx < c.minx) | (xx >= c.maxx) | (yy < c.miny) | (yy >= c.maxy));
+        const float dx2 = ((float)xx - c.cx) * ((float)xx - c.cx);
+        const float dy2 = ((float)yy - c.cy) * ((float)yy - c.cy);
+        const float tc = c.sigma * 1.0f;
+        const bool on = inb & !(dx2 + dy2 > tc * tc);
         unsigned long long m = __ballot(on);
+        if (!m)
+            continue;
+        float vv = c.v16;
+        if (!(dx2 < 0.25 && dy2 < 0.25)) {
+            float x = (float)(-0.5 * (double)(dx2 + dy2) / (double)(c.sigma * c.sigma));
+            if (x > 2 || x < -2)
+                x = 0.f;
+            else {
+                x = 1.f + x / 8;
+                x *= x;
+                x *= x;
+                x *= x;
+            }
+            vv = c.v16 * x;
+        }
         while (m) {
             const int l = __ffsll(m) - 1;
             m &= m - 1;
-            val += __shfl(vv, l);
+            val += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), l)); // (uniform l: v_readlane, not an LDS-crossbar shuffle per contribution)
             val = fminf(1.0f, val);
         }
     }
@@ -232,7 +228,7 @@ __global__ __launch_bounds__(64) void pp_seeds_kernel(const float* __restrict__ 
         float v = 0.f;
         for (unsigned long long m = __ballot(cand); m; m &= m - 1) { // one wave-wide look-up per candidate
             const int l = __ffsll(m) - 1;
-            const float r = pifhr_at_wave(fc, nc, __shfl(iy, l), __shfl(ix, l), lane);
+            const float r = pifhr_at_wave(fc, nc, __builtin_amdgcn_readlane(iy, l), __builtin_amdgcn_readlane(ix, l), lane);
             if (lane == l)
                 v = r;
         }
@@ -292,7 +288,7 @@ __global__ __launch_bounds__(64) void pp_caf_kernel(const float* __restrict__ pa
             float cifhr_t = 0.f;
             for (unsigned long long m = __ballot(cand); m; m &= m - 1) { // one wave-wide look-up per candidate
                 const int l = __ffsll(m) - 1;
-                const float r = pifhr_at_wave(fc, nc, __shfl(iy, l), __shfl(ix, l), lane);
+                const float r = pifhr_at_wave(fc, nc, __builtin_amdgcn_readlane(iy, l), __builtin_amdgcn_readlane(ix, l), lane);
                 if (lane == l)
                     cifhr_t = r;
             }
