@@ -1053,12 +1053,20 @@ __device__ pd_xysv pd_connection_blend(int gl, int gs, float x, float y, float s
         if (sc >= 0.f && sc >= m)
             m = sc, mq = q; // within a lane the positions ascend: `>=` keeps the last
     }
-    for (int off = 8; off >= 1; off >>= 1) {
-        const float om = __shfl_xor(m, off);
-        const int oq = __shfl_xor(mq, off);
-        if (om > m || (om == m && oq > mq))
-            m = om, mq = oq;
+    // reductions over the group's 16 lanes with DPP (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: after the four steps
+    // every lane holds the result) - register moves instead of four LDS-crossbar round trips per value; the combine steps are
+    // commutative and associative (a total order on (score, position)), so the butterfly shape does not matter
+#define PD_DPP_F(V, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), CTRL, 0xf, 0xf, false))
+#define PD_DPP_I(V, CTRL) __builtin_amdgcn_update_dpp(0, V, CTRL, 0xf, 0xf, false)
+#define PD_RED1(CTRL)                                                                                             \
+    {                                                                                                             \
+        const float om = PD_DPP_F(m, CTRL);                                                                       \
+        const int oq = PD_DPP_I(mq, CTRL);                                                                        \
+        if (om > m || (om == m && oq > mq))                                                                       \
+            m = om, mq = oq;                                                                                      \
     }
+    PD_RED1(0xB1) PD_RED1(0x4E) PD_RED1(0x141) PD_RED1(0x140)
+#undef PD_RED1
     // (the reference starts from score_1 = 0 and replaces it with `>=`; score_1 == 0 afterwards: nothing passed, or only zeros)
     if (mq < 0 || m == 0.f)
         return pd_xysv{ 0.f, 0.f, 0.f, 0.f };
@@ -1079,15 +1087,20 @@ __device__ pd_xysv pd_connection_blend(int gl, int gs, float x, float y, float s
         } else if (sc > sm)
             sm = sc, sq = q;
     }
-    for (int off = 8; off >= 1; off >>= 1) {
-        dup = max(dup, __shfl_xor(dup, off));
-        const float opm = __shfl_xor(pm, off), osm = __shfl_xor(sm, off);
-        const int opq = __shfl_xor(pq, off), osq = __shfl_xor(sq, off);
-        if (opm > pm || (opm == pm && opq > pq))
-            pm = opm, pq = opq;
-        if (osm > sm || (osm == sm && osq < sq))
-            sm = osm, sq = osq;
+#define PD_RED2(CTRL)                                                                                             \
+    {                                                                                                             \
+        dup = max(dup, PD_DPP_I(dup, CTRL));                                                                      \
+        const float opm = PD_DPP_F(pm, CTRL), osm = PD_DPP_F(sm, CTRL);                                           \
+        const int opq = PD_DPP_I(pq, CTRL), osq = PD_DPP_I(sq, CTRL);                                             \
+        if (opm > pm || (opm == pm && opq > pq))                                                                  \
+            pm = opm, pq = opq;                                                                                   \
+        if (osm > sm || (osm == sm && osq < sq))                                                                  \
+            sm = osm, sq = osq;                                                                                   \
     }
+    PD_RED2(0xB1) PD_RED2(0x4E) PD_RED2(0x141) PD_RED2(0x140)
+#undef PD_RED2
+#undef PD_DPP_F
+#undef PD_DPP_I
     float s2 = 0.f;
     int q2 = -1; // (-1: the reference's initial second, score 0 at list index 0)
     if (dup >= 0)
