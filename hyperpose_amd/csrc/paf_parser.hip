@@ -598,8 +598,8 @@ __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict_
             unsigned long long m;
             while ((m = __ballot(alive)) != 0ull) {
                 const int leader = __ffsll((long long)m) - 1;
-                const int la = __shfl(a, leader), lb = __shfl(b, leader);
-                const float ls = __shfl(sc, leader);
+                const int la = __builtin_amdgcn_readlane(a, leader), lb = __builtin_amdgcn_readlane(b, leader); // (uniform leader)
+                const float ls = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), leader));
                 if (lane == 0) {
                     dconn c;
                     c.cid1 = start1 + la;
