@@ -1410,8 +1410,12 @@ __global__ __launch_bounds__(64) void pp_decode_kernel(pd_params P, const int* _
         __syncthreads();
         for (int oi = 0; oi < na; ++oi) {
             pd_ann& ann = A[s_idx[oi]];
+            // joint k of this annotation in lane k: one memory round trip per annotation instead of one per joint
+            float jx = 0.f, jy = 0.f, jv = 0.f, js = 0.f;
+            if (lane < NK)
+                jx = ann.kp[lane * 3], jy = ann.kp[lane * 3 + 1], jv = ann.kp[lane * 3 + 2], js = ann.scale[lane];
             for (int k = 0; k < NK; ++k) {
-                const float x = ann.kp[k * 3], y = ann.kp[k * 3 + 1], v = ann.kp[k * 3 + 2];
+                const float x = rl_f(jx, k), y = rl_f(jy, k), v = rl_f(jv, k);
                 if (v == 0)
                     continue;
                 const int i = min(max(0, (int)roundf(x)), ww - 1);
@@ -1422,7 +1426,7 @@ __global__ __launch_bounds__(64) void pp_decode_kernel(pd_params P, const int* _
                     if (lane == 0)
                         ann.kp[k * 3 + 2] = 0.0f;
                 } else
-                    occ_add_square(occ2, lane, k, hh, ww, x, y, ann.scale[k], false);
+                    occ_add_square(occ2, lane, k, hh, ww, x, y, rl_f(js, k), false);
                 __syncthreads();
             }
         }
