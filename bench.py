@@ -332,7 +332,7 @@ def pmc_traffic(symbol_key: str, tag: str):
     return None, None
 
 
-def roofline(pipe, batch, cfg_index):
+def roofline(pipe, batch, cfg_index, frames_dev=None):
     """Per-launch timestamps on the engine stream with the schedule run in order (hp_engine_profile_sequence: every kernel sees the
     cache state of a real inference, which is what rocprofv3's per-kernel averages over this bench see too).  achieved = algorithmic
     FLOPs of the dominant kernel's launches / their summed duration.  `back_to_back_us` is the same kernel re-launched 20 times in a
@@ -367,6 +367,19 @@ def roofline(pipe, batch, cfg_index):
     }
     if warm is not None:
         out["back_to_back_us"] = round(sum(p["ms"] for p in warm if p["tile"] == dom_tile) / dom["n"] * 1e3, 2)
+    if frames_dev is not None:
+        # the same timestamps with the parser in the loop, as in the timed region with one pipe (and as rocprofv3 sees the kernel in
+        # profiles/r02_kernel_stats*.csv, collected from `bench.py --pipes 1`): the parser's kernels run between two engine passes and
+        # evict the weights from L2
+        ms = n = 0
+        for _ in range(iters):
+            pipe.submit(frames_dev, True, engine=False, parser=True)
+            pipe.collect()
+            for q in pipe.eng.profile(batch, iters=1, in_sequence=True):
+                if q["tile"] == dom_tile:
+                    ms += q["ms"]
+                    n += 1
+        out["avg_launch_us_parser_in_loop"] = round(ms / n * 1e3, 2)
     return out
 
 
@@ -446,7 +459,7 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
         del p0
     if rank == 0 and pipes:
         if not args.no_roofline:
-            res["roofline"] = roofline(pipes[0], batch, cfg_index)
+            res["roofline"] = roofline(pipes[0], batch, cfg_index, frames_dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, maps)
         if world == 1 and not args.no_from_host:
