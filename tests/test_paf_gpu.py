@@ -54,6 +54,24 @@ def test_golden_vectors(hp):
         assert _same(p.debug_conns(0), g[f"conns_{i}"]), m
 
 
+@pytest.mark.parametrize("rows,cols", [(8, 12), (20, 30), (60, 33), (13, 70)])
+def test_peaks_kernel_odd_geometries(hp, rows, cols):
+    """paf_peaks_kernel's wavefront-local column layout (46 columns + 9 halo lanes per wavefront, 184 per block) on maps that are
+    narrower than one wavefront (4 x 8 = 32 columns), that end inside a wavefront (80), that need two strips with a remainder (240),
+    and that are short (52 rows: two bands) - up-sampled / smoothed planes, peaks, connections and humans against the oracle."""
+    from hyperpose_amd.parser import Paf
+    rng = synth.rng_for(1, salt=7000 + rows * 100 + cols)
+    B = 3
+    conf, paf, _ = synth.paf_maps(rng, B, rows, cols, people=(1, 2, 3))
+    p = Paf(max_batch=B)
+    up, sm = p.debug_maps(conf[0], 4 * cols, 4 * rows)
+    ref_up = loader.resize_area(conf[0], 4 * cols, 4 * rows)
+    assert _same(up, ref_up) and _same(sm, loader.smooth(ref_up))
+    humans = p.process_batch(conf, paf)
+    for f in range(B):
+        _check_frame(p, f, conf[f], paf[f], humans[f])
+
+
 @pytest.mark.parametrize("rows,cols", [(46, 54), (46, 46), (54, 96)])
 def test_batch_parity_with_oracle(hp, rows, cols):
     from hyperpose_amd.parser import Paf
