@@ -82,3 +82,20 @@ def test_device_decoder_other_geometry_and_async(hp):
         if loader.ref_lib() is not None:
             assert got[b].tobytes() == loader.ref_pifpaf_process(paf[b], pif[b], 321, 481).tobytes()
     assert sum(len(r) for r in ref) >= 10
+
+
+@pytest.mark.parametrize("fh,fw", [(9, 9), (13, 33), (70, 25)])
+def test_device_decoder_small_and_elongated_fields(hp, fh, fw):
+    """Fields far from the 49 x 49 of configs[4]: a 65 x 65 network (9 x 9 cells, occupancy window of a few dozen cells), a wide and a tall
+    one (70 x 25 = 1750 cells per list)."""
+    B = 4
+    net_h, net_w = (fh - 1) * 8 + 1, (fw - 1) * 8 + 1
+    dev, host = _parser(False, net_h, net_w, max_batch=B), _parser(True, net_h, net_w, max_batch=B)
+    paf, pif = synth.pifpaf_maps(synth.rng_for(4, salt=100 * fh + fw), B, fh=fh, fw=fw, people=(1, 2, 0, 3), noise=0.05)
+    got, ref = dev.process_batch(paf, pif), host.process_batch(paf, pif)
+    flags = dev.decode_flags(B)
+    assert all(f in (0, 32) for f in flags), flags
+    for b in range(B):
+        assert got[b].tobytes() == ref[b].tobytes(), (b, flags[b], len(got[b]), len(ref[b]))
+        if loader.ref_lib() is not None:
+            assert got[b].tobytes() == loader.ref_pifpaf_process(paf[b], pif[b], net_h, net_w).tobytes(), b
