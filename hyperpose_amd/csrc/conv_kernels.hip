@@ -1929,6 +1929,62 @@ __global__ __launch_bounds__(256) void first_conv_f16_kernel(const first_conv_pa
     for (int i = tid; i < NCOPY * IH * PITCH / 2; i += 256)
         reinterpret_cast<unsigned*>(&s_x[0][0])[i] = 0u;
     __syncthreads();
+    if constexpr (KS == 7) {
+    {
+        constexpr int NIT = (IH * IW + 255) / 256;
+        const int c0 = p.flip_rb ? 2 : 0, c2 = p.flip_rb ? 0 : 2;
+        auto put = [&](int py, int px, int c, float x) { // normalise, round to fp16, store (both copies)
+            const _Float16 v = (_Float16)((x - p.mean[c]) * p.inv_std[c]);
+            s_x[0][py * PITCH + px * 3 + c] = v;
+            if (NCOPY == 2 && px * 3 + c >= 1)
+                s_x[NCOPY - 1][py * PITCH + px * 3 + c - 1] = v; // copy 1 [j] = copy 0 [j + 1]
+        };
+        if (KS == 7 && p.in_u8) { // (the 3 x 3 stems have three passes: batching them costs more registers than it saves)
+            // all byte loads first (clamped addresses, three bytes of a pixel packed into one register): one memory round trip for the
+            // patch instead of one per pass - the patch was half of the block's time
+            unsigned raw[NIT];
+            unsigned okm = 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = min(tid + it * 256, IH * IW - 1);
+                const int py = i / IW, px = i - py * IW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                okm |= (tid + it * 256 < IH * IW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (1u << it) : 0u;
+                const uint8_t* q = p.in_u8 + (((size_t)b * p.H + min(max(iy, 0), p.H - 1)) * p.W + min(max(ix, 0), p.W - 1)) * 3;
+                raw[it] = (unsigned)q[c0] | ((unsigned)q[1] << 8) | ((unsigned)q[c2] << 16);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (!((okm >> it) & 1u))
+                    continue; // stays zero = the convolution's padding
+                const int i = tid + it * 256;
+                const int py = i / IW, px = i - py * IW;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    put(py, px, c, (float)((double)(float)((raw[it] >> (8 * c)) & 255u) * p.factor)); // src/data.cpp:48
+            }
+        } else {
+#pragma unroll 4
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * 256;
+                if (i >= IH * IW)
+                    break;
+                const int py = i / IW, px = i - py * IW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W)
+                    continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (p.in_u8) {
+                        const int sc = c == 0 ? c0 : (c == 2 ? c2 : 1);
+                        put(py, px, c, (float)((double)(float)p.in_u8[(((size_t)b * p.H + iy) * p.W + ix) * 3 + sc] * p.factor)); // src/data.cpp:48
+                    } else
+                        put(py, px, c, p.in_f32[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix]);
+                }
+            }
+        }
+    }
+    } else {
     {
         constexpr int NIT = (IH * IW + 255) / 256;
         const int c0 = p.flip_rb ? 2 : 0, c2 = p.flip_rb ? 0 : 2;
@@ -1960,6 +2016,7 @@ __global__ __launch_bounds__(256) void first_conv_f16_kernel(const first_conv_pa
             }
         }
     }
+    }
     __syncthreads();
 
     const unsigned hmask = hh ? 0xffffffffu : 0u;
@@ -1977,6 +2034,35 @@ __global__ __launch_bounds__(256) void first_conv_f16_kernel(const first_conv_pa
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 d[mt][r] = bs[mt][r];
+        if constexpr (KS == 7) {
+        // k' = st * 16 + hh * 8 + i  ->  kernel row k' / ROWP (clamped: the tail of the last step has zero weights), offset k' % ROWP;
+        // the fragment of step st + 1 is read while step st multiplies (pinned: hipcc sinks a ds_read to just before its MFMA)
+        auto frag = [&](int st) {
+            const int ka = st * 16, kb = st * 16 + 8;
+            const int oa = min(ka / ROWP, KS - 1) * PITCH + ka % ROWP, ob = min(kb / ROWP, KS - 1) * PITCH + kb % ROWP; // compile time
+            const unsigned* q = reinterpret_cast<const unsigned*>(xb + (hh ? ob : oa));
+            u32x4 raw;
+            raw[0] = q[0], raw[1] = q[1], raw[2] = q[2], raw[3] = q[3];
+            return raw;
+        };
+        u32x4 fr[2];
+        fr[0] = frag(0);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            if (st + 1 < STEPS)
+                fr[(st + 1) & 1] = frag(st + 1);
+            half8 xv;
+            __builtin_memcpy(&xv, &fr[st & 1], 16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                d[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[mt][st], xv, d[mt], 0, 0, 0);
+            if (KS == 7) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
+                if (st + 1 < STEPS)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+        }
+        } else {
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             // k' = st * 16 + hh * 8 + i  ->  kernel row k' / ROWP (clamped: the tail of the last step has zero weights), offset k' % ROWP
@@ -1992,6 +2078,7 @@ __global__ __launch_bounds__(256) void first_conv_f16_kernel(const first_conv_pa
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 d[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[mt][st], xv, d[mt], 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
