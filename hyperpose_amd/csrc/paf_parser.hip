@@ -167,12 +167,21 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
     }
     const float* plane = conf + ((size_t)f * g.J + k) * g.R * g.Cc;
     float vmax = 0.f;
-    for (int i = tid; i < nrows * g.Cc; i += PEAK_THREADS) {
-        const float v = plane[row_base * g.Cc + i];
-        s_src[i] = v;
-        vmax = fmaxf(vmax, v); // NaN-safe for the purpose: a NaN source keeps the band alive below
-        if (!(v == v))
-            vmax = __builtin_huge_valf();
+    for (int base = 0; base < nrows * g.Cc; base += 4 * PEAK_THREADS) { // four requests per thread in flight: one round trip per 1024 floats
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            v[q] = plane[row_base * g.Cc + min(base + q * PEAK_THREADS + tid, nrows * g.Cc - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = base + q * PEAK_THREADS + tid;
+            if (i < nrows * g.Cc) {
+                s_src[i] = v[q];
+                vmax = fmaxf(vmax, v[q]); // NaN-safe for the purpose: a NaN source keeps the band alive below
+                if (!(v[q] == v[q]))
+                    vmax = __builtin_huge_valf();
+            }
+        }
     }
 
     // lane l of wavefront w owns column x0 + 46 w - 9 + l; columns outside the map read their reflection (far-out halo lanes of a
