@@ -700,9 +700,14 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
     __shared__ int s_cstart[HP_COCO_N_PAIRS + 1];
     __shared__ dconn s_conn[ASM_CONN_CAP];
     __shared__ float s_pscore[ASM_PEAK_CAP];
+    __shared__ int s_owner[ASM_PEAK_CAP];                 // peak id held at the current limb's first part -> human (parallel limbs)
+    __shared__ int s_att_cid[64], s_new_c1[64], s_new_c2[64]; // hand-over between connection lanes and human lanes
+    __shared__ float s_att_add[64], s_new_sc[64];
     const int lane = threadIdx.x;
     const int f = blockIdx.x;
     const dpeak* sorted_f = sorted + (size_t)f * HP_COCO_N_PARTS * peak_cap;
+    for (int i = lane; i < ASM_PEAK_CAP; i += 64)
+        s_owner[i] = -1;
 
     { // prefix sums of the per-part peak counts and the per-limb connection counts: one load per lane, a wave scan
         int np = 0, ncn = 0;
@@ -791,6 +796,28 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
             constexpr int pair_id = decltype(PAIR)::value, p1 = K_PAIRS[pair_id][0], p2 = K_PAIRS[pair_id][1];
             const int cbase = s_cstart[pair_id], nc = s_cstart[pair_id + 1] - cbase;
             const dconn* cl = conns + ((size_t)f * HP_COCO_N_PAIRS + pair_id) * peak_cap;
+            if (nc == 0 || too_many)
+                return;
+            // ---- the whole limb in parallel when its connections cannot influence each other: no human holds anything at part p2 yet
+            // (then a connection can only be touched through p1; the connections of a limb have distinct peaks at either end, so an
+            // attach or a new human never changes what a later connection of the same limb sees), and no two humans hold the same peak at
+            // p1 (then every connection is touched by at most one human: no merge).  True for 15-17 of the 19 limbs of a real frame.
+            // Connection c lives in lane c, human h in lane h; they meet through small LDS tables; new humans get their indices from a
+            // prefix count in connection order, i.e. the indices the sequential walk would give them.
+            bool par_ok;
+            const int myid = lane < rnh ? parts[p1] : -1;
+            {
+                const bool p2_set = lane < rnh && parts[p2] != -1;
+                const bool far = myid >= ASM_PEAK_CAP;
+                par_ok = __ballot(p2_set | far) == 0ull;
+                if (par_ok) {
+                    if (myid >= 0)
+                        s_owner[myid] = lane;
+                    __builtin_amdgcn_wave_barrier();
+                    const bool dup = myid >= 0 && s_owner[myid] != lane;
+                    par_ok = __ballot(dup) == 0ull;
+                }
+            }
             for (int cb = 0; cb < nc && !too_many; cb += 64) {
                 dconn mine{ 0, 0, 0.f };
                 float my_sc1 = 0.f, my_sc2 = 0.f;
@@ -799,6 +826,47 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
                     my_sc1 = peak_score(p1, mine.cid1), my_sc2 = peak_score(p2, mine.cid2);
                 }
                 const int nb = min(64, nc - cb);
+                if (par_ok) {
+                    s_att_cid[lane] = -2;
+                    __builtin_amdgcn_wave_barrier();
+                    const bool cv = lane < nb;
+                    int h = -1;
+                    if (cv && mine.cid1 >= 0 && mine.cid1 < ASM_PEAK_CAP)
+                        h = s_owner[mine.cid1];
+                    const bool isnew = cv && h < 0 && pair_id <= 16; // !is_virtual_pair (coco.hpp:6)
+                    const unsigned long long nm = __ballot(isnew);
+                    const int nnew = __popcll(nm);
+                    if (rnh + nnew > 64) {
+                        too_many = true;
+                        break;
+                    }
+                    if (cv && h >= 0)
+                        s_att_cid[h] = mine.cid2, s_att_add[h] = my_sc2 + mine.score;
+                    if (isnew) {
+                        const int k = __popcll(nm & ((1ull << lane) - 1ull));
+                        s_new_c1[k] = mine.cid1, s_new_c2[k] = mine.cid2, s_new_sc[k] = my_sc1 + my_sc2 + mine.score;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rnh) {
+                        const int a = s_att_cid[lane];
+                        if (a != -2) { // humans[h].parts[p2] (still unset) != cid2: attach (paf.cpp:170-176)
+                            parts[p2] = a;
+                            ++hn;
+                            hscore += s_att_add[lane];
+                        }
+                    } else if (lane < rnh + nnew) {
+                        const int k = lane - rnh;
+                        const int c1 = s_new_c1[k], c2 = s_new_c2[k];
+#pragma unroll
+                        for (int r = 0; r < HP_COCO_N_PARTS; ++r)
+                            parts[r] = r == p1 ? c1 : (r == p2 ? c2 : -1);
+                        hn = 2;
+                        hscore = s_new_sc[k];
+                    }
+                    rnh += nnew;
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
                 int ci = 0;
                 while (ci < nb) {
                     // fast loop: connections that exactly one human touches (the common case) as straight-line, predicated code with
@@ -877,6 +945,9 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
                     }
                 }
             }
+            if (myid >= 0 && myid < ASM_PEAK_CAP) // leave the table clean for the next limb (also when the limb went the sequential way)
+                s_owner[myid] = -1;
+            __builtin_amdgcn_wave_barrier();
         };
 #define HP_WP(K) walk_pair(std::integral_constant<int, K>{});
         HP_WP(0) HP_WP(1) HP_WP(2) HP_WP(3) HP_WP(4) HP_WP(5) HP_WP(6) HP_WP(7) HP_WP(8) HP_WP(9) HP_WP(10) HP_WP(11) HP_WP(12) HP_WP(13) HP_WP(14)
