@@ -1083,21 +1083,48 @@ __global__ __launch_bounds__(64) void paf_assemble_kernel(const dpeak* __restric
     // emission: (human, part) pairs spread over the wavefront
     hp_human* out = humans + (size_t)f * human_cap;
     const int nout = min(kept, human_cap);
-    for (int e = lane; e < nout * HP_COCO_N_PARTS; e += 64) {
-        const int i = e / HP_COCO_N_PARTS, part = e - i * HP_COCO_N_PARTS;
-        const int h = s_keep[i];
-        hp_body_part bp;
-        bp.has_value = 0;
-        bp.x = 0.f, bp.y = 0.f, bp.score = 0.f;
-        const int id = s_parts[h * HP_COCO_N_PARTS + part];
-        if (id != -1) {
-            const dpeak p = peak_by_id(sorted_f, s_start, peak_cap, id);
-            bp.has_value = 1;
-            bp.score = p.score;
-            bp.x = static_cast<float>(p.x) / res_w; // paf.cpp:367-368
-            bp.y = static_cast<float>(p.y) / res_h;
+    // four (human, part) items per lane at a time: their peaks are requested together (one memory round trip per 256 items instead of one
+    // per 64), the part of each id is found with 17 independent LDS reads instead of a search loop
+    const int total_ids = s_start[HP_COCO_N_PARTS];
+    for (int base = 0; base < nout * HP_COCO_N_PARTS; base += 4 * 64) {
+        int ids[4];
+        dpeak pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = base + q * 64 + lane;
+            ids[q] = -1;
+            if (e < nout * HP_COCO_N_PARTS) {
+                const int i = e / HP_COCO_N_PARTS, part = e - i * HP_COCO_N_PARTS;
+                ids[q] = s_parts[s_keep[i] * HP_COCO_N_PARTS + part];
+            }
+            // peak_by_id: an id outside the table reads as a zero peak (the reference would index out of bounds, paf.cpp:193 can synthesise such ids)
+            const bool valid = ids[q] >= 0 && ids[q] < total_ids;
+            const int idc = valid ? ids[q] : 0;
+            int c = 0;
+#pragma unroll
+            for (int k = 1; k < HP_COCO_N_PARTS; ++k)
+                c += idc >= s_start[k];
+            pk[q] = sorted_f[(size_t)c * peak_cap + (idc - s_start[c])]; // (an empty table: element 0 of part 0, allocated, unused)
+            if (!valid)
+                pk[q].x = 0, pk[q].y = 0, pk[q].score = 0.f, pk[q].lin = 0;
         }
-        out[i].parts[part] = bp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = base + q * 64 + lane;
+            if (e >= nout * HP_COCO_N_PARTS)
+                continue;
+            const int i = e / HP_COCO_N_PARTS, part = e - i * HP_COCO_N_PARTS;
+            hp_body_part bp;
+            bp.has_value = 0;
+            bp.x = 0.f, bp.y = 0.f, bp.score = 0.f;
+            if (ids[q] != -1) {
+                bp.has_value = 1;
+                bp.score = pk[q].score;
+                bp.x = static_cast<float>(pk[q].x) / res_w; // paf.cpp:367-368
+                bp.y = static_cast<float>(pk[q].y) / res_h;
+            }
+            out[i].parts[part] = bp;
+        }
     }
     for (int i = lane; i < nout; i += 64)
         out[i].score = s_score[s_keep[i]];
