@@ -72,6 +72,25 @@ def test_peaks_kernel_odd_geometries(hp, rows, cols):
         _check_frame(p, f, conf[f], paf[f], humans[f])
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_crowds_against_oracle(hp, seed):
+    """Random crowds (0 .. 30 people per frame, noisy maps, dropped joints): the assembly kernel's parallel limbs, its sequential loops
+    for limbs that revisit a part, merges, and - above 64 skeleton fragments - the restart on the LDS tables, all against the oracle's
+    peaks / connections / humans bit for bit."""
+    from hyperpose_amd.parser import Paf
+    rng = np.random.default_rng(4200 + seed)
+    B = 8
+    people = tuple(int(v) for v in rng.integers(0, 31, B))
+    conf, paf, _ = synth.paf_maps(np.random.default_rng(77 + seed), B, people=people, noise=float(rng.choice([0.01, 0.03, 0.06])),
+                                  drop_joint_prob=float(rng.choice([0.0, 0.05, 0.2])))
+    p = Paf(max_batch=B, cap_per_frame=256)
+    humans = p.process_batch(conf, paf)
+    total = 0
+    for f in range(B):
+        total += _check_frame(p, f, conf[f], paf[f], humans[f])
+    assert total >= 10
+
+
 @pytest.mark.parametrize("rows,cols", [(46, 54), (46, 46), (54, 96)])
 def test_batch_parity_with_oracle(hp, rows, cols):
     from hyperpose_amd.parser import Paf
