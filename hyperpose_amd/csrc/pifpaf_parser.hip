@@ -1131,6 +1131,7 @@ struct pd_params {
     size_t occ_stride; // bytes per frame (multiple of 16)
     float keypoint_threshold;
     int net_w, net_h;
+    int decline_odd; // test hook (HP_PIFPAF_DECLINE_ODD=1): odd frames are flagged 64 and go to the host tail, even ones stay on the device
 };
 
 // seeds ranked by their full tuple, descending (std::sort(seeds, std::greater{}) on (v, f, x, y, s) tuples, :772): a total order, so
@@ -1204,7 +1205,7 @@ __global__ __launch_bounds__(64) void pp_decode_kernel(pd_params P, const int* _
     const int fr = blockIdx.x, lane = threadIdx.x;
     const int HW = P.g.H * P.g.W;
     const int* h = hdr + fr * HDR;
-    int flags = 0;
+    int flags = (P.decline_odd && (fr & 1)) ? 64 : 0;
     int ns = h[0];
     if (ns > P.seed_cap)
         ns = P.seed_cap, flags |= 8;
@@ -1522,6 +1523,7 @@ int hp_pifpaf_create(hp_pifpaf** out, int net_h, int net_w, float thresh, int ma
     p->occ.resize(hp::frame_pool::instance().workers());
     if (const char* e = std::getenv("HP_PIFPAF_HOST_TAIL"))
         p->device_decode = !(e[0] && e[0] != '0');
+    p->dp.decline_odd = std::getenv("HP_PIFPAF_DECLINE_ODD") && std::atoi(std::getenv("HP_PIFPAF_DECLINE_ODD")) != 0; // (test hook)
     static const int links_once = [] { // BY_SOURCE_MAP into constant memory
         const pd_links L = make_links();
         return (int)hipMemcpyToSymbol(HIP_SYMBOL(c_links), &L, sizeof(L));

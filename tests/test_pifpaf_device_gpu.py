@@ -99,3 +99,25 @@ def test_device_decoder_small_and_elongated_fields(hp, fh, fw):
         assert got[b].tobytes() == ref[b].tobytes(), (b, flags[b], len(got[b]), len(ref[b]))
         if loader.ref_lib() is not None:
             assert got[b].tobytes() == loader.ref_pifpaf_process(paf[b], pif[b], net_h, net_w).tobytes(), b
+
+
+def test_mixed_batch_device_and_host_tail(hp, monkeypatch):
+    """A batch in which the device decoder hands every second frame back (test hook HP_PIFPAF_DECLINE_ODD): only those frames are packed
+    and decoded by the host tail, the others come from the kernel; the batch equals the all-host result frame by frame."""
+    B = 9
+    monkeypatch.setenv("HP_PIFPAF_DECLINE_ODD", "1")
+    dev = _parser(False, 385, 385, max_batch=B)
+    monkeypatch.delenv("HP_PIFPAF_DECLINE_ODD")
+    host = _parser(True, 385, 385, max_batch=B)
+    for salt in (41, 42):
+        paf, pif = synth.pifpaf_maps(synth.rng_for(4, salt=salt), B, people=(2, 3, 1, 4, 0, 5), noise=0.05)
+        dp, di = hp.DevBuf.from_numpy(paf), hp.DevBuf.from_numpy(pif)
+        dev.enqueue(dp, di, B, 49, 49)
+        got = dev.collect()
+        ref = host.process_batch(paf, pif)
+        flags = dev.decode_flags(B)
+        assert [f & 64 for f in flags] == [64 if b & 1 else 0 for b in range(B)], flags
+        assert all((f & ~(64 | 32)) == 0 for f in flags), flags
+        for b in range(B):
+            assert got[b].tobytes() == ref[b].tobytes(), (salt, b, flags[b])
+        assert sum(len(r) for r in ref) >= 15
