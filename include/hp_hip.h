@@ -187,7 +187,7 @@ int hp_pifpaf_enqueue(hp_pifpaf* p, int n, const float* dev_paf, const float* de
 int hp_pifpaf_collect(hp_pifpaf* p, hp_human* out, int cap_per_frame, int* n_out);
 /* Per frame of the last collected batch: 0 = decoded on the device, -1 = host tail by configuration, > 0 = why the device decoder
  * handed the frame to the host tail (1 annotations > 256, 2 soft-NMS extent, 4 sort depth, 8 seeds, 16 frontier / more than 256 list
- * entries inside one search box, 32 rounding). */
+ * entries inside one search box, 32 rounding, 64 declined by the HP_PIFPAF_DECLINE_ODD test hook). */
 int hp_pifpaf_decode_flags(const hp_pifpaf* p, int* flags, int n);
 
 /* ---- hyperpose::dnn engine: replaces dnn::tensorrt (include/hyperpose/operator/dnn/tensorrt.hpp:33-141,
