@@ -198,8 +198,9 @@ def synth_inputs(cfg, batch, rank):
 def cpu_baseline(cfg, maps, budget_s=8.0):
     """The reference's CPU parser on this host's cores with the reference's shipping flags (-Ofast) and its own parallel
     model: one parser replica per pool thread, frames round-robin (include/hyperpose/utility/thread_pool.hpp:21,
-    stream.hpp:139-144).  PAF = the restated parser ("port": src/paf.cpp needs OpenCV / stdtensor, absent here);
-    PoseProposal / PifPaf = the reference's own sources compiled in oracle/_ref ("reference")."""
+    stream.hpp:139-144).  All three parsers are the reference's own sources compiled in oracle/_ref ("reference"); for PAF
+    (src/paf.cpp + src/post_process.hpp behind the container shims of oracle/shim) the two OpenCV calls are the scalar
+    restatements of oracle/paf_oracle.cpp, i.e. without OpenCV's SIMD kernels - the sample says so."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import loader
     ncpu = os.cpu_count() or 1
@@ -207,9 +208,15 @@ def cpu_baseline(cfg, maps, budget_s=8.0):
     kind = cfg["parser"]
     nb = maps[0].shape[0]
     if kind == "paf":
-        def one(i):
-            return len(loader.paf_process(maps[0][i], maps[1][i], fast=True)[0])
-        what, tag = "restated reference PAF parser (no OpenCV SIMD), -Ofast -march=x86-64-v3", "port"
+        if loader.have_ref_paf(fast=True):
+            def one(i):
+                return len(loader.ref_paf_process(maps[0][i], maps[1][i], fast=True, debug=False)[0])
+            what, tag = ("reference src/paf.cpp + src/post_process.hpp compiled in oracle/_ref (its two OpenCV calls = scalar "
+                         "restatements, no OpenCV SIMD), -Ofast -march=x86-64-v3"), "reference"
+        else:
+            def one(i):
+                return len(loader.paf_process(maps[0][i], maps[1][i], fast=True)[0])
+            what, tag = "restated reference PAF parser (no OpenCV SIMD), -Ofast -march=x86-64-v3", "port"
     elif kind == "ppn":
         if loader.ref_lib(fast=True) is None:
             return None

@@ -52,7 +52,7 @@ SYMBOLS = [
     "hp_init", "hp_device_count", "hp_last_error", "hp_version", "hp_malloc", "hp_free", "hp_malloc_host",
     "hp_free_host", "hp_memcpy_h2d", "hp_memcpy_d2h", "hp_device_synchronize", "hp_stream_wait_stream", "hp_dist_unique_id", "hp_dist_init", "hp_dist_destroy", "hp_dist_broadcast_weights", "hp_dist_shard", "hp_preproc_u8hwc_to_f32nchw", "hp_resize_u8c3", "hp_letterbox_u8c3", "hp_letterbox_inner", "hp_resume_ratio",
     "hp_paf_create", "hp_paf_stream", "hp_paf_destroy", "hp_paf_set_conf_thresh", "hp_paf_set_paf_thresh", "hp_paf_process_batch",
-    "hp_paf_enqueue", "hp_paf_collect", "hp_paf_debug_peaks", "hp_paf_debug_conns", "hp_paf_debug_maps",
+    "hp_paf_enqueue", "hp_paf_collect", "hp_paf_debug_peaks", "hp_paf_debug_conns", "hp_paf_debug_maps", "hp_paf_debug_sort",
     "hp_pifpaf_create", "hp_pifpaf_destroy", "hp_pifpaf_process_batch", "hp_pifpaf_stream", "hp_pifpaf_enqueue", "hp_pifpaf_collect", "hp_pifpaf_decode_flags",
     "hp_ppn_create", "hp_ppn_destroy", "hp_ppn_set_thresholds", "hp_ppn_process_batch", "hp_ppn_stream", "hp_ppn_enqueue", "hp_ppn_collect",
     "hp_engine_create", "hp_engine_destroy", "hp_engine_max_batch", "hp_engine_describe", "hp_engine_input_size", "hp_engine_infer_u8",

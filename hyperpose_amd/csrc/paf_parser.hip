@@ -359,9 +359,55 @@ struct cand_t {
 // libstdc++'s std::sort (bits/stl_algo.h: __introsort_loop with median-of-three __unguarded_partition_pivot down to 16 elements, then
 // __final_insertion_sort) restated on an index array, comparator std::greater<connection_candidate> = by score (src/paf.cpp:47-50).  The
 // standard leaves the order of equal elements open; the reference's results depend on this implementation's choice, so it is
-// reproduced step by step (the sequence of comparisons and swaps is a pure function of the scores).  Returns false if the depth limit
-// (2 * floor(log2 n)) is exhausted, where libstdc++ switches to heap sort (not restated; never reached by partition-friendly data).
-__device__ bool libstdcxx_sort_greater(int* v, int n, const cand_t* c)
+// reproduced step by step (the sequence of comparisons and swaps is a pure function of the scores).  When the depth limit
+// (2 * floor(log2 n)) is exhausted libstdc++ heap-sorts the range it is looking at (`std::__partial_sort(first, last, last)` =
+// __heap_select + __sort_heap: __make_heap, then __pop_heap down to one element, both through __adjust_heap / __push_heap); that is
+// restated too (`used_heap` reports that it ran).  Returns false only if the explicit stack overflowed (impossible: depth <= 2 log2 n).
+__device__ void libstdcxx_adjust_heap(int* v, const cand_t* c, int first, int hole, int len, int value)
+{
+    // bits/stl_heap.h __adjust_heap(first, holeIndex, len, value, comp) followed by __push_heap; comp(a, b) = a.score > b.score
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (c[v[first + child]].score > c[v[first + child - 1]].score)
+            --child;
+        v[first + hole] = v[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        v[first + hole] = v[first + child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && c[v[first + parent]].score > c[value].score) {
+        v[first + hole] = v[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    v[first + hole] = value;
+}
+
+__device__ void libstdcxx_heap_sort_greater(int* v, const cand_t* c, int first, int last)
+{
+    const int len = last - first;
+    if (len >= 2) // __make_heap
+        for (int parent = (len - 2) / 2;; --parent) {
+            libstdcxx_adjust_heap(v, c, first, parent, len, v[first + parent]);
+            if (parent == 0)
+                break;
+        }
+    // __heap_select's scan over [middle, last) is empty (middle == last); __sort_heap:
+    for (int l = last; l - first > 1;) {
+        --l;
+        const int value = v[l]; // __pop_heap(first, l, l)
+        v[l] = v[first];
+        libstdcxx_adjust_heap(v, c, first, 0, l - first, value);
+    }
+}
+
+__device__ bool libstdcxx_sort_greater(int* v, int n, const cand_t* c, bool* used_heap = nullptr)
 {
 #define HP_GT(i, j) (c[v[i]].score > c[v[j]].score)
 #define HP_SWAP(i, j)                                                                                             \
@@ -386,7 +432,9 @@ __device__ bool libstdcxx_sort_greater(int* v, int n, const cand_t* c)
         // iterative form of the loop: every partition pushes the LEFT remainder to be continued after the right recursion returns
         while (last - first > 16) {
             if (depth == 0) {
-                ok = false;
+                libstdcxx_heap_sort_greater(v, c, first, last);
+                if (used_heap)
+                    *used_heap = true;
                 break;
             }
             --depth;
@@ -458,6 +506,25 @@ __device__ bool libstdcxx_sort_greater(int* v, int n, const cand_t* c)
 #undef HP_GT
 #undef HP_SWAP
     return ok;
+}
+
+// hp_paf_debug_sort: the restated std::sort alone, on an arbitrary score sequence in generation order (tests: median-of-three
+// killers that drive libstdc++ into its heap-sort fallback, mass ties) - compared with the host's real std::sort.
+__global__ void paf_debug_sort_kernel(const float* __restrict__ scores, int n, cand_t* __restrict__ cand, int* __restrict__ order,
+    int* __restrict__ flag)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        cand[i].score = scores[i];
+        cand[i].ab = i;
+        cand[i].seq = i;
+        order[i] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool heap = false;
+        const bool ok = libstdcxx_sort_greater(order, n, cand, &heap);
+        *flag = (heap ? 1 : 0) | (ok ? 0 : 2);
+    }
 }
 
 __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict__ paf, geom_t g, float paf_thresh,
@@ -614,7 +681,7 @@ __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict_
         }
         __syncthreads();
         if (tid == 0 && !libstdcxx_sort_greater(s_order, n, s_cand))
-            atomicOr(flags + f, 8); // introsort's depth limit ran out (heap-sort fallback not restated): order = generation order of ties
+            atomicOr(flags + f, 8); // (unreachable: the explicit stack of the restated introsort cannot overflow)
         __syncthreads();
     }
 
@@ -1520,6 +1587,32 @@ int hp_paf_debug_conns(hp_paf* p, int frame, hp_conn* out, int cap, int* n)
                 out[id] = hp_conn{ l, buf[i].cid1, buf[i].cid2, buf[i].score };
     }
     *n = id;
+    return HP_OK;
+}
+
+int hp_paf_debug_sort(const float* host_scores, int n, int* host_order, int* used_heap)
+{
+    HP_REQUIRE(host_scores && host_order && n >= 0 && n <= (1 << 20), HP_ERR_INVALID, "hp_paf_debug_sort: bad argument");
+    if (used_heap)
+        *used_heap = 0;
+    if (n == 0)
+        return HP_OK;
+    hp::dev_buf dsc, dcand, dord, dflag;
+    HP_TRY(dsc.alloc((size_t)n * 4));
+    HP_TRY(dcand.alloc((size_t)n * sizeof(cand_t)));
+    HP_TRY(dord.alloc((size_t)n * 4));
+    HP_TRY(dflag.alloc(4));
+    HP_HIP_TRY(hipMemcpy(dsc.p, host_scores, (size_t)n * 4, hipMemcpyHostToDevice));
+    HP_HIP_TRY(hipMemset(dflag.p, 0, 4));
+    hipLaunchKernelGGL(paf_debug_sort_kernel, dim3(1), dim3(64), 0, 0, dsc.as<float>(), n, dcand.as<cand_t>(), dord.as<int>(), dflag.as<int>());
+    HP_HIP_TRY(hipGetLastError());
+    HP_HIP_TRY(hipDeviceSynchronize());
+    HP_HIP_TRY(hipMemcpy(host_order, dord.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    int fl = 0;
+    HP_HIP_TRY(hipMemcpy(&fl, dflag.p, 4, hipMemcpyDeviceToHost));
+    if (used_heap)
+        *used_heap = fl & 1;
+    HP_REQUIRE(!(fl & 2), HP_ERR_STATE, "hp_paf_debug_sort: restated introsort stack overflow");
     return HP_OK;
 }
 

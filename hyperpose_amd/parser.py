@@ -115,6 +115,15 @@ class Paf:
         return up, sm
 
 
+def paf_debug_sort(scores: np.ndarray):
+    """The device's restated ``std::sort(..., std::greater)`` (src/paf.cpp:249) on a score sequence; returns (order, used_heap)."""
+    scores = np.ascontiguousarray(scores, np.float32)
+    order = np.zeros(len(scores), np.int32)
+    heap = C.c_int(0)
+    check(lib().hp_paf_debug_sort(scores.ctypes.data_as(_FP), len(scores), order.ctypes.data_as(C.POINTER(C.c_int)), C.byref(heap)))
+    return order, bool(heap.value)
+
+
 def preproc_u8hwc_to_f32nchw(images: np.ndarray, factor: float = 1.0 / 255, flip_rb: bool = True) -> np.ndarray:
     """``hyperpose::nhwc_images_append_nchw_batch`` (src/data.cpp:21-51) on the GPU, host arrays in/out."""
     images = np.ascontiguousarray(images, np.uint8)

@@ -146,6 +146,10 @@ int hp_paf_debug_conns(hp_paf* p, int frame, hp_conn* out, int cap, int* n);
 /* The up-sampled (resize_area) and the smoothed (GaussianBlur) confidence maps [J,res_h,res_w] of ONE frame,
  * host pointers, either output may be NULL (tests only; the production kernels never materialise them). */
 int hp_paf_debug_maps(hp_paf* p, const float* host_conf, const int conf_shape[3], float* host_up, float* host_smoothed);
+/* The device's restatement of libstdc++'s std::sort(first, last, std::greater<connection_candidate>) (src/paf.cpp:249: the order of
+ * equal scores is whatever that algorithm leaves) on n scores given in generation order; host_order[i] = index of the element
+ * that ends at position i; *used_heap = 1 when the introsort depth limit was hit and the heap-sort fall-back ran (tests only). */
+int hp_paf_debug_sort(const float* host_scores, int n, int* host_order, int* used_heap);
 
 /* ---- hyperpose::parser::pose_proposal (include/hyperpose/operator/parser/proposal_network.hpp:17-81,
  * src/pose_proposal.cpp).  GPU: threshold + box decode + per-class NMS + limb-candidate gather; host: the

@@ -84,6 +84,9 @@ def ref_lib(fast: bool = False):
         L = C.CDLL(path)
         L.ref_ppn_process.restype = C.c_int
         L.ref_pifpaf_process.restype = C.c_int
+        if hasattr(L, "ref_paf_process"):  # a prebuilt oracle/_ref older than round 3 has no PAF entry points
+            L.ref_paf_process.restype = C.c_int
+            L.ref_paf_debug.restype = C.c_int
         _libs[name] = L
     return _libs[name]
 
@@ -144,6 +147,21 @@ def paf_process(conf: np.ndarray, paf: np.ndarray, conf_thresh: float = 0.05, pa
     return h, p, c
 
 
+def std_sort_greater(scores: np.ndarray) -> np.ndarray:
+    """libstdc++'s std::sort with std::greater<connection_candidate> (src/paf.cpp:249) on scores in generation order."""
+    scores = np.ascontiguousarray(scores, np.float32)
+    order = np.zeros(len(scores), np.int32)
+    lib().oracle_std_sort_greater(_fp(scores), len(scores), order.ctypes.data_as(C.POINTER(C.c_int)))
+    return order
+
+
+def sort_killer(n: int) -> np.ndarray:
+    """A score sequence that drives this libstdc++'s introsort into its heap-sort fall-back (McIlroy's adversary)."""
+    out = np.zeros(n, np.float32)
+    lib().oracle_sort_killer(n, _fp(out))
+    return out
+
+
 def nhwc_u8_to_nchw_f32(images: np.ndarray, factor: float = 1.0 / 255, flip_rb: bool = True) -> np.ndarray:
     images = np.ascontiguousarray(images, np.uint8)
     n, h, w, _ = images.shape
@@ -167,6 +185,47 @@ def ref_ppn_process(tensors, net_w=384, net_h=384, point_thresh=0.10, limb_thres
                           *[_fp(a) for a in t], k, gh, gw, e, nh, nw, out, cap)
     assert 0 <= n <= cap
     return np.frombuffer(out, dtype=HUMAN_DTYPE, count=n).copy()
+
+
+_PEAK_DTYPE = np.dtype([("part_id", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4"), ("id", "<i4")])
+_CONN_DTYPE = np.dtype([("pair_id", "<i4"), ("cid1", "<i4"), ("cid2", "<i4"), ("score", "<f4")])
+
+
+def ref_paf_process(conf, paf, conf_thresh=0.05, paf_thresh=0.05, res_w=-1, res_h=-1, cap_humans=128,
+                    cap_peaks=8192, cap_conns=8192, fast=False, debug=True):
+    """One frame through the REFERENCE's own parser::paf::process (src/paf.cpp compiled in oracle/_ref; only its
+    two OpenCV calls are restated).  Returns (humans, peaks, conns) like paf_process(); peaks / conns come from
+    the reference's own functions called stage by stage (ref_paf_debug) and are None with debug=False."""
+    L = ref_lib(fast)
+    if L is None or not hasattr(L, "ref_paf_process"):
+        raise RuntimeError("oracle/_ref not built (or older than the PAF entry points)")
+    conf = np.ascontiguousarray(conf, np.float32)
+    paf = np.ascontiguousarray(paf, np.float32)
+    j, rows, cols = conf.shape
+    humans = (OHuman * cap_humans)()
+    n = L.ref_paf_process(_fp(conf), j, rows, cols, _fp(paf), paf.shape[0], C.c_float(conf_thresh),
+                          C.c_float(paf_thresh), res_w, res_h, humans, cap_humans)
+    if n < 0 or n > cap_humans:
+        raise RuntimeError(f"ref_paf_process overflow/err: humans={n}")
+    h = np.frombuffer(humans, dtype=HUMAN_DTYPE, count=n).copy()
+    if not debug:
+        return h, None, None
+    peaks = (OPeak * cap_peaks)()
+    conns = (OConn * cap_conns)()
+    n_peaks, n_conns = C.c_int(0), C.c_int(0)
+    n2 = L.ref_paf_debug(_fp(conf), j, rows, cols, _fp(paf), paf.shape[0], C.c_float(conf_thresh),
+                         C.c_float(paf_thresh), res_w, res_h, peaks, cap_peaks, C.byref(n_peaks), conns, cap_conns,
+                         C.byref(n_conns))
+    if n2 != n or n_peaks.value > cap_peaks or n_conns.value > cap_conns:
+        raise RuntimeError(f"ref_paf_debug: humans={n2} vs {n}, peaks={n_peaks.value} conns={n_conns.value}")
+    p = np.frombuffer(peaks, dtype=_PEAK_DTYPE, count=n_peaks.value).copy()
+    c = np.frombuffer(conns, dtype=_CONN_DTYPE, count=n_conns.value).copy()
+    return h, p, c
+
+
+def have_ref_paf(fast: bool = False) -> bool:
+    L = ref_lib(fast)
+    return L is not None and hasattr(L, "ref_paf_process")
 
 
 def ref_pifpaf_process(paf, pif, net_h=385, net_w=385, thresh=0.1, cap=256, fast=False):

@@ -1,6 +1,8 @@
-"""Generate the committed known-answer vectors for the PoseProposal and PifPaf parsers FROM THE REFERENCE'S OWN
-CODE (oracle/_ref/libhp_ref.so = src/pose_proposal.cpp, src/pifpaf.cpp, src/pifpaf_decoder/*.cpp compiled where
-they lie; only possible in a container that mounts /root/reference).
+"""Generate the committed known-answer vectors for the PAF, PoseProposal and PifPaf parsers FROM THE REFERENCE'S OWN
+CODE (oracle/_ref/libhp_ref.so = src/paf.cpp + src/post_process.hpp, src/pose_proposal.cpp, src/pifpaf.cpp,
+src/pifpaf_decoder/*.cpp compiled where they lie; only possible in a container that mounts /root/reference).
+For PAF the reference's two OpenCV calls are the restatements of oracle/paf_oracle.cpp (OpenCV is not in the image);
+everything else in the file - peaks, line integrals, std::sort + greedy assignment, assembly - is reference code.
 
     python tests/golden/make_golden_ref.py
 
@@ -24,6 +26,30 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def q16(a):
     return a.astype(np.float16).astype(np.float32)
+
+
+PAF_CASES = [  # (rows, cols, people, seed-salt)
+    (46, 54, 3, 1),   # config A geometry (non-square: anisotropic x4.696 / x3.407 up-sampling)
+    (46, 46, 5, 2),   # square: exact x4 replication path
+    (23, 31, 2, 3),   # small odd geometry
+    (46, 54, 0, 4),   # empty frame: noise only
+]
+
+
+def paf():
+    out, meta = {}, []
+    for i, (rows, cols, people, salt) in enumerate(PAF_CASES):
+        rng = synth.rng_for(1, salt=100 + salt)
+        conf, pafm, _ = synth.paf_maps(rng, 1, rows, cols, people=(people,),
+                                       **({"scale_range": (8.0, 16.0)} if rows < 40 else {}))
+        out[f"conf_{i}"], out[f"paf_{i}"] = q16(conf[0]), q16(pafm[0])  # exactly representable -> compresses well
+        humans, peaks, conns = loader.ref_paf_process(out[f"conf_{i}"], out[f"paf_{i}"])
+        out[f"humans_{i}"], out[f"peaks_{i}"], out[f"conns_{i}"] = humans, peaks, conns
+        meta.append({"rows": rows, "cols": cols, "people": people, "n_humans": int(len(humans)),
+                     "n_peaks": int(len(peaks)), "n_conns": int(len(conns))})
+        print("paf", meta[-1])
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "paf_golden.npz"), **out)
 
 
 def ppn():
@@ -60,5 +86,7 @@ def pifpaf():
 
 if __name__ == "__main__":
     assert loader.ref_lib() is not None, "oracle/_ref not built (needs /root/reference)"
+    assert loader.have_ref_paf(), "oracle/_ref is older than the PAF entry points: make -C oracle ref"
+    paf()
     ppn()
     pifpaf()

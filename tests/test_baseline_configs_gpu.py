@@ -65,7 +65,7 @@ def test_config1_lw_openpose_b8_368x432(hp):
     (_, cs, cp), (_, ps, pp) = eng.outputs
     humans = p.process_batch_device(cp, pp, 8, cs, ps)
     for b in range(8):
-        oh, _, _ = loader.paf_process(full[b][0], full[b][1])
+        oh, _, _ = loader.ref_paf_process(full[b][0], full[b][1])
         assert humans[b].tobytes() == oh.tobytes()
     # asynchronous hand-over: engine on its stream, parser on its OWN stream behind it (hp_stream_wait_stream)
     dev = __import__("hyperpose_amd")._lib.DevBuf.from_numpy(fr)
@@ -90,14 +90,14 @@ def test_config2_openpose_vgg19_b16_432x768(hp):
     (_, cs, cp), (_, ps, pp) = eng.outputs
     humans = p.process_batch_device(cp, pp, 16, cs, ps)
     for b in (0, 7, 15):
-        oh, _, _ = loader.paf_process(full[b][0], full[b][1])
+        oh, _, _ = loader.ref_paf_process(full[b][0], full[b][1])
         assert humans[b].tobytes() == oh.tobytes()
     # injected realistic maps at this geometry (54x96 -> 384 rows x 216 cols up-sampled)
     conf, paf, _ = synth.paf_maps(synth.rng_for(2, salt=1), 16, 54, 96, people=(2, 4, 8, 16))
     hs = p.process_batch(conf, paf)
     total = 0
     for b in (0, 3, 11):
-        oh, _, _ = loader.paf_process(conf[b], paf[b])
+        oh, _, _ = loader.ref_paf_process(conf[b], paf[b])
         assert hs[b].tobytes() == oh.tobytes()
         total += len(oh)
     assert total >= 10

@@ -22,7 +22,7 @@ def _same(a, b):
 
 
 def _check_frame(parser, f, conf, paf, humans):
-    oh, op, oc = loader.paf_process(conf, paf)
+    oh, op, oc = loader.ref_paf_process(conf, paf)
     gp = parser.debug_peaks(f)
     assert _same(gp, op), f"peaks differ: gpu {len(gp)} vs oracle {len(op)}"
     gc = parser.debug_conns(f)
@@ -112,7 +112,7 @@ def test_explicit_resolution_and_thresholds(hp):
     p = Paf(conf_thresh=0.1, paf_thresh=0.08, resolution_size=(216, 184), max_batch=2)  # cv::Size(w, h): un-swapped 4x
     humans = p.process_batch(conf, paf)
     for f in range(2):
-        oh, op, oc = loader.paf_process(conf[f], paf[f], 0.1, 0.08, 216, 184)
+        oh, op, oc = loader.ref_paf_process(conf[f], paf[f], 0.1, 0.08, 216, 184)
         assert _same(p.debug_peaks(f), op) and _same(p.debug_conns(f), oc) and _same(humans[f], oh)
         assert len(oh) >= 1
 
@@ -129,7 +129,7 @@ def test_device_resident_and_async(hp):
     c = p.process_batch(conf, paf)
     for f in range(4):
         assert _same(a[f], b[f]) and _same(a[f], c[f])
-        assert _same(a[f], loader.paf_process(conf[f], paf[f])[0])
+        assert _same(a[f], loader.ref_paf_process(conf[f], paf[f])[0])
 
 
 def test_errors_are_codes_not_crashes(hp):
@@ -186,7 +186,7 @@ def test_state_between_batches(hp):
     noisy[1] = conf[3]
     npaf = np.stack([paf[0] * 0, paf[3]])
     humans = p.process_batch(noisy, npaf)
-    oh, op, oc = loader.paf_process(noisy[0], npaf[0], cap_peaks=32768, cap_conns=32768)
+    oh, op, oc = loader.ref_paf_process(noisy[0], npaf[0], cap_peaks=32768, cap_conns=32768)
     assert len(op) > 18 * 600  # (the blurred grid also peaks between the bright cells at the border)
     assert _same(p.debug_peaks(0, cap=32768), op) and _same(humans[0], oh)
     _check_frame(p, 1, noisy[1], npaf[1], humans[1])   # the other frame of the grown batch
@@ -216,11 +216,11 @@ def test_lists_grow_like_the_references_vectors(hp):
     p = Paf(max_batch=2)
     humans = p.process_batch(conf, paf)
     for f in range(2):
-        oh, op, oc = loader.paf_process(conf[f], paf[f], cap_peaks=32768, cap_conns=32768)
+        oh, op, oc = loader.ref_paf_process(conf[f], paf[f], cap_peaks=32768, cap_conns=32768)
         assert _same(p.debug_peaks(f, cap=32768), op), f
         assert _same(p.debug_conns(f, cap=32768), oc), f
         assert _same(humans[f], oh), f
-    assert len(loader.paf_process(conf[0], paf[0])[2]) >= 66
+    assert len(loader.ref_paf_process(conf[0], paf[0])[2]) >= 66
 
 
 def _tie_maps(n_necks, rows=46, cols=54, gap=4):
@@ -246,16 +246,16 @@ def _tie_maps(n_necks, rows=46, cols=54, gap=4):
     return conf, paf
 
 
-@pytest.mark.parametrize("n_necks", [1, 3, 12])
+@pytest.mark.parametrize("n_necks", [1, 3, 12, 20, 30])
 def test_forced_ties_in_get_connections(hp, n_necks):
-    """Equal candidate scores (src/paf.cpp:249 `std::sort(..., std::greater)` leaves their order to the implementation): the GPU parser
-    ranks ties by generation order.  With <= 16 candidates per limb libstdc++'s std::sort is a pure insertion sort (stable), so the
-    oracle - which calls the same std::sort as the reference - must agree bit for bit (n_necks = 1, 3: 2 / 6+ candidates).  With more
-    candidates (n_necks = 12) introsort's partitioning decides; the test then requires the same humans up to WHICH of two mirror-image
-    shoulders a neck keeps, and reports whether the bits agree."""
+    """Equal candidate scores (src/paf.cpp:249 `std::sort(..., std::greater)` leaves their order to the implementation; the
+    reference's result is whatever libstdc++ leaves).  Up to 16 candidates per limb libstdc++'s std::sort is a pure insertion sort
+    (stable = generation order; n_necks = 1, 3); with more (n_necks = 12, 20, 30: 24 / 40 / 60-way ties among > 16 candidates)
+    introsort's median-of-three partitioning decides, which paf_limbs_kernel reproduces step by step (`libstdcxx_sort_greater`).
+    Connections and humans must equal the reference-compiled parser bit for bit in every case."""
     from hyperpose_amd.parser import Paf
     conf, paf = _tie_maps(n_necks)
-    oh, op, oc = loader.paf_process(conf, paf)
+    oh, op, oc = loader.ref_paf_process(conf, paf)
     limb0 = oc[oc["pair_id"] == 0]
     assert len(limb0) == n_necks, (len(limb0), n_necks)      # one survivor per neck: the ties really conflicted
     scores = limb0["score"]
@@ -264,12 +264,35 @@ def test_forced_ties_in_get_connections(hp, n_necks):
     gh = p.process(conf, paf)
     gc = p.debug_conns(0)
     assert _same(p.debug_peaks(0), op)
-    g0 = gc[gc["pair_id"] == 0]
-    assert len(g0) == n_necks and np.all(g0["score"] == scores[0])
-    if n_necks <= 3:
-        assert _same(gc, oc) and _same(gh, oh)
-    else:
-        # same necks connected, each to one of its two shoulders, same scores; the choice among equals may differ from introsort's
-        assert sorted(g0["cid1"]) == sorted(limb0["cid1"])
-        assert len(gh) == len(oh)
-        print(f"forced ties, {n_necks} necks: connections bit-equal to the libstdc++ order: {_same(gc, oc)}")
+    assert _same(gc, oc), f"{n_necks} necks: connections differ from the libstdc++ order"
+    assert _same(gh, oh)
+
+
+def test_restated_std_sort_against_libstdcxx(hp):
+    """`libstdcxx_sort_greater` alone (hp_paf_debug_sort) against the host's real std::sort (oracle_std_sort_greater, the call of
+    src/paf.cpp:249) on score sequences in generation order: random scores drawn from few distinct values (mass ties), all-equal,
+    sorted / reversed / organ-pipe runs, and McIlroy-adversary sequences built against this very libstdc++ that exhaust introsort's
+    depth limit (2 floor(log2 n)) and run its heap-sort fall-back - which the device must report (`used_heap`) and reproduce."""
+    from hyperpose_amd.parser import paf_debug_sort
+    rng = np.random.default_rng(5)
+    cases = []
+    for n in (1, 2, 16, 17, 18, 33, 100, 257, 1000, 4097):
+        cases.append((f"ties{n}", rng.integers(0, max(2, n // 8), n).astype(np.float32), None))
+        cases.append((f"rand{n}", rng.normal(size=n).astype(np.float32), None))
+    cases.append(("equal", np.full(300, 0.25, np.float32), False))
+    cases.append(("ascending", np.arange(500, dtype=np.float32), False))
+    cases.append(("descending", -np.arange(500, dtype=np.float32), False))
+    cases.append(("organ", np.concatenate([np.arange(200), np.arange(200)[::-1]]).astype(np.float32), None))
+    for n in (40, 200, 1000, 5000):
+        cases.append((f"killer{n}", loader.sort_killer(n), True))
+        k = loader.sort_killer(n)
+        cases.append((f"killer_ties{n}", np.floor(k / 3).astype(np.float32), None))
+    heaps = 0
+    for name, scores, want_heap in cases:
+        order, used_heap = paf_debug_sort(scores)
+        ref = loader.std_sort_greater(scores)
+        assert np.array_equal(order, ref), name
+        if want_heap is not None:
+            assert used_heap == want_heap, (name, used_heap)
+        heaps += used_heap
+    assert heaps >= 4

@@ -134,7 +134,7 @@ def test_fp16_engine_vs_fp32_oracle_keypoint_drift(hp, capsys):
     n_ref = n_gpu = n_kp = n_same = n_close = 0
     worst = 0.0
     for b in range(4):
-        oh, _, _ = loader.paf_process(ref["conf"][b], ref["paf"][b], 0.05, -1e9)
+        oh, _, _ = loader.ref_paf_process(ref["conf"][b], ref["paf"][b], 0.05, -1e9)
         n_ref += len(oh)
         n_gpu += len(gh[b])
         # match every oracle key-point with the nearest GPU key-point of the same part
