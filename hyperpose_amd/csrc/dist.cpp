@@ -9,6 +9,7 @@
 
 #include <memory>
 #include <mutex>
+#include <string>
 
 namespace {
 
@@ -38,14 +39,18 @@ int load_rccl(rccl_api** out)
     static rccl_api api;
     static std::once_flag once;
     static bool ok = false;
+    static std::string why = "missing symbols"; // dlerror() is consumed by its first call: captured once, here
     std::call_once(once, [] {
         for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" }) {
             api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (api.lib)
                 break;
+            const char* e = dlerror();
+            why = e ? e : "dlopen failed";
         }
         if (!api.lib)
             return;
+        why = "missing symbols";
         api.get_uid = (get_uid_t)dlsym(api.lib, "ncclGetUniqueId");
         api.init_rank = (init_rank_t)dlsym(api.lib, "ncclCommInitRank");
         api.bcast = (bcast_t)dlsym(api.lib, "ncclBroadcast");
@@ -53,7 +58,7 @@ int load_rccl(rccl_api** out)
         api.errstr = (errstr_t)dlsym(api.lib, "ncclGetErrorString");
         ok = api.get_uid && api.init_rank && api.bcast && api.destroy;
     });
-    HP_REQUIRE(ok, HP_ERR_HIP, "hp_dist: librccl.so could not be loaded (%s)", api.lib ? "missing symbols" : dlerror());
+    HP_REQUIRE(ok, HP_ERR_HIP, "hp_dist: librccl.so could not be loaded (%s)", why.c_str());
     *out = &api;
     return HP_OK;
 }

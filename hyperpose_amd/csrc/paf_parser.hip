@@ -1495,19 +1495,30 @@ int hp_paf_collect(hp_paf* p, hp_human* out, int cap_per_frame, int* n_out)
         // a list overflowed somewhere in the batch: grow what can grow and parse the batch again (the reference's vectors just grow)
         const size_t planes = (size_t)4 * 2 * p->g.R * p->g.Cc, per_cand = sizeof(cand_t) + sizeof(int);
         const int cand_max = (int)((156 * 1024 - planes) / per_cand);
+        // the new capacities are computed into locals and committed only together with the buffers that match them: leaving the loop
+        // (round limit) or failing to allocate must not leave caps larger than plist / sorted / conns / h_humans
+        if (round >= 6)
+            break;
+        int peak_cap = p->peak_cap, cand_cap = p->cand_cap, human_cap = p->human_cap;
         bool grown = false;
-        if ((fl & 1) && p->peak_cap < PEAK_CAP_MAX)
-            p->peak_cap = std::min(p->peak_cap * 2, PEAK_CAP_MAX), grown = true;
-        if ((fl & 2) && p->cand_cap < cand_max)
-            p->cand_cap = std::min(p->cand_cap * 2, cand_max), grown = true;
-        if (max_h > p->human_cap && p->human_cap < HUMAN_CAP_MAX) {
-            while (p->human_cap < max_h && p->human_cap < HUMAN_CAP_MAX)
-                p->human_cap *= 2;
+        if ((fl & 1) && peak_cap < PEAK_CAP_MAX)
+            peak_cap = std::min(peak_cap * 2, PEAK_CAP_MAX), grown = true;
+        if ((fl & 2) && cand_cap < cand_max)
+            cand_cap = std::min(cand_cap * 2, cand_max), grown = true;
+        if (max_h > human_cap && human_cap < HUMAN_CAP_MAX) {
+            while (human_cap < max_h && human_cap < HUMAN_CAP_MAX)
+                human_cap *= 2;
             grown = true;
         }
-        if (!grown || round >= 6)
+        if (!grown)
             break;
-        HP_TRY(p->alloc_lists());
+        const int old_peak = p->peak_cap, old_cand = p->cand_cap, old_human = p->human_cap;
+        p->peak_cap = peak_cap, p->cand_cap = cand_cap, p->human_cap = human_cap;
+        if (const int rc_alloc = p->alloc_lists(); rc_alloc != HP_OK) {
+            p->peak_cap = old_peak, p->cand_cap = old_cand, p->human_cap = old_human; // (buffers already re-allocated are only larger)
+            (void)p->alloc_lists();
+            return rc_alloc;
+        }
         HP_TRY(p->launch(n, p->last_conf, p->last_paf, p->stream));
         HP_HIP_TRY(hipEventSynchronize(p->done));
     }

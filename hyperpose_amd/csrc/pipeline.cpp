@@ -206,7 +206,7 @@ int hp_pipeline_collect(hp_pipeline* pl, hp_human* out, int cap_per_frame, int* 
     pl->tail = (pl->tail + 1) % pl->n_pipes;
     --pl->inflight;
     *n_frames = n;
-    if (rc == HP_OK && out && pl->keep_ratio)
+    if ((rc == HP_OK || rc == HP_ERR_CAPACITY) && out && pl->keep_ratio) // (capacity: that frame's list is cut, everything returned is valid)
         for (int i = 0; i < n; ++i) // src/stream.cpp:120-124
             hp_resume_ratio(out + (size_t)i * cap_per_frame, std::min(n_out[i], cap_per_frame), p.w[i], p.h[i], pl->in_w, pl->in_h);
     return rc;

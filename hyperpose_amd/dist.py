@@ -29,37 +29,62 @@ def init(backend: str, device=None):
     return dist
 
 
-_COLLECTIVE_DEVICE = None  # device the collectives run on: the GPU under RCCL, "cpu" after a fall-back to gloo
+_COLLECTIVE_DEVICE = None  # device the data collectives run on: the GPU under RCCL, "cpu" on gloo
+_GROUP = None              # process group of the data collectives (None = the default group)
+_BACKEND = None
+LAST_BROADCAST = {}        # {"backend", "bytes", "ms"} of the last broadcast_weights (reported by bench.py)
 
 
 def init_for_gpu(device, probe: bool = True):
-    """RCCL (`nccl`) for the start-up broadcast and the two timing reductions; if the backend cannot be brought up on this node
-    (raises at init or at the first collective) the job falls back to gloo on the host - the hot path itself has no collective, so
-    nothing measured changes.  Returns the backend name."""
-    global _COLLECTIVE_DEVICE
+    """Bring up the job's collectives on a GPU node; returns the name of the backend that carries them ("nccl" = RCCL, or "gloo").
+
+    The default group is gloo (host TCP: rendezvous, barriers - it always comes up); the start-up weight broadcast and the timing
+    reductions run on an RCCL group created next to it.  Whether RCCL is usable is decided COLLECTIVELY: every rank tries to create
+    the group and to all-reduce one element on it, the ranks then take the minimum of their success flags over gloo, and either all
+    of them use RCCL or all of them stay on gloo - no rank can end up alone in the other backend, no second rendezvous, no second
+    port.  `HP_DIST_BACKEND=gloo` (set for all ranks by the launcher) skips RCCL.  The hot path itself has no collective."""
+    global _COLLECTIVE_DEVICE, _GROUP, _BACKEND
+    import datetime
     import sys
 
     import torch
     import torch.distributed as dist
-    try:
-        init("nccl", device=device)
-        if probe:
-            t = torch.ones(1, device=device)
-            dist.all_reduce(t)
-            torch.cuda.synchronize(device)
-        _COLLECTIVE_DEVICE = device
-        return "nccl"
-    except Exception as e:  # noqa: BLE001 - any failure of the GPU backend takes the same way out
-        print(f"[hyperpose_amd.dist] RCCL unavailable ({type(e).__name__}: {e}); collectives fall back to gloo", file=sys.stderr, flush=True)
+    init("gloo")
+    ok, why, group = 1, "", None
+    if os.environ.get("HP_DIST_BACKEND", "nccl") == "gloo":
+        ok, why = 0, "HP_DIST_BACKEND=gloo"
+    else:
         try:
-            if dist.is_initialized():
-                dist.destroy_process_group()
-        except Exception:  # noqa: BLE001
-            pass
-        os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 1)  # the old store may still hold the port
-        init("gloo")
-        _COLLECTIVE_DEVICE = "cpu"
-        return "gloo"
+            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+            if probe:
+                t = torch.ones(1, device=device)
+                dist.all_reduce(t, group=group)
+                torch.cuda.synchronize(device)
+                if int(t.item()) != dist.get_world_size():
+                    raise RuntimeError(f"probe all-reduce returned {t.item()}")
+        except Exception as e:  # noqa: BLE001 - any failure of the GPU backend takes the same way out
+            ok, why = 0, f"{type(e).__name__}: {e}"
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo: the agreement
+    if int(flag.item()) == 1:
+        _GROUP, _COLLECTIVE_DEVICE, _BACKEND = group, device, "nccl"
+    else:
+        if why:
+            print(f"[hyperpose_amd.dist] rank {dist.get_rank()}: RCCL not used ({why}); all ranks carry the collectives over gloo",
+                  file=sys.stderr, flush=True)
+        _GROUP, _COLLECTIVE_DEVICE, _BACKEND = None, "cpu", "gloo"
+    return _BACKEND
+
+
+def backend_name():
+    """Backend of the data collectives after init_for_gpu / init ("nccl", "gloo") or None before."""
+    if _BACKEND is not None:
+        return _BACKEND
+    try:
+        import torch.distributed as dist
+        return dist.get_backend() if dist.is_initialized() else None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def collective_device(default):
@@ -71,6 +96,8 @@ def broadcast_weights(blob: np.ndarray | None, n: int, rank: int, world: int, de
     if world == 1:
         assert blob is not None
         return blob
+    import time
+
     import torch
     import torch.distributed as dist
     if rank == 0:
@@ -78,7 +105,14 @@ def broadcast_weights(blob: np.ndarray | None, n: int, rank: int, world: int, de
         t = torch.from_numpy(np.ascontiguousarray(blob, np.float32)).to(device)
     else:
         t = torch.empty(n, dtype=torch.float32, device=device)
-    dist.broadcast(t, src=0)
+    on_gpu = str(device) != "cpu"
+    if on_gpu:
+        torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    dist.broadcast(t, src=0, group=_GROUP)
+    if on_gpu:
+        torch.cuda.synchronize(device)
+    LAST_BROADCAST.update({"backend": backend_name(), "bytes": int(n) * 4, "ms": round((time.perf_counter() - t0) * 1e3, 3)})
     return t.cpu().numpy()
 
 
@@ -95,7 +129,7 @@ def max_over_ranks(value: float, world: int, device="cpu") -> float:
     import torch
     import torch.distributed as dist
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_GROUP)
     return float(t.item())
 
 
@@ -105,5 +139,5 @@ def sum_over_ranks(value: float, world: int, device="cpu") -> float:
     import torch
     import torch.distributed as dist
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_GROUP)
     return float(t.item())

@@ -22,6 +22,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -73,6 +74,7 @@ public:
     ~hip_stream() { hp_pipeline_destroy(m_pl); }
 
     size_t in_flight() const { return (size_t)hp_pipeline_in_flight(m_pl); }
+    size_t truncated() const { return m_truncated.load(); }
     int n_pipes() const { return m_pipes; }
     int max_batch() const { return m_max_batch; }
 
@@ -93,7 +95,11 @@ public:
     std::vector<pose_set> pop()
     {
         int nf = 0;
-        detail::hp_check(hp_pipeline_collect(m_pl, m_out.data(), CAP, m_n.data(), &nf));
+        const int rc = hp_pipeline_collect(m_pl, m_out.data(), CAP, m_n.data(), &nf);
+        if (rc == HP_ERR_CAPACITY)
+            ++m_truncated; // a frame exceeded a hard list limit of the parser: its pose list is cut, the batch is otherwise complete
+        else
+            detail::hp_check(rc);
         std::vector<pose_set> r(nf);
         for (int i = 0; i < nf; ++i)
             for (int k = 0; k < m_n[i] && k < CAP; ++k)
@@ -115,6 +121,7 @@ private:
     }
     hp_pipeline* m_pl = nullptr;
     int m_max_batch, m_pipes = 0;
+    std::atomic<size_t> m_truncated{ 0 };
     std::vector<hp_human> m_out;
     std::vector<int> m_n;
     std::vector<std::vector<uint8_t>> m_scratch;
@@ -126,14 +133,18 @@ public:
     using pose_set = std::vector<human_t>;
 
     /// Same parameters as the reference (stream.hpp:136): `parser_cnt` (CPU parser replicas there) is the number of batches kept in
-    /// flight here (0: 4), `queue_max_size` bounds the frames waiting for a batch slot.
+    /// flight here (0: 4), `queue_max_size` bounds BOTH the frames waiting for a batch slot and the finished frames waiting for a sink
+    /// (the reference bounds every one of its queues with it, src/stream.cpp:7-15).  `max_frame_size`: the largest source frame
+    /// the device staging buffers are sized for (an addition: the reference resizes on the host and has no such limit).
     explicit stream(DNNEngine& engine, Parser& parser, bool use_original_resolution = false, bool keep_ratio = false, size_t parser_cnt = 0,
-        size_t queue_max_size = 128)
+        size_t queue_max_size = 128, cv::Size max_frame_size = cv::Size(1920, 1080))
         : m_engine_ref(engine), m_main_parser_ref(parser), m_use_original_resolution(use_original_resolution), m_keep_ratio(keep_ratio)
         , m_queue_max(queue_max_size ? queue_max_size : 1)
-        , m_gpu(engine.handle(), parser.stream_desc(), engine.max_batch_size(), keep_ratio, parser_cnt == 0 ? 4 : (int)std::min<size_t>(parser_cnt, 16))
+        , m_gpu(engine.handle(), parser.stream_desc(), engine.max_batch_size(), keep_ratio, parser_cnt == 0 ? 4 : (int)std::min<size_t>(parser_cnt, 16),
+              max_frame_size)
     {
         m_worker = std::thread([this] { run(); });
+        m_input_worker = std::thread([this] { run_inputs(); });
     }
     stream(const stream&) = delete;
     ~stream()
@@ -142,8 +153,10 @@ public:
             std::lock_guard<std::mutex> lk(m_mu);
             m_shutdown = true;
         }
-        m_cv_in.notify_all();
-        m_cv_out.notify_all();
+        notify_everyone();
+        m_async_sinks.clear(); // joins the sink threads (they leave on m_shutdown)
+        if (m_input_worker.joinable())
+            m_input_worker.join();
         if (m_worker.joinable())
             m_worker.join();
     }
@@ -179,6 +192,8 @@ public:
             : m_stream(s)
         {
         }
+        // As in the reference (stream.hpp:211-215: the future of the input job is dropped), "synchronous" input is still ingested by
+        // the single input thread: `stream.sync() << frames; stream.sync() >> sink;` cannot dead-lock on the bounded queues.
         template <typename S>
         sync_handler& operator<<(S&& source)
         {
@@ -198,6 +213,8 @@ public:
     /// (the reference prints queue lengths periodically, src/stream.cpp add_queue_monitor; kept as a no-op hook)
     void add_monitor(size_t) {}
     size_t processed_num() const noexcept { return m_ingest.load(); }
+    /// frames whose pose list was cut at a hard capacity of the device parser (reported, the stream keeps running)
+    size_t truncated_num() const noexcept { return m_gpu.truncated(); }
 
 private:
     struct item {
@@ -205,39 +222,118 @@ private:
         pose_set poses;
     };
 
-    // ---- input side: src/stream.cpp:18-66
+    // ---- input side (src/stream.cpp:18-66).  Like the reference's one-thread `m_mpsc_worker` (stream.hpp:248-254) a single input
+    // thread ingests one source at a time, so `<<` returns at once and the bounded queues exert back-pressure on that thread, not on
+    // the caller.  Sources are held by value where that is a handle copy (cv::Mat, vectors of them) and by reference for a
+    // cv::VideoCapture (which must outlive the ingestion, as in the reference).
+    void post_input(std::function<void()> job)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_mu);
+            if (m_shutdown)
+                rethrow_or_ignore();
+            ++m_pending_inputs;
+            m_input_jobs.push_back(std::move(job));
+        }
+        m_cv_jobs.notify_one();
+    }
+    void rethrow_or_ignore()
+    {
+        if (!m_error.empty())
+            throw std::runtime_error(m_error);
+    }
     void add_input_stream(const std::vector<cv::Mat>& frames)
     {
-        for (const auto& f : frames)
-            enqueue(f);
+        post_input([this, frames] {
+            for (const auto& f : frames)
+                if (!enqueue(f))
+                    return;
+        });
     }
     void add_input_stream(std::vector<cv::Mat>& frames) { add_input_stream(static_cast<const std::vector<cv::Mat>&>(frames)); }
-    void add_input_stream(std::vector<cv::Mat>&& frames) { add_input_stream(static_cast<const std::vector<cv::Mat>&>(frames)); }
-    void add_input_stream(const cv::Mat& f) { enqueue(f); }
-    void add_input_stream(cv::Mat& f) { enqueue(f); }
-    void add_input_stream(cv::Mat&& f) { enqueue(f); }
+    void add_input_stream(std::vector<cv::Mat>&& frames)
+    {
+        post_input([this, frames = std::move(frames)] {
+            for (const auto& f : frames)
+                if (!enqueue(f))
+                    return;
+        });
+    }
+    void add_input_stream(const cv::Mat& f)
+    {
+        post_input([this, f] { enqueue(f); });
+    }
+    void add_input_stream(cv::Mat& f) { add_input_stream(static_cast<const cv::Mat&>(f)); }
+    void add_input_stream(cv::Mat&& f) { add_input_stream(static_cast<const cv::Mat&>(f)); }
 #ifdef HYPERPOSE_USE_OPENCV
     void add_input_stream(cv::VideoCapture& cap)
     {
-        while (cap.isOpened()) {
-            cv::Mat mat;
-            cap >> mat;
-            if (mat.empty())
-                break;
-            enqueue(mat);
-        }
+        post_input([this, &cap] {
+            while (cap.isOpened()) {
+                cv::Mat mat;
+                cap >> mat;
+                if (mat.empty() || !enqueue(mat))
+                    break;
+            }
+        });
     }
 #endif
-    void enqueue(const cv::Mat& f)
+    void run_inputs()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(m_mu);
+                m_cv_jobs.wait(lk, [this] { return !m_input_jobs.empty() || m_shutdown; });
+                if (m_shutdown)
+                    return;
+                job = std::move(m_input_jobs.front());
+                m_input_jobs.pop_front();
+            }
+            try {
+                job();
+            } catch (const std::exception& e) {
+                fail(e.what());
+            }
+            {
+                std::lock_guard<std::mutex> lk(m_mu);
+                --m_pending_inputs;
+            }
+            m_cv_out.notify_all(); // a sink waiting for "everything ingested so far" re-checks
+        }
+    }
+    // false once the stream has shut down (error or destruction): the source stops feeding
+    bool enqueue(const cv::Mat& f)
     {
         if (f.empty())
-            return;
+            return true;
         std::unique_lock<std::mutex> lk(m_mu);
         m_cv_space.wait(lk, [this] { return m_in.size() < m_queue_max || m_shutdown; });
+        if (m_shutdown)
+            return false;
         m_in.push_back(f);
         ++m_remaining;
         ++m_ingest;
         m_cv_in.notify_one();
+        return true;
+    }
+    void notify_everyone()
+    {
+        m_cv_in.notify_all();
+        m_cv_out.notify_all();
+        m_cv_space.notify_all();
+        m_cv_out_space.notify_all();
+        m_cv_jobs.notify_all();
+    }
+    void fail(const char* what)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_mu);
+            if (m_error.empty())
+                m_error = what;
+            m_shutdown = true;
+        }
+        notify_everyone(); // producers blocked on a full queue and sinks waiting for results both wake up and see the error
     }
 
     // ---- feeder: batches -> hp_pipeline -> ordered results (the reference's resize / inference / parse stages, stream.hpp:326-385)
@@ -250,43 +346,50 @@ private:
                 std::unique_lock<std::mutex> lk(m_mu);
                 if (inflight.empty())
                     m_cv_in.wait(lk, [this] { return !m_in.empty() || m_shutdown; });
-                if (m_shutdown && m_in.empty() && inflight.empty())
+                if (m_shutdown)
                     return;
                 while (!m_in.empty() && (int)batch.size() < m_gpu.max_batch()) {
                     batch.push_back(std::move(m_in.front()));
                     m_in.pop_front();
                 }
-                m_cv_space.notify_all();
             }
+            m_cv_space.notify_all();
             try {
                 if (!batch.empty()) {
                     if ((int)m_gpu.in_flight() == m_gpu.n_pipes())
-                        deliver(inflight);
+                        if (!deliver(inflight))
+                            return;
                     m_gpu.push(batch);
                     inflight.push_back(std::move(batch));
-                } else if (!inflight.empty())
-                    deliver(inflight);
+                } else if (!inflight.empty()) {
+                    if (!deliver(inflight))
+                        return;
+                }
             } catch (const std::exception& e) {
-                std::lock_guard<std::mutex> lk(m_mu);
-                m_error = e.what();
-                m_shutdown = true;
-                m_cv_out.notify_all();
+                fail(e.what());
                 return;
             }
         }
     }
-    void deliver(std::deque<std::vector<cv::Mat>>& inflight)
+    // false when the stream shut down while waiting for room in the output queue
+    bool deliver(std::deque<std::vector<cv::Mat>>& inflight)
     {
         auto poses = m_gpu.pop();
         std::vector<cv::Mat> frames = std::move(inflight.front());
         inflight.pop_front();
-        std::lock_guard<std::mutex> lk(m_mu);
+        std::unique_lock<std::mutex> lk(m_mu);
+        // bounded like the reference's m_pose_sets_queue: with no sink attached the finished frames do not pile up without limit
+        m_cv_out_space.wait(lk, [this] { return m_out.size() < m_queue_max || m_shutdown; });
+        if (m_shutdown)
+            return false;
         for (size_t i = 0; i < frames.size(); ++i)
             m_out.push_back(item{ std::move(frames[i]), i < poses.size() ? std::move(poses[i]) : pose_set{} });
+        lk.unlock();
         m_cv_out.notify_all();
+        return true;
     }
 
-    // ---- output side: blocks until everything ingested so far has been written (src/stream.cpp:114-147)
+    // ---- output side: blocks until everything handed to `<<` so far has been written (src/stream.cpp:114-147)
     template <typename F>
     void drain(F&& emit)
     {
@@ -294,11 +397,11 @@ private:
             item it;
             {
                 std::unique_lock<std::mutex> lk(m_mu);
-                m_cv_out.wait(lk, [this] { return !m_out.empty() || m_remaining == 0 || m_shutdown; });
+                m_cv_out.wait(lk, [this] { return !m_out.empty() || (m_remaining == 0 && m_pending_inputs == 0) || m_shutdown; });
                 if (!m_error.empty())
                     throw std::runtime_error(m_error);
                 if (m_out.empty()) {
-                    if (m_remaining == 0 || m_shutdown)
+                    if ((m_remaining == 0 && m_pending_inputs == 0) || m_shutdown)
                         return;
                     continue;
                 }
@@ -306,6 +409,7 @@ private:
                 m_out.pop_front();
                 --m_remaining;
             }
+            m_cv_out_space.notify_all();
             emit(m_written++, it);
         }
     }
@@ -318,6 +422,30 @@ private:
     {
         drain([&](size_t idx, item& it) { fn(idx, static_cast<const cv::Mat&>(it.frame), static_cast<const pose_set&>(it.poses)); });
     }
+
+public:
+    /// What the writers draw (src/stream.cpp:114-147).  hp_pipeline_collect has already applied resume_ratio against the ORIGINAL
+    /// frame; when the output is the letter-boxed network-sized image (use_original_resolution = false, keep_ratio = true) the
+    /// reference's `resume_ratio(pose, raw_image.size() == input_size, input_size)` is the identity, so the ratio is undone here
+    /// before drawing.  `network_sized` = the frame resized / letter-boxed to the network size by the caller (OpenCV builds: rendered()).
+    static void poses_for_network_sized_image(pose_set& poses, cv::Size original, cv::Size network, bool keep_ratio)
+    {
+        if (!keep_ratio)
+            return;
+        for (auto& h : poses) {
+            if (original.height * network.width > original.width * network.height) {
+                const double xratio = (double)network.width * original.height / ((double)network.height * original.width);
+                for (auto& par : h.parts)
+                    par.x = (float)(par.x / xratio);
+            } else {
+                const double yratio = (double)network.height * original.width / ((double)network.width * original.height);
+                for (auto& par : h.parts)
+                    par.y = (float)(par.y / yratio);
+            }
+        }
+    }
+
+private:
 #ifdef HYPERPOSE_USE_OPENCV
     cv::Mat rendered(item& it)
     {
@@ -328,8 +456,8 @@ private:
                 r = non_scaling_resize(img, m_engine_ref.input_size());
             else
                 cv::resize(img, r, m_engine_ref.input_size());
+            poses_for_network_sized_image(it.poses, img.size(), m_engine_ref.input_size(), m_keep_ratio);
             img = r;
-            // (poses are already in original-frame coordinates when keep_ratio is set; on the letter-boxed image they are re-applied)
         }
         for (auto&& pose : it.poses)
             draw_human(img, pose);
@@ -353,14 +481,15 @@ private:
     hip_stream m_gpu;
 
     std::mutex m_mu;
-    std::condition_variable m_cv_in, m_cv_out, m_cv_space;
+    std::condition_variable m_cv_in, m_cv_out, m_cv_space, m_cv_out_space, m_cv_jobs;
     std::deque<cv::Mat> m_in;
     std::deque<item> m_out;
-    size_t m_remaining = 0, m_written = 0;
+    std::deque<std::function<void()>> m_input_jobs;
+    size_t m_remaining = 0, m_written = 0, m_pending_inputs = 0;
     std::atomic<size_t> m_ingest{ 0 };
     bool m_shutdown = false;
     std::string m_error;
-    std::thread m_worker;
+    std::thread m_worker, m_input_worker;
     struct joining_thread {
         std::thread t;
         template <typename F>

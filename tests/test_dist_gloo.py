@@ -130,12 +130,13 @@ def test_bench_rank_plan_world2():
         p.join(60)
         assert p.exitcode == 0
     import bench
+    from hyperpose_amd import dist as hd
     for k, cfg in bench.CONFIGS.items():
         b = cfg["batch"]
         for r in (0, 1):
             assert res[r][(k, "weak")] == (b, 2 * b, 2.0 * b)
             mine, glob, total = res[r][(k, "strong")]
-            assert glob == b and total == float(b) and mine == b // 2
+            assert glob == b and total == float(b) and mine == hd.shard(b, r, 2)[1]   # (configs[0]: one frame, rank 1 idles)
     assert res[0][(3, "strong")][0] == 16 and res[0][(4, "strong")][0] == 32
 
 

@@ -109,35 +109,68 @@ def test_pipeline_other_parsers_equal_stages_by_hand(hp, kind):
 
 
 def test_fp16_engine_vs_fp32_oracle_keypoint_drift(hp, capsys):
-    """The reference ships an fp32 TensorRT engine; this engine stores activations in fp16 (fp32 MFMA accumulation).  The parsers are
-    bit-exact on identical heat-maps, so what an end user could see is the drift the fp16 conv stack induces THROUGH the parser.
-    Measured here: the same frames through (a) the fp16 HIP engine + GPU parser and (b) the pure-fp32 oracle conv stack
-    (oracle/ref_net.py, match_fp16 = False) + oracle parser, on weights whose output layers are blown up so that random weights give
-    O(1) maps with real peaks and limbs.  Key-points are integer positions on the 4x up-sampled map: a drifted key-point moves by whole
-    pixels or not at all."""
+    """The reference ships an fp32 TensorRT engine (docs/markdown/quick_start/prediction.md:144-147); this engine stores activations
+    in fp16 (fp32 MFMA accumulation).  The parsers are bit-exact on identical heat-maps, so what an end user could see is the drift
+    the fp16 conv stack induces THROUGH the parser.  Measured at configs[1]'s full size (8 frames of 368 x 432): the same frames
+    through (a) the fp16 HIP engine + GPU parser and (b) the pure-fp32 oracle conv stack (oracle/ref_net.py, match_fp16 = False,
+    evaluated by PyTorch) + the reference-compiled parser, on weights whose output layers are blown up so that random weights give
+    O(1) maps with real peaks and limbs.  Key-points are integer positions on the 4x up-sampled map: a drifted key-point moves by
+    whole pixels or not at all.
+
+    Random-weight maps are noise-like - plateaus and near-threshold maxima everywhere - so every fp32 peak that has no fp16 peak
+    within 1 px is CLASSIFIED against the fp32 smoothed map: `threshold` (its smoothed value is within the heat-map error of
+    conf_thresh: it exists on one side only), `plateau` (the fp16 parser found its maximum elsewhere on a surface that is flat to
+    within the heat-map error between the two positions), or `drift` (neither: a real disagreement).  `drift` must be empty.
+    Human-level differences that remain (a key-point attached to another skeleton) are assembly flips downstream of such peaks and
+    are reported, not hidden."""
+    import torch
     from oracle import ref_net
-    in_w, in_h = 160, 128
+    in_w, in_h, B = 432, 368, 8
     m = E.Model("lw_openpose_mobilenet", in_w, in_h)
     w = m.init_weights(11)
     for L in m.layers:
         if L.op == E.OP_CONV and L.cout in (19, 38) and L.out in [o.tensor for o in m.outputs]:
             w[L.w_off:L.w_off + L.cout * L.cin] *= 400.0
     rng = np.random.default_rng(21)
-    frames = rng.integers(0, 256, (4, in_h, in_w, 3), dtype=np.uint8)
-    eng = E.Engine.from_model(m, w, max_batch=4)
+    frames = rng.integers(0, 256, (B, in_h, in_w, 3), dtype=np.uint8)
+    eng = E.Engine.from_model(m, w, max_batch=B)
     got = eng.inference(frames)
-    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=frames, match_fp16=False)
-    paf = Paf(conf_thresh=0.05, paf_thresh=-1e9, max_batch=4)
-    gh = paf.process_batch(np.stack([g[0][1] for g in got]), np.stack([g[1][1] for g in got]))
-    map_err = max(float(np.abs(got[b][k][1] - ref[n][b]).max() / np.abs(ref[n][b]).max()) for b in range(4) for k, n in enumerate(("conf", "paf")))
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=frames, match_fp16=False, device="cuda" if torch.cuda.is_available() else "cpu")
+    thr = 0.05
+    paf = Paf(conf_thresh=thr, paf_thresh=-1e9, max_batch=B, cap_per_frame=256)
+    gconf, gpaf = np.stack([g[0][1] for g in got]), np.stack([g[1][1] for g in got])
+    gh = paf.process_batch(gconf, gpaf)
+    abs_err = max(float(np.abs(got[b][0][1] - ref["conf"][b]).max()) for b in range(B))
+    map_err = max(float(np.abs(got[b][k][1] - ref[n][b]).max() / np.abs(ref[n][b]).max()) for b in range(B) for k, n in enumerate(("conf", "paf")))
+    tol = 4.0 * abs_err   # what the smoothed fp16 surface can differ by from the fp32 one (the blur is a convex combination)
     res_w, res_h = 4 * (in_h // 8), 4 * (in_w // 8)  # the reference's swapped naming: width = 4 * rows (src/paf.cpp:314-315)
+    n_peaks = n_peak_same = n_peak_close = 0
+    classes = {"threshold": 0, "plateau": 0, "drift": 0}
     n_ref = n_gpu = n_kp = n_same = n_close = 0
     worst = 0.0
-    for b in range(4):
-        oh, _, _ = loader.ref_paf_process(ref["conf"][b], ref["paf"][b], 0.05, -1e9)
+    for b in range(B):
+        oh, op, _ = loader.ref_paf_process(ref["conf"][b], ref["paf"][b], thr, -1e9, cap_humans=256, cap_peaks=65536, cap_conns=65536)
+        gp = paf.debug_peaks(b, cap=65536)
+        sm = loader.smooth(loader.resize_area(ref["conf"][b][:18], res_h, res_w))
+        by_part = [gp[gp["part_id"] == k] for k in range(18)]
+        for pk in op:
+            n_peaks += 1
+            g = by_part[pk["part_id"]]
+            d = np.hypot(g["x"] - pk["x"], g["y"] - pk["y"]) if len(g) else np.array([1e9])
+            j = int(np.argmin(d))
+            n_peak_same += d[j] == 0
+            n_peak_close += d[j] <= 1.0
+            if d[j] > 1.0:
+                v = float(sm[pk["part_id"], pk["y"], pk["x"]])
+                if abs(v - thr) <= tol:
+                    classes["threshold"] += 1
+                elif len(g) and d[j] < 1e8 and abs(v - float(sm[pk["part_id"], g["y"][j], g["x"][j]])) <= tol:
+                    classes["plateau"] += 1
+                else:
+                    classes["drift"] += 1
         n_ref += len(oh)
         n_gpu += len(gh[b])
-        # match every oracle key-point with the nearest GPU key-point of the same part
+        # human level: every oracle key-point against the nearest GPU key-point of the same part
         for h in oh:
             for k in range(18):
                 if not h["parts"]["has_value"][k]:
@@ -153,9 +186,12 @@ def test_fp16_engine_vs_fp32_oracle_keypoint_drift(hp, capsys):
                 if best < 1e9:
                     worst = max(worst, best)
     with capsys.disabled():
-        print(f"\\nfp16 engine vs fp32 oracle: heat-map max rel err {map_err:.2e}; humans {n_gpu} vs {n_ref}; key-points {n_kp}: "
-              f"{n_same} identical, {n_close} within 1 px, worst matched drift {worst:.2f} px")
+        print(f"\nfp16 engine vs fp32 oracle @ {in_h}x{in_w} x {B}: heat-map max rel err {map_err:.2e} (abs {abs_err:.2e}); peaks {n_peaks}: "
+              f"{n_peak_same} identical, {n_peak_close} within 1 px, the rest = {classes}; humans {n_gpu} vs {n_ref}; key-points of humans "
+              f"{n_kp}: {n_same} identical, {n_close} within 1 px, worst nearest-same-part distance {worst:.2f} px (assembly flips)")
     assert map_err < 2e-2
-    assert n_ref > 0 and n_kp > 20
-    assert n_same >= 0.9 * n_kp, (n_same, n_kp)        # at least 9 of 10 key-points do not move at all
+    assert n_peaks > 100 and n_ref > 0 and n_kp > 20
+    assert classes["drift"] == 0, classes                       # every moved / missing peak is a threshold or plateau case
+    assert n_peak_close >= 0.97 * n_peaks, (n_peak_close, n_peaks)
+    assert n_same >= 0.9 * n_kp, (n_same, n_kp)                  # at least 9 of 10 key-points of assembled humans do not move at all
     assert abs(n_gpu - n_ref) <= max(1, n_ref // 10)
