@@ -30,6 +30,7 @@ UNITS = [
     ("ppn_parser.hip", ["-ffp-contract=off"]),
     ("pifpaf_parser.hip", ["-ffp-contract=off"]),
     ("conv_kernels.hip", []),
+    ("conv_chain.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),
     ("onnx_import.cpp", []),

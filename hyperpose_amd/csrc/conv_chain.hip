@@ -1,0 +1,419 @@
+// conv_chain.hip — a chain of 128-channel convolutions in ONE launch: [1x1 ->] 3x3 -> 3x3 [+ residual], intermediates in LDS.
+//
+// LW-OpenPose's head (hyperpose/Model/openpose/model/lw_openpose.py:106-191) is seventeen 3x3 128 -> 128 convolutions and six 1x1s
+// on a 46 x 54 map.  At batch 8 each of them is 23 MFLOP per CU: as one launch per layer the matrix pipe idles through a halo
+// prologue, an epilogue and a kernel boundary for every 7 k cycles of MFMAs (conv3x3_direct_kernel: 13 us per layer, 0.16-0.18 of
+// the fp16 MFMA peak).  Here one block owns an 8 x 12 pixel output tile and ALL 128 channels and runs the whole chain on it:
+//
+//     S0 (refinement blocks, lw_openpose.py:176-191):  X0 = input tile + 2-pixel halo (12 x 16 px) -> 1x1 + relu -> T1 (12 x 16 px)
+//        (otherwise T1 = the input tile + 2-pixel halo, straight from HBM)
+//     S1:  T1 -> 3x3 + relu [+ external residual] -> T2 (10 x 14 px: the output tile + 1-pixel halo)
+//     S2:  T2 -> 3x3 + relu [+ residual: external, or T1's interior = the 1x1's output] -> 8 x 12 px -> HBM
+//
+// The halo pixels of the intermediates are recomputed by the neighbouring blocks (x1.46 MFMAs in S1, x2 in the small S0) - MFMA
+// time is what this network has to spare - and in exchange two of three launches, their prologues / epilogues and the HBM round
+// trips of both intermediates (5 MB each way per layer) disappear.  Intermediate pixels outside the image are ZERO (the next
+// convolution's padding), not convolution outputs.
+//
+// Four wavefronts, one per SIMD, wavefront w = output channels 32w .. 32w+31 over the FULL K of every stage: no split-K exchange;
+// A fragments straight from L2 in MFMA-fragment order (conv_kernels.hpp, w_layout 1: one coalesced 1 KB load per fragment that only
+// this wavefront needs), re-requested one tap ahead as they are consumed; B fragments from the swizzled LDS tiles, read one k16
+// step ahead of their MFMAs.  Activations are stored fp16 exactly where the per-layer schedule stores them (every intermediate is
+// rounded once), so the chain's results differ from the unfused schedule only by fp32 summation order.
+#include "conv_device.hpp"
+
+#include <cstdlib>
+
+namespace hp {
+
+namespace {
+
+constexpr int CH = 128;              // channels of every tensor in the chain
+constexpr int PXB = CH * 2;          // bytes per pixel in LDS
+constexpr int KQ = CH / 16;          // k16 steps per tap
+constexpr int TH = 8, TW = 12;       // output tile
+constexpr int H2 = TH + 4, W2 = TW + 4, N2 = H2 * W2; // S0 / T1 region (halo 2): 12 x 16 = 192 px = 6 column tiles
+constexpr int H1 = TH + 2, W1 = TW + 2, N1 = H1 * W1; // T2 region (halo 1): 10 x 14 = 140 px -> 5 column tiles
+constexpr int N0 = TH * TW;                            // 96 px = 3 column tiles
+constexpr int NT2 = N2 / 32, NT1 = (N1 + 31) / 32, NT0 = N0 / 32;
+static_assert(N2 % 32 == 0 && N0 % 32 == 0, "tile geometry");
+
+// swizzle key of a pixel of a tile that is CONSUMED in pixel order of width CW: 16 consecutive consumer pixels, shifted by any tap,
+// read 16 distinct 16-byte slots of the 256-byte bank row (a pixel is exactly one bank row: 128 channels x 2 B)
+__device__ __forceinline__ int t1_key(int hy, int hx) { return (hy * W1 + hx) & 15; } // T1 [H2][W2], consumed by S1 over W1
+__device__ __forceinline__ int t2_key(int hy, int hx) { return (hy * TW + hx) & 15; } // T2 [H1][W1], consumed by S2 over TW
+
+// One stage's MFMAs for this wavefront: TAPS taps x 8 k16 steps x NT column tiles.
+//   src        LDS tile the B fragments come from, pixel stride 256 B, row width WIN pixels
+//   pix0[j]    byte offset of column tile j's pixel (this lane's) at tap (0, 0)
+//   nkey[j]    that pixel's index in consumer order (its swizzle key at tap (ky, kx) is (nkey + ky * KW + kx) & 15)
+//   a[]        A fragments of the first tap (already requested); wcur = this stage's weights (this wave's rows), wnext = the NEXT
+//              stage's (its first tap is requested while this stage's last tap is consumed), or nullptr
+template <int NT, int TAPS, int WIN, int KW, int D, int ABL = 0>
+__device__ __forceinline__ void chain_stage(floatx16 (&acc)[NT], u32x4 (&a)[KQ], const __half* wcur, long tap_stride, const __half* wnext,
+    const unsigned char* src, const int (&pix0)[NT], const int (&nkey)[NT], int fk)
+{
+    // D = how many k16 steps ahead of their MFMAs the B fragments are read (ring of 4 fragment sets).  One wavefront per SIMD issues in
+    // order: a read that has not landed when its MFMA comes up stalls the matrix pipe, and with four wavefronts keeping the LDS pipe
+    // half busy a read takes longer than the 96 (NT = 3) .. 160 (NT = 5) cycles one k16 step of MFMAs lasts.
+    static_assert(D >= 1 && D <= 3 && KQ == 8, "prefetch ring");
+    constexpr int KS = TAPS == 9 ? 3 : 1;
+    auto tap_addr = [&](int tap, int (&ad)[NT]) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int toff = (ky * WIN + kx) * PXB, tkey = ky * KW + kx; // uniform
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            ad[j] = pix0[j] + toff + ((((nkey[j] + tkey) & 15) ^ fk) << 4);
+    };
+    half8 fb[4][NT];
+    int ad[NT];
+    tap_addr(0, ad);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            fb[d][j] = *reinterpret_cast<const half8*>(src + (ad[j] ^ (d << 5)));
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+        int adn[NT];
+        tap_addr(min(tap + 1, TAPS - 1), adn);
+        const bool last = tap + 1 == TAPS; // uniform
+        // (unconditional: a conditional prefetch makes hipcc drain the load queue at the join; the last stage re-requests its own tap 0)
+        const __half* wn = last ? (wnext ? wnext : wcur) : wcur + (long)(tap + 1) * tap_stride;
+#pragma unroll
+        for (int ks = 0; ks < KQ; ++ks) {
+            // the B fragments of k16 step ks + D (of the next tap past the end of this one) are read while this step multiplies
+            if (ABL & 1) { // ablation (timing only, wrong results): no B-fragment reads inside the loop
+            } else if (ks + D < KQ) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    fb[(ks + D) & 3][j] = *reinterpret_cast<const half8*>(src + (ad[j] ^ ((ks + D) << 5)));
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    fb[(ks + D) & 3][j] = *reinterpret_cast<const half8*>(src + (adn[j] ^ ((ks + D - KQ) << 5)));
+            }
+            half8 fa;
+            __builtin_memcpy(&fa, &a[ks], 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[(ABL & 1) ? (ks & (D - 1)) : (ks & 3)][j], acc[j], 0, 0, 0);
+            if (!(ABL & 2)) // ablation bit 1: no A-fragment loads inside the loop
+                a[ks] = *reinterpret_cast<const u32x4*>(wn + (size_t)ks * 512);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            ad[j] = adn[j];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(floatx16 (&acc)[NT])
+{
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[j][r] = 0.f;
+}
+
+} // namespace
+
+// S0: the chain starts with a 1x1; RES: 0 none, 1 external tensor added to S1's output, 2 external tensor added to S2's output,
+// 3 the 1x1's output (T1) added to S2's output
+template <bool S0, int RES, int D, int ABL = 0>
+__global__ __launch_bounds__(256) void conv_chain_kernel(const chain_params p, int tiles_x, int tiles_y)
+{
+    constexpr int X0_BYTES = S0 ? N2 * PXB : 0, T1_BYTES = N2 * PXB, T2_BYTES = N1 * PXB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X0_BYTES + T1_BYTES + T2_BYTES];
+    unsigned char* const s_x0 = lds;
+    unsigned char* const s_t1 = lds + X0_BYTES;
+    unsigned char* const s_t2 = lds + X0_BYTES + T1_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int H = p.c2.OH, W = p.c2.OW; // every tensor of the chain has this size
+    int dbg_i = 0; // HP_CHAIN_DBG: s_memtime stamps of block 0 / thread 0 (engine.cpp prints the deltas)
+#define HP_CSTAMP()                                                                                               \
+    if (p.c2.dbg && blockIdx.x == 0 && tid == 0)                                                                  \
+        p.c2.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_CSTAMP();
+
+    // this wavefront's rows of the three weight matrices (fragment order: [tap][32-row tile][k16][lane][8])
+    const long tap_stride = (long)(CH / 32) * KQ * 512;
+    const __half* const w0 = S0 ? p.c0.w + ((size_t)(wave * KQ) * 64 + lane) * 8 : nullptr;
+    const __half* const w1 = p.c1.w + ((size_t)(wave * KQ) * 64 + lane) * 8;
+    const __half* const w2 = p.c2.w + ((size_t)(wave * KQ) * 64 + lane) * 8;
+    u32x4 a[KQ];
+    {
+        const __half* wf = S0 ? w0 : w1;
+#pragma unroll
+        for (int ks = 0; ks < KQ; ++ks)
+            a[ks] = *reinterpret_cast<const u32x4*>(wf + (size_t)ks * 512);
+    }
+
+    // ---- the input tile + 2-pixel halo: all loads first (one round trip), then the LDS stores; pixels outside the image are zero
+    {
+        const tview& in = S0 ? p.c0.in : p.c1.in;
+        unsigned char* const dst = S0 ? s_x0 : s_t1;
+        constexpr int NIT = N2 * 16 / 256;
+        u32x4 hv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, px = i >> 4, c = i & 15;
+            const int hy = px / W2, hx = px - hy * W2;
+            const int y = y0 - 2 + hy, x = x0 - 2 + hx;
+            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(in.p + tv_off(in, b, min(max(y, 0), H - 1), min(max(x, 0), W - 1)) + c * 8);
+            hv[it] = v & (ok ? 0xffffffffu : 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, px = i >> 4, c = i & 15;
+            const int hy = px / W2, hx = px - hy * W2;
+            const int key = S0 ? (px & 15) : t1_key(hy, hx); // X0 is consumed in its own pixel order (S0 is a 1x1)
+            *reinterpret_cast<u32x4*>(dst + px * PXB + ((c ^ key) << 4)) = hv[it];
+        }
+    }
+    HP_CSTAMP();
+    lds_barrier();
+    HP_CSTAMP();
+
+    // epilogue constants of this lane: its 16 accumulator rows are channels 32 wave + 8 g + 4 fk + {0..3}, g = 0..3
+    auto load_bias = [&](const float* bias, float (&bs)[16]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(bias + wave * 32 + 8 * g + 4 * fk);
+            bs[4 * g] = v.x, bs[4 * g + 1] = v.y, bs[4 * g + 2] = v.z, bs[4 * g + 3] = v.w;
+        }
+    };
+
+    // ---- S0: 1x1 on the 12 x 16 region -> T1
+    if (S0) {
+        floatx16 acc[NT2];
+        zero_acc(acc);
+        int pix0[NT2], nkey[NT2];
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const int n = j * 32 + fr;
+            pix0[j] = n * PXB, nkey[j] = n;
+        }
+        chain_stage<NT2, 1, W2, W2, D>(acc, a, w0, 0, w1, s_x0, pix0, nkey, fk);
+        HP_CSTAMP();
+        float bs[16];
+        load_bias(p.c0.bias, bs);
+        const float hi = p.c0.act_hi;
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const int n = j * 32 + fr, hy = n / W2, hx = n - hy * W2;
+            const int y = y0 - 2 + hy, x = x0 - 2 + hx;
+            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+            unsigned char* const row = s_t1 + n * PXB + fk * 8;
+            const int key = t1_key(hy, hx);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h[r] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc[j][4 * g + r] + bs[4 * g + r], 0.f, hi) : 0.f);
+                *reinterpret_cast<half4*>(row + (((wave * 4 + g) ^ key) << 4)) = h;
+            }
+        }
+        lds_barrier();
+        HP_CSTAMP();
+    }
+
+    // ---- S1: 3x3 on the 10 x 14 region -> T2
+    {
+        floatx16 acc[NT1];
+        zero_acc(acc);
+        int pix0[NT1], nkey[NT1];
+#pragma unroll
+        for (int j = 0; j < NT1; ++j) {
+            const int n = min(j * 32 + fr, N1 - 1), br = n / W1, bc = n - br * W1;
+            pix0[j] = (br * W2 + bc) * PXB, nkey[j] = n;
+        }
+        chain_stage<NT1, 9, W2, W1, D, ABL>(acc, a, w1, tap_stride, w2, s_t1, pix0, nkey, fk);
+        HP_CSTAMP();
+        float bs[16];
+        load_bias(p.c1.bias, bs);
+        const float hi = p.c1.act_hi;
+#pragma unroll
+        for (int j = 0; j < NT1; ++j) {
+            const int n = j * 32 + fr;
+            const int nc = min(n, N1 - 1), br = nc / W1, bc = nc - br * W1;
+            const int y = y0 - 1 + br, x = x0 - 1 + bc;
+            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+            half4 rs[4];
+            if (RES == 1) {
+                const __half* rp = p.c1.res.p + tv_off(p.c1.res, b, min(max(y, 0), H - 1), min(max(x, 0), W - 1)) + wave * 32 + 4 * fk;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    rs[g] = *reinterpret_cast<const half4*>(rp + 8 * g);
+            }
+            if (n < N1) {
+                unsigned char* const row = s_t2 + n * PXB + fk * 8;
+                const int key = t2_key(br, bc);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = __builtin_amdgcn_fmed3f(acc[j][4 * g + r] + bs[4 * g + r], 0.f, hi);
+                        if (RES == 1)
+                            v += (float)rs[g][r];
+                        h[r] = (_Float16)(ok ? v : 0.f);
+                    }
+                    *reinterpret_cast<half4*>(row + (((wave * 4 + g) ^ key) << 4)) = h;
+                }
+            }
+        }
+        lds_barrier();
+        HP_CSTAMP();
+    }
+
+    // ---- S2: 3x3 on the 8 x 12 tile; the result goes (fp16) into T1's interior, in place of the residual it may have read there
+    {
+        floatx16 acc[NT0];
+        zero_acc(acc);
+        int pix0[NT0], nkey[NT0];
+#pragma unroll
+        for (int j = 0; j < NT0; ++j) {
+            const int n = j * 32 + fr, br = n / TW, bc = n - br * TW;
+            pix0[j] = (br * W1 + bc) * PXB, nkey[j] = n;
+        }
+        half4 rs[NT0][4];
+        if (RES == 2) { // requested before the MFMAs: 12 eight-byte loads per lane, used in the epilogue
+#pragma unroll
+            for (int j = 0; j < NT0; ++j) {
+                const int n = j * 32 + fr, br = n / TW, bc = n - br * TW;
+                const __half* rp = p.c2.res.p + tv_off(p.c2.res, b, min(y0 + br, H - 1), min(x0 + bc, W - 1)) + wave * 32 + 4 * fk;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    rs[j][g] = *reinterpret_cast<const half4*>(rp + 8 * g);
+            }
+        }
+        chain_stage<NT0, 9, W1, TW, D, ABL>(acc, a, w2, tap_stride, nullptr, s_t2, pix0, nkey, fk);
+        HP_CSTAMP();
+        float bs[16];
+        load_bias(p.c2.bias, bs);
+        const float hi = p.c2.act_hi;
+#pragma unroll
+        for (int j = 0; j < NT0; ++j) {
+            const int n = j * 32 + fr, br = n / TW, bc = n - br * TW;
+            unsigned char* const row = s_t1 + ((br + 2) * W2 + bc + 2) * PXB + fk * 8;
+            const int key = t1_key(br + 2, bc + 2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned char* const at = row + (((wave * 4 + g) ^ key) << 4);
+                half4 h;
+                if (RES == 3)
+                    h = *reinterpret_cast<const half4*>(at);
+                else if (RES == 2)
+                    h = rs[j][g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = __builtin_amdgcn_fmed3f(acc[j][4 * g + r] + bs[4 * g + r], 0.f, hi);
+                    if (RES >= 2)
+                        v += (float)h[r];
+                    h[r] = (_Float16)v;
+                }
+                *reinterpret_cast<half4*>(at) = h;
+            }
+        }
+        lds_barrier();
+        HP_CSTAMP();
+    }
+
+    // ---- the finished tile: 16 lanes per pixel, 256 contiguous bytes of HBM each
+    {
+        constexpr int NIT = N0 * 16 / 256;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, px = i >> 4, c = i & 15;
+            const int br = px / TW, bc = px - br * TW;
+            const int y = y0 + br, x = x0 + bc;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(s_t1 + ((br + 2) * W2 + bc + 2) * PXB + ((c ^ t1_key(br + 2, bc + 2)) << 4));
+            if (y < H && x < W)
+                *reinterpret_cast<u32x4*>(p.c2.out.p + tv_off(p.c2.out, b, y, x) + c * 8) = v;
+        }
+    }
+    HP_CSTAMP();
+#undef HP_CSTAMP
+}
+
+// what the chain kernel takes: 128 -> 128 channels everywhere, fragment-ordered weights, relu / relu6 (one clamp), the residual
+// (if any) added after the activation, fp16 NHWC in and out with whole 16-byte channel groups
+static bool chain_conv_ok(const conv_params& c, int k)
+{
+    return c.KH == k && c.KW == k && c.stride == 1 && c.dil == 1 && c.pad_t == k / 2 && c.pad_l == k / 2 && c.Cin == CH && c.Cout == CH
+        && c.Cout_pad == CH && c.w_layout == 1 && c.OH == c.H && c.OW == c.W && !c.alpha && c.act_slope == 0.f && !c.out_f32
+        && c.in.coff % 8 == 0 && c.in.cs % 8 == 0 && c.res_before_act == 0;
+}
+
+int conv_chain_variant(const chain_params& p)
+{
+    if (!chain_conv_ok(p.c1, 3) || !chain_conv_ok(p.c2, 3) || (p.has_c0 && !chain_conv_ok(p.c0, 1)))
+        return 0;
+    if (p.c1.H != p.c2.H || p.c1.W != p.c2.W || (p.has_c0 && (p.c0.H != p.c1.H || p.c0.W != p.c1.W)))
+        return 0;
+    if (!p.c2.out.p || p.c2.out.coff % 8 || p.c2.out.cs % 8)
+        return 0;
+    const tview* res = p.res_mode == 1 ? &p.c1.res : p.res_mode == 2 ? &p.c2.res : nullptr;
+    if (res && (!res->p || res->coff % 4 || res->cs % 4))
+        return 0;
+    if (p.has_c0)
+        return p.res_mode == 3 ? 13 : p.res_mode == 0 ? 10 : 0;
+    return p.res_mode >= 0 && p.res_mode <= 2 ? 1 + p.res_mode : 0;
+}
+
+hipError_t launch_conv_chain(const chain_params& p, hipStream_t s)
+{
+    const int v = conv_chain_variant(p);
+    if (!v)
+        return hipErrorInvalidValue;
+    const int tiles_x = (p.c2.OW + TW - 1) / TW, tiles_y = (p.c2.OH + TH - 1) / TH;
+    const dim3 grid(tiles_x * tiles_y * p.c2.B);
+    static const int depth = getenv("HP_CHAIN_DEPTH") ? atoi(getenv("HP_CHAIN_DEPTH")) : 2; // (A/B of the B-fragment prefetch distance)
+#define HP_CHAIN(S0_, RES_)                                                                                       \
+    do {                                                                                                          \
+        if (depth == 1)                                                                                           \
+            HP_LAUNCH((conv_chain_kernel<S0_, RES_, 1>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);               \
+        else if (depth == 3)                                                                                      \
+            HP_LAUNCH((conv_chain_kernel<S0_, RES_, 3>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);               \
+        else                                                                                                      \
+            HP_LAUNCH((conv_chain_kernel<S0_, RES_, 2>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);               \
+    } while (0)
+    static const int abl = getenv("HP_CHAIN_ABL") ? atoi(getenv("HP_CHAIN_ABL")) : 0; // timing ablations of variant 1 (wrong results)
+    if (abl && v == 1) {
+        if (abl == 1)
+            HP_LAUNCH((conv_chain_kernel<false, 0, 2, 1>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        else if (abl == 2)
+            HP_LAUNCH((conv_chain_kernel<false, 0, 2, 2>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        else
+            HP_LAUNCH((conv_chain_kernel<false, 0, 2, 3>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
+        return hipGetLastError();
+    }
+    switch (v) {
+    case 1: HP_CHAIN(false, 0); break;
+    case 2: HP_CHAIN(false, 1); break;
+    case 3: HP_CHAIN(false, 2); break;
+    case 10: HP_CHAIN(true, 0); break;
+    default: HP_CHAIN(true, 3); break;
+    }
+#undef HP_CHAIN
+    return hipGetLastError();
+}
+
+} // namespace hp

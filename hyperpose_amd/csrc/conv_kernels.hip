@@ -19,33 +19,16 @@
 //                       fused into the load, fp32 math, HBM-bound.
 //   dwconv3x3_kernel    depthwise 3x3, one thread = one pixel x 8 channels (16-byte loads/stores), HBM/L2-bound.
 // Activations carry a zero halo in HBM (conv_kernels.hpp), so taps in the padding are ordinary loads.
-#include "conv_kernels.hpp"
+#include "conv_device.hpp"
 
 #include <cstdlib>
 #include <type_traits>
 
-#include <hip/hip_ext.h>
-
-// Every launch of this file goes through HP_LAUNCH: normally a plain launch; while hp::prof_start / prof_stop are set
-// (hp_engine_profile_sequence) the launch carries the two events, which then hold the kernel's OWN begin / end timestamps
-// (what rocprofv3's kernel trace reports) without putting extra packets between the kernels.
 namespace hp {
 thread_local hipEvent_t prof_start = nullptr, prof_stop = nullptr;
 }
-#define HP_LAUNCH(kernel, grid, block, lds, stream, ...)                                                            \
-    do {                                                                                                            \
-        if (hp::prof_start)                                                                                         \
-            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, hp::prof_start, hp::prof_stop, 0, __VA_ARGS__); \
-        else                                                                                                        \
-            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                      \
-    } while (0)
 
 namespace hp {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4))); // native 16-byte vector (HIP's uint4 struct defeats SROA here)
 
 // One MFMA, then one LDS read, four times: a single wavefront per SIMD issues in order, so the next fragments' reads
 // must sit INSIDE the 32-cycle shadows of the current MFMAs (cdna_hip_programming.md T19) instead of after them.
@@ -77,18 +60,6 @@ __device__ __forceinline__ float apply_act(float v, int act, float param, float 
     default:
         return v;
     }
-}
-
-__device__ __forceinline__ long tv_off(const tview& t, int b, int y, int x)
-{
-    return ((long)b * t.img + (long)y * t.wp + x) * t.cs + t.coff;
-}
-
-// Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also drains vmcnt, i.e. every global
-// prefetch in flight (measured: 1.5k cycles per K-chunk in sepconv_kernel when the weight prefetch crosses a barrier).
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -147,6 +147,19 @@ hipError_t launch_mlp_head(const head_params& p, hipStream_t s);
 hipError_t launch_mlp_head_pair(const head_params& p0, const head_params& p1, hipStream_t s);
 
 
+// A chain of 128 -> 128 convolutions in one launch (conv_chain.hip): [c0: 1x1 ->] c1: 3x3 -> c2: 3x3, relu-family activations,
+// intermediates in LDS.  c0 / c1 / c2 are filled exactly like stand-alone convolutions (weights in fragment order, w_layout 1);
+// only c0.in (or c1.in without c0), c2.out and the residual views are touched in HBM.
+//   res_mode 0: no residual; 1: c1.res added to c1's output; 2: c2.res added to c2's output; 3: c0's output added to c2's output
+struct chain_params {
+    conv_params c0, c1, c2;
+    int has_c0;
+    int res_mode;
+};
+// 0 when the chain kernel does not take this combination, otherwise its variant code (profile rows: tile = 7000000 + variant)
+int conv_chain_variant(const chain_params& p);
+hipError_t launch_conv_chain(const chain_params& p, hipStream_t s);
+
 struct pool_params {
     tview in;
     int B, H, W, OH, OW, C;

@@ -67,10 +67,13 @@ struct step {
     hp::head_params hp_{}; // op == OP_MLPHEAD: 1x1 conv `layer` (-> 512, relu) fused with the 1x1 conv `layer + 1`
     hp::head_params hp2_{}; // ... and, when `paired`, the sibling head on the same input (layers `layer + 2`, `layer + 3`)
     bool paired = false;
+    hp::chain_params ch{}; // op == OP_CHAIN: [1x1 ->] 3x3 -> 3x3 on 128 channels in one launch (conv_chain.hip), layers `layer` ..
+    int n_layers = 1;      // consecutive layers this step covers
     double flops = 0, bytes = 0; // per frame
 };
 constexpr int OP_SEPCONV = 100; // schedule-only op codes (not part of the hp_layer ABI)
 constexpr int OP_MLPHEAD = 101;
+constexpr int OP_CHAIN = 102;
 
 void same_pad(int in, int k, int stride, int dil, int& out, int& pad_before)
 {
@@ -678,6 +681,62 @@ int hp_engine::build(const hp_engine_desc* d)
         }
         steps.push_back(st);
     }
+    // ---- chains of 128-channel convolutions (LW-OpenPose's CPM / initial / refinement stages, lw_openpose.py:106-191): consecutive
+    // steps [1x1 ->] 3x3 -> 3x3 whose intermediates nobody else reads run as ONE launch with the intermediates in LDS
+    // (conv_chain.hip).  HP_NO_CHAIN=1 keeps one launch per layer (A/B measurements, and hp_engine_debug_tensor on an intermediate).
+    if (!getenv("HP_NO_CHAIN") && !getenv("HP_NO_FUSE")) {
+        auto plain_conv = [&](const step& st) { return st.op == HP_OP_CONV && !st.first && st.n_layers == 1; };
+        // the tensor a step writes is read only by the given layers (as input or residual) and is no network output
+        auto only_read_by = [&](int tensor, int la, int lb) {
+            for (size_t j = 0; j < layers.size(); ++j)
+                if ((int)j != la && (int)j != lb && (layers[j].in == tensor || layers[j].res == tensor))
+                    return false;
+            for (const auto& o : outputs)
+                if (o.tensor == tensor)
+                    return false;
+            int writers = 0;
+            for (const auto& L2 : layers)
+                writers += L2.out == tensor;
+            return writers == 1;
+        };
+        for (size_t k = 0; k + 1 < steps.size(); ++k) {
+            if (!plain_conv(steps[k]) || !plain_conv(steps[k + 1]))
+                continue;
+            hp::chain_params ch{};
+            int n = 0;
+            const bool three = k + 2 < steps.size() && plain_conv(steps[k + 2]) && steps[k].cp.KH == 1;
+            if (three) {
+                const int l0 = steps[k].layer, l1 = steps[k + 1].layer, l2 = steps[k + 2].layer;
+                const hp_layer &A = layers[l0], &Bn = layers[l1], &Cn = layers[l2];
+                if (Bn.in == A.out && Bn.in_coff == A.out_coff && Cn.in == Bn.out && Cn.in_coff == Bn.out_coff && A.res < 0 && Bn.res < 0
+                    && (Cn.res < 0 || Cn.res == A.out) && A.out_coff == 0 && only_read_by(A.out, l1, l2) && only_read_by(Bn.out, l2, l2)) {
+                    ch.c0 = steps[k].cp, ch.c1 = steps[k + 1].cp, ch.c2 = steps[k + 2].cp;
+                    ch.has_c0 = 1, ch.res_mode = Cn.res >= 0 ? 3 : 0;
+                    n = 3;
+                }
+            }
+            if (!n && steps[k].cp.KH == 3) {
+                const int l1 = steps[k].layer, l2 = steps[k + 1].layer;
+                const hp_layer &Bn = layers[l1], &Cn = layers[l2];
+                if (Cn.in == Bn.out && Cn.in_coff == Bn.out_coff && !(Bn.res >= 0 && Cn.res >= 0) && only_read_by(Bn.out, l2, l2)
+                    && Cn.res != Bn.out) {
+                    ch.c1 = steps[k].cp, ch.c2 = steps[k + 1].cp;
+                    ch.has_c0 = 0, ch.res_mode = Bn.res >= 0 ? 1 : Cn.res >= 0 ? 2 : 0;
+                    n = 2;
+                }
+            }
+            if (!n || !hp::conv_chain_variant(ch))
+                continue;
+            step& a = steps[k];
+            a.op = OP_CHAIN, a.ch = ch, a.n_layers = n;
+            for (int q = 1; q < n; ++q) {
+                a.flops += steps[k + q].flops;
+                tensors[layers[steps[k + q].layer].in]->elided = true; // allocated (pass 1) but never written
+            }
+            a.bytes = steps[k].bytes + steps[k + n - 1].bytes; // first layer's input + weights ... last layer's output (approximate)
+            steps.erase(steps.begin() + k + 1, steps.begin() + k + n);
+        }
+    }
     // sibling heads (conf / paf branch of one stage: same input, same geometry, neither reads the other) share a launch
     if (!getenv("HP_NO_PAIR_HEADS")) {
         for (size_t k = 0; k + 1 < steps.size(); ++k) {
@@ -708,6 +767,25 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     } else if (st.op == HP_OP_CONV) {
         st.cp.B = n, st.cp.npix = n * st.cp.OH * st.cp.OW;
         HP_HIP_TRY(hp::launch_conv_mfma(st.cp, s));
+    } else if (st.op == OP_CHAIN) {
+        st.ch.c0.B = st.ch.c1.B = st.ch.c2.B = n;
+        HP_HIP_TRY(hp::launch_conv_chain(st.ch, s));
+        if (getenv("HP_CHAIN_DBG")) { // block timeline (s_memtime deltas of block 0, thread 0), printed per launch
+            unsigned long long* dbg = nullptr;
+            HP_HIP_TRY(hipMalloc(&dbg, 32 * 8));
+            HP_HIP_TRY(hipMemset(dbg, 0, 32 * 8));
+            st.ch.c2.dbg = dbg;
+            HP_HIP_TRY(hp::launch_conv_chain(st.ch, s));
+            HP_HIP_TRY(hipStreamSynchronize(s));
+            unsigned long long h[32];
+            HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "chain layer %d variant %d timeline:", st.layer, hp::conv_chain_variant(st.ch));
+            for (int i = 1; i < 32 && h[i]; ++i)
+                fprintf(stderr, " %llu", h[i] - h[i - 1]);
+            fprintf(stderr, "\n");
+            st.ch.c2.dbg = nullptr;
+            (void)hipFree(dbg);
+        }
     } else if (st.op == OP_SEPCONV) {
         st.sp.B = n, st.sp.pw.B = n, st.sp.pw.npix = n * st.sp.OH * st.sp.OW;
         HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
@@ -1024,6 +1102,7 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
             out[k].layer = st.layer, out[k].op = st.op;
             out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
+                : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
                                                     : 0;
             out[k].ms = ms / iters;
@@ -1080,6 +1159,7 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
             out[k].layer = st.layer, out[k].op = st.op;
             out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
+                : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
                                                     : 0;
             out[k].ms = (float)(acc[k] / iters);

@@ -376,6 +376,49 @@ def test_fused_separable_block(hp, monkeypatch, c, cout, stride, dil, h, w):
         eng.debug_tensor(d, 3)  # never materialised
 
 
+@pytest.mark.parametrize("variant,h,w,act", [
+    ("pair", 52, 68, E.ACT_RELU),        # 13 x 17 map: ragged tiles in both directions (8 x 12 output tiles)
+    ("pair_res1", 40, 100, E.ACT_RELU),  # 10 x 25: residual on the FIRST 3x3 (the CPM stage's `x + main_block(x)`, lw_openpose.py:118-121)
+    ("pair_res2", 36, 44, E.ACT_RELU6),  # 9 x 11: smaller than one tile in x; residual on the second 3x3; relu6 clamp
+    ("block", 92, 108, E.ACT_RELU),      # 23 x 27: refinement block 1x1 -> 3x3 -> 3x3 + (1x1's output), lw_openpose.py:176-191
+    ("block_nores", 64, 96, E.ACT_RELU), # 16 x 24: whole tiles, 1x1 -> 3x3 -> 3x3 without the residual
+    ("block", 8, 8, E.ACT_RELU),         # 2 x 2 map: everything is halo
+])
+def test_conv_chain_variants(hp, monkeypatch, variant, h, w, act):
+    """conv_chain_kernel ([1x1 ->] 3x3 -> 3x3 [+ residual] on 128 channels, intermediates in LDS) against the torch oracle AND against
+    the one-launch-per-layer schedule (HP_NO_CHAIN=1): intermediate pixels outside the image must act as zero padding, partial
+    tiles must not write outside the map, every residual placement the LW-OpenPose head uses."""
+    net = Net(11)
+    t = net.conv(0, 3, 32, 3, 2)
+    t = net.conv(t, 32, 128, 3, 2)      # the chain's 128-channel input, 1/4 of the frame
+    if variant.startswith("block"):
+        u = net.conv(t, 128, 128, 1, act=act)
+        v = net.conv(u, 128, 128, 3, act=act)
+        y = net.conv(v, 128, 128, 3, act=act, res=u if variant == "block" else -1)
+    else:
+        v = net.conv(t, 128, 128, 3, act=act, res=t if variant == "pair_res1" else -1)
+        y = net.conv(v, 128, 128, 3, act=act, res=t if variant == "pair_res2" else -1)
+    z = net.conv(y, 128, 32, 1, act=E.ACT_NONE)  # (the chain's output must not be a network output)
+    fr = _frames(3, h, w, seed=h)
+    outs = [Out("z", z, 0, 32)]
+    eng, got, ref = _run_both(net, outs, fr, h, w)
+    _check(got, ref, 3)
+    tiles = [p["tile"] for p in eng.profile(3, 1)]
+    assert sum(7000000 <= t_ < 8000000 for t_ in tiles) == 1, tiles   # the chain kernel really ran, once
+    with pytest.raises(Exception):
+        eng.debug_tensor(v, 3)   # lives in LDS only
+    mid = eng.debug_tensor(y, 3)
+    monkeypatch.setenv("HP_NO_CHAIN", "1")
+    eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 3)
+    assert not any(7000000 <= p["tile"] < 8000000 for p in eng2.profile(3, 1))
+    got2 = eng2.inference(fr)
+    mid2 = eng2.debug_tensor(y, 3)
+    _close(mid, mid2, rel=4e-3, abs_=2e-3)          # same fp16 storage points, fp32 sums in another order
+    assert (mid != mid2).mean() < 0.2               # ... most stored values identical
+    for b in range(3):
+        _close(got[b][0][1], got2[b][0][1])
+
+
 def test_lw_openpose_fused_equals_unfused(hp, monkeypatch):
     m = E.Model("lw_openpose_mobilenet", 432, 368)
     w = m.init_weights(7)
@@ -384,6 +427,7 @@ def test_lw_openpose_fused_equals_unfused(hp, monkeypatch):
     tiles = [p["tile"] for p in eng.profile(2, 1)]
     assert sum(4000000 <= t < 5000000 for t in tiles) == 11  # every MobileNet separable block
     assert sum(6000000 <= t < 7000000 for t in tiles) == 2   # init + refinement stage: conf + paf heads share a launch
+    assert sum(7000000 <= t < 8000000 for t in tiles) == 8   # CPM (2) + init stage (1) + five refinement blocks as chained launches
     got = eng.inference(fr)
     monkeypatch.setenv("HP_NO_PAIR_HEADS", "1")              # one launch per head: same bits
     solo = E.Engine.from_model(m, w, max_batch=2)
@@ -393,6 +437,7 @@ def test_lw_openpose_fused_equals_unfused(hp, monkeypatch):
             assert n0 == n1 and np.array_equal(x0, x1)
     monkeypatch.delenv("HP_NO_PAIR_HEADS")
     monkeypatch.setenv("HP_NO_FUSE_HEAD", "1")               # separable blocks fused, heads as two launches: same bits
+    monkeypatch.setenv("HP_NO_CHAIN", "1")                   # (the chained 3x3 convolutions sum in another order: compared below)
     mid = E.Engine.from_model(m, w, max_batch=2).inference(fr)
     monkeypatch.setenv("HP_NO_FUSE", "1")
     ref = E.Engine.from_model(m, w, max_batch=2).inference(fr)

@@ -18,7 +18,7 @@ m = Model(arch, w, h)
 eng = Engine.from_model(m, m.init_weights(1), max_batch=n)
 prof = eng.profile(n, iters=20)                   # each step 20x back to back (weights warm in L2)
 seq = eng.profile(n, iters=20, in_sequence=True)  # the schedule in order, events in between (what an inference sees)
-names = {100: "sep", 101: "head", 1: "conv", 2: "dw", 3: "pool", 4: "up"}
+names = {100: "sep", 101: "head", 102: "chain", 1: "conv", 2: "dw", 3: "pool", 4: "up"}
 tot = 0.0
 print(f"{'#':>3} {'op':5} {'cin':>4} {'cout':>4} k s d  {'tile':>8} {'us':>8} {'TF/s':>7} {'GB/s':>7} {'in-seq us':>9}")
 tot_seq = 0.0
