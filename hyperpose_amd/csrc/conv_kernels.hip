@@ -287,6 +287,102 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
 }
 #undef HP_ESTAMP
 
+// The same epilogue with ALL TN pixel tiles of a wavefront staged at once (slab = TN x stage_geom<TM>::SLAB per wavefront): one
+// write phase, one wait, then every read / residual load / store of the wavefront in flight together.  conv_epilogue_staged runs
+// write -> wait -> (read -> math -> store) x passes once per pixel tile, a chain of LDS and store latencies that measured ~2.5 k
+// cycles per tile in the pixel-block GEMM (8 of a block's 27 k cycles at TM = 2, TN = 3); same arithmetic, same stores.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_wide(const conv_params& p, const floatx16 (&acc)[TM][TN], int m_wave, int lane,
+    unsigned char* slab, const int (&pb)[TN], const int (&py)[TN], const int (&px)[TN], const bool (&pv)[TN])
+{
+    using G = stage_geom<TM>;
+    const int chunk = lane % G::CPP, prow = lane / G::CPP;
+    const int mc = m_wave + chunk * 8; // first of this lane's 8 output channels on the store side (Cout % 8 == 0 here)
+    const bool mvalid = mc < p.Cout;
+    const bool has_res = p.res.p != nullptr; // uniform
+    float bs[8], sl[8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + mc), b1 = *reinterpret_cast<const float4*>(p.bias + mc + 4);
+        bs[0] = b0.x, bs[1] = b0.y, bs[2] = b0.z, bs[3] = b0.w, bs[4] = b1.x, bs[5] = b1.y, bs[6] = b1.z, bs[7] = b1.w;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            sl[r] = p.act_slope;
+        if (p.alpha) { // uniform
+            const float4 a0 = *reinterpret_cast<const float4*>(p.alpha + mc), a1 = *reinterpret_cast<const float4*>(p.alpha + mc + 4);
+            sl[0] = a0.x, sl[1] = a0.y, sl[2] = a0.z, sl[3] = a0.w, sl[4] = a1.x, sl[5] = a1.y, sl[6] = a1.z, sl[7] = a1.w;
+        }
+    }
+    const float hi = p.act_hi;
+    const bool clamp_only = !has_res && !p.alpha && p.act_slope == 0.f; // uniform
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        unsigned char* const sj = slab + j * G::SLAB;
+        long* const s_ooff = reinterpret_cast<long*>(sj + 32 * G::ROW);
+        // MFMA layout -> LDS: lane owns pixel (lane & 31), channels i*32 + 8g + 4*(lane>>5) + {0..3}
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = acc[i][j][4 * g + 0], v.y = acc[i][j][4 * g + 1], v.z = acc[i][j][4 * g + 2], v.w = acc[i][j][4 * g + 3];
+                *reinterpret_cast<float4*>(sj + (lane & 31) * G::ROW + (i * 32 + 8 * g + 4 * (lane >> 5)) * 4) = v;
+            }
+        if (lane < 32) {
+            s_ooff[lane] = pv[j] ? tv_off(p.out, pb[j], py[j], px[j]) : -1;
+            s_ooff[32 + lane] = (pv[j] && has_res) ? tv_off(p.res, pb[j], py[j], px[j]) : 0;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's LDS writes have landed (DS ops retire in order)
+    __builtin_amdgcn_wave_barrier();
+    long oo[TN][G::PASSES];
+    half8 rs[TN][G::PASSES];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long* const s_ooff = reinterpret_cast<const long*>(slab + j * G::SLAB + 32 * G::ROW);
+#pragma unroll
+        for (int ps = 0; ps < G::PASSES; ++ps) {
+            oo[j][ps] = s_ooff[ps * G::PPP + prow];
+            if (has_res) // invalid pixels read offset 0: in bounds, result unused
+                rs[j][ps] = *reinterpret_cast<const half8*>(p.res.p + s_ooff[32 + ps * G::PPP + prow] + (mvalid ? mc : 0));
+            else
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    rs[j][ps][r] = (_Float16)0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const unsigned char* const sj = slab + j * G::SLAB;
+#pragma unroll
+        for (int ps = 0; ps < G::PASSES; ++ps) {
+            const int pix = ps * G::PPP + prow;
+            const float4 a0 = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32);
+            const float4 a1 = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32 + 16);
+            const float v[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+            half8 h;
+            if (clamp_only) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    h[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r] + bs[r], 0.f, hi);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float x = v[r] + bs[r];
+                    const float rr = (float)rs[j][ps][r];
+                    if (p.res_before_act)
+                        x += rr;
+                    x = x > 0.f ? fminf(x, hi) : x * sl[r];
+                    if (!p.res_before_act)
+                        x += rr;
+                    h[r] = (_Float16)x;
+                }
+            }
+            if (oo[j][ps] >= 0 && mvalid)
+                *reinterpret_cast<half8*>(p.out.p + oo[j][ps] + mc) = h;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Generic implicit GEMM.  1-D grid; block id -> (pixel tile, cout tile) with the cout tiles of one pixel tile
 // adjacent and consecutive logical ids on the same XCD (blocks are dispatched round-robin over the 8 XCDs).
@@ -1213,6 +1309,7 @@ static bool fast_epilogue(const conv_params& p)
 
 static bool use_halo(const conv_params& p);
 static bool use_small1x1(const conv_params& p);
+static int big1x1_variant(const conv_params& p);
 static bool fast_epilogue(const conv_params& p);
 static int halo_variant(const conv_params& p);
 // conv_direct_kernel (8 wavefronts, 128 output channels x 16x12 pixels per block, any square kernel / chunked Cin) serves this layer:
@@ -1242,6 +1339,8 @@ int conv_weight_layout(const conv_params& p)
 {
     static const int off = getenv("HP_HALO_DIRECT") ? !atoi(getenv("HP_HALO_DIRECT")) : 0;
     if (use_small1x1(p) && fast_epilogue(p))
+        return 1;
+    if (big1x1_variant(p) && fast_epilogue(p))
         return 1;
     if (use_gdirect(p))
         return 1;
@@ -1397,6 +1496,176 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const conv_params p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 1x1 convolutions with >= 256 input channels (the pointwise halves of the 512-channel MobileNet blocks when they run un-fused, the
+// reductions / expansions of the ResNet bottlenecks) as a pixel-block GEMM without any LDS traffic for the weights:
+//   * block = 32 NTP consecutive pixels x 128 TM output channels; wavefront w owns TM 32-row tiles (rows (4 by + w) TM 32 ..) over the
+//     FULL K: TM x NTP accumulator tiles in registers (up to 256 of the 512 registers one wavefront per SIMD may use), no split-K;
+//   * A (weights) straight from L2 in MFMA-fragment order (w_layout 1): one coalesced 1 KB load per fragment, each feeding NTP MFMAs,
+//     re-requested one 64-channel chunk ahead as they are consumed;
+//   * B (activations) in 64-channel chunks through a double-buffered swizzled LDS tile (global -> registers one chunk ahead -> LDS,
+//     ONE LDS-only barrier per chunk); every B fragment read from LDS feeds TM MFMAs;
+//   * shared staged epilogue (bias, activation, residual, 64-byte runs per pixel).
+// Per k16 step a wavefront issues TM loads, NTP LDS reads and TM x NTP MFMAs: at TM = NTP = 4 that is 8 memory operations for 512
+// matrix-pipe cycles, against 1 + 1 per 32 cycles in the 128 x 128 LDS-staged implicit GEMM this replaces for these layers.
+template <int TM, int NTP>
+__global__ __launch_bounds__(512) void conv1x1_big_kernel(const conv_params p)
+{
+    constexpr int NPX = 32 * NTP, CK = 64, KS = 4, BUF = NPX * CK * 2;
+    constexpr int SLABS = 4 * NTP * stage_geom<TM>::SLAB; // conv_epilogue_wide: all NTP pixel tiles of a wavefront staged at once
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF > SLABS ? 2 * BUF : SLABS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * NPX, HW = p.OH * p.OW;
+    const int KQ = p.Cin / 16, NCH = p.Cin / CK;
+
+    if (wave >= 4) {
+        // ---- PRODUCER wavefronts (4-7): B chunks global -> registers -> LDS.  The activations come from HBM (~2 us under load)
+        // while a chunk's MFMAs last ~0.6 us, so FOUR chunks are kept in flight (ring slot = chunk % 4; the chunk loop is unrolled by
+        // four so that the slots are register names).  They run in wavefronts of their own because vmcnt retires in order: in one
+        // instruction stream with the weight loads - which are consumed one chunk after their request - every wait for a weight
+        // fragment also waited for all older activation loads, i.e. the ring was one chunk deep whatever its size (measured: 22 us
+        // for 512 -> 512 at 8 x 46 x 54 pixels with one stream, for 5 us of MFMAs).
+        const int pt = tid - 256;
+        long hoff[NTP];
+#pragma unroll
+        for (int k = 0; k < NTP; ++k) {
+            const int n = min(n0 + (pt >> 3) + 32 * k, p.npix - 1);
+            const int b = n / HW, r = n - b * HW, y = r / p.OW, x = r - y * p.OW;
+            hoff[k] = tv_off(p.in, b, y, x) + (pt & 7) * 8;
+        }
+        constexpr int PF = 4;
+        u32x4 hv[PF][NTP];
+        auto hload = [&](u32x4 (&slot)[NTP], int chunk) {
+#pragma unroll
+            for (int k = 0; k < NTP; ++k)
+                slot[k] = *reinterpret_cast<const u32x4*>(p.in.p + hoff[k] + chunk * CK);
+        };
+        auto to_lds = [&](int buf, const u32x4 (&slot)[NTP]) {
+#pragma unroll
+            for (int k = 0; k < NTP; ++k)
+                *reinterpret_cast<u32x4*>(lds + buf * BUF + lds_off<CK>((pt >> 3) + 32 * k, pt & 7)) = slot[k];
+        };
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            hload(hv[u], min(u, NCH - 1));
+        int pdbg = 0;
+#define HP_PSTAMP()                                                                                               \
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 256 && pdbg < 30)                                    \
+        p.dbg[32 + pdbg++] = __builtin_amdgcn_s_memtime();
+        HP_PSTAMP();
+        to_lds(0, hv[0]);
+        hload(hv[0], min(PF, NCH - 1));
+        HP_PSTAMP();
+        lds_barrier();
+        HP_PSTAMP();
+#pragma unroll 1
+        for (int c0 = 0; c0 < NCH; c0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                // chunk c + 1 (requested four iterations ago) -> the other buffer (its last readers passed the previous barrier);
+                // the slot then takes chunk c + 5
+                to_lds((u + 1) & 1, hv[(u + 1) & 3]);
+                hload(hv[(u + 1) & 3], min(c0 + u + 1 + PF, NCH - 1));
+                HP_PSTAMP();
+                lds_barrier();
+                HP_PSTAMP();
+            }
+        }
+#undef HP_PSTAMP
+        return;
+    }
+
+    // ---- CONSUMER wavefronts (0-3): wavefront w owns TM 32-row tiles over the full K
+    const int frow = lane & 31, fk = lane >> 5;
+    const int m_wave = (blockIdx.y * 4 + wave) * TM * 32;
+    const __half* const wbase = p.w + ((size_t)(m_wave / 32) * KQ * 64 + lane) * 8;
+    const size_t row_stride = (size_t)KQ * 512;
+    u32x4 a[KS][TM];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[ks][i] = *reinterpret_cast<const u32x4*>(wbase + i * row_stride + ks * 512);
+    floatx16 acc[TM][NTP];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NTP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+    int dbg_i = 0; // HP_CONV_DBG: s_memtime stamps of block 0: consumer wave 0 at [0..], producer wave 4 at [32..]
+#define HP_BSTAMP()                                                                                               \
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && dbg_i < 30)                                    \
+        p.dbg[(wave >= 4 ? 32 : 0) + dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_BSTAMP();
+    lds_barrier();
+    HP_BSTAMP();
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        const unsigned char* const bt = lds + (c & 1) * BUF;
+        const __half* const wn = wbase + (size_t)min(c + 1, NCH - 1) * (KS * 512);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 fb[NTP];
+#pragma unroll
+            for (int j = 0; j < NTP; ++j)
+                fb[j] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                half8 fa;
+                __builtin_memcpy(&fa, &a[ks][i], 16);
+#pragma unroll
+                for (int j = 0; j < NTP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[ks][i] = *reinterpret_cast<const u32x4*>(wn + i * row_stride + ks * 512);
+        }
+        HP_BSTAMP();
+        lds_barrier(); // chunk c + 1 is complete in its buffer; everyone is done reading chunk c
+        HP_BSTAMP();
+    }
+
+    int pb[NTP], py[NTP], px[NTP];
+    bool pv[NTP];
+#pragma unroll
+    for (int j = 0; j < NTP; ++j) {
+        const int n = n0 + j * 32 + frow, nc = min(n, p.npix - 1);
+        pb[j] = nc / HW;
+        const int r = nc - pb[j] * HW;
+        py[j] = r / p.OW, px[j] = r - py[j] * p.OW;
+        pv[j] = n < p.npix;
+    }
+    // (the producers are gone and the last barrier of the loop is behind every read of the B buffers: the wave-private slabs may
+    // overlay them; the staged epilogue synchronises inside a wavefront only)
+    conv_epilogue_wide<TM, NTP>(p, acc, m_wave, lane, lds + wave * (NTP * stage_geom<TM>::SLAB), pb, py, px, pv);
+    HP_BSTAMP();
+#undef HP_BSTAMP
+}
+
+// which (TM, NTP) the pixel-block GEMM runs a layer with: TM * 1000 + NTP, or 0 when the layer is not its kind
+static int big1x1_variant(const conv_params& p)
+{
+    static const bool off = getenv("HP_NO_BIG_1X1") != nullptr;
+    if (off || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_t || p.pad_l || p.OH != p.H || p.OW != p.W || p.Cin % 256 /* four-chunk ring */
+        || p.Cout_pad % 128 || p.Cout % 8 || p.in.coff % 8 || p.in.cs - p.in.coff < p.Cin)
+        return 0;
+    // (TM, NTP) by a small cost model: blocks are dealt to the 256 CUs in rounds (two blocks share a CU when each needs <= 256
+    // registers); a round costs its MFMAs at ~80 % pipe efficiency plus ~6 k cycles of prologue / epilogue; 64-pixel blocks (NTP = 2)
+    // pull twice the weights per MFMA through the texture path
+    // (TM, NTP): measured over the ResNet-50 bottlenecks at 193^2 .. 12^2 pixels and LW-OpenPose's pointwise layers (sweep of all
+    // instances, tools/profile_layers.py): 64 pixels x 256 output channels wins or ties almost everywhere - 118 registers and 72 KB
+    // of LDS let TWO blocks share a CU, so one block's prologue (first chunk from HBM) and epilogue (stores) sit under the other's
+    // MFMAs; wider or taller blocks run alone on their CU and pay both phases in full.  128-row blocks where the output has no
+    // 256-row groups.
+    if (p.Cout_pad % 256 == 0)
+        return 2002;
+    const long blocks4 = (long)((p.npix + 127) / 128) * (p.Cout_pad / 128);
+    return blocks4 >= 1024 ? 1004 : 1002;
+}
+
 static bool use_small1x1(const conv_params& p)
 {
     static const bool off = getenv("HP_NO_SMALL_1X1") != nullptr;
@@ -1408,6 +1677,8 @@ static bool use_small1x1(const conv_params& p)
 
 int conv_mfma_tile(const conv_params& p)
 {
+    if (p.w_layout == 1 && p.KH == 1 && !use_small1x1(p))
+        return 5200000 + big1x1_variant(p); // conv1x1_big_kernel<TM, NTP>
     if (p.w_layout == 1 && p.KH == 1)
         return 5100000 + p.Cin; // conv1x1_small_kernel
     if (p.w_layout == 1 && use_gdirect(p))
@@ -1433,6 +1704,25 @@ int conv_mfma_tile(const conv_params& p)
 
 hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
 {
+    if (p.w_layout == 1 && p.KH == 1 && !use_small1x1(p)) {
+        const int v = big1x1_variant(p);
+        if (!v || !fast_epilogue(p))
+            return hipErrorInvalidValue;
+        const int TM = v / 1000, NTP = v % 1000;
+        const dim3 grid((p.npix + 32 * NTP - 1) / (32 * NTP), p.Cout_pad / (128 * TM));
+#define HP_BIG(TM_, NTP_) HP_LAUNCH((conv1x1_big_kernel<TM_, NTP_>), grid, dim3(512), 0, s, p)
+        switch (v) {
+        case 4002: HP_BIG(4, 2); break;
+        case 2004: HP_BIG(2, 4); break;
+        case 2003: HP_BIG(2, 3); break;
+        case 2002: HP_BIG(2, 2); break;
+        case 1004: HP_BIG(1, 4); break;
+        case 1003: HP_BIG(1, 3); break;
+        default: HP_BIG(1, 2); break;
+        }
+#undef HP_BIG
+        return hipGetLastError();
+    }
     if (p.w_layout == 1 && p.KH == 1) {
         if (!(use_small1x1(p) && fast_epilogue(p)))
             return hipErrorInvalidValue;

@@ -767,6 +767,25 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     } else if (st.op == HP_OP_CONV) {
         st.cp.B = n, st.cp.npix = n * st.cp.OH * st.cp.OW;
         HP_HIP_TRY(hp::launch_conv_mfma(st.cp, s));
+        if (getenv("HP_CONV_DBG") && hp::conv_mfma_tile(st.cp) / 100000 == 52) { // block timeline of the pixel-block GEMM
+            unsigned long long* dbg = nullptr;
+            HP_HIP_TRY(hipMalloc(&dbg, 64 * 8));
+            HP_HIP_TRY(hipMemset(dbg, 0, 64 * 8));
+            st.cp.dbg = dbg;
+            HP_HIP_TRY(hp::launch_conv_mfma(st.cp, s));
+            HP_HIP_TRY(hipStreamSynchronize(s));
+            unsigned long long h[64];
+            HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "conv layer %d %d->%d tile %d consumer:", st.layer, st.cp.Cin, st.cp.Cout, hp::conv_mfma_tile(st.cp));
+            for (int i = 1; i < 32 && h[i]; ++i)
+                fprintf(stderr, " %llu", h[i] - h[i - 1]);
+            fprintf(stderr, " | producer (from consumer start %lld):", (long long)(h[32] - h[0]));
+            for (int i = 33; i < 64 && h[i]; ++i)
+                fprintf(stderr, " %llu", h[i] - h[i - 1]);
+            fprintf(stderr, "\n");
+            st.cp.dbg = nullptr;
+            (void)hipFree(dbg);
+        }
     } else if (st.op == OP_CHAIN) {
         st.ch.c0.B = st.ch.c1.B = st.ch.c2.B = n;
         HP_HIP_TRY(hp::launch_conv_chain(st.ch, s));
