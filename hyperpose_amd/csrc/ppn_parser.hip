@@ -8,12 +8,16 @@
 //            erase-without-index-fix-up (:110-133) — one lane per class, lists live in LDS;
 //   phase 3  limb candidates: for every surviving "from" box, gather its 81 edge confidences from the
 //            [E,nh,nw,gh,gw] tensor and match the aimed cell against the surviving "to" boxes (:172-221);
-// — and only the survivors (a few KB) cross PCIe.  The order-dependent tail (sort + pop-back selection with the
-// root rule :224-270, the 64x64 hash merge :275-325, the score filter :329-332) runs on the host inside this
-// library: it is sequential by construction (each step mutates what the next reads) and touches < 100 items.
+// the compacted lists stay in device memory, and the order-dependent tail runs on the device as well (ppn_assemble_kernel, one
+// wavefront per frame): libstdc++'s std::sort restated step by step (equal limb confidences must come out in ITS order) + the
+// pop-back selection with the root rule (:224-270), the 64x64 hash merge with its stale indices (:275-325), the score filter
+// (:329-332); humans go straight to pinned host memory.  hp_ppn_collect does no per-frame work.  The same statements as host
+// C++ (assemble_frame) remain for the frames the kernel declines (more than 256 skeleton fragments or 2048 hash entries: reported
+// by hp_ppn_decode_flags) and behind HP_PPN_HOST_TAIL=1, which the tests use to compare the two.
 //
 // Compiled with -ffp-contract=off; the float expressions keep the reference's operand order.
 #include "hp_common.hpp"
+#include "libstdcxx_sort.hpp"
 
 #include <algorithm>
 #include <array>
@@ -29,6 +33,9 @@ constexpr int PPN_MAXG = 256;   // grid cells per map supported (12x12 = 144 in 
 constexpr int PPN_MAXB = 144;   // NMS survivors kept per class (a 12x12 grid cannot yield more)
 constexpr int PPN_MAXC = 2048;  // limb candidates kept per limb
 constexpr int HDR = 64;         // ints per frame: [0,18) survivors, [18,35) candidates, [35] flags
+constexpr int PPN_MAXP = 256;   // skeleton fragments (poses before the merge) the device tail holds per frame
+constexpr int PPN_MAXE = 2048;  // entries of the 64 x 64 spatial hash the device tail holds per frame
+constexpr int PPN_FLAG_POSES = 4, PPN_FLAG_HASH = 8, PPN_FLAG_OUT = 16; // device-tail decline reasons (on top of 1 / 2 from the extract kernel)
 
 // pose_proposal.cpp:23-41
 __constant__ int c_pair_std[PPN_LIMBS][2] = {
@@ -211,6 +218,201 @@ __global__ __launch_bounds__(256) void ppn_extract_kernel(const float* __restric
 #undef s_surv
 }
 
+// ---- device tail: pose_proposal.cpp:224-332 on the compacted lists, ONE WAVEFRONT PER FRAME ------------------------------
+// Every step mutates what the next one reads (roots, the pose list, the hash buckets with their stale indices), so the walk is one
+// lane's; the other 63 lanes take the bulk work around it: staging a limb's confidences, shifting the pose list after an erase,
+// the final filter + copy to pinned host memory.  State in LDS: roots [18][144], poses [256] x 292 B, the hash as per-bucket
+// singly linked lists in insertion order (the reference's `std::vector<uint16_t>` buckets, traversed front to back).
+__global__ __launch_bounds__(64) void ppn_assemble_kernel(const int* __restrict__ hdr, const ppn_box* __restrict__ boxes,
+    const ppn_cand* __restrict__ cands, int net_w, int net_h, int n_key_points, hp_human* __restrict__ out, int out_cap, int* __restrict__ out_n,
+    int* __restrict__ out_flags)
+{
+    __shared__ int s_root[PPN_K][PPN_MAXB];
+    __shared__ hp_human s_pose[PPN_MAXP];
+    __shared__ int s_ord[PPN_MAXC];
+    __shared__ float s_conf[PPN_MAXC];
+    __shared__ unsigned short s_head[64 * 64], s_tail[64 * 64], s_val[PPN_MAXE], s_next[PPN_MAXE];
+    __shared__ int s_np, s_flags, s_cmd, s_arg, s_i, s_ne;
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int* const h = hdr + (size_t)f * HDR;
+    const ppn_box* const fb = boxes + (size_t)f * PPN_K * PPN_MAXB;
+    const ppn_cand* const fc = cands + (size_t)f * PPN_LIMBS * PPN_MAXC;
+    for (int i = lane; i < PPN_K * PPN_MAXB; i += 64)
+        (&s_root[0][0])[i] = -1;
+    for (int i = lane; i < (int)(sizeof(s_pose) / 4); i += 64)
+        reinterpret_cast<unsigned*>(s_pose)[i] = 0u;
+    for (int i = lane; i < 64 * 64; i += 64)
+        s_head[i] = 0xffff, s_tail[i] = 0xffff;
+    if (lane == 0)
+        s_np = 0, s_flags = h[PPN_K + PPN_LIMBS], s_ne = 0, s_i = 0;
+    __syncthreads();
+    if (s_flags) { // the extract kernel overflowed a list: nothing to assemble (hp_ppn_collect reports the frame)
+        if (lane == 0)
+            out_n[f] = 0, out_flags[f] = s_flags;
+        return;
+    }
+    auto set_part = [&](hp_human& hm, int part, const ppn_box& b) {
+        hm.parts[part].has_value = 1;
+        hm.parts[part].x = (float)(b.x + b.w / 2) / net_w; // integer /2, pose_proposal.cpp:252-253
+        hm.parts[part].y = (float)(b.y + b.h / 2) / net_h;
+        hm.parts[part].score = b.conf;
+    };
+
+    // ---- limbs (:172-270): std::sort ascending by confidence, pop from the back, root rule
+    for (int l = 0; l < PPN_LIMBS; ++l) {
+        const int nc = h[PPN_K + l];
+        const ppn_cand* const lc = fc + (size_t)l * PPN_MAXC;
+        for (int i = lane; i < nc; i += 64)
+            s_conf[i] = lc[i].conf, s_ord[i] = i;
+        __syncthreads();
+        if (lane == 0 && nc > 0) {
+            const float* const cf = s_conf;
+            hp::libstdcxx_sort(s_ord, nc, [cf](int a, int b) { return cf[a] < cf[b]; });
+            const int p1 = c_pair_std[l][0], p2 = c_pair_std[l][1];
+            int np = s_np;
+            for (int q = nc - 1; q >= 0; --q) {
+                const ppn_cand cur = lc[s_ord[q]];
+                int& fr = s_root[p1][cur.from];
+                int& tr = s_root[p2][cur.to];
+                int root;
+                if ((fr != -1) == (tr != -1)) { // both rooted OR both free -> a new pose (:241-244)
+                    if (np >= PPN_MAXP) {
+                        s_flags |= PPN_FLAG_POSES;
+                        break;
+                    }
+                    root = np++;
+                } else
+                    root = fr != -1 ? fr : tr;
+                hp_human& hm = s_pose[root];
+                if (!hm.parts[p1].has_value) {
+                    set_part(hm, p1, fb[(size_t)p1 * PPN_MAXB + cur.from]);
+                    fr = root;
+                    hm.score += 1.;
+                }
+                if (!hm.parts[p2].has_value) {
+                    set_part(hm, p2, fb[(size_t)p2 * PPN_MAXB + cur.to]);
+                    tr = root;
+                    hm.score += 1.;
+                }
+            }
+            s_np = np;
+        }
+        __syncthreads();
+        if (s_flags)
+            break;
+    }
+
+    // ---- merge pass (:275-325).  Lane 0 walks the poses; when one is to be erased it hands the shift of the tail of the list to all
+    // lanes (s_cmd = 1, s_arg = the index) and resumes at the same index, as the reference's `--i; break;` + `++i` does.
+    auto bucket_of = [](const hp_body_part& p) {
+        size_t xi = p.x * 64, yi = p.y * 64; // size_t x_ind = part.x * grid_size (:279-283)
+        xi = xi == 64 ? 63 : xi;
+        yi = yi == 64 ? 63 : yi;
+        return (int)(min(xi, (size_t)63) * 64 + min(yi, (size_t)63)); // (coordinates beyond 1.0: the reference indexes out of bounds)
+    };
+    auto push_back = [&](int bucket, int value) { // hash_table[..][..].push_back(value)
+        const int e = s_ne;
+        if (e >= PPN_MAXE) {
+            s_flags |= PPN_FLAG_HASH;
+            return;
+        }
+        s_val[e] = (unsigned short)value, s_next[e] = 0xffff;
+        if (s_tail[bucket] == 0xffff)
+            s_head[bucket] = (unsigned short)e;
+        else
+            s_next[s_tail[bucket]] = (unsigned short)e;
+        s_tail[bucket] = (unsigned short)e;
+        s_ne = e + 1;
+    };
+    while (!s_flags) {
+        if (lane == 0) {
+            s_cmd = 0;
+            int i = s_i;
+            int np = s_np;
+            for (; i < np && !s_flags; ++i) {
+                hp_human& cur = s_pose[i];
+                if (cur.score > n_key_points - 0.1)
+                    continue;
+                bool remove_cur = false;
+                for (int j = 0; j < HP_COCO_N_PARTS && !remove_cur; ++j) {
+                    if (!cur.parts[j].has_value)
+                        continue;
+                    const hp_body_part this_part = cur.parts[j];
+                    const int bk = bucket_of(this_part);
+                    for (int e = s_head[bk]; e != 0xffff; e = s_next[e]) {
+                        const int pid = s_val[e];
+                        if (pid == i || pid >= np) // (an index past the end: the reference reads out of bounds)
+                            continue;
+                        hp_human& other = s_pose[pid];
+                        if (other.parts[j].y != this_part.y || other.parts[j].x != this_part.x)
+                            continue;
+                        remove_cur = true;
+                        for (int u = 0; u < HP_COCO_N_PARTS; ++u)
+                            if (cur.parts[u].has_value && !other.parts[u].has_value) {
+                                other.parts[u] = cur.parts[u];
+                                other.score += 1.0;
+                                push_back(bucket_of(cur.parts[u]), i); // the reference pushes `i`, not the survivor (:310)
+                            }
+                        break;
+                    }
+                    if (!remove_cur)
+                        push_back(bk, i);
+                }
+                if (remove_cur) {
+                    s_cmd = 1, s_arg = i; // ret_poses.erase(begin + i); --i; (the loop's ++i lands on the same index)
+                    break;
+                }
+            }
+            s_i = i;
+        }
+        __syncthreads();
+        if (s_cmd != 1)
+            break;
+        { // erase pose s_arg: shift the tail of the list down by one, word by word, in index order
+            const int e = s_arg, np = s_np;
+            constexpr int WPP = (int)(sizeof(hp_human) / 4);
+            unsigned* const w = reinterpret_cast<unsigned*>(s_pose);
+            // (every lane moves the same two word columns of every row: a row's words are read one iteration before they are
+            // overwritten, by the same lane - no cross-lane hazard, no barrier inside the loop)
+            for (int k = e; k + 1 < np; ++k) {
+                if (lane < WPP)
+                    w[k * WPP + lane] = w[(k + 1) * WPP + lane];
+                if (lane + 64 < WPP)
+                    w[k * WPP + lane + 64] = w[(k + 1) * WPP + lane + 64];
+            }
+            if (lane == 0)
+                s_np = np - 1;
+        }
+        __syncthreads();
+    }
+
+    // ---- score filter (:329-332), order kept; humans -> pinned host memory
+    int n_out = 0;
+    if (!s_flags) {
+        const int np = s_np;
+        constexpr int WPP = (int)(sizeof(hp_human) / 4);
+        const unsigned* const w = reinterpret_cast<const unsigned*>(s_pose);
+        unsigned* const o = reinterpret_cast<unsigned*>(out + (size_t)f * out_cap);
+        for (int k = 0; k < np; ++k) {
+            if (!(s_pose[k].score <= 3)) { // uniform
+                if (n_out < out_cap) {
+                    if (lane < WPP)
+                        o[n_out * WPP + lane] = w[k * WPP + lane];
+                    if (lane + 64 < WPP)
+                        o[n_out * WPP + lane + 64] = w[k * WPP + lane + 64];
+                } else if (lane == 0)
+                    s_flags |= PPN_FLAG_OUT;
+                ++n_out;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        out_n[f] = n_out;
+        out_flags[f] = s_flags;
+    }
+}
+
 // ---- host tail: pose_proposal.cpp:167-336 on the compacted lists -----------------------------------------
 struct kp_t {
     ppn_box box;
@@ -320,10 +522,16 @@ struct hp_ppn {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     hp::dev_buf in[7];
-    // the kernel writes its compacted lists straight into pinned host memory: only the used prefix of every fixed-capacity row
-    // crosses PCIe, and there is no copy to wait for between the kernel and the host tail
-    hp::host_buf h_hdr, h_boxes, h_cands;
-    int pending = 0; // frames enqueued and not yet collected
+    // compacted lists: device memory (read by ppn_assemble_kernel); the host copies are filled on demand only (a declined frame,
+    // HP_PPN_HOST_TAIL=1)
+    hp::dev_buf d_hdr, d_boxes, d_cands;
+    std::vector<int> h_hdr;
+    std::vector<ppn_box> h_boxes;
+    std::vector<ppn_cand> h_cands;
+    hp::host_buf h_humans, h_counts; // pinned: [B][PPN_MAXP] humans, [n_humans(B) | flags(B)], written by ppn_assemble_kernel
+    std::vector<int> last_flags;
+    bool host_tail = false; // HP_PPN_HOST_TAIL=1: the device tail is not launched, every frame takes the host statements
+    int pending = 0;        // frames enqueued and not yet collected
     int K = 0;
 };
 
@@ -338,9 +546,14 @@ int hp_ppn_create(hp_ppn** out, int net_w, int net_h, float point_thresh, float 
     HP_HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HP_HIP_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
     const size_t B = max_batch;
-    HP_TRY(p->h_hdr.alloc(B * HDR * sizeof(int)));
-    HP_TRY(p->h_boxes.alloc(B * PPN_K * PPN_MAXB * sizeof(ppn_box)));
-    HP_TRY(p->h_cands.alloc(B * PPN_LIMBS * PPN_MAXC * sizeof(ppn_cand)));
+    HP_TRY(p->d_hdr.alloc(B * HDR * sizeof(int)));
+    HP_TRY(p->d_boxes.alloc(B * PPN_K * PPN_MAXB * sizeof(ppn_box)));
+    HP_TRY(p->d_cands.alloc(B * PPN_LIMBS * PPN_MAXC * sizeof(ppn_cand)));
+    HP_TRY(p->h_humans.alloc(B * PPN_MAXP * sizeof(hp_human)));
+    HP_TRY(p->h_counts.alloc(2 * B * sizeof(int)));
+    p->h_hdr.assign(B * HDR, 0);
+    p->last_flags.assign(B, 0);
+    p->host_tail = getenv("HP_PPN_HOST_TAIL") && atoi(getenv("HP_PPN_HOST_TAIL")) != 0;
     *out = p.release();
     return HP_OK;
 }
@@ -402,9 +615,14 @@ static int ppn_launch(hp_ppn* p, int n, const float* const tensors[7], const int
     const size_t lds = ((size_t)PPN_K * g.gh * g.gw + (size_t)PPN_K * PPN_MAXB) * sizeof(ppn_box);
     HP_REQUIRE(lds <= 150 * 1024, HP_ERR_INVALID, "ppn: grid too large for the LDS work lists");
     HP_HIP_TRY(hipFuncSetAttribute((const void*)ppn_extract_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ppn_extract_kernel, dim3(n), dim3(256), lds, s, d[0], d[2], d[3], d[4], d[5], d[6], g, p->h_hdr.as<int>(),
-        p->h_boxes.as<ppn_box>(), p->h_cands.as<ppn_cand>());
+    hipLaunchKernelGGL(ppn_extract_kernel, dim3(n), dim3(256), lds, s, d[0], d[2], d[3], d[4], d[5], d[6], g, p->d_hdr.as<int>(),
+        p->d_boxes.as<ppn_box>(), p->d_cands.as<ppn_cand>());
     HP_HIP_TRY(hipGetLastError());
+    if (!p->host_tail) {
+        hipLaunchKernelGGL(ppn_assemble_kernel, dim3(n), dim3(64), 0, s, p->d_hdr.as<int>(), p->d_boxes.as<ppn_box>(), p->d_cands.as<ppn_cand>(),
+            p->net_w, p->net_h, g.K, p->h_humans.as<hp_human>(), PPN_MAXP, p->h_counts.as<int>(), p->h_counts.as<int>() + p->max_batch);
+        HP_HIP_TRY(hipGetLastError());
+    }
     HP_HIP_TRY(hipEventRecord(p->done, s));
     p->pending = n;
     p->K = g.K;
@@ -422,21 +640,18 @@ struct ppn_job {
     hp_human* out;
     int cap;
     int* n_out;
+    std::vector<int> frames; // the frames that take the host statements
     std::vector<int> rc;
 };
-void ppn_frame(int f, int, void* ctx)
+void ppn_frame(int k, int, void* ctx)
 {
     ppn_job& j = *static_cast<ppn_job*>(ctx);
     hp_ppn* p = j.p;
-    const int* hdr = p->h_hdr.as<int>() + (size_t)f * HDR;
-    if (hdr[PPN_K + PPN_LIMBS] != 0) {
-        j.rc[f] = 1;
-        j.n_out[f] = 0;
-        return;
-    }
+    const int f = j.frames[k];
+    const int* hdr = p->h_hdr.data() + (size_t)f * HDR;
     std::vector<hp_human> poses;
-    assemble_frame(hdr, p->h_boxes.as<ppn_box>() + (size_t)f * PPN_K * PPN_MAXB, p->h_cands.as<ppn_cand>() + (size_t)f * PPN_LIMBS * PPN_MAXC,
-        p->net_w, p->net_h, p->K, poses);
+    assemble_frame(hdr, p->h_boxes.data() + (size_t)f * PPN_K * PPN_MAXB, p->h_cands.data() + (size_t)f * PPN_LIMBS * PPN_MAXC, p->net_w, p->net_h,
+        p->K, poses);
     j.n_out[f] = (int)poses.size();
     if ((int)poses.size() > j.cap)
         j.rc[f] = 2;
@@ -452,20 +667,64 @@ int hp_ppn_collect(hp_ppn* p, hp_human* out, int cap_per_frame, int* n_out)
     const int n = p->pending;
     p->pending = 0;
     HP_HIP_TRY(hipEventSynchronize(p->done));
-    ppn_job job{ p, out, cap_per_frame, n_out, std::vector<int>(n, 0) };
-    hp::frame_pool::instance().run(n, ppn_frame, &job);
+    ppn_job job{ p, out, cap_per_frame, n_out, {}, std::vector<int>(n, 0) };
+    const int* counts = p->h_counts.as<int>();
+    const int* flags = counts + p->max_batch;
+    for (int f = 0; f < n; ++f) {
+        const int fl = p->host_tail ? 0 : flags[f];
+        p->last_flags[f] = p->host_tail ? -1 : fl;
+        if (p->host_tail || (fl & (PPN_FLAG_POSES | PPN_FLAG_HASH | PPN_FLAG_OUT))) {
+            job.frames.push_back(f); // declined by the device tail (or HP_PPN_HOST_TAIL=1): the host statements take the frame
+            continue;
+        }
+        if (fl) { // an extract-kernel list overflowed
+            job.rc[f] = 1;
+            n_out[f] = 0;
+            continue;
+        }
+        const int nh = counts[f];
+        n_out[f] = nh;
+        if (nh > cap_per_frame)
+            job.rc[f] = 2;
+        if (out)
+            memcpy(out + (size_t)f * cap_per_frame, p->h_humans.as<hp_human>() + (size_t)f * PPN_MAXP, sizeof(hp_human) * std::min(nh, cap_per_frame));
+    }
+    if (!job.frames.empty()) {
+        // rare path: fetch the compacted lists of the batch and run the reference's statements on the host
+        if (p->h_boxes.empty())
+            p->h_boxes.resize((size_t)p->max_batch * PPN_K * PPN_MAXB), p->h_cands.resize((size_t)p->max_batch * PPN_LIMBS * PPN_MAXC);
+        HP_HIP_TRY(hipMemcpy(p->h_hdr.data(), p->d_hdr.p, (size_t)n * HDR * sizeof(int), hipMemcpyDeviceToHost));
+        HP_HIP_TRY(hipMemcpy(p->h_boxes.data(), p->d_boxes.p, (size_t)n * PPN_K * PPN_MAXB * sizeof(ppn_box), hipMemcpyDeviceToHost));
+        HP_HIP_TRY(hipMemcpy(p->h_cands.data(), p->d_cands.p, (size_t)n * PPN_LIMBS * PPN_MAXC * sizeof(ppn_cand), hipMemcpyDeviceToHost));
+        std::vector<int> todo;
+        for (int f : job.frames) {
+            if (p->h_hdr[(size_t)f * HDR + PPN_K + PPN_LIMBS] != 0) { // (host-tail mode: the extract kernel's own overflow flags)
+                job.rc[f] = 1;
+                n_out[f] = 0;
+            } else
+                todo.push_back(f);
+        }
+        job.frames = todo;
+        hp::frame_pool::instance().run((int)job.frames.size(), ppn_frame, &job);
+    }
     int rc = HP_OK;
     for (int f = 0; f < n; ++f)
         if (job.rc[f] == 1) {
-            const int* hdr = p->h_hdr.as<int>() + (size_t)f * HDR;
-            hp::set_error("ppn: frame %d overflowed a device list (flags=%d: 1=survivors/class>%d, 2=candidates/limb>%d)", f, hdr[PPN_K + PPN_LIMBS],
-                PPN_MAXB, PPN_MAXC);
+            hp::set_error("ppn: frame %d overflowed a device list (1=survivors/class>%d, 2=candidates/limb>%d)", f, PPN_MAXB, PPN_MAXC);
             rc = HP_ERR_CAPACITY;
         } else if (job.rc[f] == 2) {
             hp::set_error("ppn: frame %d has %d humans, capacity %d", f, n_out[f], cap_per_frame);
             rc = HP_ERR_CAPACITY;
         }
     return rc;
+}
+
+int hp_ppn_decode_flags(hp_ppn* p, int* flags, int n)
+{
+    HP_REQUIRE(p && flags && n >= 0 && n <= p->max_batch, HP_ERR_INVALID, "hp_ppn_decode_flags: bad argument");
+    for (int f = 0; f < n; ++f)
+        flags[f] = p->last_flags[f];
+    return HP_OK;
 }
 
 int hp_ppn_process_batch(hp_ppn* p, int n, const float* const tensors[7], const int conf_shape[3], const int edge_shape[5],

