@@ -1,6 +1,8 @@
-// examples/cli.cpp — `hyperpose-cli` on the MI355X engine: the flag surface and control flow of the reference's examples/cli.cpp:15-35,
-// 60-330 (model / post / w / h / max_batch_size / source / runtime / keep_ratio / alpha / saving_prefix / logging / imshow), with the
-// pieces that need gflags and OpenCV replaced by what this image has:
+// examples/cli.cpp — `hyperpose-cli` on the MI355X engine.  What is kept from the reference's examples/cli.cpp is its INTERFACE: the flag
+// names and defaults (:15-35: model / post / w / h / max_batch_size / source / runtime / keep_ratio / alpha / saving_prefix / logging /
+// imshow), the values `operator` / `stream` and `paf` / `ppn` / `pifpaf`, the model-file suffix rule (.onnx / .uff / anything else =
+// serialized engine) and the order of the work (resize + inference, parse, resume_ratio, draw, blend with weight alpha, write).  The
+// program itself is written for this engine; the pieces that need gflags and OpenCV are replaced by what this image has:
 //   * flags: `--name=value`, `--name value`, `--flag` / `--noflag` (gflags syntax), parsed below;
 //   * media: binary PPM (P6) images - one file, or every *.ppm of a directory - and `synthetic:<n>:<w>x<h>` (seeded frames); results are
 //     written as `<saving_prefix>_<id>.ppm` with the skeletons drawn (hp::draw_human) and blended with weight alpha.  With OpenCV
@@ -198,34 +200,55 @@ static std::vector<cv::Mat> load_source()
     return images;
 }
 
-class parser_variant { // examples/cli.cpp:39-54
-public:
-    using var_t = std::variant<hp::parser::pose_proposal, hp::parser::paf, hp::parser::pifpaf>;
-    template <typename Container>
-    std::vector<hp::human_t> process(Container&& feature_map_containers)
-    {
-        return std::visit([&feature_map_containers](auto& arg) { return arg.process(feature_map_containers); }, m_parser);
-    }
-    parser_variant(var_t v)
-        : m_parser(std::move(v))
-    {
-    }
-    var_t& get() { return m_parser; }
+// the three post-processing operators behind one value (the `--post` flag picks the alternative)
+using any_parser = std::variant<hp::parser::paf, hp::parser::pose_proposal, hp::parser::pifpaf>;
 
-private:
-    var_t m_parser;
-};
+static bool has_suffix(const std::string& text, std::string_view suffix)
+{
+    return text.size() >= suffix.size() && text.compare(text.size() - suffix.size(), suffix.size(), suffix) == 0;
+}
+
+// `--model`: built-in topology with synthetic weights, ONNX file, UFF file (TensorFlow frozen graphs: refused by the engine with its
+// own message), or - any other name - an engine saved with tensorrt::save
+static hp::dnn::tensorrt build_engine()
+{
+    const cv::Size net_size(FLAGS_w, FLAGS_h);
+    cli_log() << "engine: model '" << FLAGS_model << "', network input " << FLAGS_w << " x " << FLAGS_h << " (w x h), batches of up to "
+              << FLAGS_max_batch_size << (FLAGS_keep_ratio ? ", aspect ratio kept (letter-box)\n" : ", frames stretched to the network size\n");
+    if (FLAGS_model.rfind("builtin:", 0) == 0)
+        return hp::dnn::tensorrt(hp::dnn::builtin_model{ FLAGS_model.substr(8), {}, 20241 }, net_size, FLAGS_max_batch_size, FLAGS_keep_ratio);
+    if (has_suffix(FLAGS_model, ".onnx"))
+        return hp::dnn::tensorrt(hp::dnn::onnx{ FLAGS_model }, net_size, FLAGS_max_batch_size, FLAGS_keep_ratio);
+    if (has_suffix(FLAGS_model, ".uff"))
+        return hp::dnn::tensorrt(hp::dnn::uff{ FLAGS_model, "image", { "outputs/conf", "outputs/paf" } }, net_size, FLAGS_max_batch_size, FLAGS_keep_ratio);
+    cli_log() << "'" << FLAGS_model << "' is neither .onnx nor .uff: loading it as a serialized engine\n";
+    return hp::dnn::tensorrt(hp::dnn::tensorrt_serialized{ FLAGS_model }, net_size, FLAGS_max_batch_size, FLAGS_keep_ratio);
+}
+
+static any_parser build_parser(hp::dnn::tensorrt& engine) // (input_size() is non-const in the reference's class, tensorrt.hpp:98)
+{
+    const cv::Size in = engine.input_size();
+    if (FLAGS_post == kPPN)
+        return any_parser{ std::in_place_type<hp::parser::pose_proposal>, in };
+    if (FLAGS_post == kPIFPAF)
+        return any_parser{ std::in_place_type<hp::parser::pifpaf>, in.height, in.width };
+    if (FLAGS_post != kPAF) {
+        cli_log() << "ERROR: --post=" << FLAGS_post << " is not one of " kPAF ", " kPPN ", " kPIFPAF "\n";
+        std::exit(-1);
+    }
+    return any_parser{ std::in_place_type<hp::parser::paf> };
+}
 
 int main(int argc, char** argv)
 {
     if (!parse_flags(argc, argv))
         return 1;
     if (FLAGS_logging)
-        cli_log() << "Internal LOGGING enabled.\n";
+        cli_log() << "--logging: the engine reports through hp_last_error(); nothing more to switch on\n";
     if (FLAGS_alpha < 0 || FLAGS_alpha > 1) {
-        const double cl = std::clamp(FLAGS_alpha, 0., 1.);
-        cli_log() << "WARNING. The flag: alpha: " << FLAGS_alpha << " out of range. Clamped to " << cl << std::endl;
-        FLAGS_alpha = cl;
+        const double inside = std::min(1.0, std::max(0.0, FLAGS_alpha));
+        cli_log() << "WARNING: --alpha=" << FLAGS_alpha << " is outside [0, 1]; using " << inside << "\n";
+        FLAGS_alpha = inside;
     }
     if (hp_init(0) != HP_OK) {
         cli_log() << "ERROR: " << hp_last_error() << "\n";
@@ -233,7 +256,7 @@ int main(int argc, char** argv)
     }
     auto images = load_source();
     if (images.empty()) {
-        cli_log() << "ERROR: Failed to parse source: " << FLAGS_source << " (PPM files / directories and synthetic:<n>:<w>x<h> are supported"
+        cli_log() << "ERROR: no frames from --source=" << FLAGS_source << " (PPM files / directories and synthetic:<n>:<w>x<h> are supported"
 #ifndef HYPERPOSE_USE_OPENCV
                   << "; videos and the camera need a build with OpenCV"
 #endif
@@ -242,42 +265,14 @@ int main(int argc, char** argv)
     }
     if (FLAGS_imshow) {
         FLAGS_imshow = false;
-        cli_log() << "Imshow functionality needs a display and OpenCV's highgui; results are written to files.\n";
+        cli_log() << "--imshow needs a display and OpenCV's highgui: results go to files only\n";
     }
 
-    // Engine Config (examples/cli.cpp:118-145).
-    auto engine = [&] {
-        using namespace hp::dnn;
-        cli_log() << "Configuring the Engine:"
-                  << "\n--> MODEL: " << FLAGS_model << "\n--> MAX_BATCH_SIZE: " << FLAGS_max_batch_size << "\n--> (HxW): " << FLAGS_h << " x " << FLAGS_w << '\n';
-        constexpr std::string_view onnx_suffix = ".onnx";
-        constexpr std::string_view uff_suffix = ".uff";
-        if (FLAGS_model.rfind("builtin:", 0) == 0)
-            return tensorrt(builtin_model{ FLAGS_model.substr(8), {}, 20241 }, { FLAGS_w, FLAGS_h }, FLAGS_max_batch_size, FLAGS_keep_ratio);
-        if (FLAGS_model.size() >= 5 && std::equal(onnx_suffix.crbegin(), onnx_suffix.crend(), FLAGS_model.crbegin()))
-            return tensorrt(onnx{ FLAGS_model }, { FLAGS_w, FLAGS_h }, FLAGS_max_batch_size, FLAGS_keep_ratio);
-        if (FLAGS_model.size() >= 4 && std::equal(uff_suffix.crbegin(), uff_suffix.crend(), FLAGS_model.crbegin()))
-            return tensorrt(uff{ FLAGS_model, "image", { "outputs/conf", "outputs/paf" } }, { FLAGS_w, FLAGS_h }, FLAGS_max_batch_size, FLAGS_keep_ratio);
-        cli_log() << "Your model file's suffix is not [.onnx | .uff]. Your model file path: " << FLAGS_model << '\n';
-        cli_log() << "We assume this is a serialized engine, and we'll evaluate it in this way.\n";
-        return tensorrt(tensorrt_serialized{ FLAGS_model }, { FLAGS_w, FLAGS_h }, FLAGS_max_batch_size, FLAGS_keep_ratio);
-    }();
-    cli_log() << "DNN engine is built.\n";
-
-    auto parser = parser_variant{ [&engine]() -> parser_variant::var_t {
-        if (FLAGS_post == kPAF)
-            return hp::parser::paf{};
-        if (FLAGS_post == kPPN)
-            return hp::parser::pose_proposal(engine.input_size());
-        if (FLAGS_post == kPIFPAF)
-            return hp::parser::pifpaf(engine.input_size().height, engine.input_size().width);
-        cli_log() << "ERROR: Unknown post-processing flag: `" << FLAGS_post << "`. Use `paf`, `ppn` or `pifpaf` please.\n";
-        std::exit(-1);
-    }() };
-
-    if (FLAGS_runtime != kOPERATOR and FLAGS_runtime != kSTREAM) {
-        cli_log() << "WARNING: Unknown runtime flag: " << FLAGS_runtime << ". Changed this using `operator`.\n";
-        FLAGS_runtime = "operator";
+    auto engine = build_engine();
+    any_parser parser = build_parser(engine);
+    if (FLAGS_runtime != kOPERATOR && FLAGS_runtime != kSTREAM) {
+        cli_log() << "WARNING: --runtime=" << FLAGS_runtime << " is neither " kOPERATOR " nor " kSTREAM "; using " kOPERATOR "\n";
+        FLAGS_runtime = kOPERATOR;
     }
 
     using clk_t = std::chrono::high_resolution_clock;
@@ -298,27 +293,22 @@ int main(int argc, char** argv)
     };
 
     auto beg = clk_t::now();
-    if (FLAGS_runtime == kOPERATOR) { // examples/cli.cpp:232-275 (the image-vector branch)
-        std::vector<cv::Mat> tmp{};
-        size_t counter = 0;
-        while (counter != images.size()) {
-            auto stride = std::min((size_t)FLAGS_max_batch_size, images.size() - counter);
-            tmp.clear();
-            for (size_t j = 0; j < stride; ++j)
-                tmp.push_back(images[counter + j]);
-            auto feature_maps = engine.inference(tmp);
-            std::vector<std::vector<hp::human_t>> pose_vectors;
-            pose_vectors.reserve(feature_maps.size());
-            for (auto&& packet : feature_maps)
-                pose_vectors.push_back(parser.process(packet));
-            for (size_t i = 0; i < tmp.size(); ++i)
-                render(tmp[i], pose_vectors[i], FLAGS_keep_ratio);
-            counter += stride;
+    if (FLAGS_runtime == kOPERATOR) {
+        // operator API: one batch at a time - engine.inference(batch) -> one internal_t per frame -> parser.process(internal_t)
+        const size_t step = (size_t)std::max(1, FLAGS_max_batch_size);
+        for (size_t first = 0; first < images.size(); first += step) {
+            std::vector<cv::Mat> batch(images.begin() + first, images.begin() + std::min(images.size(), first + step));
+            const auto maps = engine.inference(batch);
+            for (size_t k = 0; k < batch.size(); ++k) {
+                const auto poses = std::visit([&](auto& op) { return op.process(maps[k]); }, parser);
+                render(batch[k], poses, FLAGS_keep_ratio);
+            }
         }
-    } else { // stream runtime (examples/cli.cpp:277-330): make_stream(engine, parser, use_original_resolution = true, keep_ratio)
+    } else {
+        // stream API: make_stream(engine, parser, use_original_resolution = true, keep_ratio); frames in, (frame, poses) out in order
         std::visit(
-            [&](auto& p) {
-                auto stream = hp::make_stream(engine, p, true, FLAGS_keep_ratio);
+            [&](auto& op) {
+                auto stream = hp::make_stream(engine, op, true, FLAGS_keep_ratio);
                 stream.async() << images;
                 auto sink = [&](size_t, const cv::Mat& frame, const std::vector<hp::human_t>& poses) {
                     cv::Mat img = clone(frame);
@@ -326,7 +316,7 @@ int main(int argc, char** argv)
                 };
                 stream.sync() >> sink;
             },
-            parser.get());
+            parser);
     }
     const auto ms = std::chrono::duration<double, std::milli>(clk_t::now() - beg).count();
     std::cout << images.size() << " images got processed in " << ms << " ms, FPS = " << 1000. * images.size() / ms << " (" << n_humans

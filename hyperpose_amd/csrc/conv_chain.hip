@@ -49,13 +49,13 @@ __device__ __forceinline__ int t2_key(int hy, int hx) { return (hy * TW + hx) & 
 //   nkey[j]    that pixel's index in consumer order (its swizzle key at tap (ky, kx) is (nkey + ky * KW + kx) & 15)
 //   a[]        A fragments of the first tap (already requested); wcur = this stage's weights (this wave's rows), wnext = the NEXT
 //              stage's (its first tap is requested while this stage's last tap is consumed), or nullptr
-template <int NT, int TAPS, int WIN, int KW, int D, int ABL = 0>
+template <int NT, int TAPS, int WIN, int KW, int D>
 __device__ __forceinline__ void chain_stage(floatx16 (&acc)[NT], u32x4 (&a)[KQ], const __half* wcur, long tap_stride, const __half* wnext,
     const unsigned char* src, const int (&pix0)[NT], const int (&nkey)[NT], int fk)
 {
-    // D = how many k16 steps ahead of their MFMAs the B fragments are read (ring of 4 fragment sets).  One wavefront per SIMD issues in
-    // order: a read that has not landed when its MFMA comes up stalls the matrix pipe, and with four wavefronts keeping the LDS pipe
-    // half busy a read takes longer than the 96 (NT = 3) .. 160 (NT = 5) cycles one k16 step of MFMAs lasts.
+    // D = how many k16 steps ahead of their MFMAs the B fragments are read (ring of 4 fragment sets).  Measured: D = 1, 2, 3 run within
+    // 1 % of each other, and a timing build without ANY memory operation in the loop takes 83 % of the loop's time (14.9 k of 17.9 k
+    // ticks for S1): the loop is at the matrix pipe's rate at the clock the chip sustains; the reads are not what it waits for.
     static_assert(D >= 1 && D <= 3 && KQ == 8, "prefetch ring");
     constexpr int KS = TAPS == 9 ? 3 : 1;
     auto tap_addr = [&](int tap, int (&ad)[NT]) {
@@ -83,8 +83,7 @@ __device__ __forceinline__ void chain_stage(floatx16 (&acc)[NT], u32x4 (&a)[KQ],
 #pragma unroll
         for (int ks = 0; ks < KQ; ++ks) {
             // the B fragments of k16 step ks + D (of the next tap past the end of this one) are read while this step multiplies
-            if (ABL & 1) { // ablation (timing only, wrong results): no B-fragment reads inside the loop
-            } else if (ks + D < KQ) {
+            if (ks + D < KQ) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     fb[(ks + D) & 3][j] = *reinterpret_cast<const half8*>(src + (ad[j] ^ ((ks + D) << 5)));
@@ -97,9 +96,8 @@ __device__ __forceinline__ void chain_stage(floatx16 (&acc)[NT], u32x4 (&a)[KQ],
             __builtin_memcpy(&fa, &a[ks], 16);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[(ABL & 1) ? (ks & (D - 1)) : (ks & 3)][j], acc[j], 0, 0, 0);
-            if (!(ABL & 2)) // ablation bit 1: no A-fragment loads inside the loop
-                a[ks] = *reinterpret_cast<const u32x4*>(wn + (size_t)ks * 512);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 3][j], acc[j], 0, 0, 0);
+            a[ks] = *reinterpret_cast<const u32x4*>(wn + (size_t)ks * 512);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -127,7 +125,7 @@ __device__ __forceinline__ void zero_acc(floatx16 (&acc)[NT])
 
 // S0: the chain starts with a 1x1; RES: 0 none, 1 external tensor added to S1's output, 2 external tensor added to S2's output,
 // 3 the 1x1's output (T1) added to S2's output
-template <bool S0, int RES, int D, int ABL = 0>
+template <bool S0, int RES, int D = 2>
 __global__ __launch_bounds__(256) void conv_chain_kernel(const chain_params p, int tiles_x, int tiles_y)
 {
     constexpr int X0_BYTES = S0 ? N2 * PXB : 0, T1_BYTES = N2 * PXB, T2_BYTES = N1 * PXB;
@@ -244,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_chain_kernel(const chain_params p, i
             const int n = min(j * 32 + fr, N1 - 1), br = n / W1, bc = n - br * W1;
             pix0[j] = (br * W2 + bc) * PXB, nkey[j] = n;
         }
-        chain_stage<NT1, 9, W2, W1, D, ABL>(acc, a, w1, tap_stride, w2, s_t1, pix0, nkey, fk);
+        chain_stage<NT1, 9, W2, W1, D>(acc, a, w1, tap_stride, w2, s_t1, pix0, nkey, fk);
         HP_CSTAMP();
         float bs[16];
         load_bias(p.c1.bias, bs);
@@ -304,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_chain_kernel(const chain_params p, i
                     rs[j][g] = *reinterpret_cast<const half4*>(rp + 8 * g);
             }
         }
-        chain_stage<NT0, 9, W1, TW, D, ABL>(acc, a, w2, tap_stride, nullptr, s_t2, pix0, nkey, fk);
+        chain_stage<NT0, 9, W1, TW, D>(acc, a, w2, tap_stride, nullptr, s_t2, pix0, nkey, fk);
         HP_CSTAMP();
         float bs[16];
         load_bias(p.c2.bias, bs);
@@ -385,34 +383,13 @@ hipError_t launch_conv_chain(const chain_params& p, hipStream_t s)
         return hipErrorInvalidValue;
     const int tiles_x = (p.c2.OW + TW - 1) / TW, tiles_y = (p.c2.OH + TH - 1) / TH;
     const dim3 grid(tiles_x * tiles_y * p.c2.B);
-    static const int depth = getenv("HP_CHAIN_DEPTH") ? atoi(getenv("HP_CHAIN_DEPTH")) : 2; // (A/B of the B-fragment prefetch distance)
-#define HP_CHAIN(S0_, RES_)                                                                                       \
-    do {                                                                                                          \
-        if (depth == 1)                                                                                           \
-            HP_LAUNCH((conv_chain_kernel<S0_, RES_, 1>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);               \
-        else if (depth == 3)                                                                                      \
-            HP_LAUNCH((conv_chain_kernel<S0_, RES_, 3>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);               \
-        else                                                                                                      \
-            HP_LAUNCH((conv_chain_kernel<S0_, RES_, 2>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);               \
-    } while (0)
-    static const int abl = getenv("HP_CHAIN_ABL") ? atoi(getenv("HP_CHAIN_ABL")) : 0; // timing ablations of variant 1 (wrong results)
-    if (abl && v == 1) {
-        if (abl == 1)
-            HP_LAUNCH((conv_chain_kernel<false, 0, 2, 1>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
-        else if (abl == 2)
-            HP_LAUNCH((conv_chain_kernel<false, 0, 2, 2>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
-        else
-            HP_LAUNCH((conv_chain_kernel<false, 0, 2, 3>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
-        return hipGetLastError();
-    }
     switch (v) {
-    case 1: HP_CHAIN(false, 0); break;
-    case 2: HP_CHAIN(false, 1); break;
-    case 3: HP_CHAIN(false, 2); break;
-    case 10: HP_CHAIN(true, 0); break;
-    default: HP_CHAIN(true, 3); break;
+    case 1: HP_LAUNCH((conv_chain_kernel<false, 0>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
+    case 2: HP_LAUNCH((conv_chain_kernel<false, 1>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
+    case 3: HP_LAUNCH((conv_chain_kernel<false, 2>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
+    case 10: HP_LAUNCH((conv_chain_kernel<true, 0>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
+    default: HP_LAUNCH((conv_chain_kernel<true, 3>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
     }
-#undef HP_CHAIN
     return hipGetLastError();
 }
 

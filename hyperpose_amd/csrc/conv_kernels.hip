@@ -560,267 +560,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const conv_params p)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / dilation 1 with the input tile + halo resident in LDS.  Block = BM output channels x (TH x TW)
-// output pixels; 4 wavefronts as 2 (channels) x 2 (pixel halves), each BM/2 ch x TH*TW/2 px = TM x NT MFMA tiles.
-// Halo tile: (TH+2) x (TW+2) pixels x CIN halves, per-pixel 16-byte chunks XOR-swizzled by the pixel's position so
-// that the 16 lanes of a ds_read_b128 service group (consecutive tile pixels, any tap shift) hit 16 distinct slots.
-// Weights: [tap][cout][cin] streamed in K-steps of 64 through a double-buffered LDS tile, register-prefetched two
-// steps ahead.  Two instantiations: 128 ch x 8x16 px and 64 ch x 16x12 px; the second moves 37 % fewer bytes per CU
-// at the 46 x 54 maps of the OpenPose heads (the layers are CU<-L2 bandwidth bound at batch 8).
-template <int TM, int NT>
-__device__ __forceinline__ void halo_interleave()
-{
-    if constexpr (TM == 2 && NT == 2) {
-        HP_INTERLEAVE4();
-    } else { // 1 x 3: three MFMAs shadow four LDS reads
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-}
-
-template <int CIN, int BM, int TH, int TW, int KG, int BK, int EPI>
-__global__ __launch_bounds__(256 * KG) void conv3x3_halo_kernel(const conv_params p, int tiles_x, int tiles_y)
-{
-    // 8 wavefronts = 2 K-groups x (2 channel halves x 2 pixel halves): both K-groups own the same BM/2 x TH*TW/2 wave
-    // tile and split every tap's CIN between them, so each SIMD holds two wavefronts that cover each other's LDS
-    // latency and barrier waits; the partial sums meet through LDS before the epilogue.
-    constexpr int NTHR = 256 * KG;
-    constexpr int KC = CIN / BK;  // K-steps per tap
-    constexpr int CHA = BK / 8;   // 16-byte chunks per weight-tile row
-    constexpr int HPH = TH + 2, HPW = TW + 2;
-    constexpr int TM = BM / 64, NT = TH * TW / 64; // MFMA tiles per wave
-    constexpr int CHP = CIN / 8;                   // 16-byte chunks per halo pixel
-    constexpr int NS = BK / 16 / KG;               // k16 substeps per K-group and K-step
-    constexpr int HALO_BYTES = HPH * HPW * CIN * 2;
-    constexpr int A_BYTES = BM * BK * 2;
-    constexpr int A_LD = BM * CHA / NTHR; // 16-byte loads per thread per K-step
-    constexpr int RED_BYTES = 4 * TM * NT * 16 * 64 * 4;
-    static_assert(TH * TW % 64 == 0 && BM % 64 == 0 && A_LD >= 1 && NS >= 2 && NS % 2 == 0, "wave tiles are whole 32x32 MFMA tiles");
-    constexpr int LDS_BYTES = HALO_BYTES + 2 * A_BYTES > RED_BYTES ? HALO_BYTES + 2 * A_BYTES : RED_BYTES;
-    static_assert(RED_BYTES / 4 >= stage_geom<TM>::SLAB, "a wave's epilogue slab lives in its own reduction region");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    unsigned char* const s_halo = lds;
-    unsigned char* const s_a = lds + HALO_BYTES;
-    // swizzle key of halo pixel (hy, hx): consecutive tile pixels (row-major over TW columns) get consecutive keys
-    auto hkey = [](int hy, int hx) { return CHP == 16 ? ((hy * TW + hx) & 15) : (((hy * TW + hx) >> 1) & 7); };
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y, b = t / tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
-
-    // ---- weights prefetch (two register sets), then the halo tile
-    constexpr int RPP = NTHR / CHA; // weight rows covered by one pass of the block's threads
-    const int ld_row = tid / CHA, ld_chunk = tid % CHA;
-    const __half* wrow = p.w + (size_t)(m0 + ld_row) * CIN + ld_chunk * 8;
-    const long w_tap_stride = (long)p.Cout_pad * CIN;
-    u32x4 ra0[A_LD], ra1[A_LD];
-    int l_tap = 0, l_kc = 0, l_step = 0;
-#define HP_WLOAD(RA)                                                                                              \
-    {                                                                                                             \
-        const __half* wb_ = wrow + (long)l_tap * w_tap_stride + l_kc * BK;                                        \
-        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                          \
-            RA[i] = *reinterpret_cast<const u32x4*>(wb_ + (size_t)(i * RPP) * CIN);                               \
-        if (++l_step < 9 * KC) { /* loads past the last K-step repeat it: unconditional, never used */            \
-            if (++l_kc == KC) {                                                                                   \
-                l_kc = 0;                                                                                         \
-                ++l_tap;                                                                                          \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-#define HP_WSTORE(RA, BUF)                                                                                        \
-    {                                                                                                             \
-        unsigned char* a_ = s_a + (BUF) * A_BYTES;                                                                \
-        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                          \
-            *reinterpret_cast<u32x4*>(a_ + lds_off<BK>(ld_row + i * RPP, ld_chunk)) = RA[i];                      \
-    }
-    int dbg_i = 0;
-#define HP_STAMP()                                                                                                \
-    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)                                                  \
-        p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
-    HP_STAMP();
-    HP_WLOAD(ra0);
-    HP_WLOAD(ra1);
-
-    // halo tile: issue ALL loads first (one L2 round trip), then the LDS stores
-    {
-        constexpr int NIT = (HPH * HPW * CHP + NTHR - 1) / NTHR;
-        u32x4 hv[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * NTHR;
-            const int hp = min(i, HPH * HPW * CHP - 1) / CHP, c = i % CHP;
-            const int hy = hp / HPW, hx = hp - hy * HPW;
-            const int y = y0 + hy - 1, x = x0 + hx - 1;
-            const bool ok = y <= p.H && x <= p.W; // y, x >= -1 always: inside the zero halo of the HBM tensor
-            const u32x4 v = *reinterpret_cast<const u32x4*>(p.in.p + tv_off(p.in, b, min(y, p.H), min(x, p.W)) + c * 8);
-            hv[it] = v & (ok ? 0xffffffffu : 0u);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * NTHR;
-            if (i < HPH * HPW * CHP) {
-                const int hp = i / CHP, c = i - hp * CHP;
-                const int hy = hp / HPW, hx = hp - hy * HPW;
-                *reinterpret_cast<u32x4*>(s_halo + hp * (CIN * 2) + ((c ^ hkey(hy, hx)) << 4)) = hv[it];
-            }
-        }
-    }
-
-    floatx16 acc[TM][NT];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[i][j][r] = 0.f;
-
-    const int frow = lane & 31, fk = lane >> 5;
-    // this lane's B-fragment pixels (tile coordinates): N-tile j covers tile pixels wn*TH*TW/2 + 32j .. +31
-    int brow[NT], bcol[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = wn * (TH * TW / 2) + j * 32 + (lane & 31);
-        brow[j] = n / TW;
-        bcol[j] = n - brow[j] * TW;
-    }
-    // 16-byte chunk (of the tap's CIN) this lane reads in substep ks of its K-group
-#define HP_HFRAGS(FA, FB, KS)                                                                                     \
-    {                                                                                                             \
-        const int cha_ = (kg * NS + (KS)) * 2 + fk, ch_ = c_kc * CHA + cha_;                                      \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                            \
-            FA[i] = *reinterpret_cast<const half8*>(a_ + lds_off<BK>(wm * (BM / 2) + i * 32 + frow, cha_));       \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
-            FB[j] = *reinterpret_cast<const half8*>(s_halo + hpo_[j] + ((ch_ ^ hk_[j]) << 4));                    \
-    }
-#define HP_HMMA(FA, FB)                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[i], FB[j], acc[i][j], 0, 0, 0);
-#define HP_HCOMPUTE(BUF)                                                                                          \
-    {                                                                                                             \
-        const unsigned char* a_ = s_a + (BUF) * A_BYTES;                                                          \
-        const int ky_ = c_tap / 3, kx_ = c_tap - ky_ * 3;                                                         \
-        int hpo_[NT], hk_[NT];                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
-        {                                                                                                         \
-            hpo_[j] = ((brow[j] + ky_) * HPW + bcol[j] + kx_) * (CIN * 2);                                        \
-            hk_[j] = hkey(brow[j] + ky_, bcol[j] + kx_);                                                          \
-        }                                                                                                         \
-        half8 fa0[TM], fb0[NT], fa1[TM], fb1[NT];                                                                 \
-        HP_HFRAGS(fa0, fb0, 0);                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-        _Pragma("unroll") for (int ks = 0; ks < NS; ks += 2)                                                      \
-        {                                                                                                         \
-            HP_HFRAGS(fa1, fb1, ks + 1);                                                                          \
-            HP_HMMA(fa0, fb0);                                                                                    \
-            halo_interleave<TM, NT>();                                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            if (ks + 2 < NS) {                                                                                    \
-                HP_HFRAGS(fa0, fb0, ks + 2);                                                                      \
-                HP_HMMA(fa1, fb1);                                                                                \
-                halo_interleave<TM, NT>();                                                                        \
-            } else {                                                                                              \
-                HP_HMMA(fa1, fb1);                                                                                \
-            }                                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-        }                                                                                                         \
-        if (++c_kc == KC) {                                                                                       \
-            c_kc = 0;                                                                                             \
-            ++c_tap;                                                                                              \
-        }                                                                                                         \
-    }
-
-    constexpr int steps = 9 * KC;
-    int c_tap = 0, c_kc = 0;
-    HP_STAMP();
-#pragma unroll 1
-    for (int s = 0; s < steps; s += 2) {
-        HP_WSTORE(ra0, 0);
-        lds_barrier(); // also publishes the halo tile on the first iteration; the weight prefetch stays in flight
-        HP_STAMP();
-        HP_WLOAD(ra0);
-        __builtin_amdgcn_sched_barrier(0);
-        HP_HCOMPUTE(0);
-        __builtin_amdgcn_sched_barrier(0);
-        HP_STAMP();
-        if (s + 1 < steps) {
-            HP_WSTORE(ra1, 1);
-            lds_barrier();
-            HP_STAMP();
-            HP_WLOAD(ra1);
-            __builtin_amdgcn_sched_barrier(0);
-            HP_HCOMPUTE(1);
-            __builtin_amdgcn_sched_barrier(0);
-            HP_STAMP();
-        }
-    }
-#undef HP_WLOAD
-#undef HP_WSTORE
-#undef HP_HCOMPUTE
-#undef HP_HFRAGS
-#undef HP_HMMA
-
-    // ---- K-group 1 hands its partial sums to K-group 0: [wave tile][float4 index][lane], 16 bytes per lane
-    __syncthreads(); // every wave is done with the main-loop LDS
-    HP_STAMP();
-    if constexpr (KG == 2) {
-        float4* red = reinterpret_cast<float4*>(lds) + (size_t)(wave & 3) * (TM * NT * 4 * 64) + lane;
-        if (kg == 1) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        red[((i * NT + j) * 4 + g) * 64] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-        __syncthreads();
-        if (kg == 1)
-            return;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 v = red[((i * NT + j) * 4 + g) * 64];
-                    acc[i][j][4 * g] += v.x, acc[i][j][4 * g + 1] += v.y, acc[i][j][4 * g + 2] += v.z, acc[i][j][4 * g + 3] += v.w;
-                }
-    }
-    // K-group 0 finishes alone, without further block-wide barriers
-    int pb[NT], py[NT], px[NT];
-    bool pv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        pb[j] = b;
-        py[j] = y0 + brow[j];
-        px[j] = x0 + bcol[j];
-        pv[j] = py[j] < p.OH && px[j] < p.OW;
-    }
-    HP_STAMP();
-    if (EPI == 0) {
-        // the slab re-uses this wave's own reduction region, which it has finished reading
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        conv_epilogue_staged<TM, NT>(p, acc, m0 + wm * (BM / 2), lane, lds + (wave & 3) * (RED_BYTES / 4), pb, py, px, pv);
-    } else
-        conv_epilogue<TM, NT, EPI>(p, acc, m0 + wm * (BM / 2), lane, pb, py, px, pv);
-    HP_STAMP();
-#undef HP_STAMP
-}
-
-// ---------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / dilation 1, barrier-free form (p.w_layout == 1).  Same tile as the 64 x 16x12 variant above, but the
-// weights never touch LDS: they are packed in MFMA-fragment order [tap][32-row tile][k16 step][lane][8 halves], so every
+// 3x3 / stride 1 / dilation 1, barrier-free form (p.w_layout == 1).  Block = 64 output channels x 16 x 12 output pixels, the
+// input tile + halo ((16 + 2) x (12 + 2) pixels x CIN halves, 16-byte chunks XOR-swizzled by the pixel position) staged in LDS once;
+// the weights never touch LDS: they are packed in MFMA-fragment order [tap][32-row tile][k16 step][lane][8 halves], so every
 // A fragment is one coalesced 1 KB load that exactly one wavefront needs.  The four wavefronts are 2 (32-row tiles) x
 // 2 (halves of every tap's CIN): no two of them want the same weights, all four read their B fragments from the one
 // static halo tile in LDS, and nothing synchronises them between the prologue and the final exchange of the K-halves
@@ -1143,9 +885,6 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
     HP_DSTAMP();
     lds_barrier(); // chunk 0 is complete
     HP_DSTAMP();
-    const int prio_mode = p.dbg_flags;
-    if (prio_mode == 2 && kg) // static: the younger half of the block (waves 4-7) is favoured
-        __builtin_amdgcn_s_setprio(1);
     const int cb16 = ((kg * NS) * 2 + fk) << 4;
 
     // one step = one tap of one chunk: NS k16 steps of NT MFMAs.  The B fragments are read ONE WHOLE k16 STEP (NT MFMAs = 192
@@ -1189,12 +928,6 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
                 fb[0][j] = *reinterpret_cast<const half8*>(hb_ + base_[j] + (cb16 ^ k16_[j]));                    \
         }                                                                                                         \
         const long nxt_ = a_off(min(q_ + 2, total - 1));                                                          \
-        if (prio_mode == 1) { /* the two waves of a SIMD take turns being the favoured one, tap by tap */         \
-            if (((q_ >> 2) ^ kg) & 1)                                                                             \
-                __builtin_amdgcn_s_setprio(1);                                                                    \
-            else                                                                                                  \
-                __builtin_amdgcn_s_setprio(0);                                                                    \
-        }                                                                                                         \
         _Pragma("unroll") for (int ks = 0; ks < NS; ++ks)                                                         \
         {                                                                                                         \
             if (ks + 1 < NS) {                                                                                    \
@@ -1311,22 +1044,18 @@ static bool use_halo(const conv_params& p);
 static bool use_small1x1(const conv_params& p);
 static int big1x1_variant(const conv_params& p);
 static bool fast_epilogue(const conv_params& p);
-static int halo_variant(const conv_params& p);
 // conv_direct_kernel (8 wavefronts, 128 output channels x 16x12 pixels per block, any square kernel / chunked Cin) serves this layer:
-// 0 = no, otherwise the channel chunk CK (128 or 64).  HP_GDIRECT=0 switches it off, HP_GDIRECT=2 also sends the 3x3 layers with
-// 64 / 128 input channels to it (default: they stay with conv3x3_direct_kernel, whose half-size blocks share a CU at batch 8).
+// 0 = no, otherwise the channel chunk CK (128 or 64).
 static int use_gdirect(const conv_params& p)
 {
-    const char* env = getenv("HP_GDIRECT"); // read per call: an engine must be created and run under the same setting
-    const int mode = env ? atoi(env) : 1;
-    if (!mode || p.KH != p.KW || (p.KH != 3 && p.KH != 5 && p.KH != 7) || p.stride != 1 || p.dil != 1 || p.pad_t != p.KH / 2
+    if (p.KH != p.KW || (p.KH != 3 && p.KH != 5 && p.KH != 7) || p.stride != 1 || p.dil != 1 || p.pad_t != p.KH / 2
         || p.pad_l != p.KH / 2 || p.OH != p.H || p.OW != p.W || p.Cin % 64 || p.Cout_pad % 128 || p.in.coff % 8 || !fast_epilogue(p))
         return 0;
-    if (p.KH == 3 && p.Cin <= 128 && mode < 2)
-        return 0;
+    if (p.KH == 3 && p.Cin <= 128)
+        return 0; // (these stay with conv3x3_direct_kernel, whose half-size blocks share a CU at batch 8)
     // maps smaller than two tiles: the generic implicit GEMM packs pixels of several images into one tile - worth more than the halo
     // re-use unless K is long (measured at 12 x 12: 512 -> 512 57 -> 45 us, 2048 -> 512 212 -> 163 us on this kernel)
-    if ((long)p.OH * p.OW < 256 && p.Cin < 256 && mode < 3)
+    if ((long)p.OH * p.OW < 256 && p.Cin < 256)
         return 0;
     // 128-channel chunks only where ONE chunk is the whole input (7x7 / 5x5 x 128: a 101 / 82 KB tile, single-buffered); everything
     // else runs on double-buffered 64-channel chunks (the 128-channel form of that pipeline needs more than 256 registers)
@@ -1337,20 +1066,19 @@ static int use_gdirect(const conv_params& p)
 // 1: the weights of this convolution are to be packed in MFMA-fragment order for conv3x3_direct_kernel / conv_direct_kernel
 int conv_weight_layout(const conv_params& p)
 {
-    static const int off = getenv("HP_HALO_DIRECT") ? !atoi(getenv("HP_HALO_DIRECT")) : 0;
     if (use_small1x1(p) && fast_epilogue(p))
         return 1;
     if (big1x1_variant(p) && fast_epilogue(p))
         return 1;
     if (use_gdirect(p))
         return 1;
-    return !off && use_halo(p) && fast_epilogue(p) && halo_variant(p) == 1 ? 1 : 0;
+    return use_halo(p) && fast_epilogue(p) ? 1 : 0;
 }
 
 static bool use_halo(const conv_params& p)
 {
     return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil == 1 && p.pad_t == 1 && p.pad_l == 1 && (p.Cin == 128 || p.Cin == 64)
-        && p.Cout_pad % 64 == 0 && p.in.coff % 8 == 0; // (64 output channels: only the 64-row direct variant, see halo_variant)
+        && p.Cout_pad % 64 == 0 && p.in.coff % 8 == 0;
 }
 
 template <int BM, int BN, int BK>
@@ -1361,42 +1089,6 @@ static hipError_t launch_tile(const conv_params& p, hipStream_t s)
         HP_LAUNCH((conv_mfma_kernel<BM, BN, BK, 0>), grid, dim3(256), 0, s, p);
     else
         HP_LAUNCH((conv_mfma_kernel<BM, BN, BK, 1>), grid, dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
-// Estimated bytes one CU pulls from L2 for the whole launch with tile (BM ch x TH x TW px): blocks beyond the 256 CUs
-// queue behind the first wave of blocks.
-static double halo_cost(const conv_params& p, int BM, int TH, int TW)
-{
-    const long tiles = (long)((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH) * p.B;
-    const long blocks = tiles * (p.Cout_pad / BM);
-    const double per_block = 9.0 * BM * p.Cin * 2 + (double)(TH + 2) * (TW + 2) * p.Cin * 2 + (double)TH * TW * BM * 2;
-    return per_block * (double)((blocks + 255) / 256);
-}
-// 0: 128 ch x 8x16 px, 1: 64 ch x 16x12 px
-static int g_force_halo_variant = -1;
-void debug_force_halo_variant(int v) { g_force_halo_variant = v; }
-static int halo_variant(const conv_params& p)
-{
-    if (p.Cout_pad % 128)
-        return 1; // VGG19's 64 -> 64 layer: 64-row blocks only
-    if (g_force_halo_variant >= 0)
-        return g_force_halo_variant;
-    static const int env_v = getenv("HP_HALO_VARIANT") ? atoi(getenv("HP_HALO_VARIANT")) : -1;
-    if (env_v >= 0)
-        return env_v;
-    return halo_cost(p, 64, 16, 12) < halo_cost(p, 128, 8, 16) ? 1 : 0;
-}
-
-template <int CIN, int BM, int TH, int TW, int KG = 1, int BK = 64>
-static hipError_t launch_halo(const conv_params& p, hipStream_t s)
-{
-    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
-    dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / BM);
-    if (fast_epilogue(p))
-        HP_LAUNCH((conv3x3_halo_kernel<CIN, BM, TH, TW, KG, BK, 0>), grid, dim3(256 * KG), 0, s, p, tiles_x, tiles_y);
-    else
-        HP_LAUNCH((conv3x3_halo_kernel<CIN, BM, TH, TW, KG, BK, 1>), grid, dim3(256 * KG), 0, s, p, tiles_x, tiles_y);
     return hipGetLastError();
 }
 
@@ -1648,8 +1340,7 @@ __global__ __launch_bounds__(512) void conv1x1_big_kernel(const conv_params p)
 // which (TM, NTP) the pixel-block GEMM runs a layer with: TM * 1000 + NTP, or 0 when the layer is not its kind
 static int big1x1_variant(const conv_params& p)
 {
-    static const bool off = getenv("HP_NO_BIG_1X1") != nullptr;
-    if (off || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_t || p.pad_l || p.OH != p.H || p.OW != p.W || p.Cin % 256 /* four-chunk ring */
+    if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_t || p.pad_l || p.OH != p.H || p.OW != p.W || p.Cin % 256 /* four-chunk ring */
         || p.Cout_pad % 128 || p.Cout % 8 || p.in.coff % 8 || p.in.cs - p.in.coff < p.Cin)
         return 0;
     // (TM, NTP) by a small cost model: blocks are dealt to the 256 CUs in rounds (two blocks share a CU when each needs <= 256
@@ -1668,8 +1359,7 @@ static int big1x1_variant(const conv_params& p)
 
 static bool use_small1x1(const conv_params& p)
 {
-    static const bool off = getenv("HP_NO_SMALL_1X1") != nullptr;
-    return !off && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.Cout_pad % 128 == 0 && p.Cout_pad <= 512
+    return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.Cout_pad % 128 == 0 && p.Cout_pad <= 512
         && (p.Cout_pad == 128 || p.Cin <= 128) // (wider outputs only where the layer is HBM-bound: K <= 128)
         && (p.Cin == 64 || p.Cin == 128 || p.Cin == 192 || p.Cin == 256)
         && p.in.coff % 8 == 0 && p.in.cs - p.in.coff >= p.Cin && p.OH == p.H && p.OW == p.W;
@@ -1685,17 +1375,7 @@ int conv_mfma_tile(const conv_params& p)
         return 6000000 + p.Cin * 1000 + p.KH * p.KW; // conv_direct_kernel
     if (p.w_layout == 1)
         return 5000000 + 64 * 1000 + 192;
-    if (use_halo(p))
-        return halo_variant(p) ? 3000000 + 64 * 1000 + 192 : 3000000 + 128 * 1000 + 128;
     const int BM = (p.Cout_pad % 128 == 0) ? 128 : 64;
-    // one 128 x 320 tile per CU when that covers the layer in a single round of <= 256 equal blocks: fewest bytes per
-    // CU and no tail (a 1x1 512->512 layer at 8 x 46 x 54 pixels is 252 such blocks vs 624 blocks of 128 x 128)
-    static const int big = getenv("HP_CONV_BIGTILE") ? atoi(getenv("HP_CONV_BIGTILE")) : 0;
-    if (big && BM == 128 && p.Cin % 32 == 0) {
-        const long blocks320 = (long)((p.npix + 319) / 320) * (p.Cout_pad / 128);
-        if (blocks320 <= 256 && blocks320 >= 192)
-            return 128 * 1000 + 320;
-    }
     // prefer the 128-pixel tile only when it still fills the 256 CUs at least once
     const long blocks128 = (long)((p.npix + 127) / 128) * (p.Cout_pad / BM);
     const int BN = blocks128 >= 256 ? 128 : 64;
@@ -1760,40 +1440,17 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
     if (p.w_layout == 1) {
         if (!(use_halo(p) && fast_epilogue(p)))
             return hipErrorInvalidValue; // fragment-ordered weights only fit the direct kernel
-        static const int th = getenv("HP_DIRECT_TH") ? atoi(getenv("HP_DIRECT_TH")) : 16; // experiment: 8 = half-height tiles
-        const int tiles_x = (p.OW + 11) / 12, tiles_y = th == 8 ? (p.OH + 7) / 8 : (p.OH + 15) / 16;
+        const int tiles_x = (p.OW + 11) / 12, tiles_y = (p.OH + 15) / 16;
         dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / 64);
-        if (p.Cin == 128 && th == 8)
-            HP_LAUNCH((conv3x3_direct_kernel<128, 8>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
-        else if (p.Cin == 128)
+        if (p.Cin == 128)
             HP_LAUNCH((conv3x3_direct_kernel<128, 16>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
-        else if (th == 8)
-            HP_LAUNCH((conv3x3_direct_kernel<64, 8>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
         else
             HP_LAUNCH((conv3x3_direct_kernel<64, 16>), grid, dim3(256), 0, s, p, tiles_x, tiles_y);
         return hipGetLastError();
     }
-    if (use_halo(p)) {
-        // tuning knob: HP_HALO_KG=2 selects the 8-wave split-K form, HP_HALO_BK=128 one K-step per tap (CIN=128 only)
-        static const int kg = getenv("HP_HALO_KG") ? atoi(getenv("HP_HALO_KG")) : 1;
-        static const int bk = getenv("HP_HALO_BK") ? atoi(getenv("HP_HALO_BK")) : 64;
-        const int v = halo_variant(p);
-        if (p.Cin == 64) {
-            if (kg == 2)
-                return v ? launch_halo<64, 64, 16, 12, 2, 64>(p, s) : launch_halo<64, 128, 8, 16, 2, 64>(p, s);
-            return v ? launch_halo<64, 64, 16, 12, 1, 64>(p, s) : launch_halo<64, 128, 8, 16, 1, 64>(p, s);
-        }
-        if (kg == 2 && bk == 128)
-            return v ? launch_halo<128, 64, 16, 12, 2, 128>(p, s) : launch_halo<128, 128, 8, 16, 2, 128>(p, s);
-        if (kg == 2)
-            return v ? launch_halo<128, 64, 16, 12, 2, 64>(p, s) : launch_halo<128, 128, 8, 16, 2, 64>(p, s);
-        return v ? launch_halo<128, 64, 16, 12, 1, 64>(p, s) : launch_halo<128, 128, 8, 16, 1, 64>(p, s);
-    }
     const int t = conv_mfma_tile(p);
     const int BM = t / 1000, BN = t % 1000;
     const bool k64 = (p.Cin % 64 == 0);
-    if (BM == 128 && BN == 320)
-        return launch_tile<128, 320, 32>(p, s);
     if (BM == 128 && BN == 128)
         return k64 ? launch_tile<128, 128, 64>(p, s) : launch_tile<128, 128, 32>(p, s);
     if (BM == 128 && BN == 64)
@@ -1873,276 +1530,6 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const first_conv_params
             for (int r = 0; r < 8; ++r)
                 if (g * 8 + r < p.Cout)
                     reinterpret_cast<_Float16*>(op)[r] = h[r];
-        }
-    }
-}
-
-// The common first layer - 3 x 3 taps, stride 1 or 2, <= 64 output channels in multiples of 8 - on the fp32 matrix pipe.
-// A block owns 8 rows x 32 columns of output pixels: (1) its input patch is converted ONCE (src/data.cpp:48's scaling,
-// mean / std, zero outside the image = the convolution's padding) into fp32 in LDS - the scalar kernel converts every input
-// value 9 x (taps) x Cout/8 (threads per pixel) times; (2) each wavefront computes rows of 32 pixels as
-// D[32 ch][32 px] = bias + W[32][28] x X[28][32 px] with v_mfma_f32_32x32x2f32 (k = (ky*3 + kx)*3 + c, 14 steps of 2, the
-// weights in 14 registers per lane, the im2col operand one ds_read_b32 per step); (3) the two half-wavefronts swap
-// 4-channel groups so that every lane stores 16-byte NHWC pieces.  All arithmetic stays fp32; the MFMA accumulates k in
-// order, so results differ from first_conv_kernel's fmaf chain in the last bit only (below the fp16 rounding of the store).
-template <int MT, int S, bool CLAMP> // CLAMP: the activation is none / relu / relu6 = one v_med3_f32 against [lo, hi]
-__global__ __launch_bounds__(256) void first_conv_mfma_kernel(const first_conv_params p, int tiles_x, int tiles_y, float lo, float hi)
-{
-    constexpr int TH = 8, TW = 32, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, IWC = IW * 3;
-    __shared__ float s_x[IH * IWC];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y, b = t / tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
-
-    // weights / bias of this lane (requested first: their latency hides behind the patch conversion)
-    float wa[MT][14], bs[MT][16];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int co = mt * 32 + col;
-#pragma unroll
-        for (int s2 = 0; s2 < 14; ++s2) {
-            const int k = 2 * s2 + hh;
-            wa[mt][s2] = (k < 27 && co < p.Cout) ? p.w[(size_t)co * 27 + k] : 0.f;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { // accumulator registers 4g .. 4g+3 = channels mt*32 + 8g + 4hh + (0..3)
-            const int ch = mt * 32 + 8 * g + 4 * hh;
-            const float4 bv = ch + 3 < p.Cout ? *reinterpret_cast<const float4*>(p.bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bs[mt][4 * g] = bv.x, bs[mt][4 * g + 1] = bv.y, bs[mt][4 * g + 2] = bv.z, bs[mt][4 * g + 3] = bv.w;
-        }
-    }
-    // (1) the patch: all loads first (clamped addresses, one memory round trip), then the conversions and the LDS stores
-    {
-        constexpr int NIT = (IH * IW + 255) / 256;
-        float raw[NIT][3];
-        bool ok[NIT];
-        const int c0 = p.flip_rb ? 2 : 0, c2 = p.flip_rb ? 0 : 2;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = min(tid + it * 256, IH * IW - 1);
-            const int py = i / IW, px = i - py * IW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            ok[it] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-            if (p.in_u8) {
-                const uint8_t* q = p.in_u8 + (((size_t)b * p.H + cy) * p.W + cx) * 3;
-                raw[it][0] = (float)q[c0], raw[it][1] = (float)q[1], raw[it][2] = (float)q[c2]; // exact: 0 .. 255
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    raw[it][c] = p.in_f32[(((size_t)b * 3 + c) * p.H + cy) * p.W + cx];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            if (i < IH * IW) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float x = p.in_u8 ? (float)((double)raw[it][c] * p.factor) : raw[it][c]; // src/data.cpp:48
-                    s_x[i * 3 + c] = ok[it] ? (x - p.mean[c]) * p.inv_std[c] : 0.f;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // (2) two rows of 32 pixels per wavefront
-    const unsigned hmask = hh ? 0xffffffffu : 0u;
-#pragma unroll 1
-    for (int rr = 0; rr < TH / 4; ++rr) {
-        const int row = wave * (TH / 4) + rr, oy = oy0 + row, ox = ox0 + col;
-        if (oy >= p.OH) // uniform per wavefront
-            break;
-        const float* xb = s_x + (row * S) * IWC + (col * S) * 3;
-        float xv[14];
-#pragma unroll
-        for (int s2 = 0; s2 < 14; ++s2) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int k0 = 2 * s2, k1 = min(2 * s2 + 1, 26);
-            const int o0 = (k0 / 9) * IWC + ((k0 / 3) % 3) * 3 + k0 % 3, o1 = (k1 / 9) * IWC + ((k1 / 3) % 3) * 3 + k1 % 3;
-            const float x = xb[hh ? o1 : o0];
-            xv[s2] = (2 * s2 + hh < 27) ? x : 0.f;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt * 32 >= p.Cout)
-                break;
-            floatx16 d;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                d[r] = bs[mt][r];
-#pragma unroll
-            for (int s2 = 0; s2 < 14; ++s2)
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[mt][s2], xv[s2], d, 0, 0, 0);
-            // (3) d[4g + e] = channel mt*32 + 8g + 4hh + e of pixel `col`.  Half 0 keeps groups 0, 1 and half 1 groups 2, 3:
-            // each sends the other its two foreign groups and ends with 8 consecutive channels per group.
-            unsigned mine[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float v0 = d[4 * g + 2 * e], v1 = d[4 * g + 2 * e + 1];
-                    const _Float16 h0 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v0, lo, hi) : apply_act(v0, p.act, p.act_param, 0.f));
-                    const _Float16 h1 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v1, lo, hi) : apply_act(v1, p.act, p.act_param, 0.f));
-                    unsigned short ul, uh;
-                    __builtin_memcpy(&ul, &h0, 2), __builtin_memcpy(&uh, &h1, 2);
-                    mine[g][e] = (unsigned)ul | ((unsigned)uh << 16);
-                }
-            unsigned got[2][2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    got[q][e] = (unsigned)__shfl_xor((int)((mine[q][e] & hmask) | (mine[2 + q][e] & ~hmask)), 32); // (a ?: on array elements becomes a scratch round trip)
-            if (ox < p.OW) {
-                __half* const op = p.out.p + tv_off(p.out, b, oy, ox) + mt * 32;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int g = 2 * hh + q; // the group this lane stores
-                    u32x4 v;
-                    v[0] = (got[q][0] & hmask) | (mine[q][0] & ~hmask), v[1] = (got[q][1] & hmask) | (mine[q][1] & ~hmask);
-                    v[2] = (mine[2 + q][0] & hmask) | (got[q][0] & ~hmask), v[3] = (mine[2 + q][1] & hmask) | (got[q][1] & ~hmask);
-                    if (mt * 32 + 8 * g < p.Cout)
-                        *reinterpret_cast<u32x4*>(op + 8 * g) = v;
-                }
-            }
-        }
-    }
-}
-
-// The same for the 7 x 7 / stride 2 first layer of the ResNet-50 backbones (hyperpose/Model/backbones.py:587-697; 27 % of the
-// PoseProposal configuration's conv time in its scalar form): K = 7*7*3 = 147 -> 74 steps of v_mfma_f32_32x32x2f32.  The weights do not
-// fit the registers any more (148 per 32-channel tile): they sit in LDS as [64 channels][149] (odd pitch: the 32 lanes of a ds_read_b32
-// group - 32 channels, one k - hit 32 different banks), the im2col operand comes from the fp32 patch as before.
-template <int MT, int S, bool CLAMP>
-__global__ __launch_bounds__(256) void first_conv7_mfma_kernel(const first_conv_params p, int tiles_x, int tiles_y, float lo, float hi)
-{
-    constexpr int KS = 7, K = KS * KS * 3, STEPS = (K + 1) / 2, WP = 149;
-    constexpr int TH = 8, TW = 32, IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS, IWC = IW * 3;
-    __shared__ float s_x[IH * IWC];
-    __shared__ float s_w[MT * 32 * WP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y, b = t / tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
-
-    for (int i = tid; i < MT * 32 * (K + 1); i += 256) { // [co][k], k = (ky * 7 + kx) * 3 + c = the blob's order; k = 147 is the zero pad
-        const int co = i / (K + 1), k = i - co * (K + 1);
-        s_w[co * WP + k] = (k < K && co < p.Cout) ? p.w[(size_t)co * K + k] : 0.f;
-    }
-    float bs[MT][16];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch = mt * 32 + 8 * g + 4 * hh;
-            const float4 bv = ch + 3 < p.Cout ? *reinterpret_cast<const float4*>(p.bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bs[mt][4 * g] = bv.x, bs[mt][4 * g + 1] = bv.y, bs[mt][4 * g + 2] = bv.z, bs[mt][4 * g + 3] = bv.w;
-        }
-    { // the patch: all loads first (clamped addresses, one memory round trip), then the conversions and the LDS stores
-        constexpr int NIT = (IH * IW + 255) / 256;
-        float raw[NIT][3];
-        bool ok[NIT];
-        const int c0 = p.flip_rb ? 2 : 0, c2 = p.flip_rb ? 0 : 2;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = min(tid + it * 256, IH * IW - 1);
-            const int py = i / IW, px = i - py * IW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            ok[it] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-            if (p.in_u8) {
-                const uint8_t* q = p.in_u8 + (((size_t)b * p.H + cy) * p.W + cx) * 3;
-                raw[it][0] = (float)q[c0], raw[it][1] = (float)q[1], raw[it][2] = (float)q[c2];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    raw[it][c] = p.in_f32[(((size_t)b * 3 + c) * p.H + cy) * p.W + cx];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            if (i < IH * IW) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float x = p.in_u8 ? (float)((double)raw[it][c] * p.factor) : raw[it][c]; // src/data.cpp:48
-                    s_x[i * 3 + c] = ok[it] ? (x - p.mean[c]) * p.inv_std[c] : 0.f;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    const unsigned hmask = hh ? 0xffffffffu : 0u;
-#pragma unroll 1
-    for (int rr = 0; rr < TH / 4; ++rr) {
-        const int row = wave * (TH / 4) + rr, oy = oy0 + row, ox = ox0 + col;
-        if (oy >= p.OH) // uniform per wavefront
-            break;
-        const float* xb = s_x + (row * S) * IWC + (col * S) * 3;
-        floatx16 d[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                d[mt][r] = bs[mt][r];
-        const float* wl = s_w + col * WP + hh;
-#pragma unroll
-        for (int s2 = 0; s2 < STEPS; ++s2) {
-            constexpr int ROWK = KS * 3;
-            const int k0 = 2 * s2, k1 = min(2 * s2 + 1, K - 1);
-            const int o0 = (k0 / ROWK) * IWC + k0 % ROWK, o1 = (k1 / ROWK) * IWC + k1 % ROWK; // compile-time after unrolling
-            float x = xb[hh ? o1 : o0];
-            if (2 * s2 + 1 >= K) // the pad step: the odd half multiplies the zero weight by a finite value
-                x = hh ? 0.f : x;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                d[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[mt * 32 * WP + 2 * s2], x, d[mt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt * 32 >= p.Cout)
-                break;
-            unsigned mine[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float v0 = d[mt][4 * g + 2 * e], v1 = d[mt][4 * g + 2 * e + 1];
-                    const _Float16 h0 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v0, lo, hi) : apply_act(v0, p.act, p.act_param, 0.f));
-                    const _Float16 h1 = (_Float16)(CLAMP ? __builtin_amdgcn_fmed3f(v1, lo, hi) : apply_act(v1, p.act, p.act_param, 0.f));
-                    unsigned short ul, uh;
-                    __builtin_memcpy(&ul, &h0, 2), __builtin_memcpy(&uh, &h1, 2);
-                    mine[g][e] = (unsigned)ul | ((unsigned)uh << 16);
-                }
-            unsigned got[2][2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    got[q][e] = (unsigned)__shfl_xor((int)((mine[q][e] & hmask) | (mine[2 + q][e] & ~hmask)), 32);
-            if (ox < p.OW) {
-                __half* const op = p.out.p + tv_off(p.out, b, oy, ox) + mt * 32;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int g = 2 * hh + q;
-                    u32x4 v;
-                    v[0] = (got[q][0] & hmask) | (mine[q][0] & ~hmask), v[1] = (got[q][1] & hmask) | (mine[q][1] & ~hmask);
-                    v[2] = (mine[2 + q][0] & hmask) | (got[q][0] & ~hmask), v[3] = (mine[2 + q][1] & hmask) | (got[q][1] & ~hmask);
-                    if (mt * 32 + 8 * g < p.Cout)
-                        *reinterpret_cast<u32x4*>(op + 8 * g) = v;
-                }
-            }
         }
     }
 }
@@ -2383,8 +1770,7 @@ __global__ __launch_bounds__(256) void first_conv_f16_kernel(const first_conv_pa
 
 hipError_t launch_first_conv(const first_conv_params& p, hipStream_t s)
 {
-    const bool no_f16 = getenv("HP_FIRST_F16") && atoi(getenv("HP_FIRST_F16")) == 0;
-    if (!no_f16 && p.w16 && p.KH == p.KW && (p.KH == 3 || p.KH == 7) && (p.stride == 1 || p.stride == 2) && p.Cout % 8 == 0 && p.Cout <= 64
+    if (p.w16 && p.KH == p.KW && (p.KH == 3 || p.KH == 7) && (p.stride == 1 || p.stride == 2) && p.Cout % 8 == 0 && p.Cout <= 64
         && p.out.coff % 8 == 0 && p.out.cs % 8 == 0) {
         const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 15) / 16;
         const dim3 grid(tiles_x * tiles_y * p.B);
@@ -2418,58 +1804,6 @@ hipError_t launch_first_conv(const first_conv_params& p, hipStream_t s)
         return hipGetLastError();
     }
 
-    const bool no_mfma = getenv("HP_FIRST_MFMA") && atoi(getenv("HP_FIRST_MFMA")) == 0;
-    if (!no_mfma && p.KH == 3 && p.KW == 3 && (p.stride == 1 || p.stride == 2) && p.Cout % 8 == 0 && p.Cout <= 64 && p.out.coff % 8 == 0
-        && p.out.cs % 8 == 0) {
-        const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
-        const dim3 grid(tiles_x * tiles_y * p.B);
-        const bool clamp = p.act == ACT_NONE || p.act == ACT_RELU || p.act == ACT_RELU6;
-        const float lo = p.act == ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = p.act == ACT_RELU6 ? 6.f : __builtin_huge_valf();
-        const int mt = p.Cout <= 32 ? 1 : 2;
-#define HP_FC(MT_, S_, C_) HP_LAUNCH((first_conv_mfma_kernel<MT_, S_, C_>), grid, dim3(256), 0, s, p, tiles_x, tiles_y, lo, hi)
-#define HP_FC2(MT_, S_)        \
-    do {                       \
-        if (clamp)             \
-            HP_FC(MT_, S_, true);  \
-        else                   \
-            HP_FC(MT_, S_, false); \
-    } while (0)
-        if (mt == 1 && p.stride == 2)
-            HP_FC2(1, 2);
-        else if (mt == 1)
-            HP_FC2(1, 1);
-        else if (p.stride == 2)
-            HP_FC2(2, 2);
-        else
-            HP_FC2(2, 1);
-#undef HP_FC2
-#undef HP_FC
-        return hipGetLastError();
-    }
-    if (!no_mfma && p.KH == 7 && p.KW == 7 && (p.stride == 1 || p.stride == 2) && p.Cout % 8 == 0 && p.Cout <= 64 && p.out.coff % 8 == 0
-        && p.out.cs % 8 == 0) {
-        const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
-        const dim3 grid(tiles_x * tiles_y * p.B);
-        const bool clamp = p.act == ACT_NONE || p.act == ACT_RELU || p.act == ACT_RELU6;
-        const float lo = p.act == ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = p.act == ACT_RELU6 ? 6.f : __builtin_huge_valf();
-#define HP_FC7(MT_, S_)                                                                                           \
-    do {                                                                                                          \
-        if (clamp)                                                                                                \
-            HP_LAUNCH((first_conv7_mfma_kernel<MT_, S_, true>), grid, dim3(256), 0, s, p, tiles_x, tiles_y, lo, hi);  \
-        else                                                                                                      \
-            HP_LAUNCH((first_conv7_mfma_kernel<MT_, S_, false>), grid, dim3(256), 0, s, p, tiles_x, tiles_y, lo, hi); \
-    } while (0)
-        if (p.Cout <= 32 && p.stride == 2)
-            HP_FC7(1, 2);
-        else if (p.Cout <= 32)
-            HP_FC7(1, 1);
-        else if (p.stride == 2)
-            HP_FC7(2, 2);
-        else
-            HP_FC7(2, 1);
-#undef HP_FC7
-        return hipGetLastError();
-    }
     const int G = (p.Cout + 7) / 8;
     if (G > 256)
         return hipErrorInvalidValue;
@@ -2643,277 +1977,18 @@ hipError_t launch_dwconv3x3(const dw_params& p_in, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Depthwise 3x3 + pointwise 1x1 in ONE launch (MobileNet's separable block, backbones.py MobilenetDilated): the
-// depthwise output never exists in HBM.  Every kernel boundary on this chip sends the whole activation through the
-// memory-side fabric (the per-XCD L2s are not coherent with each other), so the unfused pair writes and re-reads
-// B*H*W*C halves for nothing and pays the depthwise kernel's own launch.
-//   block  = one (image, TH x TW output-pixel tile) x ALL output channels; 4 wavefronts split the output channels
-//            (Cout_pad / 4 rows each = TM 32-row MFMA tiles), every wavefront covers all NT = TH*TW/32 pixel tiles.
-//   K loop = chunks of CK input channels: the chunk's input halo tile goes global -> registers -> LDS (prefetched one
-//            chunk ahead), the 256 threads evaluate the depthwise taps from LDS with the same arithmetic as
-//            dwconv3x3_kernel (bias first, fp32 v_fma_mix accumulation tap by tap, activation, RN to fp16) and drop the
-//            result into the swizzled B tile; the pointwise MFMAs read B from LDS and A straight from global memory:
-//            the 1x1 weights are packed in MFMA-fragment order [32-row tile][k16 step][lane][8 halves], so one
-//            wavefront-wide 16-byte load is one fully coalesced 1 KB fragment that only this wavefront needs - no
-//            LDS staging, no barrier for A, re-issued for the next chunk as soon as its MFMAs are done.
-//   epilogue = conv_epilogue_staged (bias, activation, 16-byte NHWC stores, 64 * TM bytes contiguous per pixel).
-template <int TM, int NT, int TH, int TW, int S, int D, int CK, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void sepconv_kernel(const sep_params p, int tiles_x, int tiles_y)
-{
-    // NW wavefronts split the output channels (32 * TM rows each).  NW = 8 (two wavefronts per SIMD covering each other's
-    // depthwise taps / LDS waits) and the two-slab TM = 2 form (two blocks per CU) were both tried: at <= 256 registers per
-    // lane the accumulators + weight prefetch + depthwise working set spill (300-490 B of scratch), so the kernel stays at
-    // one wavefront per SIMD and, consequently, alone on its CU
-    constexpr int NTHR = 64 * NW;
-    constexpr int NPX = TH * TW;
-    static_assert(NPX == NT * 32, "pixel tile = NT MFMA tiles");
-    constexpr int IH = (TH - 1) * S + 2 * D + 1, IW = (TW - 1) * S + 2 * D + 1;
-    constexpr int CG = CK / 8;                       // 16-byte channel groups per pixel and chunk
-    constexpr int PIECES = IH * IW * CG;             // 16-byte pieces of one halo chunk
-    constexpr int NLD = (PIECES + NTHR - 1) / NTHR;
-    constexpr int ITEMS = (NPX * CG + NTHR - 1) / NTHR; // (pixel, channel group) depthwise items per thread and chunk
-    constexpr bool RAGGED = NPX * CG % NTHR != 0;       // the last item of the upper threads does not exist
-    constexpr int KS = CK / 16;                      // k16 steps per chunk
-    constexpr int HALO_BYTES = PIECES * 16;
-    constexpr int B_BYTES = NPX * CK * 2;
-    constexpr int DWW_BYTES = 9 * SEP_CMAX * 2 + SEP_CMAX * 4;
-    constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * B_BYTES + DWW_BYTES;
-    constexpr int EPI_BYTES = NW * stage_geom<TM>::SLAB;
-    constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    unsigned char* const s_halo = lds; // two buffers: chunk k lives in buffer k & 1
-    unsigned char* const s_b = lds + 2 * HALO_BYTES;
-    __half* const s_dww = reinterpret_cast<__half*>(lds + 2 * HALO_BYTES + 2 * B_BYTES); // [9][C]
-    float* const s_dwb = reinterpret_cast<float*>(s_dww + 9 * SEP_CMAX);              // [C]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y, b = t / tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const int iy0 = y0 * S - p.pad_t, ix0 = x0 * S - p.pad_l;
-    const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1; // extent of the zero halo in HBM
-    const int C = p.C, KQ = C / 16, NCH = C / CK;
-
-    // ---- pointwise weights of chunk 0: a[ks][i] = fragment (32-row tile wave*TM + i, k16 step ks)
-    const int mt0 = (blockIdx.y * NW + wave) * TM; // first 32-row tile of this wavefront (blockIdx.y: slab of 128 * TM output channels)
-    const __half* wfrag = p.pw.w + ((size_t)mt0 * KQ * 64 + lane) * 8;
-    u32x4 a[KS][TM];
-#define HP_ALOAD(KSI, CHUNK)                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                \
-        a[KSI][i] = *reinterpret_cast<const u32x4*>(wfrag + ((size_t)i * KQ + (CHUNK) * KS + (KSI)) * 512);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        HP_ALOAD(ks, 0);
-
-    // ---- halo chunk loader (registers)
-    u32x4 hv[NLD];
-    const __half* hsrc[NLD]; // this thread's halo pieces: address of chunk 0 and the out-of-tensor mask, fixed for the kernel
-    unsigned hmask[NLD];
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int i = min(tid + k * NTHR, PIECES - 1);
-        const int hp = i / CG, c = i - hp * CG;
-        const int hy = hp / IW, hx = hp - hy * IW;
-        const int y = iy0 + hy, x = ix0 + hx;
-        hmask[k] = (y <= ymax && x <= xmax) ? 0xffffffffu : 0u;
-        hsrc[k] = p.in.p + tv_off(p.in, b, min(y, ymax), min(x, xmax)) + c * 8;
-    }
-#define HP_HLOAD(CHUNK)                                                                                           \
-    _Pragma("unroll") for (int k = 0; k < NLD; ++k)                                                               \
-        hv[k] = *reinterpret_cast<const u32x4*>(hsrc[k] + (CHUNK) * CK);
-    HP_HLOAD(0);
-    int dbg_i = 0;
-#define HP_STAMP()                                                                                                \
-    if (p.pw.dbg && blockIdx.x == 0 && tid == 0)                                                                  \
-        p.pw.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
-    HP_STAMP();
-
-    // depthwise weights + bias -> LDS (once)
-    for (int i = tid; i < 9 * C / 8; i += NTHR)
-        reinterpret_cast<u32x4*>(s_dww)[i] = reinterpret_cast<const u32x4*>(p.dw_w)[i];
-    for (int i = tid; i < C / 4; i += NTHR)
-        reinterpret_cast<float4*>(s_dwb)[i] = reinterpret_cast<const float4*>(p.dw_bias)[i];
-
-    floatx16 acc[TM][NT];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[i][j][r] = 0.f;
-
-    const int g = tid % CG;          // this thread's channel group inside the chunk
-    const int frow = lane & 31, fk = lane >> 5;
-    const float dw_hi = p.dw_hi;
-    // tile-local LDS offsets of this thread's depthwise items (tap (0,0) of the halo tile; B-tile slot)
-    int xoff[ITEMS], boff[ITEMS];
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-        const int pix = min(tid + r * NTHR, NPX * CG - 1) / CG;
-        const int py = pix / TW, px = pix - py * TW;
-        xoff[r] = ((py * S) * IW + px * S) * CG * 16 + g * 16;
-        boff[r] = lds_off<CK>(pix, g);
-    }
-
-    // One schedule "slot" = one depthwise unit (a tap = 8 v_fma_mix, or an item's activation + B-tile write) followed by
-    // its share of the chunk's MFMAs: the units of chunk kc+1 sit in the shadows of the MFMAs of chunk kc (a wave
-    // issues in order: the VALU work has to be BETWEEN the MFMAs in program order, cdna_hip_programming.md T19).
-    // sched_barrier(0) pins the order.  An item's nine inputs are re-loaded tap by tap for the NEXT item as soon as the
-    // current one has used them, so the LDS latency has a whole item to hide in.
-    constexpr int NM = KS * TM * NT; // MFMAs per chunk and wave
-    constexpr int NU = ITEMS * 10;   // depthwise units per chunk and thread: 9 taps + 1 finish per item
-    u32x4 wv[9], x[9];
-    float v[8];
-    half8 fb[2][NT];
-    // DW: emit the depthwise units of chunk `kd` into B buffer kd & 1;  MM: emit the MFMAs of chunk `km` (B buffer km & 1)
-    // (the depthwise activation is relu / relu6 here, one v_med3_f32: a second code path for the general piecewise-linear
-    // form would duplicate the MFMA schedule and hipcc then spills the accumulators at the join)
-    auto phase = [&](auto dw_tag, auto mm_tag, int kd, int km, int kn) {
-        constexpr bool DW = decltype(dw_tag)::value, MM = decltype(mm_tag)::value;
-        unsigned char* const bt_d = s_b + (kd & 1) * B_BYTES;
-        const unsigned char* const hl = s_halo + (kd & 1) * HALO_BYTES;
-        const unsigned char* const bt_m = s_b + (km & 1) * B_BYTES;
-        const int cg0 = kd * CK + g * 8;
-        float4 b0, b1;
-        if (DW) {
-            b0 = *reinterpret_cast<const float4*>(s_dwb + cg0), b1 = *reinterpret_cast<const float4*>(s_dwb + cg0 + 4);
-#pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9)
-                wv[t9] = *reinterpret_cast<const u32x4*>(s_dww + (size_t)t9 * C + cg0);
-#pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9)
-                x[t9] = *reinterpret_cast<const u32x4*>(hl + xoff[0] + (((t9 / 3) * D) * IW + (t9 % 3) * D) * CG * 16);
-        }
-        if (MM) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                fb[0][j] = *reinterpret_cast<const half8*>(bt_m + lds_off<CK>(j * 32 + frow, fk));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int SLOTS = DW ? NU : 1;
-#pragma unroll
-        for (int u = 0; u < SLOTS; ++u) {
-            if (DW) {
-                const int r = u / 10, q = u % 10;
-                if (q == 0) {
-                    v[0] = b0.x, v[1] = b0.y, v[2] = b0.z, v[3] = b0.w, v[4] = b1.x, v[5] = b1.y, v[6] = b1.z, v[7] = b1.w;
-                }
-                if (q < 9) {
-                    mac8_f16(v, x[q], wv[q]);
-                    if (r + 1 < ITEMS)
-                        x[q] = *reinterpret_cast<const u32x4*>(hl + xoff[r + 1] + (((q / 3) * D) * IW + (q % 3) * D) * CG * 16);
-                } else {
-                    half8 h;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        h[e] = (_Float16)dw_act<true>(v[e], 0.f, dw_hi);
-                    if (!RAGGED || r + 1 < ITEMS || tid + r * NTHR < NPX * CG)
-                        *reinterpret_cast<half8*>(bt_d + boff[r]) = h;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (MM) {
-                // constant trip count + predicate: hipcc unrolls inner loops first, variable bounds would leave a real loop
-                // (and the register arrays in scratch)
-                constexpr int PER = DW ? (NM + NU - 1) / NU : NM;
-                const int m_lo = DW ? u * NM / NU : 0, m_hi = DW ? (u + 1) * NM / NU : NM;
-#pragma unroll
-                for (int mm = 0; mm < PER; ++mm) {
-                    const int m = m_lo + mm;
-                    if (m >= m_hi)
-                        continue;
-                    const int ks = m / (TM * NT), idx = m % (TM * NT), i = idx / NT, j = idx % NT;
-                    if (idx == 0 && ks + 1 < KS) {
-#pragma unroll
-                        for (int jj = 0; jj < NT; ++jj)
-                            fb[(ks + 1) & 1][jj] = *reinterpret_cast<const half8*>(bt_m + lds_off<CK>(jj * 32 + frow, (ks + 1) * 2 + fk));
-                    }
-                    half8 fa;
-                    __builtin_memcpy(&fa, &a[ks][i], 16);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[i][j], 0, 0, 0);
-                    if (idx == TM * NT - 1) {
-#pragma unroll
-                        for (int ii = 0; ii < TM; ++ii)
-                            a[ks][ii] = *reinterpret_cast<const u32x4*>(wfrag + ((size_t)ii * KQ + kn * KS + ks) * 512);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    auto halo_to_lds = [&](int chunk) {
-        unsigned char* const dst = s_halo + (chunk & 1) * HALO_BYTES;
-#pragma unroll
-        for (int k = 0; k < NLD; ++k)
-            if (tid + k * NTHR < PIECES)
-                *reinterpret_cast<u32x4*>(dst + (size_t)(tid + k * NTHR) * 16) = hv[k] & hmask[k]; // mask HERE: the loads stay in flight
-    };
-
-    // ---- chunk 0: halo -> LDS, depthwise -> B[0]; chunk 1's halo lands meanwhile
-    halo_to_lds(0);
-    {
-        const int k1 = min(1, NCH - 1);
-        HP_HLOAD(k1);
-    }
-    lds_barrier(); // halo chunk 0 and the depthwise weights visible
-    HP_STAMP();
-    phase(std::true_type{}, std::false_type{}, 0, 0, 0);
-    halo_to_lds(1);
-    HP_STAMP();
-    // ---- steady state, ONE barrier per chunk: depthwise of chunk kc+1 under the MFMAs of chunk kc, then the halo of
-    // chunk kc+2 (requested at the top of the iteration) goes into the buffer chunk kc vacated
-    for (int kc = 0; kc + 1 < NCH; ++kc) {
-        lds_barrier(); // B[kc&1] and halo[(kc+1)&1] complete; B[(kc+1)&1] and halo[kc&1] free
-        HP_STAMP();
-        const int k2 = min(kc + 2, NCH - 1); // unconditional prefetches (the last is redundant): straight-line code lets hipcc
-        HP_HLOAD(k2);                        // count vmcnt exactly instead of draining at every control-flow join
-        __builtin_amdgcn_sched_barrier(0);
-        phase(std::true_type{}, std::true_type{}, kc + 1, kc, kc + 1);
-        HP_STAMP();
-        halo_to_lds(kc + 2);
-        HP_STAMP();
-    }
-    // ---- last chunk: MFMAs only
-    lds_barrier();
-    phase(std::false_type{}, std::true_type{}, 0, NCH - 1, NCH - 1);
-    HP_STAMP();
-#undef HP_STAMP
-#undef HP_ALOAD
-#undef HP_HLOAD
-
-    int pb[NT], py[NT], px[NT];
-    bool pv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = j * 32 + (lane & 31);
-        pb[j] = b;
-        py[j] = y0 + n / TW;
-        px[j] = x0 + n % TW;
-        pv[j] = py[j] < p.OH && px[j] < p.OW;
-    }
-    __syncthreads(); // every wave is done with the main-loop LDS before the slabs overwrite it
-    conv_epilogue_staged<TM, NT>(p.pw, acc, mt0 * 32, lane, lds + wave * stage_geom<TM>::SLAB, pb, py, px, pv);
-}
-
-template <int TM, int NT, int TH, int TW, int S, int D, int CK, int NW = 4>
-static hipError_t launch_sep(const sep_params& p, hipStream_t s)
-{
-    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
-    // blockIdx.y: slabs of 128 * TM output channels; each slab recomputes the depthwise tile (cheap next to a second
-    // pass through the fabric) and two slabs of one CU cover each other's depthwise / MFMA / store phases
-    HP_LAUNCH((sepconv_kernel<TM, NT, TH, TW, S, D, CK, NW>), dim3(tiles_x * tiles_y * p.B, p.pw.Cout_pad / (32 * NW * TM)), dim3(64 * NW), 0, s, p, tiles_x, tiles_y);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------
+// Depthwise 3x3 + pointwise 1x1 in ONE launch (MobileNet's separable block, backbones.py MobilenetDilated): the depthwise output
+// never exists in HBM.  Every kernel boundary on this chip sends the whole activation through the memory-side fabric (the per-XCD
+// L2s are not coherent with each other), so the unfused pair writes and re-reads B*H*W*C halves for nothing and pays the depthwise
+// kernel's own launch.  Two forms below: sepconv_slot_kernel (64 .. 512 channels in 64-channel K chunks) and sepconv_small_kernel
+// (32 .. 128 channels, all of them in LDS at once); the depthwise arithmetic is dwconv3x3_kernel's (bias first, fp32 v_fma_mix
+// accumulation tap by tap, activation, RN to fp16) and the pointwise K order the un-fused convolution's, so the fused and the
+// un-fused schedule produce the same bits (tests).
 // The separable block cut to HALF a CU (<= 256 registers, < 80 KB of LDS) for 256 / 512 output channels at stride 1.
-// With two kernels in flight a CU is two slots; sepconv_kernel above (460 registers) holds both, so its whole duration
-// shows up end to end.  Same arithmetic, different cut, and deliberately plain code (rolled loops,
-// phases not interleaved) so that hipcc's register allocation stays small - the second block on the CU provides the
-// overlap that the in-wave interleave buys above:
+// With two kernels in flight a CU is two slots; a whole-CU form (one 8 x 12 tile x all output channels, depthwise taps interleaved
+// between the MFMAs, 460 registers: rounds 1-2) held both, so its whole duration showed up end to end.
+// Deliberately plain code (rolled loops, phases not interleaved) so that hipcc's register allocation stays small - the second
+// block on the CU provides the overlap:
 //   * 8 x 8 output pixels per block; the depthwise results of ALL K chunks stay in LDS (B_all: 64 px x C halves <= 64 KB);
 //   * output channels in NP passes of 4 wavefronts x TP row tiles (128 or 256): pass 0 = per chunk depthwise -> B_all, then
 //     its MFMAs; pass 1 = MFMAs only, straight out of B_all, no barrier.  <= 64 accumulator registers, nothing recomputed;
@@ -3284,22 +2359,21 @@ static hipError_t launch_sep_small(const sep_params& p, hipStream_t s)
 }
 
 // which instantiation serves (Cout_pad, stride, dilation, C); 0 = none (the engine then keeps the two launches)
+// which fused instance serves a block (0 = none: the caller keeps dwconv3x3 + a 1x1 convolution)
 int sepconv_variant_for(int C, int cout_pad, int stride, int dil, int cout)
 {
     if (C > SEP_CMAX || C % 32 || cout_pad % 128)
         return 0;
     if (C == 32 && cout > 0 && cout <= 64 && stride == 1 && dil == 1)
         return 7; // sepconv_small_kernel<32, 1, 2>
-    const int tm = cout_pad / 128;
-    if (tm == 1 && stride == 1 && dil == 1)
-        return 1;
-    if (tm == 1 && stride == 2 && dil == 1)
-        return 2;
     if (C % 64)
         return 0;
-    if (tm == 2 && stride == 2 && dil == 1)
+    const int tm = cout_pad / 128;
+    if (tm == 1 && C <= 128 && dil == 1 && (stride == 1 || stride == 2))
+        return stride; // 1 / 2: 128 output channels
+    if (tm == 2 && stride == 2 && dil == 1 && C <= 128)
         return 3;
-    if (tm == 2 && stride == 1 && dil == 1)
+    if (tm == 2 && stride == 1 && dil == 1 && C <= 256)
         return 4;
     if (tm == 4 && stride == 1 && dil == 1)
         return 5;
@@ -3318,12 +2392,9 @@ int sepconv_variant(const sep_params& p)
 
 hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 {
-    static const bool slot = !getenv("HP_SEP_SLOT") || atoi(getenv("HP_SEP_SLOT")) != 0; // HP_SEP_SLOT=0: whole-CU form everywhere
     const int v = sepconv_variant(p);
-    if (v == 7)
-        return launch_sep_small<32, 1, 2>(p, s);
-    static const int small_mask = getenv("HP_SEP_SMALL_MASK") ? atoi(getenv("HP_SEP_SMALL_MASK")) : 0x6; // bit v: variant v as one all-channels block
-    if (slot && ((small_mask >> v) & 1) && p.pw.Cout <= 128) {
+    // <= 128 output channels at 64 / 128 input channels: ONE block of all channels (sepconv_small_kernel)
+    if (p.pw.Cout <= 128) {
         if (v == 1 && p.C == 128)
             return launch_sep_small<128, 1, 4>(p, s);
         if (v == 1 && p.C == 64)
@@ -3331,44 +2402,21 @@ hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
         if (v == 2 && p.C == 64)
             return launch_sep_small<64, 2, 4>(p, s);
     }
-    static const int slot_mask = getenv("HP_SEP_SLOT_MASK") ? atoi(getenv("HP_SEP_SLOT_MASK")) : 0x7e; // bit v: variant v in half-CU form
-    if (slot && ((slot_mask >> v) & 1) && p.C % 64 == 0) {
-        switch (v) { // <passes, row tiles per wavefront, stride, dilation, max channels, halo chunk>
-        case 1:
-            if (p.C <= 128)
-                return launch_sep_slot<1, 1, 1, 1, 128>(p, s);
-            break;
-        case 2:
-            if (p.C <= 128)
-                return launch_sep_slot<1, 1, 2, 1, 128>(p, s);
-            break;
-        case 3:
-            if (p.C <= 128)
-                return launch_sep_slot<2, 1, 2, 1, 128>(p, s); // (one pass of two row tiles spills next to the 17 x 17 halo prefetch)
-            break;
-        case 4:
-            if (p.C <= 256)
-                return launch_sep_slot<1, 2, 1, 1, 256>(p, s);
-            break;
-        case 5:
-            return launch_sep_slot<2, 2, 1, 1, 512>(p, s);
-        case 6:
-            return launch_sep_slot<2, 2, 1, 2, 512, 32>(p, s);
-        }
-    }
-    switch (v) {
+    switch (v) { // <passes, row tiles per wavefront, stride, dilation, max channels, halo chunk>
+    case 7:
+        return launch_sep_small<32, 1, 2>(p, s);
     case 1:
-        return launch_sep<1, 12, 16, 24, 1, 1, 32>(p, s);
+        return launch_sep_slot<1, 1, 1, 1, 128>(p, s);
     case 2:
-        return launch_sep<1, 6, 8, 24, 2, 1, 32>(p, s);
+        return launch_sep_slot<1, 1, 2, 1, 128>(p, s);
     case 3:
-        return launch_sep<2, 3, 8, 12, 2, 1, 64>(p, s);
+        return launch_sep_slot<2, 1, 2, 1, 128>(p, s); // (one pass of two row tiles spills next to the 17 x 17 halo prefetch)
     case 4:
-        return launch_sep<2, 3, 8, 12, 1, 1, 64>(p, s);
+        return launch_sep_slot<1, 2, 1, 1, 256>(p, s);
     case 5:
-        return launch_sep<4, 3, 8, 12, 1, 1, 64>(p, s);
+        return launch_sep_slot<2, 2, 1, 1, 512>(p, s);
     case 6:
-        return launch_sep<4, 3, 8, 12, 1, 2, 64>(p, s);
+        return launch_sep_slot<2, 2, 1, 2, 512, 32>(p, s);
     default:
         return hipErrorInvalidValue;
     }

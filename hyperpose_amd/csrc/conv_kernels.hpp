@@ -52,7 +52,6 @@ struct conv_params {
     float* out_f32; // fp32 NCHW [B][Cout][OH][OW]
     int npix;       // B*OH*OW
     unsigned long long* dbg; // optional s_memtime timeline of block 0 / wave 0 (tools/microbench), nullptr in production
-    int dbg_flags;           // scheduling experiments of conv_direct_kernel (HP_GDIRECT_PRIO), 0 in production
 };
 
 // fills act_slope / act_hi from act / act_param; false for activations the MFMA epilogue does not fuse
@@ -60,15 +59,13 @@ bool set_act(conv_params& p);
 // Dense k x k convolution as an implicit GEMM on MFMA (v_mfma_f32_32x32x16_f16).  Picks between the generic
 // implicit-GEMM kernel and the LDS-halo 3x3 kernel.  Returns hipError_t.
 hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s);
-// which kernel/tile the launcher picks (for reporting): BM*1000+BN for the generic kernel, 3000000+BM*1000+BN for
-// the 3x3 halo kernel
+// which kernel/tile the launcher picks (profile rows): BM*1000+BN for the generic implicit GEMM, 5064192 conv3x3_direct_kernel,
+// 51xxxxx conv1x1_small_kernel, 52xxxxx conv1x1_big_kernel<TM, NTP>, 6xxxxxx conv_direct_kernel
 int conv_mfma_tile(const conv_params& p);
 // Weight layout the launcher wants for this convolution (fill every other field of p first):
 //   0: [tap][Cout_pad][Cin] rows;   1: MFMA-fragment order for the barrier-free 3x3 kernel, half index
 //   ((((tap * (Cout_pad / 32) + m / 32) * (Cin / 16) + k / 16) * 64) + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8
 int conv_weight_layout(const conv_params& p);
-// tuning aid (tools/microbench): force the 3x3 halo tile variant (0: 128 ch x 8x16 px, 1: 64 ch x 16x12 px, -1: auto)
-void debug_force_halo_variant(int v);
 
 // set by hp_engine_profile_sequence around one step: the next launch records its own begin / end into these events
 extern thread_local hipEvent_t prof_start, prof_stop;

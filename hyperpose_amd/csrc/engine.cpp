@@ -253,7 +253,7 @@ int hp_engine::build(const hp_engine_desc* d)
                 continue;
             const int cout_pad = round_up(Bn.cout, 128);
             const int variant = hp::sepconv_variant_for(A.cin, cout_pad, A.stride, A.dil, Bn.cout);
-            if (!variant || (Bn.cout <= 64 && variant != 7) || (variant == 7 && getenv("HP_NO_FUSE_C32")))
+            if (!variant || (Bn.cout <= 64 && variant != 7))
                 continue; // (<= 64 output channels idle half of the general fused kernels' wavefronts - slower than two launches - except in the dedicated 32-channel form)
             fuse_with_next[i] = 1;
             tensors[A.out]->elided = true;
@@ -533,7 +533,6 @@ int hp_engine::build(const hp_engine_desc* d)
             p.out = to.view(L.out_coff);
             p.out_f32 = nullptr;
             p.dbg = nullptr;
-            p.dbg_flags = getenv("HP_GDIRECT_PRIO") ? atoi(getenv("HP_GDIRECT_PRIO")) : 0;
             for (auto& o : outputs)
                 if (o.fused_layer == (int)i)
                     p.out_f32 = o.buf->as<float>();

@@ -1355,7 +1355,7 @@ int hp_paf::shape(const int cs[3], const int ps[3])
     CW = hp::ceil_div(g.UW, strips);
     // (bands of ~40 rows: 18 halo rows are recomputed per band, but shorter bands are skipped more often - real maps are empty almost
     // everywhere - and 2.8 k wavefronts balance better over the 1024 SIMDs than 2.3 k: 56.6 -> 50.4 us per batch of 8 against 54-row bands)
-    const int band_rows = getenv("HP_PEAK_BAND") ? std::max(8, atoi(getenv("HP_PEAK_BAND"))) : 40;
+    const int band_rows = 40;
     bands = std::max(1, (g.UH + band_rows / 2) / band_rows);
     BH = hp::ceil_div(g.UH, bands);
     bands = hp::ceil_div(g.UH, BH);

@@ -97,8 +97,7 @@ def run(layers, outputs, weights: np.ndarray, frames_u8: np.ndarray = None, fram
                 groups = L.cin
             # the first layer: on the fp16 matrix pipe (normalised input and weights rounded to fp16, first_conv_f16_kernel) for the
             # common 3 x 3 / 7 x 7 stems with <= 64 output channels, all-fp32 otherwise
-            first_f16 = (first and L.op == OP_CONV and L.kh == L.kw and L.kh in (3, 7) and L.cout % 8 == 0 and L.cout <= 64 and L.stride in (1, 2)
-                         and os.environ.get("HP_FIRST_F16", "1") != "0")  # (the engine's A/B switch back to the fp32 matrix pipe)
+            first_f16 = first and L.op == OP_CONV and L.kh == L.kw and L.kh in (3, 7) and L.cout % 8 == 0 and L.cout <= 64 and L.stride in (1, 2)
             wt = _q(wt, match_fp16 and (not first or first_f16))
             if first_f16:
                 xp = _q(xp, match_fp16)

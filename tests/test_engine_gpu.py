@@ -120,15 +120,14 @@ def test_first_conv_u8_and_f32(hp):
     (1, 24, E.ACT_NONE, 19, 70, False, 3),   # stride 1, 24 channels: three 8-channel groups
     (1, 64, E.ACT_LEAKY, 21, 40, False, 3),  # two row tiles, the general (non-clamp) activation path
     (2, 40, E.ACT_RELU, 30, 34, True, 3),    # f32 NCHW input, second row tile partly filled
-    (2, 64, E.ACT_RELU, 97, 129, False, 7),  # first_conv7_mfma_kernel: the ResNet-50 stem (7x7 stride 2), odd sizes
+    (2, 64, E.ACT_RELU, 97, 129, False, 7),  # the ResNet-50 stem (7x7 stride 2), odd sizes
     (2, 24, E.ACT_LEAKY, 33, 40, False, 7),  # ... one row tile partly filled, general activation
     (1, 48, E.ACT_RELU6, 20, 37, True, 7),   # ... stride 1, f32 input
 ])
-def test_first_conv_matrix_pipe_shapes(hp, monkeypatch, stride, cout, act, h, w, f32, k):
-    """first_conv_f16_kernel (the default: fp16 matrix pipe, normalised input and weights rounded to fp16) vs the fp16-matched oracle, and
-    the three forms of the first layer against each other: fp16 pipe, fp32 matrix pipe (HP_FIRST_F16=0: first_conv_mfma_kernel /
-    first_conv7_mfma_kernel) and the scalar first_conv_kernel (HP_FIRST_MFMA=0 as well).  The two all-fp32 forms may differ in the last
-    bit before the fp16 store; the fp16 form differs from them by the operand rounding (2^-11 relative per operand)."""
+def test_first_conv_matrix_pipe_shapes(hp, stride, cout, act, h, w, f32, k):
+    """first_conv_f16_kernel (fp16 matrix pipe, normalised input and weights rounded to fp16 like every other layer's operands) vs the
+    fp16-matched oracle AND vs the all-fp32 oracle (match_fp16 = False): the fp16 form differs from fp32 arithmetic by the operand
+    rounding only (2^-11 relative per operand)."""
     net = Net(7)
     t = net.conv(0, 3, cout, k, stride, act=act, act_param=0.1)
     z = net.conv(t, cout, 8, 1, act=E.ACT_NONE)
@@ -137,16 +136,11 @@ def test_first_conv_matrix_pipe_shapes(hp, monkeypatch, stride, cout, act, h, w,
     kw = {} if f32 else dict(mean=(0.485, 0.456, 0.406), inv_std=(4.0, 4.5, 4.4))
     eng, got, ref = _run_both(net, outs, fr, h, w, f32=f32, **kw)
     _check(got, ref, 2)
-    monkeypatch.setenv("HP_FIRST_F16", "0")
-    _, pipe32, ref32 = _run_both(net, outs, fr, h, w, f32=f32, **kw)
-    _check(pipe32, ref32, 2)  # (the oracle follows HP_FIRST_F16)
-    monkeypatch.setenv("HP_FIRST_MFMA", "0")
-    _, scalar, _ = _run_both(net, outs, fr, h, w, f32=f32, **kw)
+    ref32 = ref_net.run(net.layers, outs, net.blob(), match_fp16=False, **(dict(frames_f32=fr) if f32 else dict(frames_u8=fr, **kw)))
     for b in range(2):
-        for (n0, a0), (n1, a1), (n2, a2) in zip(got[b], scalar[b], pipe32[b]):
-            _close(a2, a1, rel=1e-3, abs_=1e-3)
-            scale = float(np.abs(a1).max()) + 1e-6
-            assert np.abs(a0 - a1).max() <= 1e-2 * scale + 1e-3, (n0, "fp16 pipe vs scalar fp32")
+        for n0, a0 in got[b]:
+            scale = float(np.abs(ref32[n0][b]).max()) + 1e-6
+            assert np.abs(a0 - ref32[n0][b]).max() <= 1e-2 * scale + 1e-3, (n0, "fp16 pipe vs fp32 arithmetic")
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,dil", [
@@ -338,21 +332,21 @@ def test_pifpaf_resnet50_end_to_end(hp):
 
 
 @pytest.mark.parametrize("c,cout,stride,dil,h,w", [
-    (32, 128, 1, 1, 40, 56),     # variant 1: 128-row tile, 16x24 pixels, 32-channel chunks
+    (32, 128, 1, 1, 40, 56),     # 32 -> 128: no fused instance (the 64-channel K chunks do not divide C): depthwise + 1x1 launches
     (64, 128, 2, 1, 45, 61),     # variant 2: stride 2 (odd input: SAME pads 1/1)
     (128, 256, 2, 1, 46, 60),    # variant 3: stride 2 (even input: SAME pads 0/1)
     (256, 256, 1, 1, 23, 27),    # variant 4
     (256, 512, 1, 1, 23, 27),    # variant 5
     (512, 512, 1, 2, 19, 21),    # variant 6: dilation 2
-    (96, 72, 1, 1, 21, 30),      # ragged channels: Cout not a multiple of 32, C = 3 chunks of 32
+    (96, 72, 1, 1, 21, 30),      # ragged channels (C = 96, Cout = 72): no fused instance either, the generic kernels take it
     (128, 128, 1, 1, 29, 35),    # variant 1 in its half-CU form (C a multiple of 64), ragged edge tiles
     (64, 128, 2, 1, 46, 54),     # variant 2, even input (SAME pads 0/1)
     (32, 64, 1, 1, 37, 45),      # variant 7: the 32-channel block (sepconv_small_kernel), odd sizes
     (32, 40, 1, 1, 16, 24),      # variant 7 with fewer than 64 outputs
 ])
 def test_fused_separable_block(hp, monkeypatch, c, cout, stride, dil, h, w):
-    """depthwise 3x3 + pointwise 1x1 as one launch (sepconv_kernel): against the oracle, and bit-for-bit against
-    the two-launch schedule (same fp32 depthwise arithmetic, same fp16 rounding point, same MFMA order)."""
+    """depthwise 3x3 + pointwise 1x1 as one launch (sepconv_slot_kernel / sepconv_small_kernel): against the oracle, and bit-for-bit
+    against the two-launch schedule (same fp32 depthwise arithmetic, same fp16 rounding point, same MFMA order)."""
     net = Net(c + cout)
     a = net.conv(0, 3, c, 3, 1)
     d = net.conv(a, c, c, 3, stride, dil, op=E.OP_DWCONV, act=E.ACT_RELU6)
@@ -363,7 +357,8 @@ def test_fused_separable_block(hp, monkeypatch, c, cout, stride, dil, h, w):
     eng, got, ref = _run_both(net, outs, fr, h, w)
     _check(got, ref, 3)
     tiles = [p["tile"] for p in eng.profile(3, 1)]
-    assert any(4000000 <= t < 5000000 for t in tiles), tiles  # the fused kernel really ran
+    fused = c % 64 == 0 or (c == 32 and cout <= 64)
+    assert any(4000000 <= t < 5000000 for t in tiles) == fused, tiles  # the fused kernel really ran (where an instance exists)
     mid = eng.debug_tensor(y, 3)
     monkeypatch.setenv("HP_NO_FUSE", "1")
     eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 3)
@@ -372,8 +367,9 @@ def test_fused_separable_block(hp, monkeypatch, c, cout, stride, dil, h, w):
     assert np.array_equal(mid, eng2.debug_tensor(y, 3))
     for b in range(3):
         assert np.array_equal(got[b][0][1], got2[b][0][1])
-    with pytest.raises(Exception):
-        eng.debug_tensor(d, 3)  # never materialised
+    if fused:
+        with pytest.raises(Exception):
+            eng.debug_tensor(d, 3)  # never materialised
 
 
 @pytest.mark.parametrize("variant,h,w,act", [
@@ -670,24 +666,18 @@ def test_direct_conv_any_kernel_and_width(hp, k, cin, cout, h, w):
     assert sum(1 for p in prof if p["tile"] >= 6000000) == want, [p["tile"] for p in prof]
 
 
-def test_direct_conv_matches_generic_kernel_bit_for_bit_inputs(hp, monkeypatch):
-    """Same network through conv_direct_kernel and (HP_GDIRECT=0) the LDS-staged implicit GEMM: both within tolerance of the oracle and
-    of each other; HP_GDIRECT=3 routes every eligible layer (3x3 x 64 / 128 channels, small maps) to the 8-wavefront kernel."""
+def test_vgg19_small_through_the_direct_kernels(hp):
+    """OpenPose-VGG19 at 64 x 96: the 5x5-free 3x3 / 7x7 layers run on conv_direct_kernel / conv3x3_direct_kernel where their shapes
+    allow and on the implicit GEMM elsewhere (maps smaller than two tiles); all of it against the oracle."""
     m = E.Model("openpose_vgg19", 96, 64)
     w = m.init_weights(9)
     fr = _frames(2, 64, 96, seed=3)
-    res = {}
-    for mode in ("0", "1", "3"):  # 3: also the 3x3 layers with <= 128 input channels and the maps smaller than two tiles
-        monkeypatch.setenv("HP_GDIRECT", mode)
-        eng = E.Engine.from_model(m, w, max_batch=2)  # (the variable is read per call: created and run under the same setting)
-        res[mode] = eng.inference(fr)
-        tiles = [p["tile"] for p in eng.profile(2, 1)]
-        n_direct = sum(1 for t in tiles if t >= 6000000)
-        assert n_direct == 0 if mode == "0" else n_direct >= (3 if mode == "1" else 60), (mode, n_direct)
-        eng.close()
+    eng = E.Engine.from_model(m, w, max_batch=2)
+    got = eng.inference(fr)
+    tiles = [p["tile"] for p in eng.profile(2, 1)]
+    assert sum(1 for t in tiles if 6000000 <= t < 7000000) >= 3, tiles
     ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=True, mean=m.mean, inv_std=m.inv_std)
-    for mode in res:
-        _check(res[mode], ref, 2, rel=4e-3, abs_=2e-3)
+    _check(got, ref, 2, rel=4e-3, abs_=2e-3)
 
 
 def test_vgg_64_channel_layers_on_the_direct_kernel(hp):

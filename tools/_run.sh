@@ -1,2 +1,2 @@
-python -m pytest tests/test_pipeline_gpu.py -x -q -m gpu -s -k drift 2>&1 | grep -E "^fp16 engine|passed|failed|Error" > gpurun_out/t11.log
-cat gpurun_out/t11.log
+python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" | tail -25 > gpurun_out/t12.log
+tail -12 gpurun_out/t12.log

@@ -35,7 +35,6 @@ int main(int argc, char** argv)
     p.res = hp::tview{ nullptr, 0, 0, 0, 0 };
     p.out = hp::tview{ dout, COUT, 0, W, H * W };
     p.out_f32 = nullptr, p.npix = B * H * W, p.dbg = nullptr;
-    p.dbg_flags = getenv("HP_GDIRECT_PRIO") ? atoi(getenv("HP_GDIRECT_PRIO")) : 0;
     hp::set_act(p);
     p.w_layout = hp::conv_weight_layout(p);
     printf("w_layout %d tile %d\n", p.w_layout, hp::conv_mfma_tile(p));

@@ -196,13 +196,6 @@ int main(int argc, char** argv)
         p.w = w, p.bias = bias, p.alpha = nullptr, p.act = hp::ACT_RELU; hp::set_act(p);
         p.res = hp::tview{ nullptr, 0, 0, 0, 0 }, p.out = hp::tview{ out, c.cout, 0, c.W, c.H * c.W }, p.out_f32 = nullptr, p.npix = c.B * c.H * c.W;
         p.dbg = nullptr;
-        if (c.k == 3)
-            for (int v : {0, 1}) {
-                hp::debug_force_halo_variant(v);
-                float msv = time_ms(s, 300, [&] { CK(hp::launch_conv_mfma(p, s)); });
-                printf("  halo variant %d (tile %d): %.1f us\n", v, hp::conv_mfma_tile(p), msv * 1e3);
-            }
-        hp::debug_force_halo_variant(-1);
         p.w_layout = hp::conv_weight_layout(p);
         float ms = time_ms(s, 300, [&] { CK(hp::launch_conv_mfma(p, s)); });
         if (c.B == 8) {
