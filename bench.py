@@ -315,11 +315,22 @@ def from_host(model, weights, cfg, batch, pipes, steps=8, frame_wh=(1280, 720)):
 
 
 def kernel_label(tile: int):
-    """(substring of the kernel symbol as rocprofv3 prints it, human-readable label) for a profile row's `tile` code."""
-    halo = {3064192: (64, 16, 12), 3128128: (128, 8, 16)}
-    sep = {1: (1, 12, 16, 24, 1, 1, 32), 2: (1, 6, 8, 24, 2, 1, 32), 3: (2, 3, 8, 12, 2, 1, 64), 4: (2, 3, 8, 12, 1, 1, 64),
-           5: (4, 3, 8, 12, 1, 1, 64), 6: (4, 3, 8, 12, 1, 2, 64)}
-    if tile >= 6000000:
+    """(substring of the kernel symbol as rocprofv3 prints it, human-readable label) for a profile row's `tile` code
+    (conv_kernels.hpp: conv_mfma_tile; engine.cpp: hp_engine_profile)."""
+    sep = {7: ("sepconv_small_kernel<32,1,2>", "32-channel separable block, all channels of an 8x8 tile in LDS"),
+           1: ("sepconv_small_kernel<", "separable block -> 128 channels, all channels of an 8x8 tile in LDS"),
+           2: ("sepconv_small_kernel<", "separable block -> 128 channels, stride 2, all channels of a tile in LDS"),
+           3: ("sepconv_slot_kernel<2,1,2,1,128,64>", "separable block 128 -> 256, stride 2, half-CU form"),
+           4: ("sepconv_slot_kernel<1,2,1,1,256,64>", "separable block 256 -> 256, half-CU form"),
+           5: ("sepconv_slot_kernel<2,2,1,1,512,64>", "separable block 256 / 512 -> 512: depthwise 3x3 per 64-channel chunk -> B tile of ALL chunks in LDS -> "
+               "pointwise MFMAs in two passes of 256 output channels, 8x8 pixels per block, two blocks per CU"),
+           6: ("sepconv_slot_kernel<2,2,1,2,512,32>", "separable block 512 -> 512, dilation 2, half-CU form")}
+    chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
+    if tile >= 7000000:
+        v = tile - 7000000
+        return (f"conv_chain_kernel<{chain.get(v, '')},", "conv_chain_kernel ([1x1 ->] 3x3 -> 3x3 [+ residual] on 128 channels in one launch: 8x12 output pixels x all "
+                "128 channels per block, intermediates in LDS, weights in MFMA-fragment order straight from L2)")
+    if tile >= 6000000 and tile % 1000 in (9, 25, 49):
         v = tile - 6000000
         cin, taps = v // 1000, v % 1000
         ks = int(round(taps ** 0.5))
@@ -327,16 +338,18 @@ def kernel_label(tile: int):
         return (f"conv_direct_kernel<{ks},{ck},{nbuf}>",
                 f"conv_direct_kernel<KS={ks},CK={ck},NBUF={nbuf}> ({ks}x{ks} taps, {cin} input channels in {cin // ck} chunk(s); 8 wavefronts, 128 cout x 16x12 px "
                 "per block, halo tile of a chunk in LDS for all taps, weights in MFMA-fragment order straight from L2)")
+    if tile >= 6000000:
+        return ("mlp_head", "mlp_head(_pair)_kernel (1x1 K1 -> 512 relu -> 1x1 512 -> 19 | 38, hidden tensor in registers)")
+    if 5200000 <= tile < 5300000:
+        tm, ntp = (tile - 5200000) // 1000, tile % 1000
+        return (f"conv1x1_big_kernel<{tm},{ntp}>", f"conv1x1_big_kernel<TM={tm},NTP={ntp}> (pixel-block GEMM: {32 * ntp} pixels x {128 * tm} output channels per block, "
+                "weights from L2 in fragment order, activations through producer wavefronts + LDS)")
     if 5100000 <= tile < 5200000:
         return ("conv1x1_small_kernel", "conv1x1_small_kernel (64 pixels x all input channels in LDS, fragment-ordered weights from L2)")
     if tile >= 5000000:
         return ("conv3x3_direct_kernel<128,", "conv3x3_direct_kernel<CIN=128> (64 cout x 16x12 px tile, input halo tile in LDS, weights in MFMA-fragment order straight from L2)")
     if tile >= 4000000:
-        key = "sepconv_kernel<%d,%d,%d,%d,%d,%d,%d" % sep.get(tile - 4000000, (0,) * 7)
-        return (key, key + "> (fused depthwise 3x3 + pointwise 1x1)")
-    if tile >= 3000000:
-        bm, th, tw = halo.get(tile, (0, 0, 0))
-        return (f"conv3x3_halo_kernel<128,{bm},{th},{tw},", f"conv3x3_halo_kernel<CIN=128> ({bm} cout x {th}x{tw} px tile, input halo tile resident in LDS)")
+        return sep.get(tile - 4000000, ("sepconv", "fused depthwise 3x3 + pointwise 1x1"))
     return (f"conv_mfma_kernel<{tile // 1000},{tile % 1000},", f"conv_mfma_kernel<BM={tile // 1000},BN={tile % 1000}> (implicit GEMM, A and B staged through LDS)")
 
 

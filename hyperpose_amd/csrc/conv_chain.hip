@@ -3,14 +3,14 @@
 // LW-OpenPose's head (hyperpose/Model/openpose/model/lw_openpose.py:106-191) is seventeen 3x3 128 -> 128 convolutions and six 1x1s
 // on a 46 x 54 map.  At batch 8 each of them is 23 MFLOP per CU: as one launch per layer the matrix pipe idles through a halo
 // prologue, an epilogue and a kernel boundary for every 7 k cycles of MFMAs (conv3x3_direct_kernel: 13 us per layer, 0.16-0.18 of
-// the fp16 MFMA peak).  Here one block owns an 8 x 12 pixel output tile and ALL 128 channels and runs the whole chain on it:
+// the fp16 MFMA peak).  Here one block owns an 8 x 8 pixel output tile and ALL 128 channels and runs the whole chain on it:
 //
-//     S0 (refinement blocks, lw_openpose.py:176-191):  X0 = input tile + 2-pixel halo (12 x 16 px) -> 1x1 + relu -> T1 (12 x 16 px)
+//     S0 (refinement blocks, lw_openpose.py:176-191):  X0 = input tile + 2-pixel halo (12 x 12 px) -> 1x1 + relu -> T1 (12 x 12 px)
 //        (otherwise T1 = the input tile + 2-pixel halo, straight from HBM)
-//     S1:  T1 -> 3x3 + relu [+ external residual] -> T2 (10 x 14 px: the output tile + 1-pixel halo)
-//     S2:  T2 -> 3x3 + relu [+ residual: external, or T1's interior = the 1x1's output] -> 8 x 12 px -> HBM
+//     S1:  T1 -> 3x3 + relu [+ external residual] -> T2 (10 x 10 px: the output tile + 1-pixel halo)
+//     S2:  T2 -> 3x3 + relu [+ residual: external, or T1's interior = the 1x1's output] -> 8 x 8 px -> HBM
 //
-// The halo pixels of the intermediates are recomputed by the neighbouring blocks (x1.46 MFMAs in S1, x2 in the small S0) - MFMA
+// The halo pixels of the intermediates are recomputed by the neighbouring blocks (x2 MFMAs in S1 incl. tile padding, x2.5 in the small S0) - MFMA
 // time is what this network has to spare - and in exchange two of three launches, their prologues / epilogues and the HBM round
 // trips of both intermediates (5 MB each way per layer) disappear.  Intermediate pixels outside the image are ZERO (the next
 // convolution's padding), not convolution outputs.
@@ -31,12 +31,16 @@ namespace {
 constexpr int CH = 128;              // channels of every tensor in the chain
 constexpr int PXB = CH * 2;          // bytes per pixel in LDS
 constexpr int KQ = CH / 16;          // k16 steps per tap
-constexpr int TH = 8, TW = 12;       // output tile
-constexpr int H2 = TH + 4, W2 = TW + 4, N2 = H2 * W2; // S0 / T1 region (halo 2): 12 x 16 = 192 px = 6 column tiles
-constexpr int H1 = TH + 2, W1 = TW + 2, N1 = H1 * W1; // T2 region (halo 1): 10 x 14 = 140 px -> 5 column tiles
-constexpr int N0 = TH * TW;                            // 96 px = 3 column tiles
-constexpr int NT2 = N2 / 32, NT1 = (N1 + 31) / 32, NT0 = N0 / 32;
-static_assert(N2 % 32 == 0 && N0 % 32 == 0, "tile geometry");
+// Output tile 8 x 8: with it a block needs <= 72 KB of LDS and <= 256 registers, i.e. HALF a CU - two blocks, or one block and a kernel
+// of the other hardware queue, share a CU.  The first form (8 x 12 pixels, 85 / 134 KB, 270 registers: 8 % fewer MFMAs per pixel)
+// was 14 % faster alone (conv stack 0.59 -> 0.53 ms) and gained NOTHING end to end: a whole-CU kernel serialises the two queues
+// the four pipes run on ("a CU is two slots").
+constexpr int TH = 8, TW = 8;        // output tile
+constexpr int H2 = TH + 4, W2 = TW + 4, N2 = H2 * W2; // S0 / T1 region (halo 2): 12 x 12 = 144 px -> 5 column tiles (16 pad lanes)
+constexpr int H1 = TH + 2, W1 = TW + 2, N1 = H1 * W1; // T2 region (halo 1): 10 x 10 = 100 px -> 4 column tiles
+constexpr int N0 = TH * TW;                            // 64 px = 2 column tiles
+constexpr int NT2 = (N2 + 31) / 32, NT1 = (N1 + 31) / 32, NT0 = N0 / 32;
+static_assert(N2 * 16 % 256 == 0 && N0 % 32 == 0, "tile geometry");
 
 // swizzle key of a pixel of a tile that is CONSUMED in pixel order of width CW: 16 consecutive consumer pixels, shifted by any tap,
 // read 16 distinct 16-byte slots of the 256-byte bank row (a pixel is exactly one bank row: 128 channels x 2 B)
@@ -53,9 +57,10 @@ template <int NT, int TAPS, int WIN, int KW, int D>
 __device__ __forceinline__ void chain_stage(floatx16 (&acc)[NT], u32x4 (&a)[KQ], const __half* wcur, long tap_stride, const __half* wnext,
     const unsigned char* src, const int (&pix0)[NT], const int (&nkey)[NT], int fk)
 {
-    // D = how many k16 steps ahead of their MFMAs the B fragments are read (ring of 4 fragment sets).  Measured: D = 1, 2, 3 run within
-    // 1 % of each other, and a timing build without ANY memory operation in the loop takes 83 % of the loop's time (14.9 k of 17.9 k
-    // ticks for S1): the loop is at the matrix pipe's rate at the clock the chip sustains; the reads are not what it waits for.
+    // D = how many k16 steps ahead of their MFMAs the B fragments are read (ring of fragment sets).  Measured on the 8 x 12 form: D = 1, 2,
+    // 3 run within 1 % of each other, and a timing build without ANY memory operation in the loop takes 83 % of the loop's time (14.9 k
+    // of 17.9 k ticks for S1): the loop is at the matrix pipe's rate at the clock the chip sustains; the reads are not what it waits
+    // for.  D = 1 (two sets) keeps the block under 256 registers.
     static_assert(D >= 1 && D <= 3 && KQ == 8, "prefetch ring");
     constexpr int KS = TAPS == 9 ? 3 : 1;
     auto tap_addr = [&](int tap, int (&ad)[NT]) {
@@ -125,14 +130,16 @@ __device__ __forceinline__ void zero_acc(floatx16 (&acc)[NT])
 
 // S0: the chain starts with a 1x1; RES: 0 none, 1 external tensor added to S1's output, 2 external tensor added to S2's output,
 // 3 the 1x1's output (T1) added to S2's output
-template <bool S0, int RES, int D = 2>
-__global__ __launch_bounds__(256) void conv_chain_kernel(const chain_params p, int tiles_x, int tiles_y)
+template <bool S0, int RES, int D = 1>
+__global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p, int tiles_x, int tiles_y)
 {
-    constexpr int X0_BYTES = S0 ? N2 * PXB : 0, T1_BYTES = N2 * PXB, T2_BYTES = N1 * PXB;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[X0_BYTES + T1_BYTES + T2_BYTES];
+    // LDS: [X0 | T1] with T2 over X0 (dead once S0 is done), or [T2 | T1] without S0: 72 / 61 KB
+    constexpr int T1_BYTES = N2 * PXB, T2_BYTES = N1 * PXB, X0_BYTES = S0 ? N2 * PXB : T2_BYTES;
+    static_assert(T2_BYTES <= X0_BYTES && X0_BYTES + T1_BYTES <= 80 * 1024, "half a CU");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X0_BYTES + T1_BYTES];
     unsigned char* const s_x0 = lds;
+    unsigned char* const s_t2 = lds;
     unsigned char* const s_t1 = lds + X0_BYTES;
-    unsigned char* const s_t2 = lds + X0_BYTES + T1_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fk = lane >> 5;
@@ -197,14 +204,14 @@ __global__ __launch_bounds__(256) void conv_chain_kernel(const chain_params p, i
         }
     };
 
-    // ---- S0: 1x1 on the 12 x 16 region -> T1
+    // ---- S0: 1x1 on the 12 x 12 region -> T1
     if (S0) {
         floatx16 acc[NT2];
         zero_acc(acc);
         int pix0[NT2], nkey[NT2];
 #pragma unroll
         for (int j = 0; j < NT2; ++j) {
-            const int n = j * 32 + fr;
+            const int n = min(j * 32 + fr, N2 - 1);
             pix0[j] = n * PXB, nkey[j] = n;
         }
         chain_stage<NT2, 1, W2, W2, D>(acc, a, w0, 0, w1, s_x0, pix0, nkey, fk);
@@ -215,6 +222,8 @@ __global__ __launch_bounds__(256) void conv_chain_kernel(const chain_params p, i
 #pragma unroll
         for (int j = 0; j < NT2; ++j) {
             const int n = j * 32 + fr, hy = n / W2, hx = n - hy * W2;
+            if (n >= N2)
+                continue; // pad lanes of the last column tile
             const int y = y0 - 2 + hy, x = x0 - 2 + hx;
             const bool ok = y >= 0 && y < H && x >= 0 && x < W;
             unsigned char* const row = s_t1 + n * PXB + fk * 8;
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_chain_kernel(const chain_params p, i
         HP_CSTAMP();
     }
 
-    // ---- S1: 3x3 on the 10 x 14 region -> T2
+    // ---- S1: 3x3 on the 10 x 10 region -> T2
     {
         floatx16 acc[NT1];
         zero_acc(acc);
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_chain_kernel(const chain_params p, i
         HP_CSTAMP();
     }
 
-    // ---- S2: 3x3 on the 8 x 12 tile; the result goes (fp16) into T1's interior, in place of the residual it may have read there
+    // ---- S2: 3x3 on the 8 x 8 tile; the result goes (fp16) into T1's interior, in place of the residual it may have read there
     {
         floatx16 acc[NT0];
         zero_acc(acc);

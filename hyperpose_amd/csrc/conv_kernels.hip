@@ -2005,8 +2005,9 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     constexpr int HALO_BYTES = PIECES * 16, BCH_BYTES = NPX * CK * 2, BALL_BYTES = (CMAX / CK) * BCH_BYTES;
     constexpr int DWW_BYTES = 9 * CKH * 2, DWB_BYTES = CKH * 4;
     constexpr int MAIN_BYTES = BALL_BYTES + HALO_BYTES + 2 * DWW_BYTES + 2 * DWB_BYTES;
-    static_assert(4 * stage_geom<TP>::SLAB <= MAIN_BYTES, "the last pass's epilogue slabs overlay B_all and the halo buffer");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[MAIN_BYTES];
+    constexpr int EPI_BYTES = 4 * NT * stage_geom<TP>::SLAB; // conv_epilogue_wide: all pixel tiles of a wavefront staged at once, over B_all and the halo buffer
+    static_assert(EPI_BYTES <= 80 * 1024, "two blocks per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
     unsigned char* const s_ball = lds;
     unsigned char* const s_halo = lds + BALL_BYTES;
     unsigned char* const s_dww = s_halo + HALO_BYTES;   // [2][9][CKH] halves
@@ -2124,19 +2125,26 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         const bool wrap = kc + 1 == NCH;
         const int ps2 = wrap ? min(ps + 1, NP - 1) : ps, kc2 = wrap ? (ps + 1 < NP ? 0 : kc) : kc + 1;
         const __half* const wn = wbase + ps2 * pass_stride + (size_t)kc2 * (KS * 512);
+        // (the B fragments of step ks + 1 are read while step ks multiplies: read -> wait -> multiply per step left the matrix pipe idle
+        // for an LDS latency four times per chunk)
+        half8 fb[2][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            fb[0][j] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(j * 32 + frow, fk));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            half8 fb[NT];
+            if (ks + 1 < KS) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                fb[j] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(j * 32 + frow, ks * 2 + fk));
+                for (int j = 0; j < NT; ++j)
+                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(j * 32 + frow, (ks + 1) * 2 + fk));
+            }
 #pragma unroll
             for (int i = 0; i < TP; ++i) {
                 half8 fa;
                 __builtin_memcpy(&fa, &a[ks][i], 16);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[i][j], 0, 0, 0);
             }
             a_load(wn, ks);
         }
@@ -2182,7 +2190,8 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         HP_STAMP();
     }
     if (NP == 1) {
-        conv_epilogue_staged<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
+        __syncthreads(); // every wave is done with B_all before the slabs overwrite it
+        conv_epilogue_wide<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * (NT * stage_geom<TP>::SLAB), pb, py, px, pv);
         HP_STAMP();
         return;
     }
@@ -2196,8 +2205,10 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         if (p.pw.dbg && blockIdx.x == 0 && tid == 0)
             p.pw.dbg[42] = __builtin_amdgcn_s_memtime();
         __syncthreads(); // every wave is done with B_all before the slabs overwrite it
-        conv_epilogue_staged<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
-        conv_epilogue_staged<TP, NT>(p.pw, acc1, (4 * TP + wave * TP) * 32, lane, lds + wave * stage_geom<TP>::SLAB, pb, py, px, pv);
+        conv_epilogue_wide<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * (NT * stage_geom<TP>::SLAB), pb, py, px, pv);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's slab reads are done before pass 1's tiles overwrite the slab
+        __builtin_amdgcn_wave_barrier();
+        conv_epilogue_wide<TP, NT>(p.pw, acc1, (4 * TP + wave * TP) * 32, lane, lds + wave * (NT * stage_geom<TP>::SLAB), pb, py, px, pv);
         if (p.pw.dbg && blockIdx.x == 0 && tid == 0)
             p.pw.dbg[43] = __builtin_amdgcn_s_memtime();
     }
