@@ -151,14 +151,14 @@ class Pipe:
             self.dnn = (outs[0][2], outs[1][2])
             self.s0 = outs[1][1]  # pif [85, fh, fw]
         self.inj = injected
-        self.busy = False
+        self.busy = self.eng_only = False
 
     def submit(self, frames_dev, injected: bool, engine: bool = True, parser: bool = True):
         n = self.batch
         if engine:
             self.eng.enqueue_u8(frames_dev, n)
         if not parser:
-            self.eng.synchronize()
+            self.eng_only = True  # collect() waits for the stream
             return
         src = self.inj if injected else self.dnn
         if self.kind == "paf":
@@ -170,6 +170,9 @@ class Pipe:
         self.busy = True
 
     def collect(self):
+        if self.eng_only:
+            self.eng.synchronize()
+            self.eng_only = False
         if not self.busy:
             return 0
         humans = self.par.collect()

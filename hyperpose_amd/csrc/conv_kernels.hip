@@ -383,6 +383,81 @@ __device__ __forceinline__ void conv_epilogue_wide(const conv_params& p, const f
     }
 }
 
+// The staged epilogue with the arithmetic moved to the MFMA side of the transpose: bias, activation and the rounding to fp16 happen
+// on the accumulator registers (same operations in the same order as above, so the same bits), and the slab holds HALVES: half the
+// LDS bytes in both directions and nothing but ds_read_b128 -> global store on the store side.  A slab is 4.9 KB per (wavefront,
+// pixel tile) at TM = 2, so all TN tiles of a wavefront are staged at once even with eight wavefronts (the fp32 slabs of
+// conv_epilogue_wide would need 221 KB there).  A residual is added in fp32 BEFORE the rounding, so a convolution with one takes
+// conv_epilogue_staged (the slab area is sized for either).
+template <int TM, int TN>
+struct packed_geom {
+    static constexpr int ROW = TM * 64 + 16;      // bytes per staged pixel row (halves)
+    static constexpr int SLAB = 32 * ROW + 32 * 8; // + per-pixel output offsets
+    static constexpr int CPP = TM * 4, PPP = 64 / CPP, PASSES = 32 / PPP;
+    static constexpr int WAVE_BYTES = TN * SLAB > stage_geom<TM>::SLAB ? TN * SLAB : stage_geom<TM>::SLAB;
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_packed(const conv_params& p, const floatx16 (&acc)[TM][TN], int m_wave, int lane,
+    unsigned char* slab, const int (&pb)[TN], const int (&py)[TN], const int (&px)[TN], const bool (&pv)[TN])
+{
+    using G = packed_geom<TM, TN>;
+    if (p.res.p) { // uniform
+        conv_epilogue_staged<TM, TN>(p, acc, m_wave, lane, slab, pb, py, px, pv);
+        return;
+    }
+    const float hi = p.act_hi;
+    const bool clamp_only = !p.alpha && p.act_slope == 0.f; // uniform
+    const int mq = m_wave + 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m = mq + i * 32 + 8 * g;
+            const float4 bs = *reinterpret_cast<const float4*>(p.bias + m);
+            float4 sl = make_float4(p.act_slope, p.act_slope, p.act_slope, p.act_slope);
+            if (p.alpha)
+                sl = *reinterpret_cast<const float4*>(p.alpha + m);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v0 = acc[i][j][4 * g + 0] + bs.x, v1 = acc[i][j][4 * g + 1] + bs.y;
+                float v2 = acc[i][j][4 * g + 2] + bs.z, v3 = acc[i][j][4 * g + 3] + bs.w;
+                if (clamp_only) {
+                    v0 = __builtin_amdgcn_fmed3f(v0, 0.f, hi), v1 = __builtin_amdgcn_fmed3f(v1, 0.f, hi);
+                    v2 = __builtin_amdgcn_fmed3f(v2, 0.f, hi), v3 = __builtin_amdgcn_fmed3f(v3, 0.f, hi);
+                } else {
+                    v0 = v0 > 0.f ? fminf(v0, hi) : v0 * sl.x, v1 = v1 > 0.f ? fminf(v1, hi) : v1 * sl.y;
+                    v2 = v2 > 0.f ? fminf(v2, hi) : v2 * sl.z, v3 = v3 > 0.f ? fminf(v3, hi) : v3 * sl.w;
+                }
+                half4 h;
+                h[0] = (_Float16)v0, h[1] = (_Float16)v1, h[2] = (_Float16)v2, h[3] = (_Float16)v3;
+                *reinterpret_cast<half4*>(slab + j * G::SLAB + (lane & 31) * G::ROW + (i * 32 + 8 * g + 4 * (lane >> 5)) * 2) = h;
+            }
+        }
+    if (lane < 32) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            reinterpret_cast<long*>(slab + j * G::SLAB + 32 * G::ROW)[lane] = pv[j] ? tv_off(p.out, pb[j], py[j], px[j]) : -1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's LDS writes have landed (DS ops retire in order)
+    __builtin_amdgcn_wave_barrier();
+    const int chunk = lane % G::CPP, prow = lane / G::CPP;
+    const int mc = m_wave + chunk * 8;
+    const bool mvalid = mc < p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const unsigned char* const sj = slab + j * G::SLAB;
+#pragma unroll
+        for (int ps = 0; ps < G::PASSES; ++ps) {
+            const int pix = ps * G::PPP + prow;
+            const half8 h = *reinterpret_cast<const half8*>(sj + pix * G::ROW + chunk * 16);
+            const long oo = reinterpret_cast<const long*>(sj + 32 * G::ROW)[pix];
+            if (oo >= 0 && mvalid)
+                *reinterpret_cast<half8*>(p.out.p + oo + mc) = h;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Generic implicit GEMM.  1-D grid; block id -> (pixel tile, cout tile) with the cout tiles of one pixel tile
 // adjacent and consecutive logical ids on the same XCD (blocks are dispatched round-robin over the 8 XCDs).
@@ -1332,7 +1407,10 @@ __global__ __launch_bounds__(512) void conv1x1_big_kernel(const conv_params p)
     }
     // (the producers are gone and the last barrier of the loop is behind every read of the B buffers: the wave-private slabs may
     // overlay them; the staged epilogue synchronises inside a wavefront only)
-    conv_epilogue_wide<TM, NTP>(p, acc, m_wave, lane, lds + wave * (NTP * stage_geom<TM>::SLAB), pb, py, px, pv);
+    if (p.res.p) // uniform
+        conv_epilogue_wide<TM, NTP>(p, acc, m_wave, lane, lds + wave * (NTP * stage_geom<TM>::SLAB), pb, py, px, pv);
+    else
+        conv_epilogue_packed<TM, NTP>(p, acc, m_wave, lane, lds + wave * (NTP * stage_geom<TM>::SLAB), pb, py, px, pv);
     HP_BSTAMP();
 #undef HP_BSTAMP
 }
@@ -1391,13 +1469,9 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
         const int TM = v / 1000, NTP = v % 1000;
         const dim3 grid((p.npix + 32 * NTP - 1) / (32 * NTP), p.Cout_pad / (128 * TM));
 #define HP_BIG(TM_, NTP_) HP_LAUNCH((conv1x1_big_kernel<TM_, NTP_>), grid, dim3(512), 0, s, p)
-        switch (v) {
-        case 4002: HP_BIG(4, 2); break;
-        case 2004: HP_BIG(2, 4); break;
-        case 2003: HP_BIG(2, 3); break;
+        switch (v) { // (the instances big1x1_variant hands out; wider / taller ones were swept and lost: see there)
         case 2002: HP_BIG(2, 2); break;
         case 1004: HP_BIG(1, 4); break;
-        case 1003: HP_BIG(1, 3); break;
         default: HP_BIG(1, 2); break;
         }
 #undef HP_BIG
@@ -1834,6 +1908,14 @@ __device__ __forceinline__ void mac8_f16(float (&acc)[8], const u32x4 x, const u
     }
 }
 
+__device__ __forceinline__ void mac4_f16(float (&acc)[4], const uint2 x, const uint2 w)
+{
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[0]) : "v"(x.x), "v"(w.x));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[1]) : "v"(x.x), "v"(w.x));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[2]) : "v"(x.y), "v"(w.y));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[3]) : "v"(x.y), "v"(w.y));
+}
+
 // depthwise activation y = v > 0 ? min(v, hi) : v * slope; the relu / relu6 family (slope == 0) is one v_med3_f32
 template <bool CLAMP>
 __device__ __forceinline__ float dw_act(float v, float slope, float hi)
@@ -1999,13 +2081,16 @@ hipError_t launch_dwconv3x3(const dw_params& p_in, hipStream_t s)
 template <int NP, int TP, int S, int D, int CMAX, int CKH = 64>
 __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p, int tiles_x, int tiles_y)
 {
+    constexpr int NW = 4, NTHR = 64 * NW;
     constexpr int TH = 8, TW = 8, NPX = 64, NT = 2, CK = 64, CG = CKH / 8, KS = 4, HPK = CK / CKH;
     constexpr int IH = (TH - 1) * S + 2 * D + 1, IW = (TW - 1) * S + 2 * D + 1;
-    constexpr int PIECES = IH * IW * CG, NLD = (PIECES + 255) / 256, ITEMS = NPX * CG / 256;
+    constexpr int PIECES = IH * IW * CG, NLD = (PIECES + NTHR - 1) / NTHR, ITEMS = (NPX * CG + NTHR - 1) / NTHR;
+    static_assert(NPX * CG % NTHR == 0, "whole items");
     constexpr int HALO_BYTES = PIECES * 16, BCH_BYTES = NPX * CK * 2, BALL_BYTES = (CMAX / CK) * BCH_BYTES;
     constexpr int DWW_BYTES = 9 * CKH * 2, DWB_BYTES = CKH * 4;
     constexpr int MAIN_BYTES = BALL_BYTES + HALO_BYTES + 2 * DWW_BYTES + 2 * DWB_BYTES;
-    constexpr int EPI_BYTES = 4 * NT * stage_geom<TP>::SLAB; // conv_epilogue_wide: all pixel tiles of a wavefront staged at once, over B_all and the halo buffer
+    // epilogue slabs over B_all and the halo buffer: all pixel tiles of a wavefront (of both passes) at once (conv_epilogue_packed)
+    constexpr int EPI_BYTES = NW * NP * packed_geom<TP, NT>::WAVE_BYTES;
     static_assert(EPI_BYTES <= 80 * 1024, "two blocks per CU");
     __shared__ __attribute__((aligned(16))) unsigned char lds[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
     unsigned char* const s_ball = lds;
@@ -2025,7 +2110,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     // pointwise weights of (pass, K chunk): fragment (row tile pass*4*TP + wave*TP + i, k16 step chunk*4 + ks).  One pointer per
     // chunk, constant offsets per (i, ks): no per-load index arithmetic in the MFMA phase (it is issue-bound)
     const __half* const wbase = p.pw.w + (size_t)lane * 8 + (size_t)(wave * TP) * KQ * 512;
-    const size_t pass_stride = (size_t)4 * TP * KQ * 512, row_stride = (size_t)KQ * 512;
+    const size_t pass_stride = (size_t)NW * TP * KQ * 512, row_stride = (size_t)KQ * 512;
     u32x4 a[KS][TP];
     auto a_load = [&](const __half* wp, int ks) {
 #pragma unroll
@@ -2043,7 +2128,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         const int iy0 = y0 * S - p.pad_t, ix0 = x0 * S - p.pad_l;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
-            const int i = min(tid + k * 256, PIECES - 1);
+            const int i = min(tid + k * NTHR, PIECES - 1);
             const int hp = i / CG, c = i - hp * CG;
             const int hy = hp / IW, hx = hp - hy * IW;
             const int y = iy0 + hy, x = ix0 + hx;
@@ -2065,8 +2150,8 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     auto to_lds = [&](int chunk) {
 #pragma unroll
         for (int k = 0; k < NLD; ++k)
-            if (tid + k * 256 < PIECES)
-                *reinterpret_cast<u32x4*>(s_halo + (size_t)(tid + k * 256) * 16) = hv[k] & (((hmask >> k) & 1u) ? 0xffffffffu : 0u);
+            if (tid + k * NTHR < PIECES)
+                *reinterpret_cast<u32x4*>(s_halo + (size_t)(tid + k * NTHR) * 16) = hv[k] & (((hmask >> k) & 1u) ? 0xffffffffu : 0u);
         if (w_thread)
             *reinterpret_cast<u32x4*>(s_dww + (chunk & 1) * DWW_BYTES + tid * 16) = wreg;
         else if (b_thread)
@@ -2101,7 +2186,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
             wv[t9] = *reinterpret_cast<const u32x4*>(s_dww + (kd & 1) * DWW_BYTES + (t9 * CKH + g * 8) * 2);
 #pragma unroll 1
         for (int r = 0; r < ITEMS; ++r) {
-            const int pix = (tid + r * 256) / CG;
+            const int pix = (tid + r * NTHR) / CG;
             const int py = pix / TW, px = pix - py * TW;
             const unsigned char* xs = s_halo + ((py * S * IW + px * S) * CG + g) * 16;
             u32x4 x[9];
@@ -2191,7 +2276,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
     }
     if (NP == 1) {
         __syncthreads(); // every wave is done with B_all before the slabs overwrite it
-        conv_epilogue_wide<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * (NT * stage_geom<TP>::SLAB), pb, py, px, pv);
+        conv_epilogue_packed<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * packed_geom<TP, NT>::WAVE_BYTES, pb, py, px, pv);
         HP_STAMP();
         return;
     }
@@ -2205,10 +2290,9 @@ __global__ __launch_bounds__(256, 2) void sepconv_slot_kernel(const sep_params p
         if (p.pw.dbg && blockIdx.x == 0 && tid == 0)
             p.pw.dbg[42] = __builtin_amdgcn_s_memtime();
         __syncthreads(); // every wave is done with B_all before the slabs overwrite it
-        conv_epilogue_wide<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * (NT * stage_geom<TP>::SLAB), pb, py, px, pv);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's slab reads are done before pass 1's tiles overwrite the slab
-        __builtin_amdgcn_wave_barrier();
-        conv_epilogue_wide<TP, NT>(p.pw, acc1, (4 * TP + wave * TP) * 32, lane, lds + wave * (NT * stage_geom<TP>::SLAB), pb, py, px, pv);
+        // (both passes' tiles in their own slabs: nothing to wait for in between)
+        conv_epilogue_packed<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + (2 * wave) * packed_geom<TP, NT>::WAVE_BYTES, pb, py, px, pv);
+        conv_epilogue_packed<TP, NT>(p.pw, acc1, (NW * TP + wave * TP) * 32, lane, lds + (2 * wave + 1) * packed_geom<TP, NT>::WAVE_BYTES, pb, py, px, pv);
         if (p.pw.dbg && blockIdx.x == 0 && tid == 0)
             p.pw.dbg[43] = __builtin_amdgcn_s_memtime();
     }
@@ -2220,6 +2304,257 @@ static hipError_t launch_sep_slot(const sep_params& p, hipStream_t s)
 {
     const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 7) / 8;
     HP_LAUNCH((sepconv_slot_kernel<NP, TP, S, D, CMAX, CKH>), dim3(tiles_x * tiles_y * p.B), dim3(256), 0, s, p, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The 512-output-channel separable blocks (five of them per frame in LightWeight-OpenPose: the network's dominant kernel) as a
+// whole-CU block whose depthwise taps and MFMAs overlap INSIDE the block.  sepconv_slot_kernel's timeline (s_memtime, profiles/)
+// is taps 1.75 k -> barrier -> MFMAs 1.3 k -> barrier per K chunk: the vector and the matrix pipe take turns, and the second
+// block on the CU only partly fills the gaps.  Here eight wavefronts = two per SIMD work in ANTI-PHASE between two barriers:
+// in interval k every wavefront owes the taps of chunk k+1 (-> B_all) and the MFMAs of chunk k (<- B_all); wavefronts 0-3 do the
+// taps first, 4-7 the MFMAs first, so each SIMD has one wavefront on the vector pipe and one on the matrix pipe at any time.
+// The halo chunks are double-buffered (chunk k+2 is written while chunk k+1 is read).  12 x 8 output pixels x all 512 output
+// channels per block: 16 row tiles = 8 wavefronts x 2, three pixel tiles, ONE pass; 224 blocks for 8 x 46 x 54: one round on 256 CUs
+// (the 64-pixel tile of an eight-wavefront block needed 311 blocks = two rounds, and lost: DESIGN.md section 7).
+// Same arithmetic and K order as the two-launch form, so the results are bit-identical (tests).
+template <int D, int CMAX>
+__global__ __launch_bounds__(512, 1) void sepconv_pipe_kernel(const sep_params p, int tiles_x, int tiles_y)
+{
+    constexpr int NW = 8, NTHR = 512, TP = 2, TH = 12, TW = 8, NPX = TH * TW, NT = NPX / 32, CK = 64, CG = 8, KS = 4;
+    constexpr int IH = TH + 2 * D, IW = TW + 2 * D, PIECES = IH * IW * CG, NLD = (PIECES + NTHR - 1) / NTHR;
+    constexpr int HALO_BYTES = PIECES * 16, BCH_BYTES = NPX * CK * 2, BALL_BYTES = (CMAX / CK) * BCH_BYTES;
+    constexpr int DWW_BYTES = 9 * CK * 2, DWB_BYTES = CK * 4;
+    constexpr int MAIN_BYTES = BALL_BYTES + 2 * HALO_BYTES + 2 * DWW_BYTES + 2 * DWB_BYTES;
+    constexpr int EPI_BYTES = NW * packed_geom<TP, NT>::WAVE_BYTES;
+    static_assert(MAIN_BYTES <= 160 * 1024 && EPI_BYTES <= MAIN_BYTES, "LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MAIN_BYTES];
+    unsigned char* const s_ball = lds;
+    unsigned char* const s_halo = lds + BALL_BYTES;       // [2] halo chunks
+    unsigned char* const s_dww = s_halo + 2 * HALO_BYTES; // [2][9][64] halves
+    unsigned char* const s_dwb = s_dww + 2 * DWW_BYTES;   // [2][64] floats
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1;
+    const int C = p.C, KQ = C / 16, NCH = C / CK;
+
+    const __half* const wbase = p.pw.w + (size_t)lane * 8 + (size_t)(wave * TP) * KQ * 512;
+    const size_t row_stride = (size_t)KQ * 512;
+    u32x4 a[KS][TP];
+    auto a_load = [&](const __half* wp, int ks) {
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+            a[ks][i] = *reinterpret_cast<const u32x4*>(wp + i * row_stride + ks * 512);
+    };
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        a_load(wbase, ks);
+    u32x4 hv[NLD], wreg;
+    int hoff[NLD];
+    unsigned hmask = 0;
+    {
+        const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = min(tid + k * NTHR, PIECES - 1);
+            const int hp = i / CG, c = i - hp * CG;
+            const int hy = hp / IW, hx = hp - hy * IW;
+            const int y = iy0 + hy, x = ix0 + hx;
+            hmask |= (y <= ymax && x <= xmax) ? (1u << k) : 0u;
+            hoff[k] = (min(y, ymax) * p.in.wp + min(x, xmax)) * p.in.cs + c * 8;
+        }
+    }
+    const __half* const hbase = p.in.p + (size_t)b * p.in.img * p.in.cs + p.in.coff;
+    constexpr int NWT = 9 * CG, NBT = CK / 4;
+    const bool w_thread = tid < NWT, b_thread = tid >= NWT && tid < NWT + NBT;
+    auto hload = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            hv[k] = *reinterpret_cast<const u32x4*>(hbase + hoff[k] + chunk * CK);
+        const void* src = w_thread ? (const void*)(p.dw_w + (size_t)(tid / CG) * C + chunk * CK + (tid % CG) * 8)
+                                   : (const void*)(p.dw_bias + chunk * CK + (b_thread ? (tid - NWT) * 4 : 0));
+        wreg = *reinterpret_cast<const u32x4*>(src);
+    };
+    auto to_lds = [&](int chunk) {
+        unsigned char* const hs = s_halo + (chunk & 1) * HALO_BYTES;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (tid + k * NTHR < PIECES)
+                *reinterpret_cast<u32x4*>(hs + (size_t)(tid + k * NTHR) * 16) = hv[k] & (((hmask >> k) & 1u) ? 0xffffffffu : 0u);
+        if (w_thread)
+            *reinterpret_cast<u32x4*>(s_dww + (chunk & 1) * DWW_BYTES + tid * 16) = wreg;
+        else if (b_thread)
+            *reinterpret_cast<u32x4*>(s_dwb + (chunk & 1) * DWB_BYTES + (tid - NWT) * 16) = wreg;
+    };
+
+    floatx16 acc[TP][NT];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+    const int g = tid % CG, frow = lane & 31, fk = lane >> 5;
+    const float dw_hi = p.dw_hi;
+
+    // 96 pixels x 8 channel groups = 768 items on 512 threads: one full item (pixels 0-63) + one HALF item (pixels 64-95, four
+    // channels) per thread, so that the two wavefronts of a SIMD carry the same tap work (2 : 1 items left the one behind)
+    auto dw_chunk = [&](int kd) {
+        unsigned char* const bt = s_ball + kd * BCH_BYTES;
+        const unsigned char* const hs = s_halo + (kd & 1) * HALO_BYTES;
+        const unsigned char* const ws = s_dww + (kd & 1) * DWW_BYTES;
+        const float* const bsrc = reinterpret_cast<const float*>(s_dwb + (kd & 1) * DWB_BYTES) + g * 8;
+        {
+            const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
+            u32x4 wv[9];
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+                wv[t9] = *reinterpret_cast<const u32x4*>(ws + (t9 * CK + g * 8) * 2);
+            const int pix = tid / CG;
+            const int py = pix / TW, px = pix - py * TW;
+            const unsigned char* xs = hs + ((py * IW + px) * CG + g) * 16;
+            float v[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+            // one tap row at a time (the fence keeps hipcc from hoisting all nine reads: 24 registers the accumulators need)
+#pragma unroll
+            for (int tr = 0; tr < 3; ++tr) {
+                u32x4 x[3];
+#pragma unroll
+                for (int tc = 0; tc < 3; ++tc)
+                    x[tc] = *reinterpret_cast<const u32x4*>(xs + ((tr * D) * IW + tc * D) * CG * 16);
+#pragma unroll
+                for (int tc = 0; tc < 3; ++tc)
+                    mac8_f16(v, x[tc], wv[tr * 3 + tc]);
+                asm volatile("" ::: "memory");
+            }
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                h[e] = (_Float16)dw_act<true>(v[e], 0.f, dw_hi);
+            *reinterpret_cast<half8*>(bt + lds_off<CK>(pix, g)) = h;
+        }
+        {
+            const int hf = (tid >> 3) & 1, pix = 64 + (tid >> 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(bsrc + hf * 4);
+            uint2 wv[9];
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+                wv[t9] = *reinterpret_cast<const uint2*>(ws + (t9 * CK + g * 8 + hf * 4) * 2);
+            const int py = pix / TW, px = pix - py * TW;
+            const unsigned char* xs = hs + ((py * IW + px) * CG + g) * 16 + hf * 8;
+            float v[4] = { b0.x, b0.y, b0.z, b0.w };
+#pragma unroll
+            for (int tr = 0; tr < 3; ++tr) {
+                uint2 x[3];
+#pragma unroll
+                for (int tc = 0; tc < 3; ++tc)
+                    x[tc] = *reinterpret_cast<const uint2*>(xs + ((tr * D) * IW + tc * D) * CG * 16);
+#pragma unroll
+                for (int tc = 0; tc < 3; ++tc)
+                    mac4_f16(v, x[tc], wv[tr * 3 + tc]);
+                asm volatile("" ::: "memory");
+            }
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                h[e] = (_Float16)dw_act<true>(v[e], 0.f, dw_hi);
+            *reinterpret_cast<half4*>(bt + lds_off<CK>(pix, g) + hf * 8) = h;
+        }
+    };
+    auto mm_chunk = [&](int kc) {
+        const unsigned char* const bt = s_ball + kc * BCH_BYTES;
+        const __half* const wn = wbase + (size_t)min(kc + 1, NCH - 1) * (KS * 512);
+        half8 fb[2][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            fb[0][j] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(j * 32 + frow, fk));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(j * 32 + frow, (ks + 1) * 2 + fk));
+            }
+#pragma unroll
+            for (int i = 0; i < TP; ++i) {
+                half8 fa;
+                __builtin_memcpy(&fa, &a[ks][i], 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[i][j], 0, 0, 0);
+            }
+            a_load(wn, ks);
+        }
+    };
+
+    int dbg_i = 0;
+    // block 0: stamps of wavefront 0 (taps first) -> dbg[0..40); block 1: of wavefront 4 (MFMAs first) -> dbg[2112..2152)
+#define HP_STAMP()                                                                                   \
+    if (p.pw.dbg && blockIdx.x < 2 && tid == (int)blockIdx.x * 256 && dbg_i < 40)                    \
+        p.pw.dbg[blockIdx.x * 2112 + dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
+    if (p.pw.dbg && tid == 0 && blockIdx.x < 1024) // every block's start / end on the shared 100 MHz clock
+        p.pw.dbg[64 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    hload(0);
+    to_lds(0);
+    hload(min(1, NCH - 1));
+    lds_barrier();
+    HP_STAMP();
+    dw_chunk(0);
+    if (NCH > 1) {
+        to_lds(1);
+        hload(min(2, NCH - 1));
+    }
+    lds_barrier();
+    HP_STAMP();
+    const bool taps_first = wave < 4;
+#pragma unroll 1
+    for (int k = 0; k < NCH; ++k) {
+        const bool more = k + 1 < NCH;
+        if (k + 2 < NCH) { // halo chunk k+2 -> the buffer chunk k's taps were done with before the last barrier
+            to_lds(k + 2);
+            hload(min(k + 3, NCH - 1));
+        }
+        HP_STAMP();
+        if (more && taps_first)
+            dw_chunk(k + 1);
+        HP_STAMP();
+        mm_chunk(k);
+        HP_STAMP();
+        if (more && !taps_first)
+            dw_chunk(k + 1);
+        HP_STAMP();
+        lds_barrier();
+        HP_STAMP();
+    }
+    int pb[NT], py[NT], px[NT];
+    bool pv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + (lane & 31);
+        pb[j] = b;
+        py[j] = y0 + n / TW;
+        px[j] = x0 + n % TW;
+        pv[j] = py[j] < p.OH && px[j] < p.OW;
+    }
+    // (the loop's last barrier put every wavefront past its reads of B_all: the slabs may overwrite it)
+    conv_epilogue_packed<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * packed_geom<TP, NT>::WAVE_BYTES, pb, py, px, pv);
+    HP_STAMP();
+    if (p.pw.dbg && tid == 0 && blockIdx.x < 1024)
+        p.pw.dbg[65 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#undef HP_STAMP
+}
+
+template <int D, int CMAX>
+static hipError_t launch_sep_pipe(const sep_params& p, hipStream_t s)
+{
+    const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 11) / 12;
+    HP_LAUNCH((sepconv_pipe_kernel<D, CMAX>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
     return hipGetLastError();
 }
 
@@ -2239,7 +2574,7 @@ __global__ __launch_bounds__(256) void sepconv_small_kernel(const sep_params p, 
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, PIECES = IH * IW * CG, NLD = (PIECES + 255) / 256;
     constexpr int ITEMS = TH * TW * CG / 256;
     constexpr int HALO_BYTES = PIECES * 16, B_BYTES = TH * TW * C * 2, DWW_BYTES = 9 * C * 2, DWB_BYTES = C * 4;
-    constexpr int SLAB_BYTES = 4 * stage_geom<1>::SLAB;
+    constexpr int SLAB_BYTES = 4 * packed_geom<1, NT>::WAVE_BYTES;
     constexpr bool OVERLAY = HALO_BYTES >= SLAB_BYTES; // the epilogue slabs reuse the halo tile (dead after the taps) when it is large enough
     __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_BYTES + B_BYTES + DWW_BYTES + DWB_BYTES + (OVERLAY ? 0 : SLAB_BYTES)];
     unsigned char* const s_halo = lds;
@@ -2358,7 +2693,7 @@ __global__ __launch_bounds__(256) void sepconv_small_kernel(const sep_params p, 
         pv[j] = py1[j] < p.OH && px1[j] < p.OW;
     }
     // (where the slabs overlay the halo tile: the barrier after the taps already put every wavefront past its reads of it)
-    conv_epilogue_staged<1, NT>(p.pw, acc, wm * 32, lane, s_slab + wave * stage_geom<1>::SLAB, pb, py1, px1, pv);
+    conv_epilogue_packed<1, NT>(p.pw, acc, wm * 32, lane, s_slab + wave * packed_geom<1, NT>::WAVE_BYTES, pb, py1, px1, pv);
 }
 
 template <int C, int S, int RT>
@@ -2403,7 +2738,10 @@ int sepconv_variant(const sep_params& p)
 
 hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
 {
-    const int v = sepconv_variant(p);
+    int v = sepconv_variant(p);
+    static const bool half_cu = getenv("HP_SEP_SLOT") != nullptr; // A/B switch: the half-CU forms of the 512-channel blocks
+    if (half_cu && (v == 5 || v == 6))
+        v += 10;
     // <= 128 output channels at 64 / 128 input channels: ONE block of all channels (sepconv_small_kernel)
     if (p.pw.Cout <= 128) {
         if (v == 1 && p.C == 128)
@@ -2425,8 +2763,12 @@ hipError_t launch_sepconv(const sep_params& p, hipStream_t s)
     case 4:
         return launch_sep_slot<1, 2, 1, 1, 256>(p, s);
     case 5:
-        return launch_sep_slot<2, 2, 1, 1, 512>(p, s);
+        return launch_sep_pipe<1, 512>(p, s);
     case 6:
+        return launch_sep_pipe<2, 512>(p, s);
+    case 15: // (the half-CU forms of 5 / 6: HP_SEP_SLOT=1, kept for the A/B in DESIGN.md section 7)
+        return launch_sep_slot<2, 2, 1, 1, 512>(p, s);
+    case 16:
         return launch_sep_slot<2, 2, 1, 2, 512, 32>(p, s);
     default:
         return hipErrorInvalidValue;

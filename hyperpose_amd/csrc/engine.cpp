@@ -809,19 +809,37 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
         HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
         if (getenv("HP_SEP_DBG")) { // block timeline (s_memtime deltas of block 0, thread 0) of every separable block, printed per launch
             unsigned long long* dbg = nullptr;
-            HP_HIP_TRY(hipMalloc(&dbg, 64 * 8));
-            HP_HIP_TRY(hipMemset(dbg, 0, 64 * 8));
+            constexpr int NDBG = 64 + 2 * 1024 + 64; // [0, 64) block 0's stamps, then (start, end) of the first 1024 blocks (100 MHz clock)
+            HP_HIP_TRY(hipMalloc(&dbg, NDBG * 8));
+            HP_HIP_TRY(hipMemset(dbg, 0, NDBG * 8));
             st.sp.pw.dbg = dbg;
             HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
             HP_HIP_TRY(hipStreamSynchronize(s));
-            unsigned long long h[64];
-            HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            std::vector<unsigned long long> hbuf(NDBG);
+            unsigned long long* h = hbuf.data();
+            HP_HIP_TRY(hipMemcpy(h, dbg, NDBG * 8, hipMemcpyDeviceToHost));
             fprintf(stderr, "sep layer %d C=%d timeline:", st.layer, st.sp.C);
             for (int i = 1; i < 40 && h[i]; ++i)
                 fprintf(stderr, " %llu", h[i] - h[i - 1]);
             if (h[41])
                 fprintf(stderr, " | total-to-epi0 %llu pass1 %llu epi1 %llu | total %llu", h[41] - h[0], h[42] - h[41], h[43] - h[42], h[43] - h[0]);
             fprintf(stderr, "\n");
+            if (h[2112]) {
+                fprintf(stderr, "  wavefront 4 of block 1:");
+                for (int i = 1; i < 40 && h[2112 + i]; ++i)
+                    fprintf(stderr, " %llu", h[2112 + i] - h[2112 + i - 1]);
+                fprintf(stderr, "\n");
+            }
+            if (h[64]) {
+                unsigned long long t0 = ~0ull, t1 = 0, dmin = ~0ull, dmax = 0, smax = 0;
+                int nb = 0;
+                for (int i = 0; i < 1024 && h[64 + 2 * i]; ++i, ++nb) {
+                    t0 = std::min(t0, h[64 + 2 * i]), t1 = std::max(t1, h[65 + 2 * i]), smax = std::max(smax, h[64 + 2 * i]);
+                    dmin = std::min(dmin, h[65 + 2 * i] - h[64 + 2 * i]), dmax = std::max(dmax, h[65 + 2 * i] - h[64 + 2 * i]);
+                }
+                fprintf(stderr, "  %d blocks: first start -> last end %.2f us, starts spread over %.2f us, block duration %.2f .. %.2f us\n", nb,
+                    (t1 - t0) * 0.01, (smax - t0) * 0.01, dmin * 0.01, dmax * 0.01);
+            }
             st.sp.pw.dbg = nullptr;
             (void)hipFree(dbg);
         }
@@ -1124,6 +1142,54 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
                 : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
                                                     : 0;
             out[k].ms = ms / iters;
+            out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
+        }
+        ++k;
+    }
+    *n_out = k;
+    return HP_OK;
+}
+
+// Machine time per launch: step k of two engines of the same model launched alternately on their two streams, so that two instances of
+// the kernel share the GPU the way two pipes' kernels do; reported = elapsed / (2 * iters).  (A kernel that fills the chip gains nothing
+// from the second stream; one that leaves CUs, slots or pipes idle does - the end-to-end rate with several pipes follows this figure.)
+int hp_engine_profile_pair(hp_engine* e, hp_engine* f, int n, int iters, hp_layer_time* out, int cap, int* n_out)
+{
+    HP_REQUIRE(e && f && e != f && n >= 1 && n <= e->max_batch && n <= f->max_batch && iters >= 1 && n_out && e->steps.size() == f->steps.size(),
+        HP_ERR_INVALID, "hp_engine_profile_pair: bad argument");
+    const size_t need = (size_t)e->max_batch * e->in_h * e->in_w * 3 * sizeof(float);
+    for (hp_engine* g : { e, f })
+        if (g->in_stage.bytes < need)
+            HP_TRY(g->in_stage.alloc(need));
+    int k = 0;
+    for (size_t i = 0; i < e->steps.size(); ++i) {
+        auto &sa = e->steps[i], &sb = f->steps[i];
+        HP_TRY(e->run_step(sa, e->in_stage.as<uint8_t>(), nullptr, n, e->stream));
+        HP_TRY(f->run_step(sb, f->in_stage.as<uint8_t>(), nullptr, n, f->stream));
+        HP_HIP_TRY(hipStreamSynchronize(e->stream));
+        HP_HIP_TRY(hipStreamSynchronize(f->stream));
+        HP_HIP_TRY(hipEventRecord(e->ev0, e->stream));
+        HP_HIP_TRY(hipEventRecord(f->ev0, f->stream));
+        for (int it = 0; it < iters; ++it) {
+            HP_TRY(e->run_step(sa, e->in_stage.as<uint8_t>(), nullptr, n, e->stream));
+            HP_TRY(f->run_step(sb, f->in_stage.as<uint8_t>(), nullptr, n, f->stream));
+        }
+        HP_HIP_TRY(hipEventRecord(e->ev1, e->stream));
+        HP_HIP_TRY(hipEventRecord(f->ev1, f->stream));
+        HP_HIP_TRY(hipEventSynchronize(e->ev1));
+        HP_HIP_TRY(hipEventSynchronize(f->ev1));
+        float m0 = 0, m1 = 0;
+        HP_HIP_TRY(hipEventElapsedTime(&m0, e->ev0, e->ev1));
+        HP_HIP_TRY(hipEventElapsedTime(&m1, f->ev0, f->ev1));
+        if (out && k < cap) {
+            auto& st = sa;
+            out[k].layer = st.layer, out[k].op = st.op;
+            out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
+                : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
+                : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
+                : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
+                                                    : 0;
+            out[k].ms = std::max(m0, m1) / (2 * iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
         }
         ++k;

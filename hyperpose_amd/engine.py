@@ -235,12 +235,16 @@ class Engine:
         check(lib().hp_engine_debug_tensor(self._h, tensor, n, out.ctypes.data_as(C.POINTER(C.c_float)), shape))
         return out
 
-    def profile(self, n: int, iters: int = 10, in_sequence: bool = False):
+    def profile(self, n: int, iters: int = 10, in_sequence: bool = False, pair: "Engine | None" = None):
         """Per-step device times: each step launched back to back (default) or the whole schedule in order with events in
-        between (``in_sequence``: the cache state of a real inference; agrees with rocprofv3's per-kernel averages)."""
+        between (``in_sequence``: the cache state of a real inference; agrees with rocprofv3's per-kernel averages), or - ``pair`` =
+        a second engine of the same model - alternately on the two engines' streams (machine time per launch when two pipes overlap)."""
         cap = 1024
         buf = (LayerTime * cap)()
         cnt = C.c_int(0)
-        fn = lib().hp_engine_profile_sequence if in_sequence else lib().hp_engine_profile
-        check(fn(self._h, n, iters, buf, cap, C.byref(cnt)))
+        if pair is not None:
+            check(lib().hp_engine_profile_pair(self._h, pair._h, n, iters, buf, cap, C.byref(cnt)))
+        else:
+            fn = lib().hp_engine_profile_sequence if in_sequence else lib().hp_engine_profile
+            check(fn(self._h, n, iters, buf, cap, C.byref(cnt)))
         return [dict(layer=b.layer, op=b.op, tile=b.tile, ms=b.ms, flops=b.flops, bytes=b.bytes) for b in buf[:cnt.value]]

@@ -303,6 +303,9 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
  * between the kernels), so every kernel sees the cache state it sees in a real inference.  The back-to-back form above
  * re-runs one layer with its weights warm in L2 and reads ~10-15 % faster for the weight-heavy 3x3 layers. */
 int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* out, int cap, int* n_out);
+/* Machine time per launch: step k of two engines of the same model launched alternately on their two streams (two instances of the
+ * kernel share the GPU as two pipes' kernels do); ms = elapsed / (2 * iters).  tools/profile_layers.py --pair. */
+int hp_engine_profile_pair(hp_engine* e, hp_engine* other, int n, int iters, hp_layer_time* out, int cap, int* n_out);
 
 /* ---- built-in topologies (restating hyperpose/Model/<arch>.py) --------------------- */
 typedef struct hp_model hp_model;

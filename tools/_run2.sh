@@ -1,6 +1,4 @@
-python -m pytest tests/test_engine_gpu.py -q -m gpu -x -k "separable or fused_equals" 2>&1 | tail -3
-python tools/profile_layers.py 2>&1 | grep -E "sep|total|in seq"
-HP_SEP_DBG=1 python - 2>&1 <<'PY' | grep "sep layer" | grep "C=512" | tail -2
+HP_SEP_DBG=1 python - 2>&1 <<'PY' | grep -A2 "sep layer 21" | tail -6
 import sys; sys.path.insert(0, '.')
 from hyperpose_amd import _lib
 from hyperpose_amd.engine import Engine, Model
