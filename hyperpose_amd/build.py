@@ -31,6 +31,7 @@ UNITS = [
     ("pifpaf_parser.hip", ["-ffp-contract=off"]),
     ("conv_kernels.hip", []),
     ("conv_chain.hip", []),
+    ("conv_bottleneck.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),
     ("onnx_import.cpp", []),

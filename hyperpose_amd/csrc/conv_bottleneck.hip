@@ -1,0 +1,767 @@
+// conv_bottleneck.hip — the tail of a ResNet bottleneck block and the head of the next one in ONE launch:
+//
+//     [3x3 M -> M + relu]  ->  1x1 M -> 4M + residual + relu  (-> HBM: the next block's shortcut)  ->  [1x1 4M -> M' + relu of the NEXT block]
+//
+// ResNet-50 at 385 x 385 / 384 x 384 (configs[4] / [3]; torchvision-style bottlenecks, hyperpose/Model/pifpaf/..., pose_proposal/...) spends its
+// time in the 1x1 layers of the first two stages, and those run at the rate of a device copy: the expansion reads M
+// and the 4M-channel shortcut and writes 4M channels, the next reduction reads those 4M channels again, the 3x3 in between writes and the
+// expansion re-reads M channels.  Here a block owns 8 x 8 pixels and keeps everything but the shortcut in LDS: per pixel it moves
+// M (+ halo) + 4M in and 4M + M' out instead of 2 M + 2 (4M) + M in and M + 4M + M' out - 0.6-0.7 of the bytes - in one launch instead of three.
+//
+//   phase A  T1 = 10 x 10 input pixels (zero outside the image) -> 3x3 -> + bias, relu -> T2 [64 px][M] (fp16, LDS)
+//            (without the 3x3 - a block whose 3x3 has stride 2 - T2 is the 8 x 8 input tile itself)
+//   per 128-channel chunk c of the expansion:
+//     phase B  T2 x W_exp[chunk] -> + bias + shortcut (HBM, all chunks requested at block start) -> relu -> E [64 px][128] (fp16, LDS)
+//              barrier; E -> HBM (16 lanes per pixel: 256 contiguous bytes)
+//     phase C  acc_r += W_red[:, chunk] x E                  (the reduction's K runs over the chunks as they appear)
+//   + bias, relu -> Z staged in LDS -> HBM
+//
+// Every intermediate is rounded to fp16 exactly where the per-layer schedule stores it, and every convolution accumulates its K in the
+// per-layer order (taps outer, channels inner; the reduction in ascending channel order), so the results are bit-identical to the
+// three launches (tests).  Four wavefronts; LDS tiles are [pixel][256 B] rows whose 16-byte slots are XOR-swizzled by the pixel's
+// index in consumer order (conv_chain.hip); A fragments come straight from L2 in fragment order (w_layout 1), each unit's first
+// fragments requested while the previous unit's last k16 steps multiply.  <= 74 KB of LDS and <= 128 registers: two or three blocks
+// per CU - the kernel is HBM-bound, what it needs is loads in flight.
+#include "conv_device.hpp"
+
+#include <type_traits>
+
+namespace hp {
+
+namespace {
+
+constexpr int PXB = 256;                     // bytes per pixel row of every LDS tile (a 64-channel tile uses the first 8 slots' worth)
+constexpr int TH = 8, TW = 8, N0 = TH * TW;  // output tile
+constexpr int H1 = TH + 2, W1 = TW + 2, N1 = H1 * W1;
+
+// One unit of MFMAs: TAPS taps x KQC k16 steps for one 32-row tile of output channels and NT column tiles of 32 pixels.
+//   a[]      A fragments, a ring of G taps: on entry a[0 .. KQC) = tap 0 (already requested); taps 1 .. G-1 are requested here, and as
+//            fragment (tap, ks) is consumed its register is refilled with (tap + G, ks) - or, past the last tap, with the next unit's
+//            tap 0 (wnext, KQN fragments, which land in a[0 .. KQN): TAPS % G == 0).  G = 1 is one tap ahead; the 64-channel 3x3 (4
+//            MFMAs per tap against an L2 round trip of ~1 k cycles: measured 9.9 k cycles for 36 MFMAs) runs with G = 3.
+//   src      LDS tile, row width WIN pixels; pix0[j] = byte offset of this lane's pixel of column tile j at tap (0, 0),
+//            nkey[j] = its index in consumer order (the swizzle key of that pixel at tap (ky, kx) is (nkey + ky * KW + kx) & 15)
+//   ROWB     bytes per pixel row of src: 256 (16 slots, key = consumer index & 15) or 128 (a 64-channel tile, two pixels per bank row:
+//            key = (consumer index >> 1) & 7 - the two pixels that share a key are neighbours in a row, i.e. sit in different halves of
+//            their bank row, so 16 consecutive consumer pixels still read 16 distinct slots whatever the tap)
+template <int NT, int TAPS, int WIN, int KW, int KQC, int KQN, int G = 1, int ROWB = 256, int NA = 8>
+__device__ __forceinline__ void unit(floatx16 (&acc)[NT], u32x4 (&a)[NA], const __half* wcur, long tap_stride, const __half* wnext,
+    const unsigned char* src, const int (&pix0)[NT], const int (&nkey)[NT], int fk)
+{
+    static_assert(TAPS % G == 0 && G * KQC <= NA && KQN <= NA && (G == 1 || KQN <= KQC) && (ROWB == 256 || (ROWB == 128 && KQC <= 4 && WIN % 2 == 0 && KW % 2 == 0)), "fragment ring / tile rows");
+    constexpr int KS = TAPS == 9 ? 3 : 1;
+    auto tap_addr = [&](int tap, int (&ad)[NT]) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int toff = (ky * WIN + kx) * ROWB, tkey = ky * KW + kx; // uniform
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int q = nkey[j] + tkey;
+            ad[j] = pix0[j] + toff + (((ROWB == 256 ? (q & 15) : ((q >> 1) & 7)) ^ fk) << 4);
+        }
+    };
+#pragma unroll
+    for (int t = 1; t < G; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KQC; ++ks)
+            a[t * KQC + ks] = *reinterpret_cast<const u32x4*>(wcur + (long)t * tap_stride + (size_t)ks * 512);
+    half8 fb[2][NT];
+    int ad[NT];
+    tap_addr(0, ad);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+        fb[0][j] = *reinterpret_cast<const half8*>(src + ad[j]);
+#pragma unroll 1
+    for (int tg = 0; tg < TAPS; tg += G) {
+        const bool last = tg + G == TAPS; // uniform: the refills of this group are the next unit's
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            const int tap = tg + t;
+            int adn[NT];
+            tap_addr(min(tap + 1, TAPS - 1), adn);
+            const __half* wn = last ? wnext : wcur + (long)(tap + G) * tap_stride;
+#pragma unroll
+            for (int ks = 0; ks < KQC; ++ks) {
+                // the B fragments of the next k16 step (of the next tap past the end of this one) are read while this step multiplies
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(src + (ks + 1 < KQC ? (ad[j] ^ ((ks + 1) << 5)) : adn[j]));
+                half8 fa;
+                __builtin_memcpy(&fa, &a[t * KQC + ks], 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[(t * KQC + ks) & 1][j], acc[j], 0, 0, 0);
+                if (!last)
+                    a[t * KQC + ks] = *reinterpret_cast<const u32x4*>(wn + (size_t)ks * 512);
+                else if (t == 0 && ks < KQN)
+                    a[ks] = *reinterpret_cast<const u32x4*>(wn + (size_t)ks * 512);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                ad[j] = adn[j];
+        }
+    }
+    if (KQN > KQC) {
+#pragma unroll
+        for (int ks = KQC; ks < KQN; ++ks)
+            a[ks] = *reinterpret_cast<const u32x4*>(wnext + (size_t)ks * 512);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(floatx16 (&acc)[NT])
+{
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[j][r] = 0.f;
+}
+
+} // namespace
+
+// M = channels of the 3x3 / input of the expansion (64 or 128); MR = output channels of the trailing reduction (0 = none);
+// A3 = the block starts with the 3x3
+template <int M, int MR, bool A3>
+__global__ __launch_bounds__(256, 2) void bottleneck_kernel(const bneck_params p, int tiles_x, int tiles_y)
+{
+    constexpr int KQM = M / 16;           // k16 steps of the 3x3 (per tap) and of the expansion
+    constexpr int NC = 4 * M / 128;       // 128-channel chunks of the expansion = K chunks of the reduction
+    constexpr int RT = MR / 64;           // reduction row tiles per wavefront (wavefront = (pixel half, row group))
+    // LDS: [T1 (T2 over its first rows once the 3x3 is done) | E | R]: 57.6 KB (48 KB without the 3x3)
+    constexpr int T2_BYTES = N0 * PXB, T1_BYTES = A3 ? N1 * PXB : T2_BYTES, E_BYTES = N0 * PXB;
+    static_assert(T1_BYTES + 2 * E_BYTES + 4096 <= 80 * 1024, "half a CU");
+    static_assert(M == 64 || M == 128, "M");
+    static_assert(MR == 0 || MR == 64 || MR == 128 || MR == 256, "MR");
+    constexpr int NBIAS = M + 4 * M + MR; // the three bias vectors, fetched once (an epilogue has nothing to hide a global load behind)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[T1_BYTES + 2 * E_BYTES + NBIAS * 4];
+    unsigned char* const s_t1 = lds;
+    unsigned char* const s_t2 = lds;
+    unsigned char* const s_e = lds + T1_BYTES;
+    unsigned char* const s_r = s_e + E_BYTES; // the shortcut's chunk, staged in E's layout
+    float* const s_b3 = reinterpret_cast<float*>(s_r + E_BYTES);
+    float* const s_be = s_b3 + M;
+    float* const s_br = s_be + 4 * M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int wj = wave & 1, wr = wave >> 1; // this wavefront's pixel half and row group in phases B and C
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int H = p.ce.OH, W = p.ce.OW;
+    const size_t lane8 = (size_t)lane * 8;
+    int dbg_i = 0; // HP_BN_DBG: s_memtime stamps of block 0 / thread 0, every block's start / end on the 100 MHz clock (engine.cpp prints them)
+#define HP_NSTAMP()                                               \
+    if (p.ce.dbg && blockIdx.x == 0 && tid == 0 && dbg_i < 60)     \
+        p.ce.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    if (p.ce.dbg && tid == 0 && blockIdx.x < 1024)
+        p.ce.dbg[64 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    HP_NSTAMP();
+
+    // weights (fragment order [tap][32-row tile][k16][lane][8]): this wavefront's first unit
+    //   3x3: M = 128: row tile `wave`, both pixel halves; M = 64: row tile wr, pixel half wj
+    const int rtA = M == 128 ? wave : wr;
+    const long tapA = (long)(M / 32) * KQM * 512;
+    const __half* const wA = A3 ? p.c3.w + (size_t)(rtA * KQM) * 512 + lane8 : nullptr;
+    //   expansion chunk c, i = 0 / 1: row tile c * 4 + wr * 2 + i (K = M)
+    auto wB = [&](int c, int i) { return p.ce.w + (size_t)((c * 4 + wr * 2 + i) * KQM) * 512 + lane8; };
+    //   reduction chunk c, r: row tile wr * RT + r, k16 steps c * 8 .. c * 8 + 7 of 4M / 16
+    auto wC = [&](int c, int r) { return p.cr.w + (size_t)((wr * RT + r) * (4 * M / 16) + c * 8) * 512 + lane8; };
+    constexpr int G3 = M == 64 ? 3 : 1;                   // taps of 3x3 weight fragments in flight (unit())
+    constexpr int NA = (A3 && G3 * KQM > 8) ? G3 * KQM : 8;
+    u32x4 a[NA];
+    {
+        const __half* wf = A3 ? wA : wB(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KQM; ++ks)
+            a[ks] = *reinterpret_cast<const u32x4*>(wf + (size_t)ks * 512);
+    }
+
+    for (int i = tid; i < NBIAS; i += 256)
+        s_b3[i] = i < M ? (A3 ? p.c3.bias[i] : 0.f) : i < 5 * M ? p.ce.bias[i - M] : p.cr.bias[i - 5 * M];
+    // ---- input: the 10 x 10 halo tile of the 3x3 (-> T1, keyed for the 3x3's pixel order), or the 8 x 8 tile itself (-> T2)
+    {
+        const tview& in = A3 ? p.c3.in : p.ce.in;
+        constexpr int NPX = A3 ? N1 : N0, WIN = A3 ? W1 : TW, OFF = A3 ? 1 : 0, CG = M / 8;
+        constexpr int PIECES = NPX * CG, NIT = (PIECES + 255) / 256;
+        unsigned char* const dst = A3 ? s_t1 : s_t2;
+        u32x4 hv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(tid + it * 256, PIECES - 1), px = i / CG, c = i - px * CG;
+            const int hy = px / WIN, hx = px - hy * WIN;
+            const int y = y0 - OFF + hy, x = x0 - OFF + hx;
+            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(in.p + tv_off(in, b, min(max(y, 0), H - 1), min(max(x, 0), W - 1)) + c * 8);
+            hv[it] = v & (ok ? 0xffffffffu : 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, px = i / CG, c = i - px * CG;
+            const int hy = px / WIN, hx = px - hy * WIN;
+            const int key = A3 ? ((hy * TW + hx) & 15) : (px & 15);
+            if (i < PIECES)
+                *reinterpret_cast<u32x4*>(dst + px * PXB + ((c ^ key) << 4)) = hv[it];
+        }
+    }
+    // the shortcut: 16 lanes per pixel, 256 contiguous bytes per chunk (in the accumulator layout - 8 bytes per lane, 32 pixels per
+    // instruction - every line is touched by eight instructions: measured 1.03 ms per conv2_x block instead of ...), two chunks ahead
+    // in registers, then through LDS (R, E's layout) to the lanes that own the values
+    const int n = wj * 32 + fr; // this lane's pixel in phases B and C
+    const bool has_res = p.ce.res.p != nullptr; // uniform
+    constexpr int RIT = N0 * 16 / 256;
+    u32x4 rv[2][RIT];
+    long roff[RIT];
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+        const int i = tid + it * 256, q = i >> 4, s16 = i & 15;
+        roff[it] = has_res ? tv_off(p.ce.res, b, min(y0 + q / TW, H - 1), min(x0 + q % TW, W - 1)) + s16 * 8 : 0;
+    }
+    auto res_load = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < RIT; ++it)
+            rv[c & 1][it] = *reinterpret_cast<const u32x4*>(p.ce.res.p + roff[it] + c * 128);
+    };
+    auto res_to_lds = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < RIT; ++it) {
+            const int i = tid + it * 256, q = i >> 4, s16 = i & 15;
+            *reinterpret_cast<u32x4*>(s_r + q * PXB + ((s16 ^ (q & 15)) << 4)) = rv[c & 1][it];
+        }
+    };
+    if (has_res) {
+        res_load(0);
+        res_load(1);
+    }
+    HP_NSTAMP();
+    lds_barrier();
+    HP_NSTAMP();
+
+    // ---- phase A: 3x3 -> T2
+    if constexpr (A3) {
+        constexpr int NT = M == 128 ? 2 : 1;
+        floatx16 acc[NT];
+        zero_acc(acc);
+        int pix0[NT], nkey[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = (M == 128 ? j : wj) * 32 + fr, br = n / TW, bc = n - br * TW;
+            pix0[j] = (br * W1 + bc) * PXB, nkey[j] = n;
+        }
+        unit<NT, 9, W1, TW, KQM, KQM, G3>(acc, a, wA, tapA, wB(0, 0), s_t1, pix0, nkey, fk);
+        HP_NSTAMP();
+        lds_barrier(); // every wavefront is done reading T1: T2 goes over it
+        const float hi = p.c3.act_hi;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = (M == 128 ? j : wj) * 32 + fr;
+            unsigned char* const row = s_t2 + n * PXB + fk * 8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bs = *reinterpret_cast<const float4*>(s_b3 + rtA * 32 + 8 * g + 4 * fk);
+                half4 h;
+                h[0] = (_Float16)__builtin_amdgcn_fmed3f(acc[j][4 * g + 0] + bs.x, 0.f, hi);
+                h[1] = (_Float16)__builtin_amdgcn_fmed3f(acc[j][4 * g + 1] + bs.y, 0.f, hi);
+                h[2] = (_Float16)__builtin_amdgcn_fmed3f(acc[j][4 * g + 2] + bs.z, 0.f, hi);
+                h[3] = (_Float16)__builtin_amdgcn_fmed3f(acc[j][4 * g + 3] + bs.w, 0.f, hi);
+                *reinterpret_cast<half4*>(row + (((rtA * 4 + g) ^ (n & 15)) << 4)) = h;
+            }
+        }
+        lds_barrier();
+        HP_NSTAMP();
+    }
+
+    // ---- phases B / C per 128-channel chunk of the expansion
+    const int pix0[1] = { n * PXB }, nkey[1] = { n };
+    const float hiE = p.ce.act_hi;
+    const bool res_first = p.ce.res_before_act != 0; // uniform
+    floatx16 accr[RT > 0 ? RT : 1];
+    zero_acc(accr);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        unsigned char* const eb = s_e;
+        floatx16 accb[2][1];
+        zero_acc(accb[0]);
+        zero_acc(accb[1]);
+        unit<1, 1, TW, TW, KQM, KQM>(accb[0], a, wB(c, 0), 0, wB(c, 1), s_t2, pix0, nkey, fk);
+        const __half* const after = MR ? wC(c, 0) : wB(min(c + 1, NC - 1), 0);
+        unit<1, 1, TW, TW, KQM, (MR ? 8 : KQM)>(accb[1], a, wB(c, 1), 0, after, s_t2, pix0, nkey, fk);
+        HP_NSTAMP();
+        if (has_res)
+            res_to_lds(c); // (R's readers - the epilogue of chunk c - 1 - are behind the last barrier)
+        if (c > 0 || has_res)
+            lds_barrier(); // every wavefront is past phase C of chunk c - 1 and its copy out of E; R holds this chunk's shortcut
+        HP_NSTAMP();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned char* const row = eb + n * PXB + fk * 8;
+            const unsigned char* const rrow = s_r + n * PXB + fk * 8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bs = *reinterpret_cast<const float4*>(s_be + c * 128 + (wr * 2 + i) * 32 + 8 * g + 4 * fk);
+                const float bv[4] = { bs.x, bs.y, bs.z, bs.w };
+                half4 h, hr;
+                if (has_res)
+                    hr = *reinterpret_cast<const half4*>(rrow + ((((wr * 2 + i) * 4 + g) ^ (n & 15)) << 4));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = accb[i][0][4 * g + r] + bv[r];
+                    const float rr = has_res ? (float)hr[r] : 0.f;
+                    if (res_first)
+                        v += rr;
+                    v = __builtin_amdgcn_fmed3f(v, 0.f, hiE);
+                    if (!res_first)
+                        v += rr;
+                    h[r] = (_Float16)v;
+                }
+                *reinterpret_cast<half4*>(row + ((((wr * 2 + i) * 4 + g) ^ (n & 15)) << 4)) = h;
+            }
+        }
+        if (has_res && c + 2 < NC)
+            res_load(c + 2);
+        HP_NSTAMP();
+        lds_barrier(); // the chunk is complete in E
+        HP_NSTAMP();
+        // E -> HBM: 16 lanes per pixel, 256 contiguous bytes
+#pragma unroll
+        for (int it = 0; it < N0 * 16 / 256; ++it) {
+            const int i = tid + it * 256, q = i >> 4, s16 = i & 15;
+            const int y = y0 + q / TW, x = x0 + q % TW;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(eb + q * PXB + ((s16 ^ (q & 15)) << 4));
+            if (y < H && x < W)
+                *reinterpret_cast<u32x4*>(p.ce.out.p + tv_off(p.ce.out, b, y, x) + c * 128 + s16 * 8) = v;
+        }
+        HP_NSTAMP();
+        if (MR) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const __half* const nxt = r + 1 < RT ? wC(c, r + 1) : wB(min(c + 1, NC - 1), 0);
+                floatx16(&ar)[1] = *reinterpret_cast<floatx16(*)[1]>(&accr[r]);
+                if (r + 1 < RT)
+                    unit<1, 1, TW, TW, 8, 8>(ar, a, wC(c, r), 0, nxt, eb, pix0, nkey, fk);
+                else
+                    unit<1, 1, TW, TW, 8, KQM>(ar, a, wC(c, r), 0, nxt, eb, pix0, nkey, fk);
+            }
+        }
+    }
+
+    // ---- the reduction's result: + bias, relu -> staged [64 px][256 B] (row tiles 0-3 in the free E buffer, 4-7 in T2) -> HBM
+    if constexpr (MR != 0) {
+        unsigned char* const z0 = s_e;
+        const float hi = p.cr.act_hi;
+        lds_barrier(); // E and T2 are free
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int rt = wr * RT + r;
+            unsigned char* const row = (rt < 4 ? z0 : s_t2) + n * PXB + fk * 8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bs = *reinterpret_cast<const float4*>(s_br + rt * 32 + 8 * g + 4 * fk);
+                half4 h;
+                h[0] = (_Float16)__builtin_amdgcn_fmed3f(accr[r][4 * g + 0] + bs.x, 0.f, hi);
+                h[1] = (_Float16)__builtin_amdgcn_fmed3f(accr[r][4 * g + 1] + bs.y, 0.f, hi);
+                h[2] = (_Float16)__builtin_amdgcn_fmed3f(accr[r][4 * g + 2] + bs.z, 0.f, hi);
+                h[3] = (_Float16)__builtin_amdgcn_fmed3f(accr[r][4 * g + 3] + bs.w, 0.f, hi);
+                *reinterpret_cast<half4*>(row + ((((rt & 3) * 4 + g) ^ (n & 15)) << 4)) = h;
+            }
+        }
+        lds_barrier();
+        constexpr int SPP = MR / 8; // 16-byte pieces per pixel
+#pragma unroll
+        for (int it = 0; it < N0 * SPP / 256; ++it) {
+            const int i = tid + it * 256, q = i / SPP, s = i - q * SPP;
+            const int y = y0 + q / TW, x = x0 + q % TW;
+            const u32x4 v = *reinterpret_cast<const u32x4*>((s < 16 ? z0 : s_t2) + q * PXB + (((s & 15) ^ (q & 15)) << 4));
+            if (y < H && x < W)
+                *reinterpret_cast<u32x4*>(p.cr.out.p + tv_off(p.cr.out, b, y, x) + s * 8) = v;
+        }
+    }
+    HP_NSTAMP();
+    if (p.ce.dbg && tid == 0 && blockIdx.x < 1024)
+        p.ce.dbg[65 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#undef HP_NSTAMP
+}
+
+// The 64-channel instance (ResNet-50's first stage: 193 x 193 / 96 x 96 maps, the block that moves the most bytes per FLOP).  Two things
+// bound it, both measured:
+//   * HBM round trips in flight.  `s_waitcnt vmcnt` is in order: a wavefront that requests its shortcut early and then waits for a weight
+//     fragment (L2) waits for the shortcut (HBM) as well.  So every global read of the tile - input halo, all 256 shortcut channels - is
+//     requested up front and parked in LDS, the shortcut in the very place (R[c], E's layout) where the expansion's epilogue replaces it,
+//     value by value, with relu(conv + shortcut); HBM latency is paid once per block and three blocks share a CU (<= 50 KB, <= 168 registers).
+//   * The weights.  136 KB of them per 64-pixel tile against 80 KB of activations, out of L2 at ~40 B/clk/CU: with the wavefronts as
+//     (row group, pixel half) every fragment was fetched by two wavefronts (272 KB per tile: 0.81 ms per block; with all fragments aliased
+//     to one L1-resident KB: 0.61 ms = the HBM rate).  Here every fragment is fetched ONCE per block and multiplies both pixel halves:
+//       3x3        wavefront (wr, wj) = row tile wr, k16 steps {2 wj, 2 wj + 1} of every tap; the two partial sums of a row tile meet in LDS
+//       expansion  wavefront w = row tile 4 c + w of chunk c, all of K
+//       reduction  64 outputs: row tile wr, k16 steps 4 wj .. 4 wj + 3 of every chunk (partial sums meet in LDS); 128 outputs: row tile w
+//     One stream of fragments per wavefront, D = 12 in flight, refilled as they are consumed, across phase boundaries.
+// 64-channel tiles use 128-byte pixel rows: two pixels per bank row, key = (consumer index >> 1) & 7 (the two pixels that share a key
+// are neighbours in a row, i.e. sit in different halves of their bank row: 16 consecutive consumer pixels still read 16 distinct slots).
+template <int MR, bool A3>
+__global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params p, int tiles_x, int tiles_y)
+{
+    constexpr int M = 64, NC = 2, ROW64 = 128;
+    constexpr int X_BYTES = 4 * 4096;                                    // four partial accumulator tiles (32 x 32 fp32)
+    constexpr int Q_BYTES = A3 ? X_BYTES : N0 * ROW64;                    // T1 (12.8 KB) -> X -> T2 (8 KB), one after the other
+    constexpr int R_BYTES = N0 * PXB, NBIAS = M + 4 * M + MR;
+    static_assert(MR == 0 || MR == 64 || MR == 128, "MR");
+    static_assert(N1 * ROW64 <= X_BYTES && X_BYTES <= R_BYTES && Q_BYTES + 2 * R_BYTES + NBIAS * 4 <= 53 * 1024, "three blocks per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[Q_BYTES + 2 * R_BYTES + NBIAS * 4];
+    unsigned char* const s_q = lds;
+    unsigned char* const s_r = lds + Q_BYTES;
+    float* const s_b3 = reinterpret_cast<float*>(s_r + 2 * R_BYTES);
+    float* const s_be = s_b3 + M;
+    float* const s_br = s_be + 4 * M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int wj = wave & 1, wr = wave >> 1;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int H = p.ce.OH, W = p.ce.OW;
+    const size_t lane8 = (size_t)lane * 8;
+    int dbg_i = 0;
+#define HP_NSTAMP()                                               \
+    if (p.ce.dbg && blockIdx.x == 0 && tid == 0 && dbg_i < 60)     \
+        p.ce.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    if (p.ce.dbg && tid == 0 && blockIdx.x < 1024)
+        p.ce.dbg[64 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    HP_NSTAMP();
+
+    // ---- the fragment stream of this wavefront (fragment order: [tap][32-row tile][k16][lane][8])
+    constexpr int NFA = A3 ? 18 : 0, NFR = MR == 64 ? 4 : MR == 128 ? 8 : 0, NFC = 4 + NFR, NF = NFA + NC * NFC, D = 12;
+    const __half* const wA = A3 ? p.c3.w + (size_t)(wr * 4 + 2 * wj) * 512 + lane8 : nullptr; // + tap * 8 * 512 + kk * 512
+    const __half* const wE = p.ce.w + (size_t)(wave * 4) * 512 + lane8;                        // + c * 16 * 512 + ks * 512
+    const __half* const wR = MR == 64 ? p.cr.w + (size_t)(wr * 16 + 4 * wj) * 512 + lane8      // + c * 8 * 512 + kk * 512
+        : MR == 128                   ? p.cr.w + (size_t)(wave * 16) * 512 + lane8
+                                      : nullptr;
+    auto frag_ptr = [&](int f) -> const __half* {
+        if (f < NFA)
+            return wA + (size_t)((f / 2) * 8 + f % 2) * 512;
+        const int g = f - NFA, c = g / NFC, h = g - c * NFC;
+        if (h < 4)
+            return wE + (size_t)(c * 16 + h) * 512;
+        return wR + (size_t)(c * 8 + h - 4) * 512;
+    };
+    u32x4 a[D];
+#pragma unroll
+    for (int f = 0; f < D; ++f)
+        a[f] = *reinterpret_cast<const u32x4*>(frag_ptr(min(f, NF - 1)));
+    // S steps of (A fragment f0 + st) x (the B fragments of both pixel halves at baddr(st, j)); a consumed A fragment's ring slot is
+    // refilled with fragment f + D at once, the B fragments are read two steps ahead of their MFMAs (an LDS read waits ~200-300 cycles
+    // with three blocks on the CU: read -> wait -> multiply, step by step, made the 36 MFMAs of the 3x3 take 7-8 k cycles)
+    auto steps = [&](auto S_, int f0, floatx16 (&acc)[2], auto baddr) {
+        constexpr int S = decltype(S_)::value;
+        half8 fb[3][2];
+#pragma unroll
+        for (int st = 0; st < 2 && st < S; ++st)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fb[st][j] = *reinterpret_cast<const half8*>(baddr(st, j));
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            if (st + 2 < S) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fb[(st + 2) % 3][j] = *reinterpret_cast<const half8*>(baddr(st + 2, j));
+            }
+            const int f = f0 + st;
+            half8 fa;
+            __builtin_memcpy(&fa, &a[f % D], 16);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[st % 3][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[st % 3][1], acc[1], 0, 0, 0);
+            if (f + D < NF)
+                a[f % D] = *reinterpret_cast<const u32x4*>(frag_ptr(f + D));
+        }
+    };
+    // the two K halves of a row tile: wavefront (wr, wj) keeps pixel half wj, hands the other half's partial sums to (wr, 1 - wj) through
+    // X (4 KB per wavefront: [4 float4][64 lanes]); call between two barriers' worth of quiet on X
+    auto send_half = [&](unsigned char* x, const floatx16 (&acc)[2]) {
+        float4* const dst = reinterpret_cast<float4*>(x + wave * 4096) + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = wj ? acc[0][4 * g + 0] : acc[1][4 * g + 0], v.y = wj ? acc[0][4 * g + 1] : acc[1][4 * g + 1];
+            v.z = wj ? acc[0][4 * g + 2] : acc[1][4 * g + 2], v.w = wj ? acc[0][4 * g + 3] : acc[1][4 * g + 3];
+            dst[g * 64] = v;
+        }
+    };
+    auto recv_half = [&](const unsigned char* x, const floatx16 (&acc)[2], float (&sum)[16]) {
+        const float4* const src = reinterpret_cast<const float4*>(x + (wave ^ 1) * 4096) + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = src[g * 64];
+            // (lower K half first: the order does not depend on which wavefront adds)
+            const float m0 = wj ? acc[1][4 * g + 0] : acc[0][4 * g + 0], m1 = wj ? acc[1][4 * g + 1] : acc[0][4 * g + 1];
+            const float m2 = wj ? acc[1][4 * g + 2] : acc[0][4 * g + 2], m3 = wj ? acc[1][4 * g + 3] : acc[0][4 * g + 3];
+            sum[4 * g + 0] = wj ? v.x + m0 : m0 + v.x, sum[4 * g + 1] = wj ? v.y + m1 : m1 + v.y;
+            sum[4 * g + 2] = wj ? v.z + m2 : m2 + v.z, sum[4 * g + 3] = wj ? v.w + m3 : m3 + v.w;
+        }
+    };
+
+    // ---- every HBM read of the tile: the 3x3's 10 x 10 halo tile (or the 8 x 8 input tile), the shortcut's 64 px x 256 channels
+    const bool has_res = p.ce.res.p != nullptr; // uniform
+    {
+        const tview& in = A3 ? p.c3.in : p.ce.in;
+        constexpr int NPX = A3 ? N1 : N0, WIN = A3 ? W1 : TW, OFF = A3 ? 1 : 0, CG = M / 8;
+        constexpr int PIECES = NPX * CG, NIT = (PIECES + 255) / 256, RIT = N0 * 16 / 256;
+        u32x4 hv[NIT], rv[NC][RIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(tid + it * 256, PIECES - 1), px = i / CG, c = i - px * CG;
+            const int hy = px / WIN, hx = px - hy * WIN;
+            const int y = y0 - OFF + hy, x = x0 - OFF + hx;
+            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(in.p + tv_off(in, b, min(max(y, 0), H - 1), min(max(x, 0), W - 1)) + c * 8);
+            hv[it] = v & (ok ? 0xffffffffu : 0u);
+        }
+        if (has_res) {
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+                const int i = tid + it * 256, q = i >> 4, s16 = i & 15;
+                const __half* rp = p.ce.res.p + tv_off(p.ce.res, b, min(y0 + q / TW, H - 1), min(x0 + q % TW, W - 1)) + s16 * 8;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    rv[c][it] = *reinterpret_cast<const u32x4*>(rp + c * 128);
+            }
+        }
+        // (the biases: requested behind the tile's loads - in front of them their round trip delayed every block's HBM requests by 5 k cycles)
+        for (int i = tid; i < NBIAS; i += 256)
+            s_b3[i] = i < M ? (A3 ? p.c3.bias[i] : 0.f) : i < 5 * M ? p.ce.bias[i - M] : p.cr.bias[i - 5 * M];
+        HP_NSTAMP();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, px = i / CG, c = i - px * CG;
+            const int hy = px / WIN, hx = px - hy * WIN;
+            const int key = ((A3 ? hy * TW + hx : px) >> 1) & 7;
+            if (i < PIECES)
+                *reinterpret_cast<u32x4*>(s_q + px * ROW64 + ((c ^ key) << 4)) = hv[it];
+        }
+        if (has_res) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int it = 0; it < RIT; ++it) {
+                    const int i = tid + it * 256, q = i >> 4, s16 = i & 15;
+                    *reinterpret_cast<u32x4*>(s_r + c * R_BYTES + q * PXB + ((s16 ^ (q & 15)) << 4)) = rv[c][it];
+                }
+        }
+    }
+    lds_barrier();
+    HP_NSTAMP();
+
+    const int nj[2] = { fr, 32 + fr }; // this lane's pixel in either half
+    const int n = wj * 32 + fr;        // ... in the half this wavefront finishes
+    // ---- phase A: 3x3 (T1 in Q) -> partial sums meet in X (over T1) -> T2 (over X)
+    if constexpr (A3) {
+        floatx16 acc[2];
+        zero_acc(acc);
+        const unsigned char* t1p[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            t1p[j] = s_q + ((nj[j] / TW) * W1 + nj[j] % TW) * ROW64;
+        steps(std::integral_constant<int, 18>{}, 0, acc, [&](int st, int j) {
+            const int tap = st / 2, kk = st % 2, ky = tap / 3, kx = tap % 3;
+            const int key = ((nj[j] + ky * TW + kx) >> 1) & 7, sl = 2 * (2 * wj + kk) + fk;
+            return t1p[j] + (ky * W1 + kx) * ROW64 + ((key ^ sl) << 4);
+        });
+        HP_NSTAMP();
+        lds_barrier(); // every wavefront is done reading T1
+        send_half(s_q, acc);
+        lds_barrier();
+        float sum[16];
+        recv_half(s_q, acc, sum);
+        const float hi = p.c3.act_hi;
+        half4 h[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bs = *reinterpret_cast<const float4*>(s_b3 + wr * 32 + 8 * g + 4 * fk);
+            h[g][0] = (_Float16)__builtin_amdgcn_fmed3f(sum[4 * g + 0] + bs.x, 0.f, hi);
+            h[g][1] = (_Float16)__builtin_amdgcn_fmed3f(sum[4 * g + 1] + bs.y, 0.f, hi);
+            h[g][2] = (_Float16)__builtin_amdgcn_fmed3f(sum[4 * g + 2] + bs.z, 0.f, hi);
+            h[g][3] = (_Float16)__builtin_amdgcn_fmed3f(sum[4 * g + 3] + bs.w, 0.f, hi);
+        }
+        lds_barrier(); // every wavefront has read its partner's sums: T2 goes over X
+        unsigned char* const row = s_q + n * ROW64 + fk * 8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<half4*>(row + (((wr * 4 + g) ^ ((n >> 1) & 7)) << 4)) = h[g];
+        lds_barrier();
+        HP_NSTAMP();
+    }
+
+    // ---- per 128-channel chunk: expansion -> in place over the shortcut in R[c] -> HBM; the reduction's K chunk
+    const float hiE = p.ce.act_hi;
+    const bool res_first = p.ce.res_before_act != 0; // uniform
+    floatx16 accr[2];
+    zero_acc(accr);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        unsigned char* const rb = s_r + c * R_BYTES;
+        const int fB = NFA + c * NFC;
+        floatx16 accb[2];
+        zero_acc(accb);
+        steps(std::integral_constant<int, 4>{}, fB, accb, [&](int st, int j) {
+            return s_q + nj[j] * ROW64 + ((((nj[j] >> 1) & 7) ^ (2 * st + fk)) << 4);
+        });
+        HP_NSTAMP();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned char* const row = rb + nj[j] * PXB + fk * 8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bs = *reinterpret_cast<const float4*>(s_be + c * 128 + wave * 32 + 8 * g + 4 * fk);
+                const float bv[4] = { bs.x, bs.y, bs.z, bs.w };
+                unsigned char* const at = row + (((wave * 4 + g) ^ (nj[j] & 15)) << 4);
+                half4 h, hr;
+                if (has_res)
+                    hr = *reinterpret_cast<const half4*>(at);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = accb[j][4 * g + r] + bv[r];
+                    const float rr = has_res ? (float)hr[r] : 0.f;
+                    if (res_first)
+                        v += rr;
+                    v = __builtin_amdgcn_fmed3f(v, 0.f, hiE);
+                    if (!res_first)
+                        v += rr;
+                    h[r] = (_Float16)v;
+                }
+                *reinterpret_cast<half4*>(at) = h;
+            }
+        }
+        HP_NSTAMP();
+        lds_barrier(); // the chunk is complete in R[c]
+        HP_NSTAMP();
+#pragma unroll
+        for (int it = 0; it < N0 * 16 / 256; ++it) {
+            const int i = tid + it * 256, q = i >> 4, s16 = i & 15;
+            const int y = y0 + q / TW, x = x0 + q % TW;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(rb + q * PXB + ((s16 ^ (q & 15)) << 4));
+            if (y < H && x < W)
+                *reinterpret_cast<u32x4*>(p.ce.out.p + tv_off(p.ce.out, b, y, x) + c * 128 + s16 * 8) = v;
+        }
+        HP_NSTAMP();
+        if constexpr (MR != 0) {
+            steps(std::integral_constant<int, NFR>{}, fB + 4, accr, [&](int st, int j) {
+                const int sl = 2 * ((MR == 64 ? 4 * wj : 0) + st) + fk;
+                return rb + nj[j] * PXB + (((nj[j] & 15) ^ sl) << 4);
+            });
+        }
+    }
+
+    // ---- the reduction's result: [64 outputs: the K halves meet in R[0]] + bias, relu -> staged -> HBM
+    if constexpr (MR != 0) {
+        const float hi = p.cr.act_hi;
+        unsigned char* zb;
+        if constexpr (MR == 64) {
+            send_half(s_r, accr); // (R[0]'s readers are behind chunk 1's barrier)
+            lds_barrier();        // ... and with this one every wavefront is done with R[1]
+            float sum[16];
+            recv_half(s_r, accr, sum);
+            zb = s_r + R_BYTES;
+            unsigned char* const row = zb + n * PXB + fk * 8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bs = *reinterpret_cast<const float4*>(s_br + wr * 32 + 8 * g + 4 * fk);
+                half4 h;
+                h[0] = (_Float16)__builtin_amdgcn_fmed3f(sum[4 * g + 0] + bs.x, 0.f, hi);
+                h[1] = (_Float16)__builtin_amdgcn_fmed3f(sum[4 * g + 1] + bs.y, 0.f, hi);
+                h[2] = (_Float16)__builtin_amdgcn_fmed3f(sum[4 * g + 2] + bs.z, 0.f, hi);
+                h[3] = (_Float16)__builtin_amdgcn_fmed3f(sum[4 * g + 3] + bs.w, 0.f, hi);
+                *reinterpret_cast<half4*>(row + (((wr * 4 + g) ^ (n & 15)) << 4)) = h;
+            }
+        } else {
+            zb = s_r; // (R[0]'s readers are behind chunk 1's barrier)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned char* const row = zb + nj[j] * PXB + fk * 8;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bs = *reinterpret_cast<const float4*>(s_br + wave * 32 + 8 * g + 4 * fk);
+                    half4 h;
+                    h[0] = (_Float16)__builtin_amdgcn_fmed3f(accr[j][4 * g + 0] + bs.x, 0.f, hi);
+                    h[1] = (_Float16)__builtin_amdgcn_fmed3f(accr[j][4 * g + 1] + bs.y, 0.f, hi);
+                    h[2] = (_Float16)__builtin_amdgcn_fmed3f(accr[j][4 * g + 2] + bs.z, 0.f, hi);
+                    h[3] = (_Float16)__builtin_amdgcn_fmed3f(accr[j][4 * g + 3] + bs.w, 0.f, hi);
+                    *reinterpret_cast<half4*>(row + (((wave * 4 + g) ^ (nj[j] & 15)) << 4)) = h;
+                }
+            }
+        }
+        lds_barrier();
+        constexpr int SPP = MR / 8; // 16-byte pieces per pixel
+#pragma unroll
+        for (int it = 0; it < N0 * SPP / 256; ++it) {
+            const int i = tid + it * 256, q = i / SPP, s = i - q * SPP;
+            const int y = y0 + q / TW, x = x0 + q % TW;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(zb + q * PXB + ((s ^ (q & 15)) << 4));
+            if (y < H && x < W)
+                *reinterpret_cast<u32x4*>(p.cr.out.p + tv_off(p.cr.out, b, y, x) + s * 8) = v;
+        }
+    }
+    HP_NSTAMP();
+    if (p.ce.dbg && tid == 0 && blockIdx.x < 1024)
+        p.ce.dbg[65 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#undef HP_NSTAMP
+}
+
+// what the kernel takes: stride-1 3x3 M -> M (pad 1) and 1x1s on one map size, fragment-ordered weights, relu-family clamps, fp16
+// NHWC with whole 16-byte channel groups, the shortcut (if any) on the expansion only
+static bool bneck_conv_ok(const conv_params& c, int k, int cin, int cout)
+{
+    return c.KH == k && c.KW == k && c.stride == 1 && c.dil == 1 && c.pad_t == k / 2 && c.pad_l == k / 2 && c.Cin == cin && c.Cout == cout
+        && c.Cout_pad == cout && c.w_layout == 1 && c.OH == c.H && c.OW == c.W && !c.alpha && c.act_slope == 0.f && !c.out_f32
+        && c.in.p && c.out.p && c.in.coff % 8 == 0 && c.in.cs % 8 == 0 && c.out.coff % 8 == 0 && c.out.cs % 8 == 0;
+}
+
+int bottleneck_variant(const bneck_params& p)
+{
+    const int M = p.ce.Cin, MR = p.has_cr ? p.cr.Cout : 0;
+    if ((M != 64 && M != 128) || !bneck_conv_ok(p.ce, 1, M, 4 * M))
+        return 0;
+    if (p.ce.res.p && (p.ce.res.coff % 4 || p.ce.res.cs % 4))
+        return 0;
+    if (p.has_c3 && (!bneck_conv_ok(p.c3, 3, M, M) || p.c3.res.p || p.c3.H != p.ce.H || p.c3.W != p.ce.W))
+        return 0;
+    if (p.has_cr && (!bneck_conv_ok(p.cr, 1, 4 * M, MR) || p.cr.res.p || p.cr.H != p.ce.H || p.cr.W != p.ce.W))
+        return 0;
+    if (MR != 0 && MR != M && MR != 2 * M)
+        return 0;
+    if (!p.has_c3 && !p.has_cr)
+        return 0; // (a lone expansion stays with the 1x1 kernels)
+    return 1000 * (M / 64) + 10 * (MR / 64) + (p.has_c3 ? 1 : 0); // M / 64, MR / 64, 3x3
+}
+
+hipError_t launch_bottleneck(const bneck_params& p, hipStream_t s)
+{
+    const int v = bottleneck_variant(p);
+    if (!v)
+        return hipErrorInvalidValue;
+    const int tiles_x = (p.ce.OW + TW - 1) / TW, tiles_y = (p.ce.OH + TH - 1) / TH;
+    const dim3 grid(tiles_x * tiles_y * p.ce.B);
+#define HP_BN(M_, MR_, A3_) HP_LAUNCH((bottleneck_kernel<M_, MR_, A3_>), grid, dim3(256), 0, s, p, tiles_x, tiles_y)
+#define HP_BN64(MR_, A3_) HP_LAUNCH((bottleneck64_kernel<MR_, A3_>), grid, dim3(256), 0, s, p, tiles_x, tiles_y)
+    switch (v) {
+    case 1001: HP_BN64(0, true); break;
+    case 1010: HP_BN64(64, false); break;
+    case 1011: HP_BN64(64, true); break;
+    case 1020: HP_BN64(128, false); break;
+    case 1021: HP_BN64(128, true); break;
+    case 2001: HP_BN(128, 0, true); break;
+    case 2020: HP_BN(128, 128, false); break;
+    case 2021: HP_BN(128, 128, true); break;
+    case 2040: HP_BN(128, 256, false); break;
+    case 2041: HP_BN(128, 256, true); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef HP_BN
+#undef HP_BN64
+    return hipGetLastError();
+}
+
+} // namespace hp

@@ -157,6 +157,17 @@ struct chain_params {
 int conv_chain_variant(const chain_params& p);
 hipError_t launch_conv_chain(const chain_params& p, hipStream_t s);
 
+// A ResNet bottleneck's tail and the next block's head in one launch (conv_bottleneck.hip): [3x3 M -> M] -> 1x1 M -> 4M + shortcut
+// [-> 1x1 4M -> M' of the next block].  c3 / ce / cr are filled exactly like stand-alone convolutions (w_layout 1); c3's output and
+// (as an input) ce's output never leave the block - ce.out is still written, the next block's shortcut reads it.
+struct bneck_params {
+    conv_params c3, ce, cr;
+    int has_c3, has_cr;
+};
+// 0 when the kernel does not take this combination, otherwise 1000 * (M / 64) + 10 * (M' / 64) + has_c3 (profile rows: tile = 9000000 + variant)
+int bottleneck_variant(const bneck_params& p);
+hipError_t launch_bottleneck(const bneck_params& p, hipStream_t s);
+
 struct pool_params {
     tview in;
     int B, H, W, OH, OW, C;

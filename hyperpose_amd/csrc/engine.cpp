@@ -68,12 +68,14 @@ struct step {
     hp::head_params hp2_{}; // ... and, when `paired`, the sibling head on the same input (layers `layer + 2`, `layer + 3`)
     bool paired = false;
     hp::chain_params ch{}; // op == OP_CHAIN: [1x1 ->] 3x3 -> 3x3 on 128 channels in one launch (conv_chain.hip), layers `layer` ..
+    hp::bneck_params bn{}; // op == OP_BNECK: [3x3 ->] expansion 1x1 + shortcut [-> the next block's reduction 1x1] (conv_bottleneck.hip)
     int n_layers = 1;      // consecutive layers this step covers
     double flops = 0, bytes = 0; // per frame
 };
 constexpr int OP_SEPCONV = 100; // schedule-only op codes (not part of the hp_layer ABI)
 constexpr int OP_MLPHEAD = 101;
 constexpr int OP_CHAIN = 102;
+constexpr int OP_BNECK = 103;
 
 void same_pad(int in, int k, int stride, int dil, int& out, int& pad_before)
 {
@@ -736,6 +738,110 @@ int hp_engine::build(const hp_engine_desc* d)
             steps.erase(steps.begin() + k + 1, steps.begin() + k + n);
         }
     }
+    // ---- ResNet bottlenecks (configs[3] / [4]): [3x3 ->] expansion 1x1 (+ shortcut) [-> the NEXT block's reduction 1x1] as one launch
+    // (conv_bottleneck.hip).  The reduction may sit one or two steps further down the schedule (behind the next stage's projection
+    // shortcut, which reads the same tensor): it has no other input, so it can run here.  HP_NO_BNECK=1 keeps one launch per layer.
+    if (!getenv("HP_NO_BNECK") && !getenv("HP_NO_FUSE")) {
+        auto plain_conv = [&](const step& st) { return st.op == HP_OP_CONV && !st.first && st.n_layers == 1; };
+        auto readers_other_than = [&](int tensor, int la) { // some layer other than la reads the tensor, or it is a network output
+            for (size_t j = 0; j < layers.size(); ++j)
+                if ((int)j != la && (layers[j].in == tensor || layers[j].res == tensor))
+                    return true;
+            for (const auto& o : outputs)
+                if (o.tensor == tensor)
+                    return true;
+            return false;
+        };
+        for (size_t k = 0; k < steps.size(); ++k) {
+            if (!plain_conv(steps[k]))
+                continue;
+            hp::bneck_params bn{};
+            size_t ke = k; // the expansion's step
+            if (steps[k].cp.KH == 3 && k + 1 < steps.size() && plain_conv(steps[k + 1]) && steps[k + 1].cp.KH == 1) {
+                const hp_layer &A = layers[steps[k].layer], &E = layers[steps[k + 1].layer];
+                int writers = 0;
+                for (const auto& L2 : layers)
+                    writers += L2.out == A.out;
+                if (E.in == A.out && E.in_coff == A.out_coff && A.res < 0 && writers == 1 && !readers_other_than(A.out, steps[k + 1].layer)) {
+                    bn.c3 = steps[k].cp, bn.has_c3 = 1;
+                    ke = k + 1;
+                }
+            }
+            if (steps[ke].cp.KH != 1 || steps[ke].cp.Cout != 4 * steps[ke].cp.Cin)
+                continue;
+            bn.ce = steps[ke].cp;
+            const hp_layer& E = layers[steps[ke].layer];
+            size_t kr = 0; // the reduction's step
+            for (size_t j = ke + 1; j < steps.size() && j <= ke + 2 && !kr; ++j) {
+                if (!plain_conv(steps[j]) || steps[j].cp.KH != 1 || steps[j].cp.stride != 1)
+                    continue;
+                const hp_layer& R = layers[steps[j].layer];
+                if (R.in != E.out || R.in_coff != E.out_coff || R.res >= 0)
+                    continue;
+                bool clash = false; // a step in between must not touch the reduction's output tensor
+                for (size_t q = ke + 1; q < j; ++q) {
+                    const hp_layer& Q = layers[steps[q].layer];
+                    clash |= Q.in == R.out || Q.res == R.out || Q.out == R.out || steps[q].n_layers != 1;
+                }
+                if (!clash)
+                    kr = j;
+            }
+            if (kr)
+                bn.cr = steps[kr].cp, bn.has_cr = 1;
+            // the stand-alone kernels of some of these shapes (256 -> 64 on the generic implicit GEMM) read row-major weights: the
+            // fused kernel wants them in fragment order
+            auto want_layout1 = [&](hp::conv_params& c) { c.w_layout = 1; };
+            const int lay3 = bn.c3.w_layout, laye = bn.ce.w_layout, layr = bn.cr.w_layout;
+            if (bn.has_c3)
+                want_layout1(bn.c3);
+            want_layout1(bn.ce);
+            if (bn.has_cr)
+                want_layout1(bn.cr);
+            if (!hp::bottleneck_variant(bn)) {
+                if (!bn.has_c3 || !bn.has_cr)
+                    continue;
+                bn.has_cr = 0, kr = 0; // (e.g. a reduction to a width the kernel has no instance for: still fuse 3x3 + expansion)
+                if (!hp::bottleneck_variant(bn))
+                    continue;
+            }
+            // repack what was uploaded row-major
+            auto repack = [&](hp::conv_params& c, int had, int layer) -> int {
+                if (had == 1)
+                    return HP_OK;
+                const hp_layer& L = layers[layer];
+                const int taps = L.kh * L.kw, KQ = c.Cin / 16;
+                const float* w = blob(L.w_off, (size_t)L.cout * taps * L.cin, "weights", (size_t)layer);
+                if (!w)
+                    return HP_ERR_INVALID;
+                std::vector<__half> packed((size_t)taps * c.Cout_pad * c.Cin, __float2half(0.f));
+                for (int co = 0; co < L.cout; ++co)
+                    for (int t = 0; t < taps; ++t)
+                        for (int ci = 0; ci < L.cin; ++ci)
+                            packed[((((size_t)t * (c.Cout_pad / 32) + co / 32) * KQ + ci / 16) * 64 + (ci % 16 / 8) * 32 + co % 32) * 8 + ci % 8]
+                                = __float2half(w[((size_t)co * taps + t) * L.cin + ci]);
+                void* dw = nullptr;
+                HP_TRY(upload(packed.data(), packed.size() * sizeof(__half), &dw));
+                c.w = (const __half*)dw;
+                return HP_OK;
+            };
+            if (bn.has_c3)
+                HP_TRY(repack(bn.c3, lay3, steps[k].layer));
+            HP_TRY(repack(bn.ce, laye, steps[ke].layer));
+            if (kr)
+                HP_TRY(repack(bn.cr, layr, steps[kr].layer));
+            step& a = steps[k];
+            const double fl = (bn.has_c3 ? steps[ke].flops : 0) + (kr ? steps[kr].flops : 0);
+            const double by = (bn.has_c3 ? steps[ke].bytes : 0) + (kr ? steps[kr].bytes : 0);
+            a.op = OP_BNECK, a.bn = bn, a.n_layers = 1 + bn.has_c3 + bn.has_cr;
+            a.flops += fl, a.bytes += by;
+            if (bn.has_c3)
+                tensors[layers[steps[ke].layer].in]->elided = true; // the 3x3's output: allocated (pass 1) but never written
+            if (kr)
+                steps.erase(steps.begin() + kr);
+            if (bn.has_c3)
+                steps.erase(steps.begin() + ke);
+        }
+    }
     // sibling heads (conf / paf branch of one stage: same input, same geometry, neither reads the other) share a launch
     if (!getenv("HP_NO_PAIR_HEADS")) {
         for (size_t k = 0; k + 1 < steps.size(); ++k) {
@@ -783,6 +889,35 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
                 fprintf(stderr, " %llu", h[i] - h[i - 1]);
             fprintf(stderr, "\n");
             st.cp.dbg = nullptr;
+            (void)hipFree(dbg);
+        }
+    } else if (st.op == OP_BNECK) {
+        st.bn.c3.B = st.bn.ce.B = st.bn.cr.B = n;
+        HP_HIP_TRY(hp::launch_bottleneck(st.bn, s));
+        if (getenv("HP_BN_DBG")) { // block 0's phase timeline (s_memtime deltas) and the start / end of the first 1024 blocks (100 MHz clock)
+            constexpr int NDBG = 64 + 2 * 1024;
+            unsigned long long* dbg = nullptr;
+            HP_HIP_TRY(hipMalloc(&dbg, NDBG * 8));
+            HP_HIP_TRY(hipMemset(dbg, 0, NDBG * 8));
+            st.bn.ce.dbg = dbg;
+            HP_HIP_TRY(hp::launch_bottleneck(st.bn, s));
+            HP_HIP_TRY(hipStreamSynchronize(s));
+            std::vector<unsigned long long> h(NDBG);
+            HP_HIP_TRY(hipMemcpy(h.data(), dbg, NDBG * 8, hipMemcpyDeviceToHost));
+            fprintf(stderr, "bottleneck layer %d variant %d timeline:", st.layer, hp::bottleneck_variant(st.bn));
+            for (int i = 1; i < 60 && h[i]; ++i)
+                fprintf(stderr, " %llu", h[i] - h[i - 1]);
+            unsigned long long t0 = ~0ull, t1 = 0, dmin = ~0ull, dmax = 0, dsum = 0;
+            int nb = 0;
+            for (int i = 0; i < 1024 && h[64 + 2 * i]; ++i, ++nb) {
+                const unsigned long long d = h[65 + 2 * i] - h[64 + 2 * i];
+                t0 = std::min(t0, h[64 + 2 * i]), t1 = std::max(t1, h[65 + 2 * i]), dmin = std::min(dmin, d), dmax = std::max(dmax, d), dsum += d;
+            }
+            if (nb)
+                fprintf(stderr, "\n  first %d blocks: %.2f us from first start to last end; block duration %.2f .. %.2f us, mean %.2f", nb, (t1 - t0) * 0.01,
+                    dmin * 0.01, dmax * 0.01, dsum * 0.01 / nb);
+            fprintf(stderr, "\n");
+            st.bn.ce.dbg = nullptr;
             (void)hipFree(dbg);
         }
     } else if (st.op == OP_CHAIN) {
@@ -1139,6 +1274,7 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
             out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
+                : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
                 : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
                                                     : 0;
             out[k].ms = ms / iters;
@@ -1187,6 +1323,7 @@ int hp_engine_profile_pair(hp_engine* e, hp_engine* f, int n, int iters, hp_laye
             out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
+                : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
                 : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
                                                     : 0;
             out[k].ms = std::max(m0, m1) / (2 * iters);
@@ -1244,6 +1381,7 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
             out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
+                : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
                 : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
                                                     : 0;
             out[k].ms = (float)(acc[k] / iters);

@@ -415,6 +415,66 @@ def test_conv_chain_variants(hp, monkeypatch, variant, h, w, act):
         _close(got[b][0][1], got2[b][0][1])
 
 
+@pytest.mark.parametrize("m,mr,front,h,w", [
+    (64, 64, True, 52, 76),     # 13 x 19 map: partial tiles; 3x3 -> 64 -> 256 + shortcut -> the next block's 256 -> 64
+    (64, 128, True, 64, 64),    # stage end: the next stage's reduction 256 -> 128 sits behind its projection shortcut in the schedule
+    (64, 64, False, 36, 44),    # no 3x3 in front (its stride is 2): expansion + reduction only
+    (64, 0, True, 32, 32),      # last block of the network: nothing to reduce
+    (128, 128, True, 52, 76),
+    (128, 256, True, 40, 40),
+    (128, 128, False, 8, 8),    # 2 x 2 map
+    (128, 0, True, 36, 44),
+])
+def test_bottleneck_variants(hp, monkeypatch, m, mr, front, h, w):
+    """bottleneck_kernel ([3x3 ->] 1x1 expansion + shortcut [-> the next block's 1x1 reduction] in one launch, conv_bottleneck.hip)
+    against the torch oracle AND the one-launch-per-layer schedule (HP_NO_BNECK=1): the shortcut is added BEFORE the relu (torchvision
+    bottleneck), the 3x3's halo outside the image is zero padding, partial tiles write nothing outside the map, and both tensors
+    that leave the block (the 4M-channel sum and the reduced one) land where the per-layer schedule puts them."""
+    net = Net(m + mr)
+    t = net.conv(0, 3, 32, 3, 2)
+    x = net.conv(t, 32, 4 * m, 3, 2)                    # the block input = shortcut, 1/4 of the frame
+    if front:
+        r = net.conv(x, 4 * m, m, 1)                    # this block's reduction (a launch of its own)
+        v = net.conv(r, m, m, 3)
+    else:
+        v = net.conv(x, 4 * m, m, 3, 1)                 # (stands for the stride-2 3x3 of a stage's first block)
+    y = net.conv(v, m, 4 * m, 1, res=x, res_before_act=1)
+    outs = []
+    if mr == 2 * m:
+        pj = net.conv(y, 4 * m, 32, 1, stride=2)        # the next stage's projection shortcut comes first in the schedule
+        outs.append(Out("pj", pj, 0, 32))
+    if mr:
+        z = net.conv(y, 4 * m, mr, 1)
+        q = net.conv(z, mr, 32, 3, act=E.ACT_NONE)
+        outs.append(Out("q", q, 0, 32))
+    s2 = net.conv(y, 4 * m, 32, 1, act=E.ACT_NONE)      # a second reader of the sum (the next block's shortcut in a real network)
+    outs.append(Out("s", s2, 0, 32))
+    fr = _frames(3, h, w, seed=h + m)
+    eng, got, ref = _run_both(net, outs, fr, h, w)
+    _check(got, ref, 3, rel=3e-3)
+    tiles = [p["tile"] for p in eng.profile(3, 1)]
+    want = 9000000 + 1000 * (m // 64) + 10 * (mr // 64) + int(front)
+    assert tiles.count(want) == 1, tiles                # the fused kernel really ran, once, in the expected instance
+    if front:
+        with pytest.raises(Exception):
+            eng.debug_tensor(v, 3)                      # the 3x3's output lives in LDS only
+    ysum = eng.debug_tensor(y, 3)
+    zred = eng.debug_tensor(z, 3) if mr else None
+    monkeypatch.setenv("HP_NO_BNECK", "1")
+    eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 3)
+    assert not any(p["tile"] >= 9000000 for p in eng2.profile(3, 1))
+    got2 = eng2.inference(fr)
+    y2 = eng2.debug_tensor(y, 3)
+    _close(ysum, y2, rel=4e-3, abs_=2e-3)               # same fp16 storage points, fp32 sums in another order
+    assert (ysum != y2).mean() < 0.2
+    if mr:
+        _close(zred, eng2.debug_tensor(z, 3), rel=4e-3, abs_=2e-3)
+    for b in range(3):
+        for (n0, a0), (n1, a1) in zip(got[b], got2[b]):
+            assert n0 == n1
+            _close(a0, a1, rel=4e-3, abs_=2e-3)
+
+
 def test_lw_openpose_fused_equals_unfused(hp, monkeypatch):
     m = E.Model("lw_openpose_mobilenet", 432, 368)
     w = m.init_weights(7)

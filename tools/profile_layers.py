@@ -20,7 +20,7 @@ prof = eng.profile(n, iters=20)                   # each step 20x back to back (
 seq = eng.profile(n, iters=20, in_sequence=True)  # the schedule in order, events in between (what an inference sees)
 eng2 = Engine.from_model(m, m.init_weights(1), max_batch=n)
 pair = eng.profile(n, iters=20, pair=eng2)        # two instances on two streams: machine time per launch with overlapping pipes
-names = {100: "sep", 101: "head", 102: "chain", 1: "conv", 2: "dw", 3: "pool", 4: "up"}
+names = {100: "sep", 101: "head", 102: "chain", 103: "bneck", 1: "conv", 2: "dw", 3: "pool", 4: "up"}
 tot = 0.0
 print(f"{'#':>3} {'op':5} {'cin':>4} {'cout':>4} k s d  {'tile':>8} {'us':>8} {'TF/s':>7} {'GB/s':>7} {'in-seq us':>9} {'pair us':>8}")
 tot_seq = tot_pair = 0.0
