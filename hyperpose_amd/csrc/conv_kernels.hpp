@@ -163,8 +163,10 @@ hipError_t launch_conv_chain(const chain_params& p, hipStream_t s);
 struct bneck_params {
     conv_params c3, ce, cr;
     int has_c3, has_cr;
+    conv_params cp; // has_cp: the block's projection shortcut (1x1 M -> 4M of the block input, no activation), computed in the block
+    int has_cp;     // instead of being read: ce.res is then empty
 };
-// 0 when the kernel does not take this combination, otherwise 1000 * (M / 64) + 10 * (M' / 64) + has_c3 (profile rows: tile = 9000000 + variant)
+// 0 when the kernel does not take this combination, otherwise 1000 * (M / 64) + 100 * has_cp + 10 * (M' / 64) + has_c3 (profile rows: tile = 9000000 + variant)
 int bottleneck_variant(const bneck_params& p);
 hipError_t launch_bottleneck(const bneck_params& p, hipStream_t s);
 

@@ -788,21 +788,54 @@ int hp_engine::build(const hp_engine_desc* d)
             }
             if (kr)
                 bn.cr = steps[kr].cp, bn.has_cr = 1;
+            // the block's shortcut is a projection of the block input that nobody else reads (the first block of a stage at stride 1):
+            // computed inside the launch instead of written by one launch and read by the next
+            size_t kp = steps.size();
+            if (E.res >= 0 && bn.ce.Cin == 64 && E.res_before_act) {
+                int writers = 0;
+                for (const auto& L2 : layers)
+                    writers += L2.out == E.res;
+                for (size_t j = 0; j < k && kp == steps.size(); ++j) {
+                    if (!plain_conv(steps[j]) || layers[steps[j].layer].out != E.res)
+                        continue;
+                    const hp_layer& P = layers[steps[j].layer];
+                    if (steps[j].cp.KH == 1 && steps[j].cp.stride == 1 && P.res < 0 && P.out_coff == 0 && P.act == HP_ACT_NONE && writers == 1
+                        && !readers_other_than(E.res, steps[ke].layer))
+                        kp = j;
+                }
+            }
+            const hp::tview res_view = bn.ce.res;
+            if (kp < steps.size())
+                bn.cp = steps[kp].cp, bn.has_cp = 1, bn.ce.res = hp::tview{ nullptr, 0, 0, 0, 0 };
             // the stand-alone kernels of some of these shapes (256 -> 64 on the generic implicit GEMM) read row-major weights: the
             // fused kernel wants them in fragment order
             auto want_layout1 = [&](hp::conv_params& c) { c.w_layout = 1; };
-            const int lay3 = bn.c3.w_layout, laye = bn.ce.w_layout, layr = bn.cr.w_layout;
+            const int lay3 = bn.c3.w_layout, laye = bn.ce.w_layout, layr = bn.cr.w_layout, layp = bn.cp.w_layout;
             if (bn.has_c3)
                 want_layout1(bn.c3);
             want_layout1(bn.ce);
             if (bn.has_cr)
                 want_layout1(bn.cr);
-            if (!hp::bottleneck_variant(bn)) {
-                if (!bn.has_c3 || !bn.has_cr)
+            if (bn.has_cp)
+                want_layout1(bn.cp);
+            // the widest combination the kernel has an instance for: without the reduction (e.g. one to a width it does not serve), then
+            // without the projection, then without both
+            {
+                const int had_cr = bn.has_cr, had_cp = bn.has_cp;
+                bool ok = false;
+                for (int drop = 0; drop < 4 && !ok; ++drop) {
+                    if (((drop & 1) && !had_cr) || ((drop & 2) && !had_cp))
+                        continue;
+                    bn.has_cr = had_cr && !(drop & 1), bn.has_cp = had_cp && !(drop & 2);
+                    bn.ce.res = bn.has_cp ? hp::tview{ nullptr, 0, 0, 0, 0 } : res_view;
+                    ok = hp::bottleneck_variant(bn) != 0;
+                }
+                if (!ok)
                     continue;
-                bn.has_cr = 0, kr = 0; // (e.g. a reduction to a width the kernel has no instance for: still fuse 3x3 + expansion)
-                if (!hp::bottleneck_variant(bn))
-                    continue;
+                if (!bn.has_cr)
+                    kr = 0;
+                if (!bn.has_cp)
+                    kp = steps.size();
             }
             // repack what was uploaded row-major
             auto repack = [&](hp::conv_params& c, int had, int layer) -> int {
@@ -829,17 +862,25 @@ int hp_engine::build(const hp_engine_desc* d)
             HP_TRY(repack(bn.ce, laye, steps[ke].layer));
             if (kr)
                 HP_TRY(repack(bn.cr, layr, steps[kr].layer));
+            if (bn.has_cp)
+                HP_TRY(repack(bn.cp, layp, steps[kp].layer));
             step& a = steps[k];
-            const double fl = (bn.has_c3 ? steps[ke].flops : 0) + (kr ? steps[kr].flops : 0);
+            const double fl = (bn.has_c3 ? steps[ke].flops : 0) + (kr ? steps[kr].flops : 0) + (bn.has_cp ? steps[kp].flops : 0);
             const double by = (bn.has_c3 ? steps[ke].bytes : 0) + (kr ? steps[kr].bytes : 0);
-            a.op = OP_BNECK, a.bn = bn, a.n_layers = 1 + bn.has_c3 + bn.has_cr;
+            a.op = OP_BNECK, a.bn = bn, a.n_layers = 1 + bn.has_c3 + bn.has_cr + bn.has_cp;
             a.flops += fl, a.bytes += by;
             if (bn.has_c3)
                 tensors[layers[steps[ke].layer].in]->elided = true; // the 3x3's output: allocated (pass 1) but never written
+            if (bn.has_cp)
+                tensors[E.res]->elided = true; // the projection's output
             if (kr)
                 steps.erase(steps.begin() + kr);
             if (bn.has_c3)
                 steps.erase(steps.begin() + ke);
+            if (bn.has_cp) {
+                steps.erase(steps.begin() + kp); // (in front of this step)
+                --k;
+            }
         }
     }
     // sibling heads (conf / paf branch of one stage: same input, same geometry, neither reads the other) share a launch

@@ -1343,7 +1343,10 @@ int hp_paf::shape(const int cs[3], const int ps[3])
     memcpy(by, ty.ofs.data(), g.UH * 4), memcpy(by + g.UH, ty.ofs1.data(), g.UH * 4);
     memcpy(by + 2 * g.UH, ty.c0.data(), g.UH * 4), memcpy(by + 3 * g.UH, ty.c1.data(), g.UH * 4);
     HP_TRY(tables.alloc(blob.size() * 4));
-    HP_HIP_TRY(hipMemcpy(tables.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+    // (on this parser's own non-blocking stream: a plain hipMemcpy goes through the legacy stream, which another thread's graph capture -
+    // the engine of the same pipeline recording its schedule - turns into an error for both)
+    HP_HIP_TRY(hipMemcpyAsync(tables.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice, stream));
+    HP_HIP_TRY(hipStreamSynchronize(stream));
     const int* d = tables.as<int>();
     g.ofs_x = d, g.c0_x = (const float*)(d + g.UW), g.c1_x = (const float*)(d + 2 * g.UW);
     const int* dy = d + 3 * g.UW;
@@ -1373,8 +1376,9 @@ int hp_paf::shape(const int cs[3], const int ps[3])
     HP_TRY(flags.alloc(B * sizeof(int)));
     HP_TRY(h_counts.alloc(2 * B * sizeof(int)));
     // invariant between batches: peak counters and overflow flags are zero (the assemble kernel restores it)
-    HP_HIP_TRY(hipMemset(pcount.p, 0, B * HP_COCO_N_PARTS * sizeof(int)));
-    HP_HIP_TRY(hipMemset(flags.p, 0, B * sizeof(int)));
+    HP_HIP_TRY(hipMemsetAsync(pcount.p, 0, B * HP_COCO_N_PARTS * sizeof(int), stream)); // (own stream: see the table upload above)
+    HP_HIP_TRY(hipMemsetAsync(flags.p, 0, B * sizeof(int), stream));
+    HP_HIP_TRY(hipStreamSynchronize(stream));
     memset(h_counts.p, 0, 2 * B * sizeof(int));
     shaped = true;
     return HP_OK;

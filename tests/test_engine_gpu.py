@@ -475,6 +475,42 @@ def test_bottleneck_variants(hp, monkeypatch, m, mr, front, h, w):
             _close(a0, a1, rel=4e-3, abs_=2e-3)
 
 
+@pytest.mark.parametrize("mr,h,w", [(64, 52, 76), (128, 40, 40), (0, 36, 28)])
+def test_bottleneck_with_projection_shortcut(hp, monkeypatch, mr, h, w):
+    """The first block of ResNet's first stage: its shortcut is a 1x1 projection (64 -> 256, no activation) of the block input that only
+    this block reads.  bottleneck64_kernel<.., PJ> computes it inside the launch (K = [3x3 output ; block input]) instead of reading
+    it: the projection's tensor is never written, and the sum skips the fp16 rounding of the projection - compared with the oracle
+    (which rounds it) and the per-layer schedule at the tolerance of one fp16 rounding of an addend."""
+    net = Net(7 + mr)
+    t = net.conv(0, 3, 32, 3, 2)
+    x = net.conv(t, 32, 64, 3, 2)                       # the block input, 1/4 of the frame
+    pj = net.conv(x, 64, 256, 1, act=E.ACT_NONE)        # projection shortcut (conv + BN, no relu)
+    r = net.conv(x, 64, 64, 1)
+    v = net.conv(r, 64, 64, 3)
+    y = net.conv(v, 64, 256, 1, res=pj, res_before_act=1)
+    outs = []
+    if mr:
+        z = net.conv(y, 256, mr, 1)
+        outs.append(Out("q", net.conv(z, mr, 32, 3, act=E.ACT_NONE), 0, 32))
+    outs.append(Out("s", net.conv(y, 256, 32, 1, act=E.ACT_NONE), 0, 32))
+    fr = _frames(3, h, w, seed=h + mr)
+    eng, got, ref = _run_both(net, outs, fr, h, w)
+    _check(got, ref, 3, rel=4e-3, abs_=2e-3)
+    tiles = [p["tile"] for p in eng.profile(3, 1)]
+    assert tiles.count(9000000 + 1000 + 100 + 10 * (mr // 64) + 1) == 1, tiles
+    with pytest.raises(Exception):
+        eng.debug_tensor(pj, 3)                         # the projection is never materialised
+    ysum = eng.debug_tensor(y, 3)
+    monkeypatch.setenv("HP_NO_BNECK", "1")
+    eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 3)
+    got2 = eng2.inference(fr)
+    _close(ysum, eng2.debug_tensor(y, 3), rel=4e-3, abs_=4e-3)
+    for b in range(3):
+        for (n0, a0), (n1, a1) in zip(got[b], got2[b]):
+            assert n0 == n1
+            _close(a0, a1, rel=4e-3, abs_=4e-3)
+
+
 def test_lw_openpose_fused_equals_unfused(hp, monkeypatch):
     m = E.Model("lw_openpose_mobilenet", 432, 368)
     w = m.init_weights(7)
