@@ -325,13 +325,23 @@ def kernel_label(tile: int):
            2: ("sepconv_small_kernel<", "separable block -> 128 channels, stride 2, all channels of a tile in LDS"),
            3: ("sepconv_slot_kernel<2,1,2,1,128,64>", "separable block 128 -> 256, stride 2, half-CU form"),
            4: ("sepconv_slot_kernel<1,2,1,1,256,64>", "separable block 256 -> 256, half-CU form"),
-           5: ("sepconv_slot_kernel<2,2,1,1,512,64>", "separable block 256 / 512 -> 512: depthwise 3x3 per 64-channel chunk -> B tile of ALL chunks in LDS -> "
-               "pointwise MFMAs in two passes of 256 output channels, 8x8 pixels per block, two blocks per CU"),
-           6: ("sepconv_slot_kernel<2,2,1,2,512,32>", "separable block 512 -> 512, dilation 2, half-CU form")}
+           5: ("sepconv_pipe_kernel<1,512>", "separable block 256 / 512 -> 512: 12x8 pixels x all 512 output channels per block, eight wavefronts; per 64-channel "
+               "chunk the depthwise taps of chunk k+1 and the pointwise MFMAs of chunk k run in anti-phase on the two wavefronts of a SIMD"),
+           6: ("sepconv_pipe_kernel<2,512>", "separable block 512 -> 512, dilation 2, same form")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
+    if tile >= 9000000:
+        v = tile - 9000000
+        m, pj, mr, a3 = v // 1000 * 64, v // 100 % 10, v // 10 % 10 * 64, v % 10
+        what = (f"{'3x3 -> ' if a3 else ''}1x1 {m} -> {4 * m} + {'projection' if pj else 'shortcut'}{f' -> 1x1 {4 * m} -> {mr} of the next block' if mr else ''} in one "
+                "launch, 8x8 pixels per block, intermediates in LDS")
+        if m == 64:
+            return (f"bottleneck64_kernel<{mr},{'true' if a3 else 'false'},{'true' if pj else 'false'}>", "bottleneck64_kernel (" + what + ")")
+        if a3:
+            return (f"bottleneck_kernel<128,{mr},true>", "bottleneck_kernel (" + what + ")")
+        return (f"bottleneck128_kernel<{mr},false>", "bottleneck128_kernel (" + what + ")")
     if tile >= 7000000:
         v = tile - 7000000
-        return (f"conv_chain_kernel<{chain.get(v, '')},", "conv_chain_kernel ([1x1 ->] 3x3 -> 3x3 [+ residual] on 128 channels in one launch: 8x12 output pixels x all "
+        return (f"conv_chain_kernel<{chain.get(v, '')},", "conv_chain_kernel ([1x1 ->] 3x3 -> 3x3 [+ residual] on 128 channels in one launch: 8x8 output pixels x all "
                 "128 channels per block, intermediates in LDS, weights in MFMA-fragment order straight from L2)")
     if tile >= 6000000 and tile % 1000 in (9, 25, 49):
         v = tile - 6000000

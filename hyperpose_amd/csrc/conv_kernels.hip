@@ -1132,6 +1132,10 @@ static int use_gdirect(const conv_params& p)
     // re-use unless K is long (measured at 12 x 12: 512 -> 512 57 -> 45 us, 2048 -> 512 212 -> 163 us on this kernel)
     if ((long)p.OH * p.OW < 256 && p.Cin < 256)
         return 0;
+    // 3x3 on maps the 16 x 12 tiles cover badly (49 x 49: 20 tiles for 12.5 tiles of pixels, 25 x 25: 6 for 3.3): the generic kernel has no
+    // tiles to round up to (measured at batch 64: 256 channels at 49 x 49 253 -> 223 us, 512 channels at 25 x 25 276 -> 220 us)
+    if (p.KH == 3 && (double)p.OH * p.OW < 0.68 * ((p.OH + 15) / 16 * 16) * ((p.OW + 11) / 12 * 12))
+        return 0;
     // 128-channel chunks only where ONE chunk is the whole input (7x7 / 5x5 x 128: a 101 / 82 KB tile, single-buffered); everything
     // else runs on double-buffered 64-channel chunks (the 128-channel form of that pipeline needs more than 256 registers)
     // (measured: 7x7 x 128 as two pipelined 64-channel chunks is 10 % slower than as one 128-channel chunk - the chunk barrier waits for

@@ -736,8 +736,8 @@ def test_onnx_pads_block_the_fused_kernels(hp):
 
 
 @pytest.mark.parametrize("k,cin,cout,h,w", [
-    (7, 128, 128, 23, 29), (7, 185, 128, 23, 29), (7, 128, 256, 37, 50), (3, 256, 256, 23, 29), (3, 512, 128, 33, 25),
-    (3, 192, 384, 19, 40), (5, 128, 128, 23, 29), (5, 320, 128, 17, 31),
+    (7, 128, 128, 23, 29), (7, 185, 128, 23, 29), (7, 128, 256, 37, 50), (3, 256, 256, 30, 35), (3, 512, 128, 31, 23),
+    (3, 192, 384, 15, 47), (3, 256, 256, 23, 29), (5, 128, 128, 23, 29), (5, 320, 128, 17, 31),
 ])
 def test_direct_conv_any_kernel_and_width(hp, k, cin, cout, h, w):
     """conv_direct_kernel (8 wavefronts, halo tile of a channel chunk in LDS for all k*k taps, fragment-ordered weights from L2,
@@ -759,6 +759,8 @@ def test_direct_conv_any_kernel_and_width(hp, k, cin, cout, h, w):
     prof = eng.profile(3, 1)
     # the k x k layers whose output stays fp16 NHWC really ran on conv_direct_kernel (z_mid is also a network output: generic epilogue)
     want = 2 if (k > 3 or cout > 128) else 1  # (3x3 layers with 128 input channels stay on conv3x3_direct_kernel)
+    if k == 3 and h * w < 0.68 * (-(-h // 16) * 16) * (-(-w // 12) * 12):
+        want = 0                              # (3x3 on a map the 16 x 12 tiles cover badly - 23 x 29: 4 x 3 tiles for 3.5 - goes to the generic kernel)
     assert sum(1 for p in prof if p["tile"] >= 6000000) == want, [p["tile"] for p in prof]
 
 
