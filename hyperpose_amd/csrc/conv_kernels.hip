@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(512) void conv1x1_big_kernel(const conv_params p)
         for (int k = 0; k < NTP; ++k) {
             const int n = min(n0 + (pt >> 3) + 32 * k, p.npix - 1);
             const int b = n / HW, r = n - b * HW, y = r / p.OW, x = r - y * p.OW;
-            hoff[k] = tv_off(p.in, b, y, x) + (pt & 7) * 8;
+            hoff[k] = tv_off(p.in, b, y * p.stride, x * p.stride) + (pt & 7) * 8;
         }
         constexpr int PF = 4;
         u32x4 hv[PF][NTP];
@@ -1422,8 +1422,10 @@ __global__ __launch_bounds__(512) void conv1x1_big_kernel(const conv_params p)
 // which (TM, NTP) the pixel-block GEMM runs a layer with: TM * 1000 + NTP, or 0 when the layer is not its kind
 static int big1x1_variant(const conv_params& p)
 {
-    if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_t || p.pad_l || p.OH != p.H || p.OW != p.W || p.Cin % 256 /* four-chunk ring */
-        || p.Cout_pad % 128 || p.Cout % 8 || p.in.coff % 8 || p.in.cs - p.in.coff < p.Cin)
+    // (any stride: a strided 1x1 is the same GEMM over every stride-th pixel - the producers gather them; ResNet's projection shortcuts)
+    if (p.KH != 1 || p.KW != 1 || p.stride < 1 || p.pad_t || p.pad_l || p.OH != (p.H + p.stride - 1) / p.stride
+        || p.OW != (p.W + p.stride - 1) / p.stride || p.Cin % 256 /* four-chunk ring */ || p.Cout_pad % 128 || p.Cout % 8 || p.in.coff % 8
+        || p.in.cs - p.in.coff < p.Cin)
         return 0;
     // (TM, NTP) by a small cost model: blocks are dealt to the 256 CUs in rounds (two blocks share a CU when each needs <= 256
     // registers); a round costs its MFMAs at ~80 % pipe efficiency plus ~6 k cycles of prologue / epilogue; 64-pixel blocks (NTP = 2)
