@@ -1283,10 +1283,19 @@ template <int TM, int NTP>
 __global__ __launch_bounds__(512) void conv1x1_big_kernel(const conv_params p)
 {
     constexpr int NPX = 32 * NTP, CK = 64, KS = 4, BUF = NPX * CK * 2;
-    constexpr int SLABS = 4 * NTP * stage_geom<TM>::SLAB; // conv_epilogue_wide: all NTP pixel tiles of a wavefront staged at once
+    constexpr int SLABS = 4 * NTP * stage_geom<TM>::SLAB; // conv_epilogue_wide / _packed: all NTP pixel tiles of a wavefront staged at once
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF > SLABS ? 2 * BUF : SLABS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * NPX, HW = p.OH * p.OW;
+    // 1-D grid, XCD-aware: blocks are dealt round-robin to the eight XCDs, whose L2s do not share.  The CG output-channel groups of one
+    // pixel tile read the same activations, so they get ids that are congruent mod 8 (same XCD, same L2) and within 8 * CG of each other
+    // (in flight together): id = (t / 8) * 8 * CG + cg * 8 + t % 8.  (As a 2-D grid the four groups of ResNet's 256 -> 1024 expansion
+    // landed on four XCDs and the input was fetched from HBM four times: 945 MB per launch instead of 709.)
+    const int CG = p.Cout_pad / (128 * TM);
+    const int within = blockIdx.x % (8 * CG);
+    const int ptile = (blockIdx.x / (8 * CG)) * 8 + within % 8, cgrp = within / 8;
+    if (ptile * NPX >= p.npix)
+        return; // (the grid is padded to a multiple of eight pixel tiles)
+    const int n0 = ptile * NPX, HW = p.OH * p.OW;
     const int KQ = p.Cin / 16, NCH = p.Cin / CK;
 
     if (wave >= 4) {
@@ -1348,7 +1357,7 @@ __global__ __launch_bounds__(512) void conv1x1_big_kernel(const conv_params p)
 
     // ---- CONSUMER wavefronts (0-3): wavefront w owns TM 32-row tiles over the full K
     const int frow = lane & 31, fk = lane >> 5;
-    const int m_wave = (blockIdx.y * 4 + wave) * TM * 32;
+    const int m_wave = (cgrp * 4 + wave) * TM * 32;
     const __half* const wbase = p.w + ((size_t)(m_wave / 32) * KQ * 64 + lane) * 8;
     const size_t row_stride = (size_t)KQ * 512;
     u32x4 a[KS][TM];
@@ -1411,6 +1420,9 @@ __global__ __launch_bounds__(512) void conv1x1_big_kernel(const conv_params p)
     }
     // (the producers are gone and the last barrier of the loop is behind every read of the B buffers: the wave-private slabs may
     // overlay them; the staged epilogue synchronises inside a wavefront only)
+    // (a residual parked in LDS by the producers while the MFMAs run - no HBM round trip after the last MFMA - was built and measured:
+    // 205 -> 223 us for ResNet's 256 -> 1024 expansion.  That layer is bound by what its blocks pull through the L2s - 1.2 GB of weights
+    // per launch for 64-pixel tiles, next to 0.95 GB of activations - not by its epilogue.)
     if (p.res.p) // uniform
         conv_epilogue_wide<TM, NTP>(p, acc, m_wave, lane, lds + wave * (NTP * stage_geom<TM>::SLAB), pb, py, px, pv);
     else
@@ -1473,7 +1485,8 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
         if (!v || !fast_epilogue(p))
             return hipErrorInvalidValue;
         const int TM = v / 1000, NTP = v % 1000;
-        const dim3 grid((p.npix + 32 * NTP - 1) / (32 * NTP), p.Cout_pad / (128 * TM));
+        const int ptiles = (p.npix + 32 * NTP - 1) / (32 * NTP);
+        const dim3 grid((ptiles + 7) / 8 * 8 * (p.Cout_pad / (128 * TM)));
 #define HP_BIG(TM_, NTP_) HP_LAUNCH((conv1x1_big_kernel<TM_, NTP_>), grid, dim3(512), 0, s, p)
         switch (v) { // (the instances big1x1_variant hands out; wider / taller ones were swept and lost: see there)
         case 2002: HP_BIG(2, 2); break;

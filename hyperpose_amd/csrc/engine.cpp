@@ -1334,6 +1334,10 @@ int hp_engine_profile_pair(hp_engine* e, hp_engine* f, int n, int iters, hp_laye
 {
     HP_REQUIRE(e && f && e != f && n >= 1 && n <= e->max_batch && n <= f->max_batch && iters >= 1 && n_out && e->steps.size() == f->steps.size(),
         HP_ERR_INVALID, "hp_engine_profile_pair: bad argument");
+    for (size_t i = 0; i < e->steps.size(); ++i) // the same schedule: step by step the same operation on the same amount of work
+        HP_REQUIRE(e->steps[i].op == f->steps[i].op && e->steps[i].layer == f->steps[i].layer && e->steps[i].flops == f->steps[i].flops
+                && e->steps[i].bytes == f->steps[i].bytes,
+            HP_ERR_INVALID, "hp_engine_profile_pair: the engines' schedules differ at step %zu", i);
     const size_t need = (size_t)e->max_batch * e->in_h * e->in_w * 3 * sizeof(float);
     for (hp_engine* g : { e, f })
         if (g->in_stage.bytes < need)

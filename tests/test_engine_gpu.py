@@ -625,6 +625,17 @@ def test_profile_in_sequence_reports_every_step(hp):
     assert all(p["ms"] > 0 for p in b)
     ta, tb = sum(p["ms"] for p in a), sum(p["ms"] for p in b)
     assert 0.2 * ta < tb < 5 * ta
+    # hp_engine_profile_pair: the same steps with a second engine of the same model on its own stream (machine time per launch)
+    eng2 = E.Engine.from_model(m, m.init_weights(3), max_batch=2)
+    c = eng.profile(2, 3, pair=eng2)
+    assert [(p["layer"], p["op"], p["tile"]) for p in a] == [(p["layer"], p["op"], p["tile"]) for p in c]
+    tc = sum(p["ms"] for p in c)
+    assert all(p["ms"] > 0 for p in c) and 0.02 * ta < tc < 20 * ta, (ta, tc)
+    with pytest.raises(Exception):
+        eng.profile(2, 3, pair=eng)          # the same engine twice
+    other = E.Model("lw_openpose_vggtiny", 96, 80)
+    with pytest.raises(Exception):
+        eng.profile(1, 1, pair=E.Engine.from_model(other, other.init_weights(1), max_batch=2))   # another schedule
 
 
 def test_corrupted_engine_files_are_rejected_not_crashed(hp, tmp_path):
