@@ -861,8 +861,11 @@ struct direct_geom {
 
 // one block's work on the TH x 12 pixel tile at (b, y0, x0); TH = 16 is the full tile, TH = 8 serves tile rows of which at most 8 rows
 // exist (the last tile row of a 54-row map has 6): half the MFMAs and halo rows instead of multiplying rows that are thrown away
+// chunk_base / nchunks: the channel chunks this block multiplies (split-K: a slice of them - the partial sums then go to p.splitk
+// instead of through the epilogue, slot = this block's index among the (tile, output-channel group) pairs)
 template <int KS, int CK, int TH, int NBUF>
-__device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned char* lds, int b, int y0, int x0, int nchunks)
+__device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned char* lds, int b, int y0, int x0, int nchunks, int chunk_base = 0,
+    bool park_partial = false)
 {
     using G = direct_geom<KS, CK, TH, NBUF>;
     constexpr int TW = 12, HPH = G::HPH, HPW = G::HPW, NT = G::NT, PAD = KS / 2, TAPS = KS * KS;
@@ -891,14 +894,14 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
     const __half* wfrag = p.w + ((size_t)((m0 / 32 + wm) * KQ + kg * NS) * 64 + lane) * 8;
     auto a_off = [&](int q) -> long { // element offset of step q's first A fragment of this wave
         const int ch = q / TAPS, tp = q - ch * TAPS;
-        return (long)tp * tap_stride + (long)ch * (KQC * 512);
+        return (long)tp * tap_stride + (long)(chunk_base + ch) * (KQC * 512);
     };
     u32x4 a0[NS], a1[NS];
     {
-        const long o1 = a_off(min(1, total - 1));
+        const long o0 = a_off(0), o1 = a_off(min(1, total - 1));
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
-            a0[ks] = *reinterpret_cast<const u32x4*>(wfrag + (size_t)ks * 512);
+            a0[ks] = *reinterpret_cast<const u32x4*>(wfrag + o0 + (size_t)ks * 512);
             a1[ks] = *reinterpret_cast<const u32x4*>(wfrag + o1 + (size_t)ks * 512);
         }
     }
@@ -917,7 +920,7 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
             // y, x >= -PAD always; rows / columns up to H + PAD - 1 lie in the zero halo of the HBM tensor, beyond that clamp + zero
             const bool ok = y < p.H + PAD && x < p.W + PAD;
             const u32x4 v = *reinterpret_cast<const u32x4*>(
-                p.in.p + tv_off(p.in, b, min(y, p.H + PAD - 1), min(x, p.W + PAD - 1)) + chunk * CK + c * 8);
+                p.in.p + tv_off(p.in, b, min(y, p.H + PAD - 1), min(x, p.W + PAD - 1)) + (chunk_base + chunk) * CK + c * 8);
             hv[it] = v & (ok ? 0xffffffffu : 0u);
         }
     };
@@ -1076,6 +1079,16 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
         pv[j] = py[j] < p.OH && px[j] < p.OW && (!kg || j < K1);
     }
     HP_DSTAMP();
+    if (park_partial) { // uniform: split-K - this block's sums wait in HBM for conv_direct_finish_kernel, in this lane layout
+        const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x, nslots = (size_t)gridDim.x * gridDim.y;
+        float4* const dst = reinterpret_cast<float4*>(p.splitk) + ((blockIdx.z * nslots + slot) * 8 + wave) * (K0 * 4 * 64) + lane;
+#pragma unroll
+        for (int j = 0; j < K0; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                dst[(j * 4 + g4) * 64] = make_float4(mine[0][j][4 * g4], mine[0][j][4 * g4 + 1], mine[0][j][4 * g4 + 2], mine[0][j][4 * g4 + 3]);
+        return;
+    }
     // the slabs live behind the parking area: no wave can still be reading what another overwrites
     conv_epilogue_staged<1, K0>(p, mine, m0 + wm * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
     HP_DSTAMP();
@@ -1104,8 +1117,58 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(const conv_params p, i
     // (the two-path form of the chunk-pipelined kernels needs more than 256 registers: they always take the full tile)
     if (NBUF == 1 && p.OH - y0 <= 8) // uniform
         conv_direct_body<KS, CK, 8, NBUF>(p, lds, b, y0, x0, nchunks);
+    else if (NBUF == 2 && gridDim.z > 1) // split-K: gridDim.z blocks per tile, nchunks / gridDim.z chunks each
+        conv_direct_body<KS, CK, 16, NBUF>(p, lds, b, y0, x0, nchunks / gridDim.z, blockIdx.z * (nchunks / gridDim.z), true);
     else
         conv_direct_body<KS, CK, 16, NBUF>(p, lds, b, y0, x0, nchunks);
+}
+
+// split-K, second launch: the same grid without z; every wavefront adds the ksplit partial sums of the tiles it finishes (parked in its
+// own lane layout) and runs the kernel's epilogue.  A kernel boundary between the two makes the sums visible across the XCDs' L2s.
+template <int KS, int CK>
+__global__ __launch_bounds__(512) void conv_direct_finish_kernel(const conv_params p, int tiles_x, int tiles_y)
+{
+    using G = direct_geom<KS, CK, 16, 2>;
+    constexpr int TW = 12, NT = G::NT, K0 = (NT + 1) / 2, K1 = NT / 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[8 * stage_geom<1>::SLAB];
+    int tx, ty, b;
+    {
+        const int t = blockIdx.x, per_full = tiles_x * (tiles_y - 1), full = per_full * p.B;
+        if (t < full) {
+            b = t / per_full;
+            const int r = t - b * per_full;
+            ty = r / tiles_x, tx = r - ty * tiles_x;
+        } else {
+            const int r = t - full;
+            b = r / tiles_x, tx = r - b * tiles_x, ty = tiles_y - 1;
+        }
+    }
+    const int y0 = ty * 16, x0 = tx * 12;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 3, kg = wave >> 2;
+    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x, nslots = (size_t)gridDim.x * gridDim.y;
+    floatx16 mine[1][K0];
+    int pb[K0], py[K0], px[K0];
+    bool pv[K0];
+#pragma unroll
+    for (int j = 0; j < K0; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            mine[0][j][r] = 0.f;
+        for (int z = 0; z < p.ksplit; ++z) { // (ascending K: the order does not depend on which block finished first)
+            const float4* src = reinterpret_cast<const float4*>(p.splitk) + ((z * nslots + slot) * 8 + wave) * (K0 * 4 * 64) + lane;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 o = src[(j * 4 + g4) * 64];
+                mine[0][j][4 * g4] += o.x, mine[0][j][4 * g4 + 1] += o.y, mine[0][j][4 * g4 + 2] += o.z, mine[0][j][4 * g4 + 3] += o.w;
+            }
+        }
+        const int jt = K0 + j < NT ? K0 + j : NT - 1;
+        const int n = (kg ? jt : j) * 32 + (lane & 31);
+        const int br = n / TW, bc = n - br * TW;
+        pb[j] = b, py[j] = y0 + br, px[j] = x0 + bc;
+        pv[j] = py[j] < p.OH && px[j] < p.OW && (!kg || j < K1);
+    }
+    conv_epilogue_staged<1, K0>(p, mine, blockIdx.y * 128 + wm * 32, lane, lds + wave * stage_geom<1>::SLAB, pb, py, px, pv);
 }
 
 // fast epilogue (aligned fp16 NHWC vectors) when every 8-channel chunk is whole and 16-byte aligned
@@ -1478,6 +1541,26 @@ int conv_mfma_tile(const conv_params& p)
     return BM * 1000 + BN;
 }
 
+// split-K for the chunk-pipelined 3x3 instance when its tiles leave CUs idle (configs[3]: 12 x 12 maps at batch 32 = 32 tiles x 4
+// output-channel groups = 128 blocks; the 2048 -> 512 head convolution alone is 8 % of that network's conv time)
+int conv_splitk(const conv_params& p, size_t* scratch_bytes)
+{
+    if (scratch_bytes)
+        *scratch_bytes = 0;
+    if (p.w_layout != 1 || p.KH != 3 || use_gdirect(p) != 64)
+        return 1;
+    const int nchunks = p.Cin / 64;
+    const long blocks = (long)((p.OW + 11) / 12) * ((p.OH + 15) / 16) * p.B * (p.Cout_pad / 128);
+    int ks = 1;
+    if (blocks <= 64 && nchunks >= 8 && nchunks % 4 == 0)
+        ks = 4;
+    else if (blocks <= 160 && nchunks >= 4 && nchunks % 2 == 0)
+        ks = 2;
+    if (ks > 1 && scratch_bytes)
+        *scratch_bytes = (size_t)ks * blocks * 8 * 3 * 4 * 64 * sizeof(float4); // [z][slot][wave][K0 = 3][4][64 lanes] float4
+    return ks;
+}
+
 hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
 {
     if (p.w_layout == 1 && p.KH == 1 && !use_small1x1(p)) {
@@ -1525,7 +1608,17 @@ hipError_t launch_conv_mfma(const conv_params& p, hipStream_t s)
             HP_GD(3, 128, 1);
         else if (nchunks == 1)
             HP_GD(3, 64, 1);
-        else
+        else if (p.ksplit > 1 && p.splitk && nchunks % p.ksplit == 0) { // (the engine sized the scratch for its largest batch)
+            const dim3 grid3(grid.x, grid.y, p.ksplit);
+            hipEvent_t const ev0 = hp::prof_start, ev1 = hp::prof_stop; // (hp_engine_profile_sequence: begin of the first, end of the second launch)
+            if (ev0) {
+                hipExtLaunchKernelGGL((conv_direct_kernel<3, 64, 2>), grid3, dim3(512), 0, s, ev0, nullptr, 0, p, tiles_x, tiles_y, nchunks);
+                hipExtLaunchKernelGGL((conv_direct_finish_kernel<3, 64>), grid, dim3(512), 0, s, nullptr, ev1, 0, p, tiles_x, tiles_y);
+            } else {
+                hipLaunchKernelGGL((conv_direct_kernel<3, 64, 2>), grid3, dim3(512), 0, s, p, tiles_x, tiles_y, nchunks);
+                hipLaunchKernelGGL((conv_direct_finish_kernel<3, 64>), grid, dim3(512), 0, s, p, tiles_x, tiles_y);
+            }
+        } else
             HP_GD(3, 64, 2);
 #undef HP_GD
         return hipGetLastError();

@@ -52,7 +52,15 @@ struct conv_params {
     float* out_f32; // fp32 NCHW [B][Cout][OH][OW]
     int npix;       // B*OH*OW
     unsigned long long* dbg; // optional s_memtime timeline of block 0 / wave 0 (tools/microbench), nullptr in production
+    // split-K (conv_direct_kernel on maps with fewer tiles than CUs): ksplit >= 2 blocks share a tile's channel chunks, park their fp32
+    // partial sums in `splitk` (conv_splitk() bytes) and a second launch adds them and runs the epilogue.  0 / nullptr: off.
+    int ksplit;
+    float* splitk;
 };
+
+// how many ways the launcher would split the K of this convolution (1 = not at all) and the scratch bytes that needs; the engine
+// allocates the scratch and sets ksplit / splitk (a convolution without scratch runs unsplit)
+int conv_splitk(const conv_params& p, size_t* scratch_bytes);
 
 // fills act_slope / act_hi from act / act_param; false for activations the MFMA epilogue does not fuse
 bool set_act(conv_params& p);

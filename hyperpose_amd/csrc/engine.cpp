@@ -682,6 +682,27 @@ int hp_engine::build(const hp_engine_desc* d)
         }
         steps.push_back(st);
     }
+    // ---- split-K scratch: convolutions whose tiles leave CUs idle at this engine's batch (conv_splitk) share one buffer - the
+    // schedule is serial on one stream, a convolution's partial sums are consumed by its own second launch
+    {
+        size_t need = 0;
+        for (auto& st : steps) {
+            size_t bytes = 0;
+            if (st.op == HP_OP_CONV && !st.first && !getenv("HP_NO_SPLITK") && hp::conv_splitk(st.cp, &bytes) > 1)
+                need = std::max(need, bytes);
+        }
+        if (need) {
+            weight_bufs.push_back(std::make_unique<hp::dev_buf>());
+            HP_TRY(weight_bufs.back()->alloc(need));
+            void* const d = weight_bufs.back()->p;
+            for (auto& st : steps)
+                if (st.op == HP_OP_CONV && !st.first) {
+                    const int ks = hp::conv_splitk(st.cp, nullptr);
+                    if (ks > 1)
+                        st.cp.ksplit = ks, st.cp.splitk = (float*)d;
+                }
+        }
+    }
     // ---- chains of 128-channel convolutions (LW-OpenPose's CPM / initial / refinement stages, lw_openpose.py:106-191): consecutive
     // steps [1x1 ->] 3x3 -> 3x3 whose intermediates nobody else reads run as ONE launch with the intermediates in LDS
     // (conv_chain.hip).  HP_NO_CHAIN=1 keeps one launch per layer (A/B measurements, and hp_engine_debug_tensor on an intermediate).

@@ -775,6 +775,33 @@ def test_direct_conv_any_kernel_and_width(hp, k, cin, cout, h, w):
     assert sum(1 for p in prof if p["tile"] >= 6000000) == want, [p["tile"] for p in prof]
 
 
+@pytest.mark.parametrize("cin,cout,h,w,batch", [(512, 256, 12, 12, 3), (256, 128, 16, 24, 4), (2048, 128, 12, 12, 2)])
+def test_direct_conv_split_k_on_small_maps(hp, monkeypatch, cin, cout, h, w, batch):
+    """3x3 convolutions whose 16x12 tiles are fewer than the CUs (12 x 12 maps of the ResNet heads) split their channel chunks over 2 or
+    4 blocks per tile (conv_splitk); the fp32 partial sums meet in a second launch that runs the epilogue (bias, PReLU, residual).
+    Against the oracle and against the unsplit launch (HP_NO_SPLITK=1: same kernel, other fp32 summation order)."""
+    net = Net(cin + cout)
+    cat = net.new_tensor()
+    for c0 in range(0, cin, 128):
+        net.conv(0, 3, 128, 3, 1, out=cat, out_coff=c0, act=E.ACT_LEAKY, act_param=0.1 + c0 / 4096)
+    u = net.conv(cat, cin, cout, 3, act=E.ACT_PRELU)
+    v = net.conv(u, cout, cout, 1, act=E.ACT_NONE)
+    fr = _frames(batch, h, w, seed=cin)
+    outs = [Out("v", v, 0, cout)]
+    eng, got, ref = _run_both(net, outs, fr, h, w)
+    _check(got, ref, batch, rel=3e-3)
+    mid = eng.debug_tensor(u, batch)
+    refu = ref_net.run(net.layers, [Out("u", u, 0, cout)], net.blob(), frames_u8=fr, match_fp16=True)["u"]
+    _close(mid, refu, rel=2e-3, abs_=1e-3)      # the split convolution's own output against the oracle
+    monkeypatch.setenv("HP_NO_SPLITK", "1")
+    eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, batch)
+    got2 = eng2.inference(fr)
+    mid2 = eng2.debug_tensor(u, batch)
+    _close(mid, mid2, rel=2e-3, abs_=1e-3)
+    assert (mid != mid2).mean() < 0.25          # mostly the same fp16 values ...
+    assert (mid != mid2).any()                   # ... but the split really happened (another summation order somewhere)
+
+
 def test_vgg19_small_through_the_direct_kernels(hp):
     """OpenPose-VGG19 at 64 x 96: the 5x5-free 3x3 / 7x7 layers run on conv_direct_kernel / conv3x3_direct_kernel where their shapes
     allow and on the implicit GEMM elsewhere (maps smaller than two tiles); all of it against the oracle."""
