@@ -338,7 +338,7 @@ def kernel_label(tile: int):
             return (f"bottleneck64_kernel<{mr},{'true' if a3 else 'false'},{'true' if pj else 'false'}>", "bottleneck64_kernel (" + what + ")")
         if a3:
             return (f"bottleneck_kernel<128,{mr},true>", "bottleneck_kernel (" + what + ")")
-        return (f"bottleneck128_kernel<{mr},false>", "bottleneck128_kernel (" + what + ")")
+        return (f"bottleneck128_kernel<{mr}>", "bottleneck128_kernel (" + what + ")")
     if tile >= 7000000:
         v = tile - 7000000
         return (f"conv_chain_kernel<{chain.get(v, '')},", "conv_chain_kernel ([1x1 ->] 3x3 -> 3x3 [+ residual] on 128 channels in one launch: 8x8 output pixels x all "

@@ -164,16 +164,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const bneck_params p
 
     // weights (fragment order [tap][32-row tile][k16][lane][8]): this wavefront's first unit
     //   3x3: M = 128: row tile `wave`, both pixel halves; M = 64: row tile wr, pixel half wj
-    const int rtA = M == 128 ? wave : wr;
+    const int rtA = wave; // the 3x3's row tile of this wavefront (both pixel halves)
     const long tapA = (long)(M / 32) * KQM * 512;
     const __half* const wA = A3 ? p.c3.w + (size_t)(rtA * KQM) * 512 + lane8 : nullptr;
     //   expansion chunk c, i = 0 / 1: row tile c * 4 + wr * 2 + i (K = M)
     auto wB = [&](int c, int i) { return p.ce.w + (size_t)((c * 4 + wr * 2 + i) * KQM) * 512 + lane8; };
     //   reduction chunk c, r: row tile wr * RT + r, k16 steps c * 8 .. c * 8 + 7 of 4M / 16
     auto wC = [&](int c, int r) { return p.cr.w + (size_t)((wr * RT + r) * (4 * M / 16) + c * 8) * 512 + lane8; };
-    constexpr int G3 = M == 64 ? 3 : 1;                   // taps of 3x3 weight fragments in flight (unit())
-    constexpr int NA = (A3 && G3 * KQM > 8) ? G3 * KQM : 8;
-    u32x4 a[NA];
+    u32x4 a[8];
     {
         const __half* wf = A3 ? wA : wB(0, 0);
 #pragma unroll
@@ -243,22 +241,22 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const bneck_params p
 
     // ---- phase A: 3x3 -> T2
     if constexpr (A3) {
-        constexpr int NT = M == 128 ? 2 : 1;
+        constexpr int NT = 2;
         floatx16 acc[NT];
         zero_acc(acc);
         int pix0[NT], nkey[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = (M == 128 ? j : wj) * 32 + fr, br = n / TW, bc = n - br * TW;
+            const int n = j * 32 + fr, br = n / TW, bc = n - br * TW;
             pix0[j] = (br * W1 + bc) * PXB, nkey[j] = n;
         }
-        unit<NT, 9, W1, TW, KQM, KQM, G3>(acc, a, wA, tapA, wB(0, 0), s_t1, pix0, nkey, fk);
+        unit<NT, 9, W1, TW, KQM, KQM>(acc, a, wA, tapA, wB(0, 0), s_t1, pix0, nkey, fk);
         HP_NSTAMP();
         lds_barrier(); // every wavefront is done reading T1: T2 goes over it
         const float hi = p.c3.act_hi;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = (M == 128 ? j : wj) * 32 + fr;
+            const int n = j * 32 + fr;
             unsigned char* const row = s_t2 + n * PXB + fk * 8;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -741,10 +739,10 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
 // K (no partial sums to exchange); the shortcut is 64 px x 512 channels = 64 KB, too much LDS for two blocks per CU: chunks 0 / 1 are
 // parked in R[0] / R[1] at once, chunks 2 / 3 wait in registers until their buffer has been copied out.  544 KB of weights per tile
 // against 170 KB of activations: this instance runs at the rate L2 delivers fragments (D = 16 in flight per wavefront).
-template <int MR, bool A3>
+template <int MR>
 __global__ __launch_bounds__(256, 2) void bottleneck128_kernel(const bneck_params p, int tiles_x, int tiles_y)
 {
-    static_assert(!A3, "with the 3x3 in front the chained form is faster (launch_bottleneck): the A3 path below is kept for the A/B");
+    constexpr bool A3 = false; // (with the 3x3 in front the chained form is faster: launch_bottleneck; that path of this kernel is in the history)
     constexpr int M = 128, NC = 4;
     constexpr int Q_BYTES = (A3 ? N1 : N0) * PXB, R_BYTES = N0 * PXB, NBIAS = M + 4 * M + MR;
     static_assert(MR == 0 || MR == 128 || MR == 256, "MR");
@@ -872,39 +870,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck128_kernel(const bneck_param
     HP_NSTAMP();
 
     const int nj[2] = { fr, 32 + fr }; // this lane's pixel in either half
-    // ---- phase A: 3x3 (T1) -> T2 (over T1)
-    if constexpr (A3) {
-        floatx16 acc[2];
-        zero_acc(acc);
-        const unsigned char* t1p[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            t1p[j] = s_q + ((nj[j] / TW) * W1 + nj[j] % TW) * PXB;
-        steps(std::integral_constant<int, 72>{}, 0, acc, [&](int st, int j) {
-            const int tap = st / 8, ks = st % 8, ky = tap / 3, kx = tap % 3;
-            return t1p[j] + (ky * W1 + kx) * PXB + ((((nj[j] + ky * TW + kx) & 15) ^ (2 * ks + fk)) << 4);
-        });
-        HP_NSTAMP();
-        lds_barrier(); // every wavefront is done reading T1
-        const float hi = p.c3.act_hi;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            unsigned char* const row = s_q + nj[j] * PXB + fk * 8;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 bs = *reinterpret_cast<const float4*>(s_b3 + wave * 32 + 8 * g + 4 * fk);
-                half4 h;
-                h[0] = (_Float16)__builtin_amdgcn_fmed3f(acc[j][4 * g + 0] + bs.x, 0.f, hi);
-                h[1] = (_Float16)__builtin_amdgcn_fmed3f(acc[j][4 * g + 1] + bs.y, 0.f, hi);
-                h[2] = (_Float16)__builtin_amdgcn_fmed3f(acc[j][4 * g + 2] + bs.z, 0.f, hi);
-                h[3] = (_Float16)__builtin_amdgcn_fmed3f(acc[j][4 * g + 3] + bs.w, 0.f, hi);
-                *reinterpret_cast<half4*>(row + (((wave * 4 + g) ^ (nj[j] & 15)) << 4)) = h;
-            }
-        }
-        lds_barrier();
-        HP_NSTAMP();
-    }
-
     // ---- per 128-channel chunk: expansion -> in place over the shortcut in R[c & 1] -> HBM; the reduction's K chunk
     const float hiE = p.ce.act_hi;
     const bool res_first = p.ce.res_before_act != 0; // uniform
@@ -1050,7 +1015,7 @@ hipError_t launch_bottleneck(const bneck_params& p, hipStream_t s)
     const dim3 grid(tiles_x * tiles_y * p.ce.B);
 #define HP_BN(M_, MR_, A3_) HP_LAUNCH((bottleneck_kernel<M_, MR_, A3_>), grid, dim3(256), 0, s, p, tiles_x, tiles_y)
 #define HP_BN64(MR_, A3_) HP_LAUNCH((bottleneck64_kernel<MR_, A3_>), grid, dim3(256), 0, s, p, tiles_x, tiles_y)
-#define HP_BN128(MR_, A3_) HP_LAUNCH((bottleneck128_kernel<MR_, A3_>), grid, dim3(256), 0, s, p, tiles_x, tiles_y)
+#define HP_BN128(MR_) HP_LAUNCH((bottleneck128_kernel<MR_>), grid, dim3(256), 0, s, p, tiles_x, tiles_y)
     switch (v) {
     case 1001: HP_BN64(0, true); break;
     case 1010: HP_BN64(64, false); break;
@@ -1065,9 +1030,9 @@ hipError_t launch_bottleneck(const bneck_params& p, hipStream_t s)
     // 128 channels: with the 3x3 in front the chained form (its weight stream overlaps the shortcut's HBM round trip) measures 0.61 ms per
     // block at 97 x 97 x 64 against 0.72 ms for the up-front form; without it the up-front form wins (0.39 vs 0.47 ms)
     case 2001: HP_BN(128, 0, true); break;
-    case 2020: HP_BN128(128, false); break;
+    case 2020: HP_BN128(128); break;
     case 2021: HP_BN(128, 128, true); break;
-    case 2040: HP_BN128(256, false); break;
+    case 2040: HP_BN128(256); break;
     case 2041: HP_BN(128, 256, true); break;
     default: return hipErrorInvalidValue;
     }
