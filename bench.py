@@ -72,7 +72,7 @@ CONFIGS = {
     2: dict(label="configs[2]: OpenPose-COCO (VGG19) + PAF parser, batch 16 @ 432x768", arch="openpose_vgg19",
             w=768, h=432, batch=16, parser="paf", pipes=2, seed=20242, steps=24, people=(2, 4, 8, 16)),
     3: dict(label="configs[3]: PoseProposal ResNet-50 + NMS decoder, batch 32 @ 384x384", arch="pose_proposal_resnet50",
-            w=384, h=384, batch=32, parser="ppn", pipes=4, seed=20243, steps=60, people=(1, 2, 3, 4)),
+            w=384, h=384, batch=32, parser="ppn", pipes=8, seed=20243, steps=60, people=(1, 2, 3, 4)),
     4: dict(label="configs[4]: OpenPifPaf ResNet-50 + pif/paf seed-grow decoder, batch 64 @ 385x385", arch="pifpaf_resnet50",
             w=385, h=385, batch=64, parser="pifpaf", pipes=3, seed=20244, steps=16, people=(1, 2, 3, 4)),
 }
