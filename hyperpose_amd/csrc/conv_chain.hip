@@ -3,12 +3,12 @@
 // LW-OpenPose's head (hyperpose/Model/openpose/model/lw_openpose.py:106-191) is seventeen 3x3 128 -> 128 convolutions and six 1x1s
 // on a 46 x 54 map.  At batch 8 each of them is 23 MFLOP per CU: as one launch per layer the matrix pipe idles through a halo
 // prologue, an epilogue and a kernel boundary for every 7 k cycles of MFMAs (conv3x3_direct_kernel: 13 us per layer, 0.16-0.18 of
-// the fp16 MFMA peak).  Here one block owns an 8 x 8 pixel output tile and ALL 128 channels and runs the whole chain on it:
+// the fp16 MFMA peak).  Here one block owns a 10 x 6 pixel output tile and ALL 128 channels and runs the whole chain on it:
 //
-//     S0 (refinement blocks, lw_openpose.py:176-191):  X0 = input tile + 2-pixel halo (12 x 12 px) -> 1x1 + relu -> T1 (12 x 12 px)
+//     S0 (refinement blocks, lw_openpose.py:176-191):  X0 = input tile + 2-pixel halo (14 x 10 px) -> 1x1 + relu -> T1 (14 x 10 px)
 //        (otherwise T1 = the input tile + 2-pixel halo, straight from HBM)
-//     S1:  T1 -> 3x3 + relu [+ external residual] -> T2 (10 x 10 px: the output tile + 1-pixel halo)
-//     S2:  T2 -> 3x3 + relu [+ residual: external, or T1's interior = the 1x1's output] -> 8 x 8 px -> HBM
+//     S1:  T1 -> 3x3 + relu [+ external residual] -> T2 (12 x 8 px: the output tile + 1-pixel halo)
+//     S2:  T2 -> 3x3 + relu [+ residual: external, or T1's interior = the 1x1's output] -> 10 x 6 px -> HBM
 //
 // The halo pixels of the intermediates are recomputed by the neighbouring blocks (x2 MFMAs in S1 incl. tile padding, x2.5 in the small S0) - MFMA
 // time is what this network has to spare - and in exchange two of three launches, their prologues / epilogues and the HBM round
@@ -31,16 +31,18 @@ namespace {
 constexpr int CH = 128;              // channels of every tensor in the chain
 constexpr int PXB = CH * 2;          // bytes per pixel in LDS
 constexpr int KQ = CH / 16;          // k16 steps per tap
-// Output tile 8 x 8: with it a block needs <= 72 KB of LDS and <= 256 registers, i.e. HALF a CU - two blocks, or one block and a kernel
+// Output tile <= 64 pixels: with it a block needs <= 72 KB of LDS and <= 256 registers, i.e. HALF a CU - two blocks, or one block and a kernel
 // of the other hardware queue, share a CU.  The first form (8 x 12 pixels, 85 / 134 KB, 270 registers: 8 % fewer MFMAs per pixel)
 // was 14 % faster alone (conv stack 0.59 -> 0.53 ms) and gained NOTHING end to end: a whole-CU kernel serialises the two queues
 // the four pipes run on ("a CU is two slots").
-constexpr int TH = 8, TW = 8;        // output tile
-constexpr int H2 = TH + 4, W2 = TW + 4, N2 = H2 * W2; // S0 / T1 region (halo 2): 12 x 12 = 144 px -> 5 column tiles (16 pad lanes)
-constexpr int H1 = TH + 2, W1 = TW + 2, N1 = H1 * W1; // T2 region (halo 1): 10 x 10 = 100 px -> 4 column tiles
-constexpr int N0 = TH * TW;                            // 64 px = 2 column tiles
-constexpr int NT2 = (N2 + 31) / 32, NT1 = (N1 + 31) / 32, NT0 = N0 / 32;
-static_assert(N2 * 16 % 256 == 0 && N0 % 32 == 0, "tile geometry");
+// 10 x 6 (round 3; 8 x 8 before): the middle stage - the bulk of the MFMAs - covers 12 x 8 = 96 pixels = exactly three column tiles
+// (10 x 10 = 100 needed four: 22 % of that stage multiplied padding), and 46 x 54 is 5 x 9 tiles with 4 spare rows instead of 6 x 7 with
+// 2 rows + 2 columns: 576 k instead of 634 k MFMAs per batch of 8.  71.7 KB of LDS with the 1x1 in front.
+constexpr int TH = 10, TW = 6;       // output tile
+constexpr int H2 = TH + 4, W2 = TW + 4, N2 = H2 * W2; // S0 / T1 region (halo 2): 14 x 10 = 140 px -> 5 column tiles (20 pad lanes)
+constexpr int H1 = TH + 2, W1 = TW + 2, N1 = H1 * W1; // T2 region (halo 1): 12 x 8 = 96 px -> 3 column tiles
+constexpr int N0 = TH * TW;                            // 60 px -> 2 column tiles (4 pad lanes)
+constexpr int NT2 = (N2 + 31) / 32, NT1 = (N1 + 31) / 32, NT0 = (N0 + 31) / 32;
 
 // swizzle key of a pixel of a tile that is CONSUMED in pixel order of width CW: 16 consecutive consumer pixels, shifted by any tap,
 // read 16 distinct 16-byte slots of the 256-byte bank row (a pixel is exactly one bank row: 128 channels x 2 B)
@@ -172,11 +174,11 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
     {
         const tview& in = S0 ? p.c0.in : p.c1.in;
         unsigned char* const dst = S0 ? s_x0 : s_t1;
-        constexpr int NIT = N2 * 16 / 256;
+        constexpr int NIT = (N2 * 16 + 255) / 256;
         u32x4 hv[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256, px = i >> 4, c = i & 15;
+            const int i = min(tid + it * 256, N2 * 16 - 1), px = i >> 4, c = i & 15;
             const int hy = px / W2, hx = px - hy * W2;
             const int y = y0 - 2 + hy, x = x0 - 2 + hx;
             const bool ok = y >= 0 && y < H && x >= 0 && x < W;
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
             const int i = tid + it * 256, px = i >> 4, c = i & 15;
             const int hy = px / W2, hx = px - hy * W2;
             const int key = S0 ? (px & 15) : t1_key(hy, hx); // X0 is consumed in its own pixel order (S0 is a 1x1)
-            *reinterpret_cast<u32x4*>(dst + px * PXB + ((c ^ key) << 4)) = hv[it];
+            if (i < N2 * 16)
+                *reinterpret_cast<u32x4*>(dst + px * PXB + ((c ^ key) << 4)) = hv[it];
         }
     }
     HP_CSTAMP();
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
         }
     };
 
-    // ---- S0: 1x1 on the 12 x 12 region -> T1
+    // ---- S0: 1x1 on the 14 x 10 region -> T1
     if (S0) {
         floatx16 acc[NT2];
         zero_acc(acc);
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
         HP_CSTAMP();
     }
 
-    // ---- S1: 3x3 on the 10 x 10 region -> T2
+    // ---- S1: 3x3 on the 12 x 8 region -> T2
     {
         floatx16 acc[NT1];
         zero_acc(acc);
@@ -290,21 +293,21 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
         HP_CSTAMP();
     }
 
-    // ---- S2: 3x3 on the 8 x 8 tile; the result goes (fp16) into T1's interior, in place of the residual it may have read there
+    // ---- S2: 3x3 on the 10 x 6 tile; the result goes (fp16) into T1's interior, in place of the residual it may have read there
     {
         floatx16 acc[NT0];
         zero_acc(acc);
         int pix0[NT0], nkey[NT0];
 #pragma unroll
         for (int j = 0; j < NT0; ++j) {
-            const int n = j * 32 + fr, br = n / TW, bc = n - br * TW;
+            const int n = min(j * 32 + fr, N0 - 1), br = n / TW, bc = n - br * TW; // (pad lanes of the last column tile redo its last pixel)
             pix0[j] = (br * W1 + bc) * PXB, nkey[j] = n;
         }
         half4 rs[NT0][4];
         if (RES == 2) { // requested before the MFMAs: 12 eight-byte loads per lane, used in the epilogue
 #pragma unroll
             for (int j = 0; j < NT0; ++j) {
-                const int n = j * 32 + fr, br = n / TW, bc = n - br * TW;
+                const int n = min(j * 32 + fr, N0 - 1), br = n / TW, bc = n - br * TW;
                 const __half* rp = p.c2.res.p + tv_off(p.c2.res, b, min(y0 + br, H - 1), min(x0 + bc, W - 1)) + wave * 32 + 4 * fk;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -319,6 +322,8 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
 #pragma unroll
         for (int j = 0; j < NT0; ++j) {
             const int n = j * 32 + fr, br = n / TW, bc = n - br * TW;
+            if (n >= N0)
+                continue; // pad lanes
             unsigned char* const row = s_t1 + ((br + 2) * W2 + bc + 2) * PXB + fk * 8;
             const int key = t1_key(br + 2, bc + 2);
 #pragma unroll
@@ -345,14 +350,14 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
 
     // ---- the finished tile: 16 lanes per pixel, 256 contiguous bytes of HBM each
     {
-        constexpr int NIT = N0 * 16 / 256;
+        constexpr int NIT = (N0 * 16 + 255) / 256;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256, px = i >> 4, c = i & 15;
+            const int i = tid + it * 256, px = min(i >> 4, N0 - 1), c = i & 15;
             const int br = px / TW, bc = px - br * TW;
             const int y = y0 + br, x = x0 + bc;
             const u32x4 v = *reinterpret_cast<const u32x4*>(s_t1 + ((br + 2) * W2 + bc + 2) * PXB + ((c ^ t1_key(br + 2, bc + 2)) << 4));
-            if (y < H && x < W)
+            if (i < N0 * 16 && y < H && x < W)
                 *reinterpret_cast<u32x4*>(p.c2.out.p + tv_off(p.c2.out, b, y, x) + c * 8) = v;
         }
     }
