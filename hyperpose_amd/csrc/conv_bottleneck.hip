@@ -34,36 +34,23 @@ constexpr int PXB = 256;                     // bytes per pixel row of every LDS
 constexpr int TH = 8, TW = 8, N0 = TH * TW;  // output tile
 constexpr int H1 = TH + 2, W1 = TW + 2, N1 = H1 * W1;
 
-// One unit of MFMAs: TAPS taps x KQC k16 steps for one 32-row tile of output channels and NT column tiles of 32 pixels.
-//   a[]      A fragments, a ring of G taps: on entry a[0 .. KQC) = tap 0 (already requested); taps 1 .. G-1 are requested here, and as
-//            fragment (tap, ks) is consumed its register is refilled with (tap + G, ks) - or, past the last tap, with the next unit's
-//            tap 0 (wnext, KQN fragments, which land in a[0 .. KQN): TAPS % G == 0).  G = 1 is one tap ahead; the 64-channel 3x3 (4
-//            MFMAs per tap against an L2 round trip of ~1 k cycles: measured 9.9 k cycles for 36 MFMAs) runs with G = 3.
-//   src      LDS tile, row width WIN pixels; pix0[j] = byte offset of this lane's pixel of column tile j at tap (0, 0),
-//            nkey[j] = its index in consumer order (the swizzle key of that pixel at tap (ky, kx) is (nkey + ky * KW + kx) & 15)
-//   ROWB     bytes per pixel row of src: 256 (16 slots, key = consumer index & 15) or 128 (a 64-channel tile, two pixels per bank row:
-//            key = (consumer index >> 1) & 7 - the two pixels that share a key are neighbours in a row, i.e. sit in different halves of
-//            their bank row, so 16 consecutive consumer pixels still read 16 distinct slots whatever the tap)
-template <int NT, int TAPS, int WIN, int KW, int KQC, int KQN, int G = 1, int ROWB = 256, int NA = 8>
-__device__ __forceinline__ void unit(floatx16 (&acc)[NT], u32x4 (&a)[NA], const __half* wcur, long tap_stride, const __half* wnext,
+// One unit of MFMAs of the chained form: TAPS taps x KQC k16 steps for one 32-row tile of output channels and NT column tiles of 32 pixels.
+//   a[]      A fragments of tap 0 (already requested).  As a tap's fragments are consumed their registers take the next tap's; while the
+//            last tap multiplies, the KQN fragments at wnext (the next unit's tap 0) are requested into a[].
+//   src      LDS tile of 256-byte pixel rows, row width WIN pixels; pix0[j] = byte offset of this lane's pixel of column tile j at tap
+//            (0, 0), nkey[j] = its index in consumer order (the swizzle key of that pixel at tap (ky, kx) is (nkey + ky * KW + kx) & 15)
+template <int NT, int TAPS, int WIN, int KW, int KQC, int KQN>
+__device__ __forceinline__ void unit(floatx16 (&acc)[NT], u32x4 (&a)[8], const __half* wcur, long tap_stride, const __half* wnext,
     const unsigned char* src, const int (&pix0)[NT], const int (&nkey)[NT], int fk)
 {
-    static_assert(TAPS % G == 0 && G * KQC <= NA && KQN <= NA && (G == 1 || KQN <= KQC) && (ROWB == 256 || (ROWB == 128 && KQC <= 4 && WIN % 2 == 0 && KW % 2 == 0)), "fragment ring / tile rows");
     constexpr int KS = TAPS == 9 ? 3 : 1;
     auto tap_addr = [&](int tap, int (&ad)[NT]) {
         const int ky = tap / KS, kx = tap - ky * KS;
-        const int toff = (ky * WIN + kx) * ROWB, tkey = ky * KW + kx; // uniform
+        const int toff = (ky * WIN + kx) * PXB, tkey = ky * KW + kx; // uniform
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int q = nkey[j] + tkey;
-            ad[j] = pix0[j] + toff + (((ROWB == 256 ? (q & 15) : ((q >> 1) & 7)) ^ fk) << 4);
-        }
+        for (int j = 0; j < NT; ++j)
+            ad[j] = pix0[j] + toff + ((((nkey[j] + tkey) & 15) ^ fk) << 4);
     };
-#pragma unroll
-    for (int t = 1; t < G; ++t)
-#pragma unroll
-        for (int ks = 0; ks < KQC; ++ks)
-            a[t * KQC + ks] = *reinterpret_cast<const u32x4*>(wcur + (long)t * tap_stride + (size_t)ks * 512);
     half8 fb[2][NT];
     int ad[NT];
     tap_addr(0, ad);
@@ -71,34 +58,28 @@ __device__ __forceinline__ void unit(floatx16 (&acc)[NT], u32x4 (&a)[NA], const 
     for (int j = 0; j < NT; ++j)
         fb[0][j] = *reinterpret_cast<const half8*>(src + ad[j]);
 #pragma unroll 1
-    for (int tg = 0; tg < TAPS; tg += G) {
-        const bool last = tg + G == TAPS; // uniform: the refills of this group are the next unit's
+    for (int tap = 0; tap < TAPS; ++tap) {
+        int adn[NT];
+        tap_addr(min(tap + 1, TAPS - 1), adn);
+        const bool last = tap + 1 == TAPS; // uniform
+        const __half* wn = last ? wnext : wcur + (long)(tap + 1) * tap_stride;
 #pragma unroll
-        for (int t = 0; t < G; ++t) {
-            const int tap = tg + t;
-            int adn[NT];
-            tap_addr(min(tap + 1, TAPS - 1), adn);
-            const __half* wn = last ? wnext : wcur + (long)(tap + G) * tap_stride;
-#pragma unroll
-            for (int ks = 0; ks < KQC; ++ks) {
-                // the B fragments of the next k16 step (of the next tap past the end of this one) are read while this step multiplies
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(src + (ks + 1 < KQC ? (ad[j] ^ ((ks + 1) << 5)) : adn[j]));
-                half8 fa;
-                __builtin_memcpy(&fa, &a[t * KQC + ks], 16);
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[(t * KQC + ks) & 1][j], acc[j], 0, 0, 0);
-                if (!last)
-                    a[t * KQC + ks] = *reinterpret_cast<const u32x4*>(wn + (size_t)ks * 512);
-                else if (t == 0 && ks < KQN)
-                    a[ks] = *reinterpret_cast<const u32x4*>(wn + (size_t)ks * 512);
-            }
+        for (int ks = 0; ks < KQC; ++ks) {
+            // the B fragments of the next k16 step (of the next tap past the end of this one) are read while this step multiplies
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                ad[j] = adn[j];
+                fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(src + (ks + 1 < KQC ? (ad[j] ^ ((ks + 1) << 5)) : adn[j]));
+            half8 fa;
+            __builtin_memcpy(&fa, &a[ks], 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[j], 0, 0, 0);
+            if (!last || ks < KQN)
+                a[ks] = *reinterpret_cast<const u32x4*>(wn + (size_t)ks * 512);
         }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            ad[j] = adn[j];
     }
     if (KQN > KQC) {
 #pragma unroll
