@@ -332,10 +332,12 @@ def kernel_label(tile: int):
     if tile >= 9000000:
         v = tile - 9000000
         m, pj, mr, a3 = v // 1000 * 64, v // 100 % 10, v // 10 % 10 * 64, v % 10
-        what = (f"{'3x3 -> ' if a3 else ''}1x1 {m} -> {4 * m} + {'projection' if pj else 'shortcut'}{f' -> 1x1 {4 * m} -> {mr} of the next block' if mr else ''} in one "
-                "launch, 8x8 pixels per block, intermediates in LDS")
+        own, pj = pj >= 2, pj % 2
+        what = (f"{'own 1x1 reduction -> ' if own else ''}{'3x3 -> ' if a3 else ''}1x1 {m} -> {4 * m} + {'projection' if pj else 'shortcut'}"
+                f"{f' -> 1x1 {4 * m} -> {mr} of the next block' if mr else ''} in one launch, 8x8 pixels per block, intermediates in LDS")
         if m == 64:
-            return (f"bottleneck64_kernel<{mr},{'true' if a3 else 'false'},{'true' if pj else 'false'}>", "bottleneck64_kernel (" + what + ")")
+            t = lambda x: "true" if x else "false"
+            return (f"bottleneck64_kernel<{mr},{t(a3)},{t(pj)},{t(own)}>", "bottleneck64_kernel (" + what + ")")
         if a3:
             return (f"bottleneck_kernel<128,{mr},true>", "bottleneck_kernel (" + what + ")")
         return (f"bottleneck128_kernel<{mr}>", "bottleneck128_kernel (" + what + ")")

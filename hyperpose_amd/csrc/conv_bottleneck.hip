@@ -384,13 +384,17 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const bneck_params p
 // a launch that writes 256 channels and a shortcut read of 256 channels, X's 8 x 8 tile (8 KB) is read and the expansion's K runs over
 // [T2 ; X] with the weights [W_exp W_proj] and the bias b_exp + b_proj: relu(W_exp T2 + b_exp + W_proj X + b_proj) - the same sum
 // without the fp16 rounding of the projection in between.  X waits in R[1] until chunk 1's results need the buffer.
-template <int MR, bool A3, bool PJ = false>
+// R0 (with A3 and PJ: the whole first block of the stage): the block's own reduction (1x1 64 -> 64 + relu of the block input X) runs on the
+// 3x3's 10 x 10 halo tile - X's halo tile is the only thing the block reads; it waits in R[1], where the projection finds its 8 x 8 centre.
+// Halo pixels outside the image are ZERO in T1 (the 3x3's padding), not relu(bias).
+template <int MR, bool A3, bool PJ = false, bool R0 = false>
 __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params p, int tiles_x, int tiles_y)
 {
     constexpr int M = 64, NC = 2, ROW64 = 128;
     constexpr int X_BYTES = 4 * 4096;                                    // four partial accumulator tiles (32 x 32 fp32)
     constexpr int Q_BYTES = A3 ? X_BYTES : N0 * ROW64;                    // T1 (12.8 KB) -> X -> T2 (8 KB), one after the other
-    constexpr int R_BYTES = N0 * PXB, NBIAS = M + 4 * M + MR;
+    static_assert(!R0 || (A3 && PJ), "the in-block reduction belongs to the first block of a stage");
+    constexpr int R_BYTES = N0 * PXB, NBIAS = M + 4 * M + MR + (R0 ? M : 0);
     static_assert(MR == 0 || MR == 64 || MR == 128, "MR");
     static_assert(N1 * ROW64 <= X_BYTES && X_BYTES <= R_BYTES && Q_BYTES + 2 * R_BYTES + NBIAS * 4 <= 53 * 1024, "three blocks per CU");
     __shared__ __attribute__((aligned(16))) unsigned char lds[Q_BYTES + 2 * R_BYTES + NBIAS * 4];
@@ -399,6 +403,8 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
     float* const s_b3 = reinterpret_cast<float*>(s_r + 2 * R_BYTES);
     float* const s_be = s_b3 + M;
     float* const s_br = s_be + 4 * M;
+    float* const s_b0 = s_br + MR; // (R0)
+    unsigned char* const s_xh = s_r + R_BYTES; // (R0) X's halo tile, 128-byte rows keyed by the halo pixel's own index
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fk = lane >> 5;
@@ -419,7 +425,9 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
     HP_NSTAMP();
 
     // ---- the fragment stream of this wavefront (fragment order: [tap][32-row tile][k16][lane][8])
-    constexpr int NFA = A3 ? 18 : 0, NFE = PJ ? 8 : 4, NFR = MR == 64 ? 4 : MR == 128 ? 8 : 0, NFC = NFE + NFR, NF = NFA + NC * NFC, D = 12;
+    constexpr int NF0 = R0 ? 4 : 0, NFA = NF0 + (A3 ? 18 : 0), NFE = PJ ? 8 : 4, NFR = MR == 64 ? 4 : MR == 128 ? 8 : 0, NFC = NFE + NFR,
+                  NF = NFA + NC * NFC, D = 12;
+    const __half* const w0 = R0 ? p.c0.w + (size_t)(wr * 4) * 512 + lane8 : nullptr;             // + ks * 512
     const __half* const wA = A3 ? p.c3.w + (size_t)(wr * 4 + 2 * wj) * 512 + lane8 : nullptr; // + tap * 8 * 512 + kk * 512
     const __half* const wE = p.ce.w + (size_t)(wave * 4) * 512 + lane8;                        // + c * 16 * 512 + ks * 512
     const __half* const wP = PJ ? p.cp.w + (size_t)(wave * 4) * 512 + lane8 : nullptr;          // (same rows, K = X's 64 channels)
@@ -427,8 +435,10 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
         : MR == 128                   ? p.cr.w + (size_t)(wave * 16) * 512 + lane8
                                       : nullptr;
     auto frag_ptr = [&](int f) -> const __half* {
+        if (f < NF0)
+            return w0 + (size_t)f * 512;
         if (f < NFA)
-            return wA + (size_t)((f / 2) * 8 + f % 2) * 512;
+            return wA + (size_t)(((f - NF0) / 2) * 8 + (f - NF0) % 2) * 512;
         const int g = f - NFA, c = g / NFC, h = g - c * NFC;
         if (h < 4)
             return wE + (size_t)(c * 16 + h) * 512;
@@ -495,7 +505,7 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
     // ---- every HBM read of the tile: the 3x3's 10 x 10 halo tile (or the 8 x 8 input tile), the shortcut's 64 px x 256 channels
     const bool has_res = p.ce.res.p != nullptr; // uniform
     {
-        const tview& in = A3 ? p.c3.in : p.ce.in;
+        const tview& in = R0 ? p.c0.in : A3 ? p.c3.in : p.ce.in;
         constexpr int NPX = A3 ? N1 : N0, WIN = A3 ? W1 : TW, OFF = A3 ? 1 : 0, CG = M / 8;
         constexpr int PIECES = NPX * CG, NIT = (PIECES + 255) / 256, RIT = N0 * 16 / 256;
         u32x4 hv[NIT], rv[NC][RIT];
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
             }
         }
         u32x4 xv[2];
-        if constexpr (PJ) {
+        if constexpr (PJ && !R0) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int i = tid + it * 256, q = i >> 3, c = i & 7;
@@ -528,15 +538,17 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
         }
         // (the biases: requested behind the tile's loads - in front of them their round trip delayed every block's HBM requests by 5 k cycles)
         for (int i = tid; i < NBIAS; i += 256)
-            s_b3[i] = i < M ? (A3 ? p.c3.bias[i] : 0.f) : i < 5 * M ? p.ce.bias[i - M] + (PJ ? p.cp.bias[i - M] : 0.f) : p.cr.bias[i - 5 * M];
+            s_b3[i] = i < M ? (A3 ? p.c3.bias[i] : 0.f) : i < 5 * M ? p.ce.bias[i - M] + (PJ ? p.cp.bias[i - M] : 0.f)
+                : i < 5 * M + MR                                   ? p.cr.bias[i - 5 * M]
+                                                                   : p.c0.bias[i - 5 * M - MR];
         HP_NSTAMP();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256, px = i / CG, c = i - px * CG;
             const int hy = px / WIN, hx = px - hy * WIN;
-            const int key = ((A3 ? hy * TW + hx : px) >> 1) & 7;
+            const int key = ((R0 ? px : A3 ? hy * TW + hx : px) >> 1) & 7;
             if (i < PIECES)
-                *reinterpret_cast<u32x4*>(s_q + px * ROW64 + ((c ^ key) << 4)) = hv[it];
+                *reinterpret_cast<u32x4*>((R0 ? s_xh : s_q) + px * ROW64 + ((c ^ key) << 4)) = hv[it];
         }
         if (has_res) {
 #pragma unroll
@@ -547,7 +559,7 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
                     *reinterpret_cast<u32x4*>(s_r + c * R_BYTES + q * PXB + ((s16 ^ (q & 15)) << 4)) = rv[c][it];
                 }
         }
-        if constexpr (PJ) {
+        if constexpr (PJ && !R0) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int i = tid + it * 256, q = i >> 3, c = i & 7;
@@ -560,6 +572,42 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
 
     const int nj[2] = { fr, 32 + fr }; // this lane's pixel in either half
     const int n = wj * 32 + fr;        // ... in the half this wavefront finishes
+    // ---- (R0) the block's own reduction on the halo tile: X (R[1]) -> 1x1 + relu -> T1 (Q), zero outside the image
+    if constexpr (R0) {
+        floatx16 acc0[2];
+        zero_acc(acc0);
+        int mj[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            mj[j] = min((2 * wj + j) * 32 + fr, N1 - 1);
+        steps(std::integral_constant<int, 4>{}, 0, acc0, [&](int st, int j) {
+            return s_xh + mj[j] * ROW64 + ((((mj[j] >> 1) & 7) ^ (2 * st + fk)) << 4);
+        });
+        const float hi0 = p.c0.act_hi;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = (2 * wj + j) * 32 + fr, hy = mj[j] / W1, hx = mj[j] - hy * W1;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+            if (m < N1) {
+                unsigned char* const row = s_q + m * ROW64 + fk * 8;
+                const int key = ((hy * TW + hx) >> 1) & 7;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bs = *reinterpret_cast<const float4*>(s_b0 + wr * 32 + 8 * g + 4 * fk);
+                    half4 h;
+                    h[0] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc0[j][4 * g + 0] + bs.x, 0.f, hi0) : 0.f);
+                    h[1] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc0[j][4 * g + 1] + bs.y, 0.f, hi0) : 0.f);
+                    h[2] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc0[j][4 * g + 2] + bs.z, 0.f, hi0) : 0.f);
+                    h[3] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc0[j][4 * g + 3] + bs.w, 0.f, hi0) : 0.f);
+                    *reinterpret_cast<half4*>(row + (((wr * 4 + g) ^ key) << 4)) = h;
+                }
+            }
+        }
+        lds_barrier();
+        HP_NSTAMP();
+    }
+
     // ---- phase A: 3x3 (T1 in Q) -> partial sums meet in X (over T1) -> T2 (over X)
     if constexpr (A3) {
         floatx16 acc[2];
@@ -568,7 +616,7 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             t1p[j] = s_q + ((nj[j] / TW) * W1 + nj[j] % TW) * ROW64;
-        steps(std::integral_constant<int, 18>{}, 0, acc, [&](int st, int j) {
+        steps(std::integral_constant<int, 18>{}, NF0, acc, [&](int st, int j) {
             const int tap = st / 2, kk = st % 2, ky = tap / 3, kx = tap % 3;
             const int key = ((nj[j] + ky * TW + kx) >> 1) & 7, sl = 2 * (2 * wj + kk) + fk;
             return t1p[j] + (ky * W1 + kx) * ROW64 + ((key ^ sl) << 4);
@@ -610,7 +658,11 @@ __global__ __launch_bounds__(256, 3) void bottleneck64_kernel(const bneck_params
         floatx16 accb[2];
         zero_acc(accb);
         steps(std::integral_constant<int, NFE>{}, fB, accb, [&](int st, int j) {
-            return (st < 4 ? s_q : s_r + R_BYTES) + nj[j] * ROW64 + ((((nj[j] >> 1) & 7) ^ (2 * (st & 3) + fk)) << 4);
+            if (R0 && st >= 4) { // X's 8 x 8 centre inside its halo tile
+                const int hp = (nj[j] / TW + 1) * W1 + nj[j] % TW + 1;
+                return (const unsigned char*)(s_xh + hp * ROW64 + ((((hp >> 1) & 7) ^ (2 * (st & 3) + fk)) << 4));
+            }
+            return (const unsigned char*)((st < 4 ? s_q : s_r + R_BYTES) + nj[j] * ROW64 + ((((nj[j] >> 1) & 7) ^ (2 * (st & 3) + fk)) << 4));
         });
         HP_NSTAMP();
         if (PJ && c == 1)
@@ -978,13 +1030,16 @@ int bottleneck_variant(const bneck_params& p)
         return 0;
     if (p.has_c3 && (!bneck_conv_ok(p.c3, 3, M, M) || p.c3.res.p || p.c3.H != p.ce.H || p.c3.W != p.ce.W))
         return 0;
+    if (p.has_c0 && (!p.has_cp || !p.has_c3 || !bneck_conv_ok(p.c0, 1, M, M) || p.c0.res.p || p.c0.H != p.ce.H || p.c0.W != p.ce.W || p.c0.in.p != p.cp.in.p
+            || p.c0.in.coff != p.cp.in.coff))
+        return 0;
     if (p.has_cr && (!bneck_conv_ok(p.cr, 1, 4 * M, MR) || p.cr.res.p || p.cr.H != p.ce.H || p.cr.W != p.ce.W))
         return 0;
     if (MR != 0 && MR != M && MR != 2 * M)
         return 0;
     if (!p.has_c3 && !p.has_cr)
         return 0; // (a lone expansion stays with the 1x1 kernels)
-    return 1000 * (M / 64) + 100 * (p.has_cp ? 1 : 0) + 10 * (MR / 64) + (p.has_c3 ? 1 : 0); // M / 64, projection, MR / 64, 3x3
+    return 1000 * (M / 64) + 100 * ((p.has_cp ? 1 : 0) + (p.has_c0 ? 2 : 0)) + 10 * (MR / 64) + (p.has_c3 ? 1 : 0); // M / 64, projection (+ own reduction), MR / 64, 3x3
 }
 
 hipError_t launch_bottleneck(const bneck_params& p, hipStream_t s)
@@ -1008,6 +1063,9 @@ hipError_t launch_bottleneck(const bneck_params& p, hipStream_t s)
     case 1111: HP_LAUNCH((bottleneck64_kernel<64, true, true>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
     case 1120: HP_LAUNCH((bottleneck64_kernel<128, false, true>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
     case 1121: HP_LAUNCH((bottleneck64_kernel<128, true, true>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
+    case 1301: HP_LAUNCH((bottleneck64_kernel<0, true, true, true>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
+    case 1311: HP_LAUNCH((bottleneck64_kernel<64, true, true, true>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
+    case 1321: HP_LAUNCH((bottleneck64_kernel<128, true, true, true>), grid, dim3(256), 0, s, p, tiles_x, tiles_y); break;
     // 128 channels: with the 3x3 in front the chained form (its weight stream overlaps the shortcut's HBM round trip) measures 0.61 ms per
     // block at 97 x 97 x 64 against 0.72 ms for the up-front form; without it the up-front form wins (0.39 vs 0.47 ms)
     case 2001: HP_BN(128, 0, true); break;

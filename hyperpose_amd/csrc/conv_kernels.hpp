@@ -173,8 +173,10 @@ struct bneck_params {
     int has_c3, has_cr;
     conv_params cp; // has_cp: the block's projection shortcut (1x1 M -> 4M of the block input, no activation), computed in the block
     int has_cp;     // instead of being read: ce.res is then empty
+    conv_params c0; // has_c0 (with has_cp and has_c3): the block's OWN reduction (1x1 M -> M of the same block input), computed on the
+    int has_c0;     // 3x3's halo tile: the block reads nothing but its input
 };
-// 0 when the kernel does not take this combination, otherwise 1000 * (M / 64) + 100 * has_cp + 10 * (M' / 64) + has_c3 (profile rows: tile = 9000000 + variant)
+// 0 when the kernel does not take this combination, otherwise 1000 * (M / 64) + 100 * (has_cp + 2 * has_c0) + 10 * (M' / 64) + has_c3 (profile rows: tile = 9000000 + variant)
 int bottleneck_variant(const bneck_params& p);
 hipError_t launch_bottleneck(const bneck_params& p, hipStream_t s);
 

@@ -828,10 +828,30 @@ int hp_engine::build(const hp_engine_desc* d)
             const hp::tview res_view = bn.ce.res;
             if (kp < steps.size())
                 bn.cp = steps[kp].cp, bn.has_cp = 1, bn.ce.res = hp::tview{ nullptr, 0, 0, 0, 0 };
+            // ... and the block's own reduction reads the same block input and feeds only this 3x3: computed on the 3x3's halo tile
+            size_t k0 = steps.size();
+            if (kp < steps.size() && bn.has_c3) {
+                const hp_layer &A3 = layers[steps[k].layer], &P = layers[steps[kp].layer];
+                int writers = 0;
+                for (const auto& L2 : layers)
+                    writers += L2.out == A3.in;
+                for (size_t j = 0; j < k && k0 == steps.size(); ++j) {
+                    if (!plain_conv(steps[j]) || layers[steps[j].layer].out != A3.in)
+                        continue;
+                    const hp_layer& R = layers[steps[j].layer];
+                    if (steps[j].cp.KH == 1 && steps[j].cp.stride == 1 && R.res < 0 && R.out_coff == 0 && A3.in_coff == 0 && R.in == P.in && R.in_coff == P.in_coff
+                        && writers == 1 && !readers_other_than(A3.in, steps[k].layer))
+                        k0 = j;
+                }
+                if (k0 < steps.size())
+                    bn.c0 = steps[k0].cp, bn.has_c0 = 1;
+            }
             // the stand-alone kernels of some of these shapes (256 -> 64 on the generic implicit GEMM) read row-major weights: the
             // fused kernel wants them in fragment order
             auto want_layout1 = [&](hp::conv_params& c) { c.w_layout = 1; };
-            const int lay3 = bn.c3.w_layout, laye = bn.ce.w_layout, layr = bn.cr.w_layout, layp = bn.cp.w_layout;
+            const int lay3 = bn.c3.w_layout, laye = bn.ce.w_layout, layr = bn.cr.w_layout, layp = bn.cp.w_layout, lay0 = bn.c0.w_layout;
+            if (bn.has_c0)
+                want_layout1(bn.c0);
             if (bn.has_c3)
                 want_layout1(bn.c3);
             want_layout1(bn.ce);
@@ -842,12 +862,12 @@ int hp_engine::build(const hp_engine_desc* d)
             // the widest combination the kernel has an instance for: without the reduction (e.g. one to a width it does not serve), then
             // without the projection, then without both
             {
-                const int had_cr = bn.has_cr, had_cp = bn.has_cp;
+                const int had_cr = bn.has_cr, had_cp = bn.has_cp, had_c0 = bn.has_c0;
                 bool ok = false;
-                for (int drop = 0; drop < 4 && !ok; ++drop) {
-                    if (((drop & 1) && !had_cr) || ((drop & 2) && !had_cp))
+                for (int drop = 0; drop < 8 && !ok; ++drop) { // bit 0: without the next reduction, bit 1: without the own reduction, bit 2: without the projection
+                    if (((drop & 1) && !had_cr) || ((drop & 2) && !had_c0) || ((drop & 4) && !had_cp))
                         continue;
-                    bn.has_cr = had_cr && !(drop & 1), bn.has_cp = had_cp && !(drop & 2);
+                    bn.has_cr = had_cr && !(drop & 1), bn.has_cp = had_cp && !(drop & 4), bn.has_c0 = had_c0 && !(drop & 2) && bn.has_cp;
                     bn.ce.res = bn.has_cp ? hp::tview{ nullptr, 0, 0, 0, 0 } : res_view;
                     ok = hp::bottleneck_variant(bn) != 0;
                 }
@@ -857,6 +877,8 @@ int hp_engine::build(const hp_engine_desc* d)
                     kr = 0;
                 if (!bn.has_cp)
                     kp = steps.size();
+                if (!bn.has_c0)
+                    k0 = steps.size();
             }
             // repack what was uploaded row-major
             auto repack = [&](hp::conv_params& c, int had, int layer) -> int {
@@ -885,10 +907,12 @@ int hp_engine::build(const hp_engine_desc* d)
                 HP_TRY(repack(bn.cr, layr, steps[kr].layer));
             if (bn.has_cp)
                 HP_TRY(repack(bn.cp, layp, steps[kp].layer));
+            if (bn.has_c0)
+                HP_TRY(repack(bn.c0, lay0, steps[k0].layer));
             step& a = steps[k];
-            const double fl = (bn.has_c3 ? steps[ke].flops : 0) + (kr ? steps[kr].flops : 0) + (bn.has_cp ? steps[kp].flops : 0);
+            const double fl = (bn.has_c3 ? steps[ke].flops : 0) + (kr ? steps[kr].flops : 0) + (bn.has_cp ? steps[kp].flops : 0) + (bn.has_c0 ? steps[k0].flops : 0);
             const double by = (bn.has_c3 ? steps[ke].bytes : 0) + (kr ? steps[kr].bytes : 0);
-            a.op = OP_BNECK, a.bn = bn, a.n_layers = 1 + bn.has_c3 + bn.has_cr + bn.has_cp;
+            a.op = OP_BNECK, a.bn = bn, a.n_layers = 1 + bn.has_c3 + bn.has_cr + bn.has_cp + bn.has_c0;
             a.flops += fl, a.bytes += by;
             if (bn.has_c3)
                 tensors[layers[steps[ke].layer].in]->elided = true; // the 3x3's output: allocated (pass 1) but never written
@@ -898,10 +922,17 @@ int hp_engine::build(const hp_engine_desc* d)
                 steps.erase(steps.begin() + kr);
             if (bn.has_c3)
                 steps.erase(steps.begin() + ke);
-            if (bn.has_cp) {
-                steps.erase(steps.begin() + kp); // (in front of this step)
-                --k;
-            }
+            if (bn.has_c0)
+                tensors[layers[steps[k].layer].in]->elided = true; // the own reduction's output
+            // (the projection and the own reduction sit in front of this step: erase the later one first)
+            size_t front[2] = { bn.has_cp ? kp : steps.size(), bn.has_c0 ? k0 : steps.size() };
+            if (front[0] < front[1])
+                std::swap(front[0], front[1]);
+            for (size_t q : front)
+                if (q < steps.size()) {
+                    steps.erase(steps.begin() + q);
+                    --k;
+                }
         }
     }
     // sibling heads (conf / paf branch of one stage: same input, same geometry, neither reads the other) share a launch

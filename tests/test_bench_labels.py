@@ -27,9 +27,9 @@ CASES = [
     (4000005, ""), (4000006, ""), (4000004, ""), (4000003, ""), (4000007, ""), (7000013, ""), (7000001, ""), (7000002, ""), (7000003, ""),
     (5064192, ""), (6000128, ""), (5201002, ""), (5100192, ""),
     (6128049, "_config2"), (6256009, "_config2"), (6192049, "_config2"),
-    (5202002, "_config3"), (9001111, "_config3"), (9001011, "_config3"), (9001021, "_config3"), (9002020, "_config3"), (9002021, "_config3"),
+    (5202002, "_config3"), (9001311, "_config3"), (9001011, "_config3"), (9001021, "_config3"), (9002020, "_config3"), (9002021, "_config3"),
     (9002041, "_config3"), (6512009, "_config3"),
-    (5202002, "_config4"), (9001111, "_config4"), (9002021, "_config4"), (128128, "_config4"),
+    (5202002, "_config4"), (9001311, "_config4"), (9002021, "_config4"), (128128, "_config4"),
 ]
 
 

@@ -475,12 +475,14 @@ def test_bottleneck_variants(hp, monkeypatch, m, mr, front, h, w):
             _close(a0, a1, rel=4e-3, abs_=2e-3)
 
 
-@pytest.mark.parametrize("mr,h,w", [(64, 52, 76), (128, 40, 40), (0, 36, 28)])
-def test_bottleneck_with_projection_shortcut(hp, monkeypatch, mr, h, w):
+@pytest.mark.parametrize("mr,h,w,own", [(64, 52, 76, True), (128, 40, 40, True), (0, 36, 28, True), (64, 44, 36, False)])
+def test_bottleneck_with_projection_shortcut(hp, monkeypatch, mr, h, w, own):
     """The first block of ResNet's first stage: its shortcut is a 1x1 projection (64 -> 256, no activation) of the block input that only
     this block reads.  bottleneck64_kernel<.., PJ> computes it inside the launch (K = [3x3 output ; block input]) instead of reading
     it: the projection's tensor is never written, and the sum skips the fp16 rounding of the projection - compared with the oracle
-    (which rounds it) and the per-layer schedule at the tolerance of one fp16 rounding of an addend."""
+    (which rounds it) and the per-layer schedule at the tolerance of one fp16 rounding of an addend.  `own`: the block's own reduction
+    (1x1 64 -> 64 of the same input) feeds only the 3x3 and is computed on the 3x3's halo tile as well (pixels outside the image must come
+    out as the 3x3's zero padding, not relu(bias)) - the launch then reads nothing but the block input."""
     net = Net(7 + mr)
     t = net.conv(0, 3, 32, 3, 2)
     x = net.conv(t, 32, 64, 3, 2)                       # the block input, 1/4 of the frame
@@ -493,13 +495,18 @@ def test_bottleneck_with_projection_shortcut(hp, monkeypatch, mr, h, w):
         z = net.conv(y, 256, mr, 1)
         outs.append(Out("q", net.conv(z, mr, 32, 3, act=E.ACT_NONE), 0, 32))
     outs.append(Out("s", net.conv(y, 256, 32, 1, act=E.ACT_NONE), 0, 32))
+    if not own:
+        outs.append(Out("r2", net.conv(r, 64, 32, 1, act=E.ACT_NONE), 0, 32))   # a second reader keeps the reduction a launch of its own
     fr = _frames(3, h, w, seed=h + mr)
     eng, got, ref = _run_both(net, outs, fr, h, w)
     _check(got, ref, 3, rel=4e-3, abs_=2e-3)
     tiles = [p["tile"] for p in eng.profile(3, 1)]
-    assert tiles.count(9000000 + 1000 + 100 + 10 * (mr // 64) + 1) == 1, tiles
+    assert tiles.count(9000000 + 1000 + (300 if own else 100) + 10 * (mr // 64) + 1) == 1, tiles
     with pytest.raises(Exception):
         eng.debug_tensor(pj, 3)                         # the projection is never materialised
+    if own:
+        with pytest.raises(Exception):
+            eng.debug_tensor(r, 3)                      # ... nor the reduction
     ysum = eng.debug_tensor(y, 3)
     monkeypatch.setenv("HP_NO_BNECK", "1")
     eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 3)
