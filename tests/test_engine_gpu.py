@@ -475,7 +475,8 @@ def test_bottleneck_variants(hp, monkeypatch, m, mr, front, h, w):
             _close(a0, a1, rel=4e-3, abs_=2e-3)
 
 
-@pytest.mark.parametrize("mr,h,w,own", [(64, 52, 76, True), (128, 40, 40, True), (0, 36, 28, True), (64, 44, 36, False)])
+@pytest.mark.parametrize("mr,h,w,own", [(64, 52, 76, True), (128, 40, 40, True), (0, 36, 28, True), (64, 44, 36, False), (128, 36, 52, False),
+                                        (64, 40, 44, None), (128, 28, 36, None)])
 def test_bottleneck_with_projection_shortcut(hp, monkeypatch, mr, h, w, own):
     """The first block of ResNet's first stage: its shortcut is a 1x1 projection (64 -> 256, no activation) of the block input that only
     this block reads.  bottleneck64_kernel<.., PJ> computes it inside the launch (K = [3x3 output ; block input]) instead of reading
@@ -487,8 +488,12 @@ def test_bottleneck_with_projection_shortcut(hp, monkeypatch, mr, h, w, own):
     t = net.conv(0, 3, 32, 3, 2)
     x = net.conv(t, 32, 64, 3, 2)                       # the block input, 1/4 of the frame
     pj = net.conv(x, 64, 256, 1, act=E.ACT_NONE)        # projection shortcut (conv + BN, no relu)
-    r = net.conv(x, 64, 64, 1)
-    v = net.conv(r, 64, 64, 3)
+    if own is None:                                     # (no 3x3 the kernel takes in front of the expansion: projection + expansion [+ reduction] only)
+        r = net.conv(x, 64, 96, 1)
+        v = net.conv(r, 96, 64, 3)
+    else:
+        r = net.conv(x, 64, 64, 1)
+        v = net.conv(r, 64, 64, 3)
     y = net.conv(v, 64, 256, 1, res=pj, res_before_act=1)
     outs = []
     if mr:
@@ -501,7 +506,7 @@ def test_bottleneck_with_projection_shortcut(hp, monkeypatch, mr, h, w, own):
     eng, got, ref = _run_both(net, outs, fr, h, w)
     _check(got, ref, 3, rel=4e-3, abs_=2e-3)
     tiles = [p["tile"] for p in eng.profile(3, 1)]
-    assert tiles.count(9000000 + 1000 + (300 if own else 100) + 10 * (mr // 64) + 1) == 1, tiles
+    assert tiles.count(9000000 + 1000 + (300 if own else 100) + 10 * (mr // 64) + (0 if own is None else 1)) == 1, tiles
     with pytest.raises(Exception):
         eng.debug_tensor(pj, 3)                         # the projection is never materialised
     if own:
