@@ -423,6 +423,8 @@ def test_conv_chain_variants(hp, monkeypatch, variant, h, w, act):
     (128, 128, True, 52, 76),
     (128, 256, True, 40, 40),
     (128, 128, False, 8, 8),    # 2 x 2 map
+    (128, 256, False, 24, 40),  # stage end without a 3x3 in front
+    (64, 128, False, 20, 28),
     (128, 0, True, 36, 44),
 ])
 def test_bottleneck_variants(hp, monkeypatch, m, mr, front, h, w):
