@@ -147,6 +147,7 @@ def test_first_conv_matrix_pipe_shapes(hp, stride, cout, act, h, w, f32, k):
     (32, 64, 1, 1, 1), (64, 128, 1, 1, 1), (128, 128, 3, 1, 1), (128, 512, 1, 1, 1), (512, 19, 1, 1, 1),
     (512, 38, 1, 1, 1), (64, 64, 3, 2, 1), (96, 128, 3, 1, 2), (128, 128, 7, 1, 1), (256, 200, 3, 1, 1),
     (64, 256, 1, 2, 1), (64, 64, 3, 1, 1), (128, 64, 3, 1, 1),
+    (256, 512, 1, 2, 1), (512, 256, 1, 1, 1), (256, 1024, 1, 1, 1), (512, 128, 1, 3, 1),   # conv1x1_big_kernel: strided (odd map), 128- / 256-row blocks
 ])
 def test_mfma_conv_shapes(hp, cin, cout, k, stride, dil):
     net = Net(cin * 7 + cout)
