@@ -40,6 +40,7 @@ static bool FLAGS_keep_ratio = true;
 static double FLAGS_alpha = 0.5;
 static std::string FLAGS_saving_prefix = "output";
 static bool FLAGS_logging = false;
+static bool FLAGS_half = false; // addition: data_type::kHALF engines (the reference CLI always builds data_type::kFLOAT ones)
 
 static std::ostream& cli_log() { return std::cout << "[HyperPose::CLI] "; }
 
@@ -48,7 +49,7 @@ static bool parse_flags(int argc, char** argv)
     std::map<std::string, std::string*> sflags = { { "model", &FLAGS_model }, { "post", &FLAGS_post }, { "source", &FLAGS_source },
         { "runtime", &FLAGS_runtime }, { "saving_prefix", &FLAGS_saving_prefix } };
     std::map<std::string, int*> iflags = { { "w", &FLAGS_w }, { "h", &FLAGS_h }, { "max_batch_size", &FLAGS_max_batch_size } };
-    std::map<std::string, bool*> bflags = { { "imshow", &FLAGS_imshow }, { "keep_ratio", &FLAGS_keep_ratio }, { "logging", &FLAGS_logging } };
+    std::map<std::string, bool*> bflags = { { "imshow", &FLAGS_imshow }, { "keep_ratio", &FLAGS_keep_ratio }, { "logging", &FLAGS_logging }, { "half", &FLAGS_half } };
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a.rfind("--", 0) != 0 && a.rfind("-", 0) == 0)
@@ -215,10 +216,11 @@ static hp::dnn::tensorrt build_engine()
     const cv::Size net_size(FLAGS_w, FLAGS_h);
     cli_log() << "engine: model '" << FLAGS_model << "', network input " << FLAGS_w << " x " << FLAGS_h << " (w x h), batches of up to "
               << FLAGS_max_batch_size << (FLAGS_keep_ratio ? ", aspect ratio kept (letter-box)\n" : ", frames stretched to the network size\n");
+    const hp::data_type dtype = FLAGS_half ? hp::data_type::kHALF : hp::data_type::kFLOAT;
     if (FLAGS_model.rfind("builtin:", 0) == 0)
-        return hp::dnn::tensorrt(hp::dnn::builtin_model{ FLAGS_model.substr(8), {}, 20241 }, net_size, FLAGS_max_batch_size, FLAGS_keep_ratio);
+        return hp::dnn::tensorrt(hp::dnn::builtin_model{ FLAGS_model.substr(8), {}, 20241 }, net_size, FLAGS_max_batch_size, FLAGS_keep_ratio, dtype);
     if (has_suffix(FLAGS_model, ".onnx"))
-        return hp::dnn::tensorrt(hp::dnn::onnx{ FLAGS_model }, net_size, FLAGS_max_batch_size, FLAGS_keep_ratio);
+        return hp::dnn::tensorrt(hp::dnn::onnx{ FLAGS_model }, net_size, FLAGS_max_batch_size, FLAGS_keep_ratio, dtype);
     if (has_suffix(FLAGS_model, ".uff"))
         return hp::dnn::tensorrt(hp::dnn::uff{ FLAGS_model, "image", { "outputs/conf", "outputs/paf" } }, net_size, FLAGS_max_batch_size, FLAGS_keep_ratio);
     cli_log() << "'" << FLAGS_model << "' is neither .onnx nor .uff: loading it as a serialized engine\n";

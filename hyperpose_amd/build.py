@@ -32,6 +32,7 @@ UNITS = [
     ("conv_kernels.hip", []),
     ("conv_chain.hip", []),
     ("conv_bottleneck.hip", []),
+    ("conv_fp32.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),
     ("onnx_import.cpp", []),

@@ -1,0 +1,494 @@
+// conv_fp32.hip — the fp32-faithful kernel family for gfx950 (interface and rationale: conv_fp32.hpp).
+//
+// The reference's engine computes in fp32 unless the caller asks for kHALF (include/hyperpose/operator/dnn/tensorrt.hpp:14-21,48;
+// src/tensorrt.cpp:327,353 hand the data type to the TensorRT builder).  An engine created with HP_DTYPE_F32 runs every layer of the
+// exported graphs through the kernels below, one launch per layer:
+//   conv32_kernel          dense KH x KW convolution, implicit GEMM D[cout][pixel] = sum_{tap,cin} W[tap][cout][cin] * X[pixel@tap][cin]
+//                          on v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, 157 TFLOP/s: MI355X_MICROARCH.md) - exact fp32 products and sums;
+//   first_conv32_kernel    the 3-channel input layer with the u8 -> f32 pre-processing of src/data.cpp:21-51 folded into its load;
+//   dwconv32_kernel        depthwise 3 x 3;   maxpool32_kernel / upsample32_kernel;   output_transform32_kernel (NHWC fp32 -> NCHW fp32).
+// Activations keep the zero-halo NHWC layout of the fp16 path with 4-byte elements.
+#include "conv_fp32.hpp"
+
+#include "conv_device.hpp"
+
+#include <algorithm>
+
+namespace hp {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act32(float v, int act, float param, float alpha)
+{
+    switch (act) {
+    case ACT_RELU:
+        return fmaxf(v, 0.f);
+    case ACT_RELU6:
+        return fminf(fmaxf(v, 0.f), 6.f);
+    case ACT_LEAKY:
+        return v > 0.f ? v : v * param;
+    case ACT_PRELU:
+        return v > 0.f ? v : v * alpha;
+    case ACT_SIGMOID:
+        return 1.f / (1.f + expf(-v));
+    case ACT_SOFTPLUS:
+        return v > 20.f ? v : log1pf(expf(v));
+    default:
+        return v;
+    }
+}
+
+__device__ __forceinline__ long tv32_off(const tview32& t, int b, int y, int x)
+{
+    return ((long)b * t.img + (long)y * t.wp + x) * t.cs + t.coff;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// Block = 256 threads = WM x WN wavefronts; block tile BM output channels x BN pixels, K-step of 16 input channels of one tap.
+// A (weights) and B (activations) tiles go global -> registers -> LDS, double-buffered, ONE LDS-only barrier per K-step; the global
+// loads of step s + 1 are in flight while step s multiplies (32 MFMAs of 64 cycles per wavefront at 128 x 128: the loads hide).
+// K order inside a group of 8 channels: lane (row, h) reads channels [4h, 4h + 4) of its row with one ds_read_b128 and feeds element e
+// to MFMA e, i.e. MFMA e multiplies channels {e, 4 + e} - A and B use the same permutation, so the sum over the 8 channels is complete.
+// LDS rows are 20 floats (80 B): the 16 lanes of a ds_read_b128 service group then touch 64 distinct banks.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
+{
+    constexpr int BK = 16, LDR = 20;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NA = BM / 64, NB = BN / 64;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && NA >= 1 && NB >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * LDR];
+    __shared__ __attribute__((aligned(16))) float sB[2][BN * LDR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int lrow = tid >> 2, lchunk = (tid & 3) * 4;
+    const int OHW = p.OH * p.OW, kc = p.Cin / BK, steps = p.KH * p.KW * kc;
+
+    long bbase[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = min(n0 + lrow + 64 * j, p.npix - 1);
+        const int b = n / OHW, rem = n - b * OHW;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        bbase[j] = tv32_off(p.in, b, oy * p.stride - p.pad_t, ox * p.stride - p.pad_l) + lchunk;
+    }
+    const float* const wrow = p.w + (long)(m0 + lrow) * p.Cin + lchunk;
+
+    f32x4 ra[NA], rb[NB];
+    auto gload = [&](int s) {
+        const int tap = s / kc, k0 = (s - tap * kc) * BK;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const long toff = ((long)(ky * p.dil) * p.in.wp + kx * p.dil) * p.in.cs + k0;
+        const float* const wt = wrow + (long)tap * p.Cout_pad * p.Cin + k0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            ra[j] = *reinterpret_cast<const f32x4*>(wt + (long)(64 * j) * p.Cin);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            rb[j] = *reinterpret_cast<const f32x4*>(p.in.p + bbase[j] + toff);
+    };
+    auto to_lds = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            *reinterpret_cast<f32x4*>(&sA[buf][(lrow + 64 * j) * LDR + lchunk]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<f32x4*>(&sB[buf][(lrow + 64 * j) * LDR + lchunk]) = rb[j];
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fh = (lane >> 5) * 4;
+    gload(0);
+    to_lds(0);
+    lds_barrier();
+#pragma unroll 1
+    for (int s = 0; s < steps; ++s) {
+        gload(min(s + 1, steps - 1));
+        const float* const a_s = &sA[s & 1][(wm * TM * 32 + frow) * LDR + fh];
+        const float* const b_s = &sB[s & 1][(wn * TN * 32 + frow) * LDR + fh];
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * 32 * LDR + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const f32x4*>(b_s + j * 32 * LDR + kk * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        to_lds((s + 1) & 1);
+        lds_barrier();
+    }
+
+    // epilogue: lane (n, h) of a 32 x 32 tile holds rows (r & 3) + 8 (r >> 2) + 4 h of column n: four consecutive channels per r >> 2
+    const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
+    const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
+    const float pre = p.res_before_act ? 1.f : 0.f, post = 1.f - pre; // (the residual is 0 when there is none)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + frow;
+        const bool pix_ok = n < p.npix;
+        const int nc = min(n, p.npix - 1);
+        const int b = nc / OHW, rem = nc - b * OHW;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const long ooff = p.out.p ? tv32_off(p.out, b, oy, ox) : 0;
+        const long roff = p.res.p ? tv32_off(p.res, b, oy, ox) : 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + (wm * TM + i) * 32 + 8 * q + fh;
+                if (pix_ok && m < p.Cout) {
+                    const bool full = m + 3 < p.Cout;
+                    float v[4], rr[4] = { 0.f, 0.f, 0.f, 0.f };
+                    if (p.res.p) {
+                        if (full && res_vec) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(p.res.p + roff + m);
+                            rr[0] = t[0], rr[1] = t[1], rr[2] = t[2], rr[3] = t[3];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (m + e < p.Cout)
+                                    rr[e] = p.res.p[roff + m + e];
+                        }
+                    }
+                    // (m + 3 < Cout_pad: m is a multiple of 4 below Cout <= Cout_pad, a multiple of 64)
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + m);
+                    f32x4 sl = { p.act_slope, p.act_slope, p.act_slope, p.act_slope };
+                    if (p.alpha)
+                        sl = *reinterpret_cast<const f32x4*>(p.alpha + m);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][4 * q + e] + bs[e] + pre * rr[e];
+                        x = x > 0.f ? fminf(x, p.act_hi) : x * sl[e];
+                        v[e] = x + post * rr[e];
+                    }
+                    if (p.out.p) {
+                        if (full && out_vec) {
+                            f32x4 t = { v[0], v[1], v[2], v[3] };
+                            *reinterpret_cast<f32x4*>(p.out.p + ooff + m) = t;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (m + e < p.Cout)
+                                    p.out.p[ooff + m + e] = v[e];
+                        }
+                    }
+                    if (p.out_f32) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (m + e < p.Cout)
+                                p.out_f32[((long)b * p.Cout + m + e) * OHW + rem] = v[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+int conv32_tile(const conv32_params& p)
+{
+    const int BM = p.Cout_pad % 128 == 0 ? 128 : 64;
+    return 32000000 + BM * 1000 + 128;
+}
+
+bool set_act32(conv32_params& p)
+{
+    const float inf = __builtin_huge_valf();
+    switch (p.act) {
+    case ACT_NONE:
+        p.act_slope = 1.f, p.act_hi = inf;
+        return true;
+    case ACT_RELU:
+        p.act_slope = 0.f, p.act_hi = inf;
+        return true;
+    case ACT_RELU6:
+        p.act_slope = 0.f, p.act_hi = 6.f;
+        return true;
+    case ACT_LEAKY:
+        p.act_slope = p.act_param, p.act_hi = inf;
+        return true;
+    case ACT_PRELU:
+        p.act_slope = 0.f, p.act_hi = inf;
+        return p.alpha != nullptr;
+    default:
+        return false;
+    }
+}
+
+hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
+{
+    if (p.Cin % 16 || p.Cout_pad % 64 || p.npix <= 0)
+        return hipErrorInvalidValue;
+    const int BM = p.Cout_pad % 128 == 0 ? 128 : 64;
+    const dim3 grid((p.npix + 127) / 128, p.Cout_pad / BM);
+    if (BM == 128)
+        HP_LAUNCH((conv32_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
+    else
+        HP_LAUNCH((conv32_kernel<64, 128, 1, 4>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// First layer: Cin = 3.  Block = 256 threads = (256 / G) pixels x G groups of 8 output channels, weights in LDS.
+__global__ __launch_bounds__(256) void first_conv32_kernel(const first_conv32_params p)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_w32[]; // [KH*KW*3][Cout_pad8]
+    const int G = (p.Cout + 7) / 8, CP = G * 8, taps = p.KH * p.KW;
+    for (int i = threadIdx.x; i < taps * 3 * CP; i += 256) {
+        const int co = i % CP, t = i / CP; // t = tap * 3 + c
+        s_w32[i] = co < p.Cout ? p.w[(size_t)co * taps * 3 + t] : 0.f;
+    }
+    __syncthreads();
+    const int ppb = 256 / G;
+    const int g = threadIdx.x % G, pl = threadIdx.x / G;
+    if (pl >= ppb)
+        return;
+    const int OHW = p.OH * p.OW;
+    const long npix = (long)p.B * OHW;
+    for (long n = (long)blockIdx.x * ppb + pl; n < npix; n += (long)gridDim.x * ppb) {
+        const int b = (int)(n / OHW), rem = (int)(n - (long)b * OHW);
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            acc[r] = (g * 8 + r < p.Cout) ? p.bias[g * 8 + r] : 0.f;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            const int iy = oy * p.stride - p.pad_t + ky;
+            if (iy < 0 || iy >= p.H)
+                continue;
+            for (int kx = 0; kx < p.KW; ++kx) {
+                const int ix = ox * p.stride - p.pad_l + kx;
+                if (ix < 0 || ix >= p.W)
+                    continue;
+                float x[3];
+                if (p.in_u8) {
+                    const uint8_t* px = p.in_u8 + (((size_t)b * p.H + iy) * p.W + ix) * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        x[c] = (float)((double)px[p.flip_rb ? 2 - c : c] * p.factor); // src/data.cpp:48
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        x[c] = p.in_f32[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix];
+                }
+                const float* wt = s_w32 + (size_t)((ky * p.KW + kx) * 3) * CP + g * 8;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float xv = (x[c] - p.mean[c]) * p.inv_std[c];
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + c * CP);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wt + c * CP + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[e] = fmaf(xv, w0[e], acc[e]), acc[4 + e] = fmaf(xv, w1[e], acc[4 + e]);
+                }
+            }
+        }
+        float* op = p.out.p + tv32_off(p.out, b, oy, ox) + g * 8;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (g * 8 + r < p.Cout)
+                op[r] = act32(acc[r], p.act, p.act_param, 0.f);
+    }
+}
+
+hipError_t launch_first_conv32(const first_conv32_params& p, hipStream_t s)
+{
+    const int G = (p.Cout + 7) / 8;
+    if (G > 256)
+        return hipErrorInvalidValue;
+    const size_t lds = (size_t)p.KH * p.KW * 3 * G * 8 * sizeof(float);
+    if (lds > 64 * 1024)
+        return hipErrorInvalidValue;
+    const long npix = (long)p.B * p.OH * p.OW;
+    const int ppb = 256 / G;
+    const int blocks = (int)std::min<long>((npix + ppb - 1) / ppb, 256 * 32);
+    HP_LAUNCH(first_conv32_kernel, dim3(blocks), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Depthwise 3 x 3: one thread = one output pixel x 4 channels; taps in the padding read the zero halo.
+__global__ __launch_bounds__(256) void dwconv32_kernel(const dw32_params p)
+{
+    const int CG = p.C / 4;
+    const long total = (long)p.B * p.OH * p.OW * CG;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        const long n = i / CG;
+        const int ox = (int)(n % p.OW);
+        const long t = n / p.OW;
+        const int oy = (int)(t % p.OH), b = (int)(t / p.OH);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(p.bias + cg * 4);
+        const float* const x0 = p.in.p + tv32_off(p.in, b, oy * p.stride - p.pad_t, ox * p.stride - p.pad_l) + cg * 4;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(x0 + ((long)(ky * p.dil) * p.in.wp + kx * p.dil) * p.in.cs);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + (ky * 3 + kx) * p.C + cg * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[e] = fmaf(x[e], w[e], acc[e]);
+            }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = act32(acc[e], p.act, p.act_param, 0.f);
+        *reinterpret_cast<f32x4*>(p.out.p + tv32_off(p.out, b, oy, ox) + cg * 4) = o;
+    }
+}
+
+hipError_t launch_dwconv32(const dw32_params& p, hipStream_t s)
+{
+    if (p.C % 4)
+        return hipErrorInvalidValue;
+    const long total = (long)p.B * p.OH * p.OW * (p.C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 32);
+    HP_LAUNCH(dwconv32_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool32_kernel(const pool32_params p)
+{
+    const int CG = p.C / 4;
+    const long total = (long)p.B * p.OH * p.OW * CG;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        const long n = i / CG;
+        const int ox = (int)(n % p.OW);
+        const long t = n / p.OW;
+        const int oy = (int)(t % p.OH), b = (int)(t / p.OH);
+        f32x4 m = { -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf() };
+        for (int ky = 0; ky < p.k; ++ky) {
+            const int iy = oy * p.stride - p.pad_t + ky;
+            if (iy < 0 || iy >= p.H) // SAME max-pool pads with -inf, not with the zero halo
+                continue;
+            for (int kx = 0; kx < p.k; ++kx) {
+                const int ix = ox * p.stride - p.pad_l + kx;
+                if (ix < 0 || ix >= p.W)
+                    continue;
+                const f32x4 x = *reinterpret_cast<const f32x4*>(p.in.p + tv32_off(p.in, b, iy, ix) + cg * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    m[e] = fmaxf(m[e], x[e]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(p.out.p + tv32_off(p.out, b, oy, ox) + cg * 4) = m;
+    }
+}
+
+hipError_t launch_maxpool32(const pool32_params& p, hipStream_t s)
+{
+    if (p.C % 4)
+        return hipErrorInvalidValue;
+    const long total = (long)p.B * p.OH * p.OW * (p.C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 32);
+    HP_LAUNCH(maxpool32_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// Integer up-scaling: nearest, or bilinear with half-pixel centres (the fp16 kernel's definition, conv_kernels.hip upsample_kernel).
+__global__ __launch_bounds__(256) void upsample32_kernel(const pool32_params p)
+{
+    const int CG = p.C / 4, sc = p.stride;
+    const float inv = 1.f / (float)sc;
+    const long total = (long)p.B * p.OH * p.OW * CG;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        const long n = i / CG;
+        const int ox = (int)(n % p.OW);
+        const long t = n / p.OW;
+        const int oy = (int)(t % p.OH), b = (int)(t / p.OH);
+        f32x4 o;
+        if (p.k == 0) {
+            o = *reinterpret_cast<const f32x4*>(p.in.p + tv32_off(p.in, b, oy / sc, ox / sc) + cg * 4);
+        } else {
+            const float sy = fmaxf(((float)oy + 0.5f) * inv - 0.5f, 0.f), sx = fmaxf(((float)ox + 0.5f) * inv - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = min(y0 + 1, p.H - 1), x1 = min(x0 + 1, p.W - 1);
+            const float fy = sy - (float)y0, fx = sx - (float)x0;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.in.p + tv32_off(p.in, b, y0, x0) + cg * 4);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(p.in.p + tv32_off(p.in, b, y0, x1) + cg * 4);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p.in.p + tv32_off(p.in, b, y1, x0) + cg * 4);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(p.in.p + tv32_off(p.in, b, y1, x1) + cg * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float top = a[e] * (1.f - fx) + bq[e] * fx;
+                const float bot = c[e] * (1.f - fx) + d[e] * fx;
+                o[e] = top * (1.f - fy) + bot * fy;
+            }
+        }
+        *reinterpret_cast<f32x4*>(p.out.p + tv32_off(p.out, b, oy, ox) + cg * 4) = o;
+    }
+}
+
+hipError_t launch_upsample32(const pool32_params& p, hipStream_t s)
+{
+    if (p.C % 4)
+        return hipErrorInvalidValue;
+    const long total = (long)p.B * p.OH * p.OW * (p.C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 32);
+    HP_LAUNCH(upsample32_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void output_transform32_kernel(tview32 in, int B, int H, int W, out_xform x, float* __restrict__ out)
+{
+    const int sc = x.shuffle, CO = x.C / (sc * sc), OH = x.out_h, OW = x.out_w;
+    const long total = (long)B * CO * OH * OW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ox = (int)(i % OW);
+        long t = i / OW;
+        const int oy = (int)(t % OH);
+        t /= OH;
+        const int c = (int)(t % CO), b = (int)(t / CO);
+        // pixel_shuffle: [b, c, sy, sx, h, w] -> [b, c, h, sy, w, sx]  (hyperpose/Model/pifpaf/utils.py:371-379)
+        const int y = oy / sc, sy = oy - y * sc, xx = ox / sc, sx = ox - xx * sc;
+        const int cin = c * sc * sc + sy * sc + sx;
+        float v = in.p[tv32_off(in, b, y, xx) + cin];
+        int act = x.act;
+        if (x.group > 0) {
+            const int comp = c % x.group;
+            act = ((x.sigmoid_mask >> comp) & 1u) ? ACT_SIGMOID : (((x.softplus_mask >> comp) & 1u) ? ACT_SOFTPLUS : ACT_NONE);
+        }
+        v = act32(v, act, 0.f, 0.f);
+        if (x.grid == 1)
+            v += (float)ox;
+        else if (x.grid == 2)
+            v += (float)oy;
+        out[i] = v * x.scale;
+    }
+}
+
+hipError_t launch_output_transform32(tview32 in, int B, int H, int W, const out_xform& x, float* out, hipStream_t s)
+{
+    const long total = (long)B * (x.C / (x.shuffle * x.shuffle)) * x.out_h * x.out_w;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 32);
+    HP_LAUNCH(output_transform32_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, x, out);
+    return hipGetLastError();
+}
+
+} // namespace hp

@@ -1,0 +1,82 @@
+// conv_fp32.hpp — launch interface of the fp32-faithful kernel family (conv_fp32.hip): what the engine runs when it is created with
+// HP_DTYPE_F32, i.e. behind `data_type::kFLOAT` of the reference's engine (include/hyperpose/operator/dnn/tensorrt.hpp:14-21,48: fp32 is
+// the reference's default precision; docs/markdown/quick_start/prediction.md:145).  Storage AND arithmetic are fp32: activations NHWC fp32
+// with the same zero halo as the fp16 path (conv_kernels.hpp), weights fp32, products and sums on the fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: exact fp32 multiply-add, no TF32-style truncation) or the fp32 vector pipe.  One generic kernel per operator,
+// no fusion: this is the faithful mode, not the fast path (HP_DTYPE_F16 keeps every fused fp16 kernel).
+#pragma once
+#include "conv_kernels.hpp"
+
+namespace hp {
+
+// fp32 NHWC view with halo: element (b, y, x, c) is p[((long)b * img + (long)y * wp + x) * cs + coff + c]
+struct tview32 {
+    float* p;
+    int cs, coff, wp, img;
+};
+
+struct conv32_params {
+    tview32 in;
+    int B, H, W, OH, OW;
+    int Cin;      // channels read per tap, multiple of 16 (the slice [coff, coff + Cin) must lie inside the buffer's channel stride)
+    int Cout;     // real output channels
+    int Cout_pad; // rows of the packed weight matrix, multiple of 64
+    int KH, KW, stride, dil, pad_t, pad_l;
+    const float* w;     // [KH*KW][Cout_pad][Cin] fp32, zero rows / columns in the padding
+    const float* bias;  // [Cout_pad]
+    const float* alpha; // PReLU slopes [Cout_pad] or nullptr
+    int act; // ACT_NONE / RELU / RELU6 / LEAKY / PRELU
+    float act_param;
+    float act_slope, act_hi; // y = v > 0 ? min(v, act_hi) : v * act_slope (PReLU: alpha[] per channel), filled by set_act32()
+    tview32 res; // res.p == nullptr: none
+    int res_before_act;
+    tview32 out;    // out.p may be null
+    float* out_f32; // fp32 NCHW [B][Cout][OH][OW] network output, or nullptr
+    int npix;       // B * OH * OW
+};
+// fills act_slope / act_hi from act / act_param; false for activations the epilogue does not evaluate (sigmoid / softplus are output post-ops)
+bool set_act32(conv32_params& p);
+// Dense KH x KW convolution (any stride / dilation) as an implicit GEMM on v_mfma_f32_32x32x2_f32.
+hipError_t launch_conv32(const conv32_params& p, hipStream_t s);
+int conv32_tile(const conv32_params& p); // profile rows: 32000000 + BM * 1000 + BN
+
+struct first_conv32_params {
+    const uint8_t* in_u8; // [B][H][W][3] or nullptr
+    const float* in_f32;  // [B][3][H][W] or nullptr
+    double factor;
+    int flip_rb;
+    float mean[3], inv_std[3];
+    int B, H, W, OH, OW;
+    int Cout, KH, KW, stride, pad_t, pad_l;
+    const float* w; // fp32 [Cout][KH][KW][3]
+    const float* bias;
+    int act;
+    float act_param;
+    tview32 out;
+};
+// The 3-channel network input (u8 HWC or f32 NCHW), pre-processing of src/data.cpp:21-51 folded into the load; all-fp32.
+hipError_t launch_first_conv32(const first_conv32_params& p, hipStream_t s);
+
+struct dw32_params {
+    tview32 in;
+    int B, H, W, OH, OW, C; // C multiple of 4
+    int stride, dil, pad_t, pad_l;
+    const float* w;    // [9][C]
+    const float* bias; // [C]
+    int act;
+    float act_param;
+    tview32 out;
+};
+hipError_t launch_dwconv32(const dw32_params& p, hipStream_t s);
+
+struct pool32_params {
+    tview32 in;
+    int B, H, W, OH, OW, C; // C multiple of 4
+    int k, stride, pad_t, pad_l;
+    tview32 out;
+};
+hipError_t launch_maxpool32(const pool32_params& p, hipStream_t s);
+hipError_t launch_upsample32(const pool32_params& p, hipStream_t s); // stride = integer scale, k = 0 nearest / 1 bilinear
+hipError_t launch_output_transform32(tview32 in, int B, int H, int W, const out_xform& x, float* out, hipStream_t s);
+
+} // namespace hp

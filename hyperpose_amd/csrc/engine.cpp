@@ -10,6 +10,7 @@
 //   * activations are NHWC fp16 with fp32 MFMA accumulation, concat is a channel offset into a shared buffer;
 //   * heads write fp32 NCHW straight from the conv epilogue into the buffers the parser kernels read —
 //     feature maps never cross PCIe.
+#include "conv_fp32.hpp"
 #include "conv_kernels.hpp"
 #include "hp_common.hpp"
 
@@ -42,6 +43,14 @@ struct tensor_info {
         v.cs = cs, v.coff = coff, v.wp = wp, v.img = (H + 2 * P) * wp;
         return v;
     }
+    hp::tview32 view32(int coff) const // the same geometry with 4-byte elements (HP_DTYPE_F32 engines)
+    {
+        hp::tview32 v;
+        const int wp = W + 2 * P;
+        v.p = buf.as<float>() + ((size_t)P * wp + P) * cs;
+        v.cs = cs, v.coff = coff, v.wp = wp, v.img = (H + 2 * P) * wp;
+        return v;
+    }
 };
 
 struct out_info {
@@ -69,6 +78,12 @@ struct step {
     bool paired = false;
     hp::chain_params ch{}; // op == OP_CHAIN: [1x1 ->] 3x3 -> 3x3 on 128 channels in one launch (conv_chain.hip), layers `layer` ..
     hp::bneck_params bn{}; // op == OP_BNECK: [3x3 ->] expansion 1x1 + shortcut [-> the next block's reduction 1x1] (conv_bottleneck.hip)
+    // HP_DTYPE_F32 engines (conv_fp32.hip): one launch per layer, `op` = the layer's op, `f32` set
+    bool f32 = false;
+    hp::conv32_params cp32{};
+    hp::first_conv32_params fp32{};
+    hp::dw32_params dp32{};
+    hp::pool32_params pp32{};
     int n_layers = 1;      // consecutive layers this step covers
     double flops = 0, bytes = 0; // per frame
 };
@@ -89,6 +104,8 @@ void same_pad(int in, int k, int stride, int dil, int& out, int& pad_before)
 
 struct hp_engine {
     int in_w = 0, in_h = 0, max_batch = 0;
+    int dtype = HP_DTYPE_F16; // HP_DTYPE_F32: fp32 storage and arithmetic (the reference's data_type::kFLOAT), conv_fp32.hip
+    bool dbg_conv = false, dbg_bn = false, dbg_chain = false, dbg_sep = false; // HP_*_DBG block timelines, read once at creation
     double factor = 1.0 / 255;
     int flip_rb = 1;
     float mean[3] = { 0, 0, 0 }, inv_std[3] = { 1, 1, 1 };
@@ -135,6 +152,11 @@ int hp_engine::build(const hp_engine_desc* d)
     HP_REQUIRE(d->in_w > 0 && d->in_h > 0 && d->max_batch >= 1, HP_ERR_INVALID, "engine: bad input size / batch");
     HP_REQUIRE(d->layers && d->n_layers > 0 && d->weights, HP_ERR_INVALID, "engine: no layers / weights");
     in_w = d->in_w, in_h = d->in_h, max_batch = d->max_batch, factor = d->factor, flip_rb = d->flip_rb;
+    HP_REQUIRE(d->dtype == HP_DTYPE_F16 || d->dtype == HP_DTYPE_F32, HP_ERR_INVALID, "engine: dtype %d is neither HP_DTYPE_F16 nor HP_DTYPE_F32", d->dtype);
+    dtype = d->dtype;
+    const bool f32 = dtype == HP_DTYPE_F32;
+    dbg_conv = getenv("HP_CONV_DBG") != nullptr, dbg_bn = getenv("HP_BN_DBG") != nullptr;
+    dbg_chain = getenv("HP_CHAIN_DBG") != nullptr, dbg_sep = getenv("HP_SEP_DBG") != nullptr;
     for (int c = 0; c < 3; ++c)
         mean[c] = d->mean[c], inv_std[c] = d->inv_std[c];
     layers.assign(d->layers, d->layers + d->n_layers);
@@ -223,7 +245,7 @@ int hp_engine::build(const hp_engine_desc* d)
     // ---- separable blocks: a depthwise layer whose only consumer is the next layer, a plain 1x1 convolution, runs
     // as ONE launch (sepconv_kernel) and its output tensor is never materialised.  HP_NO_FUSE=1 keeps the two launches.
     std::vector<char> fuse_with_next(layers.size(), 0);
-    if (!getenv("HP_NO_FUSE")) {
+    if (!getenv("HP_NO_FUSE") && !f32) {
         for (size_t i = 0; i + 1 < layers.size(); ++i) {
             const hp_layer &A = layers[i], &Bn = layers[i + 1];
             if (A.op != HP_OP_DWCONV || A.kh != 3 || A.kw != 3 || A.in == 0 || A.out_coff != 0 || A.in_coff % 8)
@@ -263,7 +285,7 @@ int hp_engine::build(const hp_engine_desc* d)
     }
     // ---- two-layer heads: 1x1 K1 -> 512 (relu) whose only consumer is the next layer, a 1x1 512 -> <= 64 channels
     std::vector<char> head_with_next(layers.size(), 0);
-    if (!getenv("HP_NO_FUSE")) {
+    if (!getenv("HP_NO_FUSE") && !f32) {
         for (size_t i = 0; i + 1 < layers.size(); ++i) {
             const hp_layer &A = layers[i], &Bn = layers[i + 1];
             if (A.op != HP_OP_CONV || A.kh != 1 || A.kw != 1 || A.stride != 1 || A.in == 0 || A.res >= 0 || A.out_coff != 0 || A.in_coff % 8
@@ -297,7 +319,7 @@ int hp_engine::build(const hp_engine_desc* d)
         if (!ti.defined || ti.elided)
             continue;
         ti.cs = round_up(ti.C, 32);
-        const size_t bytes = (size_t)max_batch * (ti.H + 2 * ti.P) * (ti.W + 2 * ti.P) * ti.cs * sizeof(__half);
+        const size_t bytes = (size_t)max_batch * (ti.H + 2 * ti.P) * (ti.W + 2 * ti.P) * ti.cs * (f32 ? sizeof(float) : sizeof(__half));
         HP_TRY(ti.buf.alloc(bytes));
         HP_HIP_TRY(hipMemset(ti.buf.p, 0, bytes)); // the halo and the pad channels must read as zero, forever
     }
@@ -378,6 +400,122 @@ int hp_engine::build(const hp_engine_desc* d)
         step st;
         st.layer = (int)i, st.op = L.op;
         const double opix = (double)g.OH * g.OW;
+        if (f32) {
+            // ---- HP_DTYPE_F32: one fp32 launch per layer (conv_fp32.hip), weights uploaded as they are
+            st.f32 = true;
+            auto padded = [&](int64_t off, int n, int n_pad, const char* what, std::vector<float>& v) -> bool {
+                v.assign(n_pad, 0.f);
+                if (off < 0)
+                    return true;
+                const float* src = blob(off, n, what, i);
+                if (!src)
+                    return false;
+                std::copy(src, src + n, v.begin());
+                return true;
+            };
+            if (L.op == HP_OP_CONV && L.in == 0) {
+                HP_REQUIRE(L.cin == 3 && L.in_coff == 0, HP_ERR_INVALID, "layer %zu: the network input has 3 channels", i);
+                HP_REQUIRE(L.dil == 1 && L.res < 0 && L.act != HP_ACT_PRELU, HP_ERR_INVALID, "layer %zu: unsupported first-layer options", i);
+                const size_t nw = (size_t)L.cout * L.kh * L.kw * 3;
+                const float* w = blob(L.w_off, nw, "weights", i);
+                std::vector<float> bias;
+                if (!w || !padded(L.b_off, L.cout, round_up(L.cout, 8), "bias", bias))
+                    return HP_ERR_INVALID;
+                st.first = true;
+                auto& p = st.fp32;
+                p.factor = factor, p.flip_rb = flip_rb;
+                for (int c = 0; c < 3; ++c)
+                    p.mean[c] = mean[c], p.inv_std[c] = inv_std[c];
+                p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.Cout = L.cout, p.KH = L.kh, p.KW = L.kw, p.stride = L.stride;
+                p.pad_t = g.pt, p.pad_l = g.pl, p.act = L.act, p.act_param = L.act_param;
+                void *dw = nullptr, *db = nullptr;
+                HP_TRY(upload(w, nw * sizeof(float), &dw));
+                HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
+                p.w = (const float*)dw, p.bias = (const float*)db;
+                p.out = to.view32(L.out_coff);
+                st.flops = 2.0 * opix * L.cout * L.kh * L.kw * 3;
+                st.bytes = (double)ti.H * ti.W * 3 + opix * L.cout * 4 + nw * 4;
+            } else if (L.op == HP_OP_CONV) {
+                const int cin_pad = round_up(L.cin, 16), cout_pad = round_up(L.cout, 64), taps = L.kh * L.kw;
+                HP_REQUIRE(L.in_coff % 4 == 0 && L.in_coff + cin_pad <= ti.cs, HP_ERR_INVALID,
+                    "layer %zu: channel slice [%d,+%d) not 4-aligned / exceeds the padded stride %d", i, L.in_coff, cin_pad, ti.cs);
+                const size_t nw = (size_t)L.cout * taps * L.cin;
+                const float* w = blob(L.w_off, nw, "weights", i);
+                std::vector<float> bias, alpha;
+                if (!w || !padded(L.b_off, L.cout, cout_pad, "bias", bias))
+                    return HP_ERR_INVALID;
+                auto& p = st.cp32;
+                p.alpha = nullptr;
+                if (L.act == HP_ACT_PRELU) {
+                    HP_REQUIRE(L.alpha_off >= 0, HP_ERR_INVALID, "layer %zu: PReLU without slopes", i);
+                    if (!padded(L.alpha_off, L.cout, cout_pad, "prelu slopes", alpha))
+                        return HP_ERR_INVALID;
+                    void* da = nullptr;
+                    HP_TRY(upload(alpha.data(), alpha.size() * sizeof(float), &da));
+                    p.alpha = (const float*)da;
+                }
+                std::vector<float> packed((size_t)taps * cout_pad * cin_pad, 0.f);
+                for (int co = 0; co < L.cout; ++co)
+                    for (int t = 0; t < taps; ++t)
+                        std::copy(w + ((size_t)co * taps + t) * L.cin, w + ((size_t)co * taps + t + 1) * L.cin, packed.begin() + ((size_t)t * cout_pad + co) * cin_pad);
+                void *dw = nullptr, *db = nullptr;
+                HP_TRY(upload(packed.data(), packed.size() * sizeof(float), &dw));
+                HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
+                p.w = (const float*)dw, p.bias = (const float*)db;
+                p.in = ti.view32(L.in_coff);
+                p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.Cin = cin_pad, p.Cout = L.cout, p.Cout_pad = cout_pad;
+                p.KH = L.kh, p.KW = L.kw, p.stride = L.stride, p.dil = L.dil, p.pad_t = g.pt, p.pad_l = g.pl;
+                p.act = L.act, p.act_param = L.act_param;
+                p.res = hp::tview32{ nullptr, 0, 0, 0, 0 }, p.res_before_act = L.res_before_act;
+                if (L.res >= 0)
+                    p.res = tensors[L.res]->view32(0);
+                p.out = to.view32(L.out_coff);
+                p.out_f32 = nullptr;
+                for (auto& o : outputs)
+                    if (o.fused_layer == (int)i)
+                        p.out_f32 = o.buf->as<float>();
+                if (p.out_f32 && !tensor_is_read(L.out) && tensors[L.out]->C == L.cout)
+                    p.out.p = nullptr, to.unwritten = true; // only the fp32 network output is wanted
+                HP_REQUIRE(hp::set_act32(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
+                p.B = max_batch, p.npix = max_batch * g.OH * g.OW;
+                st.flops = 2.0 * opix * L.cout * taps * L.cin;
+                st.bytes = (double)ti.H * ti.W * L.cin * 4 + opix * L.cout * 4 + (double)nw * 4;
+            } else if (L.op == HP_OP_DWCONV) {
+                HP_REQUIRE(L.kh == 3 && L.kw == 3, HP_ERR_INVALID, "layer %zu: depthwise kernels are 3x3", i);
+                HP_REQUIRE(L.cin % 4 == 0 && L.in_coff % 4 == 0 && L.out_coff % 4 == 0, HP_ERR_INVALID, "layer %zu: depthwise needs 4-aligned channels", i);
+                const float* w = blob(L.w_off, (size_t)L.cin * 9, "weights", i);
+                std::vector<float> bias;
+                if (!w || !padded(L.b_off, L.cin, L.cin, "bias", bias))
+                    return HP_ERR_INVALID;
+                std::vector<float> packed((size_t)9 * L.cin);
+                for (int c = 0; c < L.cin; ++c)
+                    for (int t = 0; t < 9; ++t)
+                        packed[(size_t)t * L.cin + c] = w[(size_t)c * 9 + t];
+                auto& p = st.dp32;
+                void *dw = nullptr, *db = nullptr;
+                HP_TRY(upload(packed.data(), packed.size() * sizeof(float), &dw));
+                HP_TRY(upload(bias.data(), bias.size() * sizeof(float), &db));
+                p.w = (const float*)dw, p.bias = (const float*)db;
+                p.in = ti.view32(L.in_coff);
+                p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.C = L.cin, p.stride = L.stride, p.dil = L.dil;
+                p.pad_t = g.pt, p.pad_l = g.pl, p.act = L.act, p.act_param = L.act_param;
+                p.out = to.view32(L.out_coff);
+                st.flops = 2.0 * opix * L.cin * 9;
+                st.bytes = (double)ti.H * ti.W * L.cin * 4 + opix * L.cin * 4;
+            } else { // max-pool / up-sampling
+                HP_REQUIRE(L.cin % 4 == 0 && L.in_coff % 4 == 0 && L.out_coff % 4 == 0 && (L.op == HP_OP_UPSAMPLE || L.kh == L.kw), HP_ERR_INVALID,
+                    "layer %zu: pooling / up-sampling needs 4-aligned channels and a square window", i);
+                auto& p = st.pp32;
+                p.in = ti.view32(L.in_coff);
+                p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.C = L.cin, p.k = L.kh, p.stride = L.stride;
+                p.pad_t = L.op == HP_OP_UPSAMPLE ? 0 : g.pt, p.pad_l = L.op == HP_OP_UPSAMPLE ? 0 : g.pl;
+                p.out = to.view32(L.out_coff);
+                st.flops = 0;
+                st.bytes = (double)ti.H * ti.W * L.cin * 4 + opix * L.cin * 4;
+            }
+            steps.push_back(st);
+            continue;
+        }
         if (L.op == HP_OP_CONV && L.in == 0) {
             HP_REQUIRE(L.cin == 3 && L.in_coff == 0, HP_ERR_INVALID, "layer %zu: the network input has 3 channels", i);
             HP_REQUIRE(L.dil == 1 && L.res < 0 && L.act != HP_ACT_PRELU, HP_ERR_INVALID, "layer %zu: unsupported first-layer options", i);
@@ -688,7 +826,7 @@ int hp_engine::build(const hp_engine_desc* d)
         size_t need = 0;
         for (auto& st : steps) {
             size_t bytes = 0;
-            if (st.op == HP_OP_CONV && !st.first && !getenv("HP_NO_SPLITK") && hp::conv_splitk(st.cp, &bytes) > 1)
+            if (st.op == HP_OP_CONV && !st.first && !st.f32 && !getenv("HP_NO_SPLITK") && hp::conv_splitk(st.cp, &bytes) > 1)
                 need = std::max(need, bytes);
         }
         if (need) {
@@ -696,7 +834,7 @@ int hp_engine::build(const hp_engine_desc* d)
             HP_TRY(weight_bufs.back()->alloc(need));
             void* const d = weight_bufs.back()->p;
             for (auto& st : steps)
-                if (st.op == HP_OP_CONV && !st.first) {
+                if (st.op == HP_OP_CONV && !st.first && !st.f32) {
                     const int ks = hp::conv_splitk(st.cp, nullptr);
                     if (ks > 1)
                         st.cp.ksplit = ks, st.cp.splitk = (float*)d;
@@ -706,7 +844,7 @@ int hp_engine::build(const hp_engine_desc* d)
     // ---- chains of 128-channel convolutions (LW-OpenPose's CPM / initial / refinement stages, lw_openpose.py:106-191): consecutive
     // steps [1x1 ->] 3x3 -> 3x3 whose intermediates nobody else reads run as ONE launch with the intermediates in LDS
     // (conv_chain.hip).  HP_NO_CHAIN=1 keeps one launch per layer (A/B measurements, and hp_engine_debug_tensor on an intermediate).
-    if (!getenv("HP_NO_CHAIN") && !getenv("HP_NO_FUSE")) {
+    if (!getenv("HP_NO_CHAIN") && !getenv("HP_NO_FUSE") && !f32) {
         auto plain_conv = [&](const step& st) { return st.op == HP_OP_CONV && !st.first && st.n_layers == 1; };
         // the tensor a step writes is read only by the given layers (as input or residual) and is no network output
         auto only_read_by = [&](int tensor, int la, int lb) {
@@ -762,7 +900,7 @@ int hp_engine::build(const hp_engine_desc* d)
     // ---- ResNet bottlenecks (configs[3] / [4]): [3x3 ->] expansion 1x1 (+ shortcut) [-> the NEXT block's reduction 1x1] as one launch
     // (conv_bottleneck.hip).  The reduction may sit one or two steps further down the schedule (behind the next stage's projection
     // shortcut, which reads the same tensor): it has no other input, so it can run here.  HP_NO_BNECK=1 keeps one launch per layer.
-    if (!getenv("HP_NO_BNECK") && !getenv("HP_NO_FUSE")) {
+    if (!getenv("HP_NO_BNECK") && !getenv("HP_NO_FUSE") && !f32) {
         auto plain_conv = [&](const step& st) { return st.op == HP_OP_CONV && !st.first && st.n_layers == 1; };
         auto readers_other_than = [&](int tensor, int la) { // some layer other than la reads the tensor, or it is a network output
             for (size_t j = 0; j < layers.size(); ++j)
@@ -936,7 +1074,7 @@ int hp_engine::build(const hp_engine_desc* d)
         }
     }
     // sibling heads (conf / paf branch of one stage: same input, same geometry, neither reads the other) share a launch
-    if (!getenv("HP_NO_PAIR_HEADS")) {
+    if (!getenv("HP_NO_PAIR_HEADS") && !f32) {
         for (size_t k = 0; k + 1 < steps.size(); ++k) {
             step &a = steps[k], &b = steps[k + 1];
             if (a.op != OP_MLPHEAD || b.op != OP_MLPHEAD || a.paired)
@@ -959,13 +1097,32 @@ int hp_engine::build(const hp_engine_desc* d)
 
 int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hipStream_t s)
 {
+    if (st.f32) {
+        if (st.first) {
+            st.fp32.in_u8 = u8, st.fp32.in_f32 = f32, st.fp32.B = n;
+            HP_HIP_TRY(hp::launch_first_conv32(st.fp32, s));
+        } else if (st.op == HP_OP_CONV) {
+            st.cp32.B = n, st.cp32.npix = n * st.cp32.OH * st.cp32.OW;
+            HP_HIP_TRY(hp::launch_conv32(st.cp32, s));
+        } else if (st.op == HP_OP_DWCONV) {
+            st.dp32.B = n;
+            HP_HIP_TRY(hp::launch_dwconv32(st.dp32, s));
+        } else if (st.op == HP_OP_UPSAMPLE) {
+            st.pp32.B = n;
+            HP_HIP_TRY(hp::launch_upsample32(st.pp32, s));
+        } else {
+            st.pp32.B = n;
+            HP_HIP_TRY(hp::launch_maxpool32(st.pp32, s));
+        }
+        return HP_OK;
+    }
     if (st.first) {
         st.fp.in_u8 = u8, st.fp.in_f32 = f32, st.fp.B = n;
         HP_HIP_TRY(hp::launch_first_conv(st.fp, s));
     } else if (st.op == HP_OP_CONV) {
         st.cp.B = n, st.cp.npix = n * st.cp.OH * st.cp.OW;
         HP_HIP_TRY(hp::launch_conv_mfma(st.cp, s));
-        if (getenv("HP_CONV_DBG") && hp::conv_mfma_tile(st.cp) / 100000 == 52) { // block timeline of the pixel-block GEMM
+        if (dbg_conv && hp::conv_mfma_tile(st.cp) / 100000 == 52) { // block timeline of the pixel-block GEMM
             unsigned long long* dbg = nullptr;
             HP_HIP_TRY(hipMalloc(&dbg, 64 * 8));
             HP_HIP_TRY(hipMemset(dbg, 0, 64 * 8));
@@ -987,7 +1144,7 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     } else if (st.op == OP_BNECK) {
         st.bn.c3.B = st.bn.ce.B = st.bn.cr.B = n;
         HP_HIP_TRY(hp::launch_bottleneck(st.bn, s));
-        if (getenv("HP_BN_DBG")) { // block 0's phase timeline (s_memtime deltas) and the start / end of the first 1024 blocks (100 MHz clock)
+        if (dbg_bn) { // block 0's phase timeline (s_memtime deltas) and the start / end of the first 1024 blocks (100 MHz clock)
             constexpr int NDBG = 64 + 2 * 1024;
             unsigned long long* dbg = nullptr;
             HP_HIP_TRY(hipMalloc(&dbg, NDBG * 8));
@@ -1016,7 +1173,7 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     } else if (st.op == OP_CHAIN) {
         st.ch.c0.B = st.ch.c1.B = st.ch.c2.B = n;
         HP_HIP_TRY(hp::launch_conv_chain(st.ch, s));
-        if (getenv("HP_CHAIN_DBG")) { // block timeline (s_memtime deltas of block 0, thread 0), printed per launch
+        if (dbg_chain) { // block timeline (s_memtime deltas of block 0, thread 0), printed per launch
             unsigned long long* dbg = nullptr;
             HP_HIP_TRY(hipMalloc(&dbg, 32 * 8));
             HP_HIP_TRY(hipMemset(dbg, 0, 32 * 8));
@@ -1035,7 +1192,7 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     } else if (st.op == OP_SEPCONV) {
         st.sp.B = n, st.sp.pw.B = n, st.sp.pw.npix = n * st.sp.OH * st.sp.OW;
         HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
-        if (getenv("HP_SEP_DBG")) { // block timeline (s_memtime deltas of block 0, thread 0) of every separable block, printed per launch
+        if (dbg_sep) { // block timeline (s_memtime deltas of block 0, thread 0) of every separable block, printed per launch
             unsigned long long* dbg = nullptr;
             constexpr int NDBG = 64 + 2 * 1024 + 64; // [0, 64) block 0's stamps, then (start, end) of the first 1024 blocks (100 MHz clock)
             HP_HIP_TRY(hipMalloc(&dbg, NDBG * 8));
@@ -1098,7 +1255,10 @@ int hp_engine::enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s
     for (auto& o : outputs)
         if (o.fused_layer < 0) {
             const tensor_info& ti = *tensors[o.tensor];
-            HP_HIP_TRY(hp::launch_output_transform(ti.view(o.coff), n, o.H, o.W, o.x, o.buf->as<float>(), s));
+            if (dtype == HP_DTYPE_F32)
+                HP_HIP_TRY(hp::launch_output_transform32(ti.view32(o.coff), n, o.H, o.W, o.x, o.buf->as<float>(), s));
+            else
+                HP_HIP_TRY(hp::launch_output_transform(ti.view(o.coff), n, o.H, o.W, o.x, o.buf->as<float>(), s));
         }
     return HP_OK;
 }
@@ -1123,7 +1283,7 @@ int hp_engine_create(hp_engine** out, const hp_engine_desc* desc)
 // was given - topology, outputs, pre-processing, fp32 weights - so loading rebuilds the identical engine without the model
 // source; the packing into kernel layouts happens at load (tens of ms), there is no per-device tuning cache to carry.
 namespace {
-constexpr char ENGINE_MAGIC[8] = { 'H', 'P', 'E', 'N', 'G', '0', '0', '1' };
+constexpr char ENGINE_MAGIC[8] = { 'H', 'P', 'E', 'N', 'G', '0', '0', '2' }; // 002: + dtype
 struct engine_file_header {
     char magic[8];
     int32_t layer_size, output_size; // sizeof(hp_layer) / sizeof(hp_output_desc): ABI guard
@@ -1132,6 +1292,7 @@ struct engine_file_header {
     float mean[3], inv_std[3];
     int32_t n_layers, n_outputs;
     uint64_t n_weights;
+    int32_t dtype, reserved; // HP_DTYPE_*: TensorRT bakes the builder's precision into the plan it serializes, so does this file
 };
 } // namespace
 
@@ -1147,6 +1308,7 @@ int hp_engine_save(const hp_engine* e, const char* path)
     for (int c = 0; c < 3; ++c)
         h.mean[c] = e->mean[c], h.inv_std[c] = e->inv_std[c];
     h.n_layers = (int32_t)e->layers.size(), h.n_outputs = (int32_t)e->out_descs.size(), h.n_weights = e->weights_blob.size();
+    h.dtype = e->dtype;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
     ok = ok && fwrite(e->layers.data(), sizeof(hp_layer), e->layers.size(), f) == e->layers.size();
     ok = ok && fwrite(e->out_descs.data(), sizeof(hp_output_desc), e->out_descs.size(), f) == e->out_descs.size();
@@ -1167,7 +1329,7 @@ int hp_engine_load(hp_engine** out, const char* path, int max_batch)
     std::vector<float> w;
     bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, ENGINE_MAGIC, 8) == 0 && h.layer_size == (int32_t)sizeof(hp_layer)
         && h.output_size == (int32_t)sizeof(hp_output_desc) && h.n_layers > 0 && h.n_layers < (1 << 20) && h.n_outputs > 0
-        && h.n_outputs < 4096 && h.n_weights < ((uint64_t)1 << 34);
+        && h.n_outputs < 4096 && h.n_weights < ((uint64_t)1 << 34) && (h.dtype == HP_DTYPE_F16 || h.dtype == HP_DTYPE_F32);
     if (ok) { // the counts must account for the file exactly before anything is allocated from them
         const long at = ftell(f);
         ok = fseek(f, 0, SEEK_END) == 0;
@@ -1187,6 +1349,7 @@ int hp_engine_load(hp_engine** out, const char* path, int max_batch)
     for (int c = 0; c < 3; ++c)
         d.mean[c] = h.mean[c], d.inv_std[c] = h.inv_std[c];
     d.layers = layers.data(), d.n_layers = h.n_layers, d.outputs = outs.data(), d.n_outputs = h.n_outputs, d.weights = w.data(), d.n_weights = w.size();
+    d.dtype = h.dtype;
     return hp_engine_create(out, &d);
 }
 
@@ -1210,8 +1373,11 @@ int hp_engine_describe(const hp_engine* e, hp_engine_desc* d)
     d->layers = e->layers.data(), d->n_layers = (int32_t)e->layers.size();
     d->outputs = e->out_descs.data(), d->n_outputs = (int32_t)e->out_descs.size();
     d->weights = e->weights_blob.data(), d->n_weights = e->weights_blob.size();
+    d->dtype = e->dtype;
     return HP_OK;
 }
+
+int hp_engine_dtype(const hp_engine* e) { return e ? e->dtype : HP_ERR_INVALID; }
 
 int hp_engine_input_size(const hp_engine* e, int* w, int* h)
 {
@@ -1338,7 +1504,10 @@ int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int sha
     HP_TRY(tmp.alloc((size_t)n * ti.C * ti.H * ti.W * sizeof(float)));
     hp::out_xform px{};
     px.C = ti.C, px.act = 0, px.shuffle = 1, px.group = 0, px.out_h = ti.H, px.out_w = ti.W, px.scale = 1.f, px.grid = 0;
-    HP_HIP_TRY(hp::launch_output_transform(ti.view(0), n, ti.H, ti.W, px, tmp.as<float>(), e->stream));
+    if (e->dtype == HP_DTYPE_F32)
+        HP_HIP_TRY(hp::launch_output_transform32(ti.view32(0), n, ti.H, ti.W, px, tmp.as<float>(), e->stream));
+    else
+        HP_HIP_TRY(hp::launch_output_transform(ti.view(0), n, ti.H, ti.W, px, tmp.as<float>(), e->stream));
     HP_HIP_TRY(hipStreamSynchronize(e->stream));
     HP_HIP_TRY(hipMemcpy(host, tmp.p, tmp.bytes, hipMemcpyDeviceToHost));
     return HP_OK;
@@ -1368,7 +1537,7 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? hp::conv32_tile(st.cp32) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = ms / iters;
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1421,7 +1590,7 @@ int hp_engine_profile_pair(hp_engine* e, hp_engine* f, int n, int iters, hp_laye
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? hp::conv32_tile(st.cp32) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = std::max(m0, m1) / (2 * iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1479,7 +1648,7 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? hp::conv_mfma_tile(st.cp)
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? hp::conv32_tile(st.cp32) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = (float)(acc[k] / iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;

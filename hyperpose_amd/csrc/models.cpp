@@ -367,6 +367,12 @@ int hp_model_init_weights(const hp_model* m, uint64_t seed, float* blob, size_t 
 int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
     const float* weights, size_t n_weights)
 {
+    return hp_engine_create_from_model_dtype(out, m, max_batch, factor, flip_rb, weights, n_weights, HP_DTYPE_F16);
+}
+
+int hp_engine_create_from_model_dtype(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
+    const float* weights, size_t n_weights, int dtype)
+{
     HP_REQUIRE(out && m, HP_ERR_INVALID, "hp_engine_create_from_model: null argument");
     if (!weights) // imported models carry their own
         weights = m->weights.data(), n_weights = m->weights.size();
@@ -379,6 +385,7 @@ int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batc
     d.layers = m->layers.data(), d.n_layers = (int)m->layers.size();
     d.outputs = m->outputs.data(), d.n_outputs = (int)m->outputs.size();
     d.weights = weights, d.n_weights = n_weights;
+    d.dtype = dtype;
     return hp_engine_create(out, &d);
 }
 

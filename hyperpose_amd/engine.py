@@ -35,7 +35,13 @@ class EngineDesc(C.Structure):
     _fields_ = [("in_w", C.c_int32), ("in_h", C.c_int32), ("max_batch", C.c_int32), ("factor", C.c_double),
                 ("flip_rb", C.c_int32), ("mean", C.c_float * 3), ("inv_std", C.c_float * 3),
                 ("layers", C.POINTER(Layer)), ("n_layers", C.c_int32), ("outputs", C.POINTER(OutputDesc)),
-                ("n_outputs", C.c_int32), ("weights", C.POINTER(C.c_float)), ("n_weights", C.c_size_t)]
+                ("n_outputs", C.c_int32), ("weights", C.POINTER(C.c_float)), ("n_weights", C.c_size_t),
+                ("dtype", C.c_int32)]
+
+
+DTYPE_F16, DTYPE_F32 = 0, 1  # HP_DTYPE_*: data_type::kHALF / data_type::kFLOAT of the reference's engine
+_DTYPES = {"f16": DTYPE_F16, "fp16": DTYPE_F16, "half": DTYPE_F16, DTYPE_F16: DTYPE_F16,
+           "f32": DTYPE_F32, "fp32": DTYPE_F32, "float": DTYPE_F32, DTYPE_F32: DTYPE_F32}
 
 
 class LayerTime(C.Structure):
@@ -128,13 +134,17 @@ class Engine:
     """``hyperpose::dnn`` engine: (layers, outputs, weights) -> device-resident fp32 NCHW feature maps."""
 
     def __init__(self, layers, outputs, weights: np.ndarray, in_w: int, in_h: int, max_batch: int = 8,
-                 factor: float = 1.0 / 255, flip_rgb: bool = True, mean=(0, 0, 0), inv_std=(1, 1, 1)):
+                 factor: float = 1.0 / 255, flip_rgb: bool = True, mean=(0, 0, 0), inv_std=(1, 1, 1), dtype="f16"):
+        """``dtype``: "f16" (fp16 storage, fp32 accumulation: the fast path, ``data_type::kHALF``) or "f32" (fp32 storage and
+        arithmetic: what ``data_type::kFLOAT``, the reference's default, promises)."""
         self._h = C.c_void_p()
+        self.dtype = _DTYPES[dtype]
         weights = np.ascontiguousarray(weights, np.float32)
         larr = (Layer * len(layers))(*layers)
         oarr = (OutputDesc * len(outputs))(*outputs)
         d = EngineDesc(in_w, in_h, max_batch, factor, int(flip_rgb), (C.c_float * 3)(*mean), (C.c_float * 3)(*inv_std),
-                       larr, len(layers), oarr, len(outputs), weights.ctypes.data_as(C.POINTER(C.c_float)), weights.size)
+                       larr, len(layers), oarr, len(outputs), weights.ctypes.data_as(C.POINTER(C.c_float)), weights.size,
+                       self.dtype)
         check(lib().hp_engine_create(C.byref(self._h), C.byref(d)))
         self.in_w, self.in_h, self.max_batch = in_w, in_h, max_batch
         lib().hp_engine_stream.restype = C.c_void_p
@@ -147,15 +157,16 @@ class Engine:
 
     @classmethod
     def from_model(cls, model: Model, weights: np.ndarray, max_batch: int = 8, factor: float = 1.0 / 255,
-                   flip_rgb: bool = True) -> "Engine":
+                   flip_rgb: bool = True, dtype="f16") -> "Engine":
         return cls(model.layers, model.outputs, weights, model.in_w, model.in_h, max_batch, factor, flip_rgb,
-                   model.mean, model.inv_std)
+                   model.mean, model.inv_std, dtype)
 
     def _adopt(self, handle, max_batch: int):
         self._h = handle
         w, h = C.c_int(), C.c_int()
         check(lib().hp_engine_input_size(self._h, C.byref(w), C.byref(h)))
         self.in_w, self.in_h, self.max_batch = w.value, h.value, lib().hp_engine_max_batch(self._h)
+        self.dtype = lib().hp_engine_dtype(self._h)
         lib().hp_engine_stream.restype = C.c_void_p
         self.stream = lib().hp_engine_stream(self._h)
         self.outputs = []

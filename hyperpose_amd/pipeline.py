@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import HUMAN_DTYPE, Human, check, lib
-from .engine import EngineDesc, Layer, OutputDesc
+from .engine import _DTYPES, EngineDesc, Layer, OutputDesc
 
 
 class ParserDesc(C.Structure):
@@ -23,14 +23,14 @@ class Pipeline:
 
     def __init__(self, model, weights: np.ndarray, max_batch: int = 8, n_pipes: int = 4, keep_ratio: bool = False,
                  conf_thresh: float = 0.05, paf_thresh: float = 0.05, max_frame_wh=(1920, 1080), factor: float = 1.0 / 255,
-                 flip_rgb: bool = True, cap_per_frame: int = 128, parser: str = "paf", thresholds=None):
+                 flip_rgb: bool = True, cap_per_frame: int = 128, parser: str = "paf", thresholds=None, dtype="f16"):
         self._h = C.c_void_p()
         weights = np.ascontiguousarray(weights, np.float32)
         larr = (Layer * len(model.layers))(*model.layers)
         oarr = (OutputDesc * len(model.outputs))(*model.outputs)
         d = EngineDesc(model.in_w, model.in_h, max_batch, factor, int(flip_rgb), (C.c_float * 3)(*model.mean),
                        (C.c_float * 3)(*model.inv_std), larr, len(model.layers), oarr, len(model.outputs),
-                       weights.ctypes.data_as(C.POINTER(C.c_float)), weights.size)
+                       weights.ctypes.data_as(C.POINTER(C.c_float)), weights.size, _DTYPES[dtype])
         kind = {"paf": PARSER_PAF, "ppn": PARSER_PPN, "pifpaf": PARSER_PIFPAF}[parser]
         th = thresholds if thresholds is not None else {PARSER_PAF: (conf_thresh, paf_thresh, 0.0), PARSER_PPN: (0.10, 0.05, 0.3),
                                                         PARSER_PIFPAF: (0.1, 0.0, 0.0)}[kind]

@@ -242,6 +242,11 @@ typedef struct hp_output_desc {
     int32_t grid;            /* 1: add the column index, 2: add the row index before scaling */
 } hp_output_desc;
 
+/* Arithmetic of the engine.  HP_DTYPE_F16: fp16 storage, fp16 MFMA products, fp32 accumulation - the fast path (data_type::kHALF).
+ * HP_DTYPE_F32: fp32 storage and fp32 matrix-pipe arithmetic, one launch per layer - what data_type::kFLOAT, the reference's default,
+ * promises: outputs agree with an fp32 evaluation of the graph to ~1e-5 relative (tests/test_engine_fp32_gpu.py). */
+enum { HP_DTYPE_F16 = 0, HP_DTYPE_F32 = 1 };
+
 typedef struct hp_engine_desc {
     int32_t in_w, in_h, max_batch;   /* tensorrt(..., cv::Size input_size, int max_batch_size = 8, ...) */
     double factor;                   /* tensorrt.hpp:49: every input element is multiplied by factor (default 1/255) */
@@ -253,6 +258,8 @@ typedef struct hp_engine_desc {
     int32_t n_outputs;
     const float* weights;            /* host fp32 blob */
     size_t n_weights;
+    int32_t dtype;                   /* HP_DTYPE_F16 (0, the zero-initialised default) or HP_DTYPE_F32: the reference's data_type argument
+                                      * (include/hyperpose/operator/dnn/tensorrt.hpp:14-21,48; src/tensorrt.cpp:327,353) */
 } hp_engine_desc;
 
 typedef struct hp_engine hp_engine;
@@ -336,6 +343,10 @@ int hp_model_input_size(const hp_model* m, int* w, int* h);
 /* Convenience: build an engine for a topology with blob weights (NULL = the model's own, imported models only). */
 int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
                                 const float* weights, size_t n_weights);
+/* the same with the arithmetic chosen (HP_DTYPE_*); hp_engine_create_from_model is the HP_DTYPE_F16 form */
+int hp_engine_create_from_model_dtype(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
+                                      const float* weights, size_t n_weights, int dtype);
+int hp_engine_dtype(const hp_engine* e); /* HP_DTYPE_* of an engine (serialized engines carry theirs) */
 
 /* ---- hyperpose::stream on the GPU (reference include/hyperpose/stream/stream.hpp:119-390, src/stream.cpp:60-147): host frames of
  * any size in, humans out, in submission order.  Each submit copies one batch (<= max_batch frames, 8-bit BGR HWC, packed rows) to

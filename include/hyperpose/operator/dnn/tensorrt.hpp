@@ -3,8 +3,10 @@
 // examples/operator_api_batched_images_paf.example.cpp:36-56 compile and run unchanged:
 //     tensorrt(onnx{file}, {w, h}, batch)          tensorrt(uff{...}, {w, h}, batch)          tensorrt(tensorrt_serialized{file}, {w, h}, batch)
 //     engine.inference(std::vector<cv::Mat>)       engine.inference(std::vector<float> nchw, n)       engine.save(path)
-// Header-only on top of the C ABI (include/hp_hip.h); the network runs as hand-written gfx950 kernels (fp16 storage, fp32 MFMA
-// accumulation - `data_type` is accepted for source compatibility and does not select a precision).  Frames of any size are resized on
+// Header-only on top of the C ABI (include/hp_hip.h); the network runs as hand-written gfx950 kernels.  `data_type` selects the
+// arithmetic as it does in the reference (src/tensorrt.cpp:327,353): kFLOAT - the default, as there - is fp32 storage and fp32
+// matrix-pipe arithmetic (HP_DTYPE_F32), kHALF the fused fp16 kernels with fp32 accumulation (HP_DTYPE_F16, the fast path); the integer
+// types have no meaning for these networks and are refused like an engine-build failure.  Frames of any size are resized on
 // the DEVICE exactly as the reference does on the host: cv::resize (INTER_LINEAR) or, with keep_ratio, non_scaling_resize
 // (src/tensorrt.cpp:446-451, src/data.cpp:53-69) through hp_resize_u8c3 / hp_letterbox_u8c3.
 #pragma once
@@ -35,6 +37,8 @@ struct data_type {
         : val(v)
     {
     }
+    /// HP_DTYPE_* of the C ABI, or -1 for the types no engine is built in
+    inline int hp_dtype() const { return val == kFLOAT ? HP_DTYPE_F32 : val == kHALF ? HP_DTYPE_F16 : -1; }
 };
 
 namespace detail {
@@ -76,10 +80,11 @@ namespace dnn {
             data_type dtype = data_type::kFLOAT, double factor = 1. / 255, bool flip_rgb = true)
             : m_inp_size(input_size), m_max_batch_size(max_batch_size), m_keep_ratio(keep_ratio), m_factor(factor), m_flip_rgb(flip_rgb)
         {
-            (void)dtype;
+            if (dtype.hp_dtype() < 0)
+                fatal("hyperpose::dnn::tensorrt: only data_type::kFLOAT and data_type::kHALF engines can be built");
             if (hp_model_from_onnx_file(&m_model, onnx_model.model_path.c_str(), input_size.width, input_size.height) != HP_OK)
                 fatal(hp_last_error());
-            if (hp_engine_create_from_model(&m_engine, m_model, max_batch_size, factor, flip_rgb ? 1 : 0, nullptr, 0) != HP_OK)
+            if (hp_engine_create_from_model_dtype(&m_engine, m_model, max_batch_size, factor, flip_rgb ? 1 : 0, nullptr, 0, dtype.hp_dtype()) != HP_OK)
                 fatal(hp_last_error());
         }
 
@@ -98,9 +103,11 @@ namespace dnn {
 
         /// Addition: a built-in topology (no model file needed).
         explicit tensorrt(const builtin_model& model, cv::Size input_size, int max_batch_size = 8, bool keep_ratio = false,
-            double factor = 1. / 255, bool flip_rgb = true)
+            data_type dtype = data_type::kFLOAT, double factor = 1. / 255, bool flip_rgb = true)
             : m_inp_size(input_size), m_max_batch_size(max_batch_size), m_keep_ratio(keep_ratio), m_factor(factor), m_flip_rgb(flip_rgb)
         {
+            if (dtype.hp_dtype() < 0)
+                fatal("hyperpose::dnn::tensorrt: only data_type::kFLOAT and data_type::kHALF engines can be built");
             if (hp_model_build(&m_model, model.arch.c_str(), input_size.width, input_size.height) != HP_OK)
                 fatal(hp_last_error());
             std::vector<float> w = model.weights;
@@ -108,7 +115,7 @@ namespace dnn {
                 w.resize(hp_model_num_weights(m_model));
                 hp_model_init_weights(m_model, model.seed, w.data(), w.size());
             }
-            if (hp_engine_create_from_model(&m_engine, m_model, max_batch_size, factor, flip_rgb ? 1 : 0, w.data(), w.size()) != HP_OK)
+            if (hp_engine_create_from_model_dtype(&m_engine, m_model, max_batch_size, factor, flip_rgb ? 1 : 0, w.data(), w.size(), dtype.hp_dtype()) != HP_OK)
                 fatal(hp_last_error());
         }
 

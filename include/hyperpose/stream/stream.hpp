@@ -55,10 +55,10 @@ public:
 
     hip_stream(const dnn::builtin_model& model, cv::Size input_size, int max_batch_size = 8, bool keep_ratio = false,
         int n_pipes = 4, cv::Size max_frame = cv::Size(1920, 1080), float conf_thresh = 0.05f, float paf_thresh = 0.05f,
-        double factor = 1. / 255, bool flip_rgb = true)
+        double factor = 1. / 255, bool flip_rgb = true, data_type dtype = data_type::kFLOAT)
         : m_max_batch(max_batch_size)
     {
-        dnn::tensorrt engine(model, input_size, max_batch_size, keep_ratio, factor, flip_rgb);
+        dnn::tensorrt engine(model, input_size, max_batch_size, keep_ratio, dtype, factor, flip_rgb);
         hp_parser_desc pd{};
         pd.kind = HP_PARSER_PAF, pd.thresh[0] = conf_thresh, pd.thresh[1] = paf_thresh, pd.res_w = pd.res_h = -1;
         init(engine.handle(), pd, max_batch_size, keep_ratio, n_pipes, max_frame);

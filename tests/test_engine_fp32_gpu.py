@@ -1,0 +1,186 @@
+"""GPU: the fp32-faithful engine (HP_DTYPE_F32 = the reference's data_type::kFLOAT, conv_fp32.hip) against the PURE fp32 oracle
+(oracle/ref_net.py with match_fp16=False: no rounding anywhere).  Storage and arithmetic are fp32 on both sides, so what remains is
+summation order: |err| <= 1e-4 * max|ref| (+ 1e-6), two orders of magnitude tighter than the fp16 engine's bound and the tolerance
+VERDICT r3 item 3 asks for.  Small graphs cover every operator / option of the kernel family on the CPU oracle; the four BASELINE
+configurations run at their FULL size against the same definition evaluated by PyTorch's own fp32 GPU kernels.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from hyperpose_amd import engine as E
+from hyperpose_amd import synth
+from oracle import ref_net
+from test_engine_gpu import Net, Out, _frames
+
+pytestmark = pytest.mark.gpu
+
+REL, ABS = 1e-4, 1e-6
+
+
+def _close32(got, ref, what=""):
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    assert err <= REL * scale + ABS, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+    return err / max(scale, 1e-30)
+
+
+def _run32(net, outs, frames, h, w, f32_input=False, **kw):
+    blob = net.blob()
+    eng = E.Engine(net.layers, [o.c() for o in outs], blob, w, h, len(frames), dtype="f32", **kw)
+    assert eng.dtype == E.DTYPE_F32
+    if f32_input:
+        got = eng.inference_f32(frames)
+        ref = ref_net.run(net.layers, outs, blob, frames_f32=frames, match_fp16=False)
+    else:
+        got = eng.inference(frames)
+        ref = ref_net.run(net.layers, outs, blob, frames_u8=frames, match_fp16=False, factor=kw.get("factor", 1 / 255),
+                          flip_rb=kw.get("flip_rgb", True), mean=kw.get("mean", (0, 0, 0)), inv_std=kw.get("inv_std", (1, 1, 1)))
+    names = sorted(ref)
+    for b in range(len(frames)):
+        assert [nm for nm, _ in got[b]] == names
+        for nm, arr in got[b]:
+            _close32(arr, ref[nm][b], nm)
+    return eng, got, ref
+
+
+def test_first_layer_u8_and_f32_inputs(hp):
+    for stride, k, cout in ((2, 3, 32), (1, 3, 64), (2, 7, 64), (1, 5, 20)):
+        net = Net(1)
+        t = net.conv(0, 3, cout, k, stride, act=E.ACT_LEAKY if k == 5 else E.ACT_RELU, act_param=0.1)
+        _run32(net, [Out("y", t, 0, cout)], _frames(2, 37, 45), 37, 45, flip_rgb=True, mean=(0.4, 0.45, 0.5), inv_std=(2., 3., 4.))
+    net = Net(2)
+    t = net.conv(0, 3, 24, 3, 1)
+    x = np.random.default_rng(3).normal(0, 1, (2, 3, 20, 28)).astype(np.float32)
+    _run32(net, [Out("y", t, 0, 24)], x, 20, 28, f32_input=True)
+
+
+@pytest.mark.parametrize("k,stride,dil,cin,cout", [(1, 1, 1, 32, 64), (1, 2, 1, 64, 40), (3, 1, 1, 48, 128), (3, 2, 1, 128, 96),
+                                                    (3, 1, 2, 64, 64), (5, 1, 1, 16, 19), (7, 1, 1, 185, 128), (1, 1, 1, 512, 260)])
+def test_dense_conv_shapes(hp, k, stride, dil, cin, cout):
+    net = Net(10 + k)
+    t0 = net.conv(0, 3, cin, 3, 1)
+    t1 = net.conv(t0, cin, cout, k, stride, dil, act=E.ACT_PRELU if k == 7 else E.ACT_RELU)
+    _run32(net, [Out("y", t1, 0, cout)], _frames(3, 30, 41, seed=k), 30, 41)
+
+
+def test_residuals_concat_and_unaligned_slices(hp):
+    # concat buffer [128 | 19 | 38] like LW-OpenPose's stage input: the third slice starts at channel 147 (not 4-aligned)
+    net = Net(5)
+    cat = net.new_tensor()
+    t0 = net.conv(0, 3, 32, 3, 2)
+    net.conv(t0, 32, 128, 3, 1, out=cat, out_coff=0)
+    net.conv(t0, 32, 19, 1, 1, out=cat, out_coff=128, act=E.ACT_NONE)
+    net.conv(t0, 32, 38, 1, 1, out=cat, out_coff=147, act=E.ACT_NONE)
+    a = net.conv(cat, 185, 128, 1, 1)
+    b = net.conv(a, 128, 128, 3, 1)
+    c = net.conv(b, 128, 128, 3, 1, res=a, res_before_act=0)        # residual after the activation
+    d = net.conv(c, 128, 128, 3, 1, res=c, res_before_act=1)        # ... and before it (ResNet style)
+    e = net.conv(d, 128, 38, 1, 1, act=E.ACT_NONE)
+    _run32(net, [Out("paf", e, 0, 38), Out("mid", d, 0, 128), Out("conf_slice", cat, 128, 19)], _frames(2, 40, 56, seed=5), 40, 56)
+
+
+def test_depthwise_pool_upsample(hp):
+    net = Net(6)
+    t0 = net.conv(0, 3, 32, 3, 2)
+    d1 = net.conv(t0, 32, 32, 3, 1, op=E.OP_DWCONV)
+    p1 = net.conv(d1, 32, 64, 1, 1)
+    d2 = net.conv(p1, 64, 64, 3, 2, op=E.OP_DWCONV, act=E.ACT_RELU6)
+    p2 = net.conv(d2, 64, 64, 1, 1)
+    d3 = net.conv(p2, 64, 64, 3, 1, dil=2, op=E.OP_DWCONV)
+    mp = net.conv(d3, 64, 64, 3, 2, op=E.OP_MAXPOOL, act=E.ACT_NONE)
+    mp2 = net.conv(mp, 64, 64, 2, 2, op=E.OP_MAXPOOL, act=E.ACT_NONE)
+    up = net.conv(mp2, 64, 64, 0, 2, op=E.OP_UPSAMPLE, act=E.ACT_NONE)       # nearest x2
+    up2 = net.conv(up, 64, 64, 1, 2, op=E.OP_UPSAMPLE, act=E.ACT_NONE)       # bilinear x2
+    y = net.conv(up2, 64, 24, 3, 1, act=E.ACT_NONE)
+    _run32(net, [Out("y", y, 0, 24), Out("pooled", mp2, 0, 64), Out("up", up2, 0, 64)], _frames(2, 50, 66, seed=6), 50, 66)
+
+
+def test_output_post_ops(hp):
+    # pixel shuffle + crop + per-component sigmoid / softplus (PifPaf heads) and the PoseProposal grid / scale map
+    net = Net(7)
+    t0 = net.conv(0, 3, 32, 3, 2)
+    h1 = net.conv(t0, 32, 17 * 5 * 4, 1, 1, act=E.ACT_NONE)
+    h2 = net.conv(t0, 32, 18, 1, 1, act=E.ACT_NONE)
+    outs = [Out("pif", h1, 0, 17 * 5 * 4, shuffle=2, group=5, sigmoid_mask=1, softplus_mask=16, out_h=2 * 13 - 1, out_w=2 * 17 - 1),
+            Out("px", h2, 0, 18, act=E.ACT_SIGMOID, grid=1, scale=32.0),
+            Out("sig", h2, 0, 18, act=E.ACT_SIGMOID)]
+    _run32(net, outs, _frames(2, 26, 34, seed=7), 26, 34)
+
+
+@pytest.mark.parametrize("arch", ["lw_openpose_mobilenet", "lw_openpose_vggtiny", "openpose_vgg19", "pose_proposal_resnet50", "pifpaf_resnet50"])
+def test_builtin_topologies_small(hp, arch):
+    w_, h_ = (97, 97) if arch.startswith("pifpaf") else (160, 128) if arch.startswith("pose_proposal") else (96, 80)
+    m = E.Model(arch, w_, h_)
+    w = m.init_weights(3)
+    eng = E.Engine.from_model(m, w, max_batch=2, dtype="f32")
+    fr = synth.images_u8(synth.rng_for(8), 2, h_, w_)
+    got = eng.inference(fr)
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=False, mean=m.mean, inv_std=m.inv_std)
+    worst = 0.0
+    for b in range(2):
+        for nm, arr in got[b]:
+            worst = max(worst, _close32(arr, ref[nm][b], f"{arch}/{nm}"))
+    # batch invariance, bit for bit
+    alone = eng.inference(fr[1:2])[0]
+    for (_, a), (_, bq) in zip(alone, got[1]):
+        assert np.array_equal(a, bq)
+
+
+def test_serialized_engine_keeps_its_dtype(hp):
+    m = E.Model("lw_openpose_mobilenet", 64, 48)
+    w = m.init_weights(4)
+    fr = synth.images_u8(synth.rng_for(9), 2, 48, 64)
+    with tempfile.TemporaryDirectory() as d:
+        for dtype in ("f32", "f16"):
+            eng = E.Engine.from_model(m, w, max_batch=2, dtype=dtype)
+            path = os.path.join(d, dtype + ".engine")
+            eng.save(path)
+            back = E.Engine.load(path)
+            assert back.dtype == eng.dtype == E._DTYPES[dtype]
+            for (_, a), (_, b) in zip(eng.inference(fr)[0], back.inference(fr)[0]):
+                assert np.array_equal(a, b)
+    # the two precisions really are different engines
+    a32 = E.Engine.from_model(m, w, max_batch=2, dtype="f32").inference(fr)[0][0][1]
+    a16 = E.Engine.from_model(m, w, max_batch=2, dtype="f16").inference(fr)[0][0][1]
+    assert not np.array_equal(a32, a16) and np.abs(a32 - a16).max() <= 2e-2 * np.abs(a32).max() + 1e-3
+
+
+def test_bad_dtype_is_refused(hp):
+    m = E.Model("lw_openpose_mobilenet", 64, 48)
+    with pytest.raises(KeyError):
+        E.Engine.from_model(m, m.init_weights(4), max_batch=1, dtype="int8")
+    larr = (E.Layer * len(m.layers))(*m.layers)
+    oarr = (E.OutputDesc * len(m.outputs))(*m.outputs)
+    w = m.init_weights(4)
+    import ctypes as C
+    d = E.EngineDesc(64, 48, 1, 1 / 255, 1, (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(1, 1, 1), larr, len(m.layers), oarr, len(m.outputs),
+                     w.ctypes.data_as(C.POINTER(C.c_float)), w.size, 7)
+    h = C.c_void_p()
+    assert hp.lib().hp_engine_create(C.byref(h), C.byref(d)) == -1  # HP_ERR_INVALID
+
+
+# ---- the BASELINE configurations at FULL size, one probed frame each, against PyTorch's own fp32 GPU kernels
+FULL = [("lw_openpose_mobilenet", 432, 368, 8, 20241), ("openpose_vgg19", 768, 432, 16, 20242),
+        ("pose_proposal_resnet50", 384, 384, 32, 20243), ("pifpaf_resnet50", 385, 385, 64, 20244)]
+
+
+@pytest.mark.parametrize("arch,w_,h_,batch,seed", FULL)
+def test_full_size_configs_fp32(hp, arch, w_, h_, batch, seed, capsys):
+    import torch
+    m = E.Model(arch, w_, h_)
+    w = m.init_weights(seed)
+    n = min(batch, 4)  # fp32 activations of the full batch are not needed to probe frames; the kernels see the same per-frame geometry
+    eng = E.Engine.from_model(m, w, max_batch=n, dtype="f32")
+    fr = synth.images_u8(synth.rng_for(seed), n, h_, w_)
+    got = eng.inference(fr)
+    worst = 0.0
+    for i in (0, n - 1):
+        ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr[i:i + 1], match_fp16=False, mean=m.mean, inv_std=m.inv_std, device="cuda")
+        for nm, arr in got[i]:
+            worst = max(worst, _close32(arr, ref[nm][0], f"{arch} frame {i} {nm}"))
+    torch.cuda.empty_cache()
+    with capsys.disabled():
+        print(f"\nfp32 engine {arch} @ {h_}x{w_}: worst relative error vs the fp32 oracle {worst:.2e}")
