@@ -30,12 +30,13 @@ runs the FULL conv stack AND parses seeded synthetic heat-maps with several peop
 ("injected": strictly more parser work, nothing skipped); the same loop parsing the network's own output is reported as
 `fps_dnn_output`.
 
-Extra objects: `roofline` for the dominant kernel (per-launch timestamps in schedule order; `frac_rocprof` = the same FLOPs over
-the kernel's average duration in the committed rocprofv3 kernel trace of this command, profiles/*_kernel_stats*.csv),
+Extra objects: `roofline` for the dominant kernel (per-launch timestamps in schedule order; `bound` = the roof its arithmetic intensity
+puts it under, with `frac_mfma` and `frac_hbm` both given; `committed_profile` = the same kernel in the newest committed rocprofv3 kernel
+trace of this command, profiles/*_kernel_stats*.csv - read from the file, not measured in the run),
 `parser_roofline` (HBM: frames/s of the parser alone x the compulsory bytes of SURVEY.md 8d / 8 TB/s), `cpu_baseline` (the
 reference's CPU parser on this box's host cores, rank 0, N = 1), `single_pipe_fps` (one engine + parser pair, one batch in
-flight), `h2d_inclusive` (the same step with network-sized u8 frames starting in pinned HOST memory - the PCIe-inclusive rate,
-never `value`), `from_host` (1280x720 camera frames through the GPU letterbox) and, at N > 1, `collective` (which backend
+flight), `h2d_inclusive` / top-level `value_h2d_inclusive` (the same step with network-sized u8 frames starting in pinned HOST memory - the
+PCIe-inclusive rate, never `value`; measured on all ranks at once at N > 1), `from_host` (1280x720 camera frames through the GPU letterbox) and, at N > 1, `collective` (which backend
 carried the start-up weight broadcast, its bytes and time).  Every secondary leg runs for a minimum wall time (0.3 s ramp +
 >= 0.5 s timed) whatever --steps is, so the driver's short runs reproduce the long ones.
 """
@@ -152,6 +153,9 @@ class Pipe:
             self.s0 = outs[1][1]  # pif [85, fh, fw]
         self.inj = injected
         self.busy = self.eng_only = False
+        # frames the device decoders handed to the host statements (PoseProposal / PifPaf: hp_*_decode_flags > 0) and batches in which a
+        # fixed-capacity list of the PAF parser overflowed (HP_ERR_CAPACITY; the reference's vectors are unbounded) - reported, never hidden
+        self.declined_frames = self.capacity_truncations = self.frames_parsed = 0
 
     def submit(self, frames_dev, injected: bool, engine: bool = True, parser: bool = True):
         n = self.batch
@@ -175,8 +179,18 @@ class Pipe:
             self.eng_only = False
         if not self.busy:
             return 0
-        humans = self.par.collect()
+        from hyperpose_amd._lib import HpError
         self.busy = False
+        try:
+            humans = self.par.collect()
+        except HpError as e:
+            if e.code != -3:  # HP_ERR_CAPACITY: counted; anything else is a failure of the run
+                raise
+            self.capacity_truncations += 1
+            return 0
+        self.frames_parsed += self.batch
+        if self.kind != "paf":
+            self.declined_frames += int(sum(1 for f in self.par.decode_flags(self.batch) if f > 0))
         return sum(len(h) for h in humans)
 
 
@@ -325,9 +339,9 @@ def kernel_label(tile: int):
            2: ("sepconv_small_kernel<", "separable block -> 128 channels, stride 2, all channels of a tile in LDS"),
            3: ("sepconv_slot_kernel<2,1,2,1,128,64>", "separable block 128 -> 256, stride 2, half-CU form"),
            4: ("sepconv_slot_kernel<1,2,1,1,256,64>", "separable block 256 -> 256, half-CU form"),
-           5: ("sepconv_pipe_kernel<1,512>", "separable block 256 / 512 -> 512: 12x8 pixels x all 512 output channels per block, eight wavefronts; per 64-channel "
-               "chunk the depthwise taps of chunk k+1 and the pointwise MFMAs of chunk k run in anti-phase on the two wavefronts of a SIMD"),
-           6: ("sepconv_pipe_kernel<2,512>", "separable block 512 -> 512, dilation 2, same form")}
+           5: ("sepconv_pipe2_kernel<1>", "separable block 256 / 512 -> 512: 12x8 pixels x all 512 output channels per block, eight wavefronts; per 64-channel "
+               "chunk the depthwise taps of chunk k+1 are issued between the pointwise MFMAs of chunk k in the SAME wavefront (one stream of 24 slots)"),
+           6: ("sepconv_pipe2_kernel<2>", "separable block 512 -> 512, dilation 2, same form")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
     if tile >= 9000000:
         v = tile - 9000000
@@ -385,20 +399,26 @@ def pmc_traffic(symbol_key: str, tag: str):
 
 
 def rocprof_avg_us(symbol_key: str, tag: str):
-    """Average duration of the kernel in the committed `rocprofv3 --kernel-trace --stats` summary of this bench command
-    (profiles/<round>_kernel_stats<tag>.csv, newest round first): (us, file name) or (None, None)."""
+    """Average duration of the kernel in the NEWEST committed `rocprofv3 --kernel-trace --stats` summary of this bench command
+    (profiles/<round>_kernel_stats<tag>.csv): (us, file name), or (None, file name) unless the key names EXACTLY ONE row of that file -
+    an ambiguous or missing key (a renamed kernel, a template instance the key does not pin down) must not produce a number."""
     import csv
     import glob
     want = symbol_key.replace(" ", "")
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_kernel_stats{tag}.csv")), reverse=True):
-        try:
-            with open(path, newline="") as f:
-                for row in csv.DictReader(f):
-                    if want in row.get("Name", "").replace(" ", ""):
-                        return float(row["AverageNs"]) / 1e3, os.path.basename(path)
-        except (OSError, KeyError, ValueError):
-            continue
-    return None, None
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_kernel_stats{tag}.csv")), reverse=True)
+    if not paths:
+        return None, None
+    try:
+        with open(paths[0], newline="") as f:
+            hits = [row for row in csv.DictReader(f) if want in row.get("Name", "").replace(" ", "")]
+        if len(hits) == 1:
+            return float(hits[0]["AverageNs"]) / 1e3, os.path.basename(paths[0])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, os.path.basename(paths[0])
+
+
+RIDGE_FLOP_PER_BYTE = 2500.0e12 / 8000.0e9  # 312.5: below it a kernel's binding roof is HBM, above it the matrix pipe
 
 
 def roofline(pipe, batch, cfg_index, frames_dev=None):
@@ -412,30 +432,47 @@ def roofline(pipe, batch, cfg_index, frames_dev=None):
     mfma = [p for p in prof if p["tile"] != 0]
     by_tile = {}
     for p in mfma:
-        d = by_tile.setdefault(p["tile"], {"ms": 0.0, "flops": 0.0, "n": 0})
+        d = by_tile.setdefault(p["tile"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
         d["ms"] += p["ms"]
         d["flops"] += p["flops"]
+        d["bytes"] += p["bytes"]
         d["n"] += 1
     dom_tile, dom = max(by_tile.items(), key=lambda kv: kv[1]["ms"])
     tot_ms = sum(p["ms"] for p in prof)
     mfma_ms = sum(p["ms"] for p in mfma)
     mfma_fl = sum(p["flops"] for p in mfma)
-    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9   # ALGORITHMIC bytes of the launches (input + output + weights once, engine.cpp st.bytes)
+    intensity = dom["flops"] / dom["bytes"]
+    bound = "mfma" if intensity >= RIDGE_FLOP_PER_BYTE else "hbm"
+    frac_mfma, frac_hbm = tflops / PEAK_F16_TFLOPS, gbs / PEAK_HBM_GBS
     key, label = kernel_label(dom_tile)
     tag = "" if cfg_index == 1 else f"_config{cfg_index}"
     traffic, src = pmc_traffic(key, tag)
     prof_us, prof_src = rocprof_avg_us(key, tag)
     out = {
-        "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+        # the roof that binds THIS kernel: its arithmetic intensity against the ridge of 2.5 PFLOP/s / 8 TB/s = 312.5 FLOP/byte; `achieved`
+        # / `peak` / `frac` are quoted on that roof, both fractions are given below
+        "bound": bound,
+        "achieved": round(tflops, 2) if bound == "mfma" else round(gbs, 1),
+        "peak": PEAK_F16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "frac": round(frac_mfma if bound == "mfma" else frac_hbm, 4),
+        "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": RIDGE_FLOP_PER_BYTE,
+        "frac_mfma": round(frac_mfma, 4), "achieved_tflops": round(tflops, 2),
+        "frac_hbm": round(frac_hbm, 4), "achieved_gbs": round(gbs, 1),
+        # the largest fraction of the MFMA peak this kernel could reach at 8 TB/s given its intensity (1 when it is right of the ridge)
+        "mfma_frac_ceiling_at_hbm_peak": round(min(1.0, intensity / RIDGE_FLOP_PER_BYTE), 4),
+        "traffic": traffic, "traffic_source": src,
         "kernel": label,
         "launches_per_step": dom["n"], "avg_launch_us": round(dom["ms"] / dom["n"] * 1e3, 2),
-        "flops_per_launch": round(dom["flops"] / dom["n"]),
-        # the same FLOPs over the kernel's average duration under the rocprofv3 tracer (committed summary of `bench.py --config N
-        # --pipes 1`; the tracer adds ~1 us per launch) - the figure the judge recomputes
-        "avg_launch_us_rocprof": None if prof_us is None else round(prof_us, 2),
-        "frac_rocprof": None if prof_us is None else round(dom["flops"] / dom["n"] / (prof_us * 1e-6) / 1e12 / PEAK_F16_TFLOPS, 4),
-        "rocprof_source": prof_src,
+        "flops_per_launch": round(dom["flops"] / dom["n"]), "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
+        # NOT measured in this run: the kernel's average duration in the newest COMMITTED rocprofv3 kernel trace of `bench.py --config N
+        # --pipes 1` (the tracer adds ~1 us per launch) and this run's FLOPs over it - for the reader who recomputes the fraction from
+        # profiles/; null unless the kernel's name matches exactly one row of that file
+        "committed_profile": {"source": prof_src, "avg_launch_us": None if prof_us is None else round(prof_us, 2),
+                              "frac_mfma": None if prof_us is None else round(dom["flops"] / dom["n"] / (prof_us * 1e-6) / 1e12 / PEAK_F16_TFLOPS, 4),
+                              "frac_hbm": None if prof_us is None else round(dom["bytes"] / dom["n"] / (prof_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)},
         "all_mfma_convs": {"achieved": round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2), "frac": round(mfma_fl / (mfma_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                            "ms_per_step": round(mfma_ms, 4), "launches_per_step": len(mfma)},
         "serial_layer_ms_per_step": round(tot_ms, 4),
@@ -518,6 +555,11 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
     dt_dnn = None if (args.no_dnn_output or not headline) else timed(False)[0]
     total_frames = global_batch * steps
     fps = total_frames / dt
+    # host fall-backs / truncations over every step this rank ran (warm-up and both timed phases): frames a device decoder declined and
+    # handed to the host statements (PoseProposal / PifPaf), batches with an overflowed PAF list
+    parsed = sum(p.frames_parsed for p in pipes)
+    res.update({"device_declined_frames": sum(p.declined_frames for p in pipes), "capacity_truncations": sum(p.capacity_truncations for p in pipes),
+                "frames_parsed_for_these_counts": parsed})
     res.update({"value": round(fps, 1), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
                 "humans_per_step": n_humans / max(1, steps),
                 "fps_dnn_output": round(total_frames / dt_dnn, 1) if dt_dnn else None,
@@ -560,10 +602,22 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
             res["roofline"] = roofline(pipes[0], batch, cfg_index, frames_dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, maps)
-        if world == 1 and not args.no_from_host:
-            del pipes[:]
-            res["h2d_inclusive"] = h2d_inclusive(model, w_host, cfg, batch, n_pipes, 8)
-            if headline:
+    if not args.no_from_host:
+        # the PCIe-inclusive step, on EVERY rank at once (each with its own pinned frames and pipes, all feeding from
+        # the same host): the aggregate is the sum of the ranks' rates over a common window, which is what the host feed limits at N > 1
+        del pipes[:]
+        if world > 1:
+            barrier()
+        mine = h2d_inclusive(model, w_host, cfg, batch, n_pipes, 8) if batch else {"value": 0.0, "unit": "frames/s", "steps": 0, "what": "idle rank"}
+        total = hd.sum_over_ranks(mine["value"], world, device=hd.collective_device(dev))
+        if world > 1:
+            barrier()
+        if rank == 0:
+            mine["value_per_rank0"] = mine["value"]
+            mine["value"] = round(total, 1)
+            mine["n_gpus"] = world
+            res["h2d_inclusive"] = mine
+            if headline and world == 1:
                 res["from_host"] = from_host(model, w_host, cfg, batch, n_pipes)
     del pipes
     return res, model
@@ -605,6 +659,10 @@ def main():
                    "humans_per_step": head["humans_per_step"], "gflop_per_frame": head["gflop_per_frame"]},
         "fps_dnn_output": head["fps_dnn_output"],
         "conv_tflops_end_to_end": head["conv_tflops_end_to_end"],
+        # SURVEY.md 8d's strictest reading: the same step with the u8 frames starting in pinned HOST memory (one H2D copy per batch) and the
+        # parser fed by the network's own heat-maps; aggregate over the ranks.  `value` keeps the contract's definition (inputs resident in HBM).
+        "value_h2d_inclusive": head.get("h2d_inclusive", {}).get("value"),
+        "device_declined_frames": head["device_declined_frames"], "capacity_truncations": head["capacity_truncations"],
     }
     out["collective_backend"] = backend
     for k in ("roofline", "parser_roofline", "cpu_baseline", "single_pipe_fps", "h2d_inclusive", "from_host", "parser_only_ms_per_step", "engine_only_ms_per_step",

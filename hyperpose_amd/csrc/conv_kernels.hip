@@ -23,6 +23,7 @@
 
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace hp {
 thread_local hipEvent_t prof_start = nullptr, prof_stop = nullptr;
@@ -2032,6 +2033,15 @@ __device__ __forceinline__ void mac4_f16(float (&acc)[4], const uint2 x, const u
     asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[3]) : "v"(x.y), "v"(w.y));
 }
 
+// the first tap of an output: acc = x * w + bias in one instruction (no copy of the bias into the accumulator first)
+__device__ __forceinline__ void mac4_f16_init(float (&acc)[4], const uint2 x, const uint2 w, const float4 bias)
+{
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(acc[0]) : "v"(x.x), "v"(w.x), "v"(bias.x));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(acc[1]) : "v"(x.x), "v"(w.x), "v"(bias.y));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(acc[2]) : "v"(x.y), "v"(w.y), "v"(bias.z));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(acc[3]) : "v"(x.y), "v"(w.y), "v"(bias.w));
+}
+
 // depthwise activation y = v > 0 ? min(v, hi) : v * slope; the relu / relu6 family (slope == 0) is one v_med3_f32
 template <bool CLAMP>
 __device__ __forceinline__ float dw_act(float v, float slope, float hi)
@@ -2666,11 +2676,346 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe_kernel(const sep_params p
 #undef HP_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------
+// sepconv_pipe_kernel with the depthwise taps INSIDE the matrix-pipe stream of the same wavefront (round 4).  The anti-phase form above
+// lets the two wavefronts of a SIMD overlap each other, but every wavefront still runs its own taps (1.6-1.8 k cycles, latency-bound on
+// its LDS reads) and its own 24 MFMAs (1.05-1.3 k) back to back: the interval between two barriers is their SUM (2.85 k, DESIGN.md
+// section 7).  Here interval k of a wavefront is ONE instruction stream of 24 slots - one MFMA of chunk k, then a few tap instructions
+// of chunk k + 1 - so the tap reads' LDS latency sits under the MFMAs and the interval tends to max(matrix pipe, vector issue).
+// The tap work is re-cut so that it is the same in every thread and re-uses its operands:
+//   thread = (channel quad q of the 64-channel chunk, column, row triple): three vertically adjacent output pixels x 4 channels.
+//   The 3 + 2 D input rows of the triple are read once (3 x ds_read_b64 per row: 15 / 21 reads instead of 27) and each feeds every
+//   output row it is a tap of; the 9 x 4 depthwise weights of the quad are read once per chunk (9 x b64: 18 registers instead of 36).
+//   108 v_fma_mix_f32 per thread and chunk as before (bias first, tap order (ky, kx) ascending per output: the same fp32 sums, bit for
+//   bit, as dwconv3x3_kernel), one v_med3 + rounding, one ds_write_b64 per output pixel into the swizzled B tile.
+// B tiles and halo chunks are double-buffered (24 + 36 / 49 KB; the staged epilogue is what sizes the LDS), one barrier per chunk.
+template <int... I, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <int D, int FIRST>
+struct pipe2_sched {
+    static constexpr int ROWS = 3 + 2 * D; // input rows of a triple of output rows
+    // the nine (output row o, kernel row t) pairs in the order their input row o + t D arrives; within an output the kernel rows ascend
+    static constexpr int pair_o(int i) { return D == 1 ? (int[9]){ 0, 0, 1, 0, 1, 2, 1, 2, 2 }[i] : (int[9]){ 0, 1, 2, 0, 1, 2, 0, 1, 2 }[i]; }
+    static constexpr int pair_t(int i) { return D == 1 ? (int[9]){ 0, 1, 0, 2, 1, 0, 2, 1, 2 }[i] : (int[9]){ 0, 0, 0, 1, 1, 1, 2, 2, 2 }[i]; }
+    static constexpr int pair_row(int i) { return pair_o(i) + pair_t(i) * D; }
+    // program of 30 units: 27 column steps (pair i, column c) and, after the last step of an output row, its activation + store
+    static constexpr int N_UNITS = 30;
+    // unit u -> kind: >= 0: column step index 0 .. 26; -1 - o: finish output row o
+    static constexpr int unit_kind(int u)
+    {
+        int n = 0;
+        for (int i = 0; i < 9; ++i) {
+            for (int c = 0; c < 3; ++c, ++n)
+                if (n == u)
+                    return i * 3 + c;
+            if (pair_t(i) == 2) { // the last kernel row of output pair_o(i)
+                if (n == u)
+                    return -1 - pair_o(i);
+                ++n;
+            }
+        }
+        return 1 << 20;
+    }
+    static constexpr int FIRST_SLOT = FIRST, SLOTS = 24;
+    static constexpr int unit_slot(int u) { return FIRST_SLOT + u * (SLOTS - FIRST_SLOT) / N_UNITS; }
+    // the unit after which kernel row t's three weight registers are dead (its last pair's last column): they are re-loaded in place
+    // with the NEXT chunk's weights right there, a good part of an interval before their first use
+    static constexpr int last_unit_of_kernel_row(int t)
+    {
+        int last = -1;
+        for (int u = 0; u < N_UNITS; ++u) {
+            const int k = unit_kind(u);
+            if (k >= 0 && pair_t(k / 3) == t)
+                last = u;
+        }
+        return last;
+    }
+    static constexpr int last_bias_unit() // the first column step of the last output row to start: the bias registers are dead after it
+    {
+        int last = -1;
+        for (int u = 0; u < N_UNITS; ++u) {
+            const int k = unit_kind(u);
+            if (k >= 0 && pair_t(k / 3) == 0 && k % 3 == 0)
+                last = u;
+        }
+        return last;
+    }
+};
+
+template <int D, int FIRST = 1, bool DBG = false>
+__global__ __launch_bounds__(512, 1) void sepconv_pipe2_kernel(const sep_params p, int tiles_x, int tiles_y)
+{
+    using S = pipe2_sched<D, FIRST>;
+    constexpr int NW = 8, NTHR = 512, TP = 2, TH = 12, TW = 8, NPX = TH * TW, NT = NPX / 32, CK = 64, CG = 8, KS = 4, CMAX = 512;
+    constexpr int IH = TH + 2 * D, IW = TW + 2 * D, PIECES = IH * IW * CG, NLD = (PIECES + NTHR - 1) / NTHR;
+    // (every staging store is unconditional - a branch around one makes hipcc drain vmcnt, i.e. the weight-fragment prefetch, at the
+    //  join: the halo buffer is padded to NLD full rounds of pieces)
+    constexpr int HALO_BYTES = NLD * NTHR * 16, BCH_BYTES = NPX * CK * 2;
+    // the depthwise weights and biases of ALL chunks stay in LDS for the whole block ([chunk][9][64] halves, [C] floats: 11 KB at 512
+    // channels): a chunk's weights can then be read BEFORE the barrier that opens its interval
+    constexpr int DWW_CHUNK = 9 * CK * 2, DWW_BYTES = (CMAX / CK) * DWW_CHUNK, DWB_BYTES = CMAX * 4;
+    constexpr int MAIN_BYTES = 2 * BCH_BYTES + 2 * HALO_BYTES + DWW_BYTES + DWB_BYTES;
+    constexpr int EPI_BYTES = NW * packed_geom<TP, NT>::WAVE_BYTES;
+    constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    unsigned char* const s_b = lds;                        // [2] B tiles (depthwise results of a chunk, swizzled)
+    unsigned char* const s_halo = lds + 2 * BCH_BYTES;     // [2] halo chunks
+    unsigned char* const s_dww = s_halo + 2 * HALO_BYTES;  // [C / 64][9][64] halves
+    unsigned char* const s_dwb = s_dww + DWW_BYTES;        // [C] floats
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ymax = p.H + p.halo - 1, xmax = p.W + p.halo - 1;
+    const int C = p.C, KQ = C / 16, NCH = C / CK;
+
+    const __half* const wbase = p.pw.w + (size_t)lane * 8 + (size_t)(wave * TP) * KQ * 512;
+    const size_t row_stride = (size_t)KQ * 512;
+    u32x4 a[KS][TP];
+    auto a_load = [&](const __half* wp, int ks) {
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+            a[ks][i] = *reinterpret_cast<const u32x4*>(wp + i * row_stride + ks * 512);
+    };
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        a_load(wbase, ks);
+    u32x4 hv[NLD];
+    int hoff[NLD];
+    {   // halo pixels beyond the tensor's own zero halo (ragged bottom / right tiles) are read from its last halo row / column, which is
+        // zero as well (sepconv_variant: halo >= dilation >= 1) - no mask needed
+        const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = min(tid + k * NTHR, PIECES - 1);
+            const int hp = i / CG, c = i - hp * CG;
+            const int hy = hp / IW, hx = hp - hy * IW;
+            hoff[k] = (min(iy0 + hy, ymax) * p.in.wp + min(ix0 + hx, xmax)) * p.in.cs + c * 8;
+        }
+    }
+    const __half* const hbase = p.in.p + (size_t)b * p.in.img * p.in.cs + p.in.coff;
+    auto hload = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            hv[k] = *reinterpret_cast<const u32x4*>(hbase + hoff[k] + chunk * CK);
+    };
+    auto to_lds = [&](int chunk) {
+        unsigned char* const hs = s_halo + (chunk & 1) * HALO_BYTES;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            *reinterpret_cast<u32x4*>(hs + (size_t)(tid + k * NTHR) * 16) = hv[k];
+    };
+
+    floatx16 acc[TP][NT];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
+    const float dw_hi = p.dw_hi;
+    // tap role of this thread: channel quad q, column tcol, output rows 3 trow .. 3 trow + 2 of the tile
+    const int q = tid & 15, tcol = (tid >> 4) & 7, trow = tid >> 7;
+    const int x_off = ((3 * trow * IW + tcol) * CG) * 16 + q * 8;  // first input row / column of the triple inside a halo chunk
+    int b_off[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+        b_off[o] = lds_off<CK>((3 * trow + o) * TW + tcol, q >> 1) + (q & 1) * 8;
+    // depthwise weights / bias of the chunk whose taps run next: loaded in place as the previous chunk's die (see `interval`)
+    uint2 wv[9];
+    float4 bs;
+    auto w_load = [&](int chunk, auto t_) {
+        constexpr int tr = decltype(t_)::value;
+        const unsigned char* const ws = s_dww + chunk * DWW_CHUNK + q * 8;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            wv[tr * 3 + c] = *reinterpret_cast<const uint2*>(ws + (tr * 3 + c) * CK * 2);
+    };
+    auto b_load = [&](int chunk) { bs = *reinterpret_cast<const float4*>(s_dwb + (chunk * CK + q * 4) * 4); };
+
+    int dbg_i = 0;
+    // one chunk interval: the MFMAs of chunk kc (MM) and / or the taps of chunk kd (TAPS) as one stream of 24 slots; NEXT: the chunk
+    // whose depthwise weights replace kd's as they die (clamped by the caller).
+    // (with both: the halo chunk kd + 1 goes registers -> LDS and chunk kd + 2 is requested in the MIDDLE of the interval.  At the top
+    //  of the loop the store's s_waitcnt would have to be vmcnt(0) - the waitcnt pass merges the loop entry, where the halo loads are
+    //  the youngest requests, with the back edge - and would drain the weight-fragment prefetch every iteration; mid-interval the
+    //  merged count only covers fragments requested half an interval earlier.)
+    auto interval = [&](auto mm_, auto taps_, int kc, int kd, int knext) {
+        constexpr bool MM = decltype(mm_)::value, TAPS = decltype(taps_)::value;
+        constexpr int STAGE_SLOT = MM && TAPS ? S::SLOTS / 2 : -1;
+        const unsigned char* const bt = s_b + (kc & 1) * BCH_BYTES;
+        const __half* const wn = wbase + (size_t)min(kc + 1, NCH - 1) * (KS * 512);
+        unsigned char* const bd = s_b + (kd & 1) * BCH_BYTES;
+        const unsigned char* const xs = s_halo + (kd & 1) * HALO_BYTES + x_off;
+        half8 fb[2][NT];
+        uint2 xr[S::ROWS][3];
+        float v[3][4];
+        auto read_row = [&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                xr[r][c] = *reinterpret_cast<const uint2*>(xs + ((r * IW + c * D) * CG) * 16);
+        };
+        if (MM) { // the first MFMA's operands first: its s_waitcnt then only covers these three reads
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                fb[0][j] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(j * 32 + frow, fk));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (TAPS) {
+            read_row(std::integral_constant<int, 0>{});
+            read_row(std::integral_constant<int, 1>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<S::SLOTS>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            constexpr int ks = s / (TP * NT), i = (s % (TP * NT)) / NT, j = s % NT;
+            if constexpr (MM) {
+                if constexpr (s % (TP * NT) == 0 && ks + 1 < KS) {
+#pragma unroll
+                    for (int jj = 0; jj < NT; ++jj)
+                        fb[(ks + 1) & 1][jj] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(jj * 32 + frow, (ks + 1) * 2 + fk));
+                }
+                half8 fa;
+                __builtin_memcpy(&fa, &a[ks][i], 16);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                if constexpr (s % (TP * NT) == TP * NT - 1)
+                    a_load(wn, ks);
+            }
+            if constexpr (TAPS) {
+                static_for<S::N_UNITS>([&](auto u_) {
+                    constexpr int u = decltype(u_)::value;
+                    if constexpr (S::unit_slot(u) == s) {
+                        constexpr int kind = S::unit_kind(u);
+                        if constexpr (kind >= 0) {
+                            constexpr int pi = kind / 3, c = kind % 3, o = S::pair_o(pi), tr = S::pair_t(pi), r = S::pair_row(pi);
+                            // input rows are requested two rows ahead of their first use
+                            if constexpr (c == 0 && r + 2 < S::ROWS && (pi == 0 || S::pair_row(pi - 1) != r))
+                                read_row(std::integral_constant<int, r + 2>{});
+                            if constexpr (tr == 0 && c == 0)
+                                mac4_f16_init(v[o], xr[r][c], wv[0], bs);
+                            else
+                                mac4_f16(v[o], xr[r][c], wv[tr * 3 + c]);
+                            // the next chunk's weights / bias into the registers that just died
+                            if constexpr (u == S::last_unit_of_kernel_row(tr))
+                                w_load(knext, std::integral_constant<int, tr>{});
+                            if constexpr (u == S::last_bias_unit())
+                                b_load(knext);
+                        } else {
+                            constexpr int o = -1 - kind;
+                            half4 h;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                h[e] = (_Float16)dw_act<true>(v[o][e], 0.f, dw_hi);
+                            *reinterpret_cast<half4*>(bd + b_off[o]) = h;
+                        }
+                    }
+                });
+            }
+            if constexpr (s == STAGE_SLOT) {
+                to_lds(kd + 1);
+                hload(min(kd + 2, NCH - 1));
+            }
+            if constexpr (DBG && MM && TAPS && (s == 0 || s == 3 || s == 7 || s == 11 || s == 12 || s == 15 || s == 19 || s == 23)) {
+                // (timeline build only: stamps of intervals 2 and 3 of wavefront 0 of block 0 / wavefront 4 of block 1)
+                if ((kc == 2 || kc == 3) && blockIdx.x < 2 && tid == (int)blockIdx.x * 256 && dbg_i < 40)
+                    p.pw.dbg[blockIdx.x * 2112 + dbg_i++] = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    constexpr std::true_type YES{};
+    constexpr std::false_type NO{};
+
+#define HP_STAMP()                                                                                   \
+    if (p.pw.dbg && blockIdx.x < 2 && tid == (int)blockIdx.x * 256 && dbg_i < 40)                    \
+        p.pw.dbg[blockIdx.x * 2112 + dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
+    if (p.pw.dbg && tid == 0 && blockIdx.x < 1024) // every block's start / end on the shared 100 MHz clock
+        p.pw.dbg[64 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    hload(0);
+    {   // all depthwise weights ([9][C] halves in HBM -> [chunk][9][64]) and biases of the block, once
+        const int wpieces = 9 * (C / 8);
+#pragma unroll 1
+        for (int i = tid; i < wpieces; i += NTHR) {
+            const int tp = i / (C / 8), cg = i - tp * (C / 8);
+            *reinterpret_cast<u32x4*>(s_dww + ((cg >> 3) * 9 + tp) * (CK * 2) + (cg & 7) * 16) = *reinterpret_cast<const u32x4*>(p.dw_w + (size_t)tp * C + cg * 8);
+        }
+        if (tid < C / 4)
+            *reinterpret_cast<u32x4*>(s_dwb + tid * 16) = *reinterpret_cast<const u32x4*>(p.dw_bias + tid * 4);
+    }
+    to_lds(0);
+    hload(min(1, NCH - 1));
+    lds_barrier();
+    HP_STAMP();
+    static_for<3>([&](auto t_) { w_load(0, t_); });
+    b_load(0);
+    interval(NO, YES, 0, 0, min(1, NCH - 1));
+    to_lds(1);
+    hload(min(2, NCH - 1));
+    lds_barrier();
+    HP_STAMP();
+#pragma unroll 1
+    for (int k = 0; k + 1 < NCH; ++k) {
+        // (inside: halo chunk k + 2 -> the buffer chunk k's taps were done with before the last barrier; past the last chunk the store
+        //  repeats the last chunk into a buffer nobody reads any more)
+        interval(YES, YES, k, k + 1, min(k + 2, NCH - 1));
+        lds_barrier();
+    }
+    interval(YES, NO, NCH - 1, 0, 0);
+    HP_STAMP();
+    lds_barrier(); // (every wavefront past its reads of the B tiles: the slabs may overwrite them)
+    int pb[NT], py[NT], px[NT];
+    bool pv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + (lane & 31);
+        pb[j] = b;
+        py[j] = y0 + n / TW;
+        px[j] = x0 + n % TW;
+        pv[j] = py[j] < p.OH && px[j] < p.OW;
+    }
+    conv_epilogue_packed<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * packed_geom<TP, NT>::WAVE_BYTES, pb, py, px, pv);
+    HP_STAMP();
+    if (p.pw.dbg && tid == 0 && blockIdx.x < 1024)
+        p.pw.dbg[65 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#undef HP_STAMP
+}
+
 template <int D, int CMAX>
 static hipError_t launch_sep_pipe(const sep_params& p, hipStream_t s)
 {
     const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 11) / 12;
-    HP_LAUNCH((sepconv_pipe_kernel<D, CMAX>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
+    static const bool anti_phase = getenv("HP_SEP_PIPE1") != nullptr; // A/B switch: the round-3 form (taps and MFMAs of a wavefront back to back)
+    if (anti_phase)
+        HP_LAUNCH((sepconv_pipe_kernel<D, CMAX>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
+    else if (p.pw.dbg) // HP_SEP_DBG: the build with s_memtime stamps inside the interval (tools/sep_timeline.py)
+        HP_LAUNCH((sepconv_pipe2_kernel<D, 1, true>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
+    else {
+        static const int first = getenv("HP_SEP_FIRST") ? atoi(getenv("HP_SEP_FIRST")) : 1; // A/B: slots at the head of an interval that carry no taps
+        if (first == 3)
+            HP_LAUNCH((sepconv_pipe2_kernel<D, 3>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
+        else if (first == 5)
+            HP_LAUNCH((sepconv_pipe2_kernel<D, 5>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
+        else
+            HP_LAUNCH((sepconv_pipe2_kernel<D, 1>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
+    }
     return hipGetLastError();
 }
 

@@ -35,14 +35,31 @@ _BACKEND = None
 LAST_BROADCAST = {}        # {"backend", "bytes", "ms"} of the last broadcast_weights (reported by bench.py)
 
 
-def init_for_gpu(device, probe: bool = True):
+def _rccl_usable() -> bool:
+    """Whether THIS rank could take part in an RCCL group at all (a local property, checked before any collective call on it)."""
+    if os.environ.get("HP_DIST_BACKEND", "nccl") == "gloo":
+        return False
+    try:
+        import torch
+        import torch.distributed as dist
+        return bool(dist.is_nccl_available() and torch.cuda.is_available())
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def init_for_gpu(device, probe: bool = True, probe_timeout_s: float = 45.0):
     """Bring up the job's collectives on a GPU node; returns the name of the backend that carries them ("nccl" = RCCL, or "gloo").
 
     The default group is gloo (host TCP: rendezvous, barriers - it always comes up); the start-up weight broadcast and the timing
-    reductions run on an RCCL group created next to it.  Whether RCCL is usable is decided COLLECTIVELY: every rank tries to create
-    the group and to all-reduce one element on it, the ranks then take the minimum of their success flags over gloo, and either all
-    of them use RCCL or all of them stay on gloo - no rank can end up alone in the other backend, no second rendezvous, no second
-    port.  `HP_DIST_BACKEND=gloo` (set for all ranks by the launcher) skips RCCL.  The hot path itself has no collective."""
+    reductions run on an RCCL group created next to it.  Whether RCCL is used is decided COLLECTIVELY, in two rounds over gloo, so that
+    no rank can end up alone inside an RCCL call:
+      1. before anything touches RCCL the ranks take the MINIMUM of "this rank wants and can load RCCL" (`HP_DIST_BACKEND=gloo` on any
+         one rank, a torch build without NCCL, no visible GPU -> every rank stays on gloo and nobody calls `new_group`);
+      2. then every rank creates the group and runs ONE probe all-reduce with a bounded wait (`probe_timeout_s`; the watchdog's
+         process-abort is switched off for it, so a rank whose peers failed gets an exception instead of being killed at the group's
+         timeout), and the ranks take the minimum of their success flags: either all use RCCL or all stay on gloo.
+    The probe always runs (`probe` is kept for source compatibility): a group nobody has tried is never committed to.  The hot path
+    itself has no collective."""
     global _COLLECTIVE_DEVICE, _GROUP, _BACKEND
     import datetime
     import sys
@@ -50,22 +67,29 @@ def init_for_gpu(device, probe: bool = True):
     import torch
     import torch.distributed as dist
     init("gloo")
+    del probe
+    want = torch.tensor([1 if _rccl_usable() else 0], dtype=torch.int32)
+    dist.all_reduce(want, op=dist.ReduceOp.MIN)  # gloo: round 1
     ok, why, group = 1, "", None
-    if os.environ.get("HP_DIST_BACKEND", "nccl") == "gloo":
-        ok, why = 0, "HP_DIST_BACKEND=gloo"
+    if int(want.item()) == 0:
+        ok, why = 0, "a rank asked for gloo (HP_DIST_BACKEND) or cannot load RCCL"
     else:
+        # a failed collective must surface as an exception on the ranks that wait for it, not as the watchdog aborting the process
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        wait = datetime.timedelta(seconds=probe_timeout_s)
         try:
-            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
-            if probe:
-                t = torch.ones(1, device=device)
-                dist.all_reduce(t, group=group)
-                torch.cuda.synchronize(device)
-                if int(t.item()) != dist.get_world_size():
-                    raise RuntimeError(f"probe all-reduce returned {t.item()}")
+            group = dist.new_group(backend="nccl", timeout=wait)
+            t = torch.ones(1, device=device)
+            work = dist.all_reduce(t, group=group, async_op=True)
+            if work.wait(wait) is False:
+                raise RuntimeError("probe all-reduce did not complete")
+            torch.cuda.synchronize(device)
+            if int(t.item()) != dist.get_world_size():
+                raise RuntimeError(f"probe all-reduce returned {t.item()}")
         except Exception as e:  # noqa: BLE001 - any failure of the GPU backend takes the same way out
             ok, why = 0, f"{type(e).__name__}: {e}"
     flag = torch.tensor([ok], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo: the agreement
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo: round 2, the agreement
     if int(flag.item()) == 1:
         _GROUP, _COLLECTIVE_DEVICE, _BACKEND = group, device, "nccl"
     else:

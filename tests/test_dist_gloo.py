@@ -83,6 +83,46 @@ def test_rccl_failure_falls_back_to_gloo():
         assert wsum == float(np.arange(1000, dtype=np.float32).sum()) and t == 4.0
 
 
+def _asymmetric_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if rank == 0:
+        os.environ["HP_DIST_BACKEND"] = "gloo"  # set on ONE rank only
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from hyperpose_amd import dist as hd
+    if rank == 1:
+        hd._rccl_usable = lambda: True  # this rank believes RCCL is fine and would go on to create the group
+    t0 = time.perf_counter()
+    backend = hd.init_for_gpu(torch.device("cuda", rank))
+    q.put((rank, backend, time.perf_counter() - t0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_backend_choice_is_agreed_before_any_rccl_call():
+    """with HP_DIST_BACKEND=gloo on a subset of the ranks the others must not walk into `new_group(backend="nccl")` alone (they
+    would sit in its store barrier until the timeout): the wish is reduced over gloo FIRST and every rank stays on gloo at once."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_asymmetric_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, backend, dt in res:
+        assert backend == "gloo" and dt < 30.0, (rank, backend, dt)
+
+
 def test_shard_covers_everything():
     from hyperpose_amd import dist as hd
     for total in (0, 1, 8, 13, 64):
