@@ -21,7 +21,8 @@ have settled whatever W is), then exactly K steps bracketed by barrier + torch.c
 prints ONE JSON line.
 
 The other BASELINE configurations are measured the same way and reported under `workloads` in the same line
-(`--extra`, default 0,2,3,4 at N = 1 and 3,4 strong-scaled at N > 1): configs[0] TinyVGG-V2 + PAF on a single image; configs[2] OpenPose-VGG19 + PAF, batch 16 @ 432x768;
+(`--extra`, default 0,2,3,4,5 at N = 1 - 5 = configs[1] behind data_type::kFLOAT, the fp32-faithful engine, as workloads["configs[1]/fp32"] -
+and 3,4 strong-scaled at N > 1): configs[0] TinyVGG-V2 + PAF on a single image; configs[2] OpenPose-VGG19 + PAF, batch 16 @ 432x768;
 configs[3] PoseProposal ResNet-50 + NMS decoder, batch 32 @ 384x384; configs[4] OpenPifPaf ResNet-50 + seed/grow
 decoder, batch 64 @ 385x385 - each with its own `roofline` and (N = 1) `cpu_baseline`.
 
@@ -56,6 +57,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32: the fp32 matrix pipe an HP_DTYPE_F32 (data_type::kFLOAT) engine computes on
 # Independent engine+parser instances per GPU, one HIP stream each, batches round-robin over them.  Throughput depends
 # on how those streams land on the runtime's hardware queues (measured on MI355X, tools/queue_probe.py, us/batch, config 1):
 # 4 pipes on 2 queues (2+2) 606-617 | 3 pipes on 3 queues 657-667 | 6 pipes on 2 queues 668 | 4 pipes on 4 queues 790-820
@@ -76,6 +78,11 @@ CONFIGS = {
             w=384, h=384, batch=32, parser="ppn", pipes=8, seed=20243, steps=60, people=(1, 2, 3, 4)),
     4: dict(label="configs[4]: OpenPifPaf ResNet-50 + pif/paf seed-grow decoder, batch 64 @ 385x385", arch="pifpaf_resnet50",
             w=385, h=385, batch=64, parser="pifpaf", pipes=3, seed=20244, steps=16, people=(1, 2, 3, 4)),
+    # configs[1] behind data_type::kFLOAT, the reference engine's default precision (include/hyperpose/operator/dnn/tensorrt.hpp:48): fp32
+    # storage and fp32 matrix-pipe arithmetic (HP_DTYPE_F32, conv_fp32.hip), one launch per layer - the faithful mode, reported next to the
+    # fp16 headline under workloads["configs[1]/fp32"] with its own roofline against the 157 TFLOP/s fp32 MFMA peak
+    5: dict(label="configs[1] with data_type::kFLOAT (fp32 storage + fp32 MFMA): Lightweight-OpenPose + PAF parser, batch 8 @ 368x432", arch="lw_openpose_mobilenet",
+            w=432, h=368, batch=8, parser="paf", pipes=2, seed=20241, steps=40, people=(1, 2, 4, 8, 16, 3, 5, 6), dtype="f32", key="configs[1]/fp32"),
 }
 
 
@@ -84,7 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps of the headline workload (default: per config)")
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="headline workload (BASELINE.json configs index)")
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="headline workload (BASELINE.json configs index; 5 = configs[1] behind data_type::kFLOAT)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--extra", default=None, help="comma-separated configs also measured and reported under `workloads` ('' = none)")
     ap.add_argument("--pipes", type=int, default=0, help="engine+parser pairs per GPU (0 = per config)")
@@ -133,7 +140,7 @@ class Pipe:
         from hyperpose_amd.engine import Engine
         from hyperpose_amd import parser as P
         self.kind, self.batch = cfg["parser"], batch
-        self.eng = Engine.from_model(model, weights, max_batch=batch)
+        self.eng = Engine.from_model(model, weights, max_batch=batch, dtype=cfg.get("dtype", "f16"))
         self.stream = self.eng.stream
         outs = self.eng.outputs  # sorted by name = the parsers' argument order
         if self.kind == "paf":
@@ -286,7 +293,8 @@ def _host_pipeline_rate(model, weights, cfg, batch, pipes, steps, frame_wh, keep
     C.memmove(host, src.ctypes.data, src.nbytes)
     ptrs = (C.POINTER(C.c_uint8) * batch)(*[C.cast(host.value + i * nbytes, C.POINTER(C.c_uint8)) for i in range(batch)])
     ws, hs = (C.c_int * batch)(*([w_] * batch)), (C.c_int * batch)(*([h_] * batch))
-    pl = Pipeline(model, weights, max_batch=batch, n_pipes=pipes, keep_ratio=keep_ratio, max_frame_wh=frame_wh, parser=cfg["parser"])
+    pl = Pipeline(model, weights, max_batch=batch, n_pipes=pipes, keep_ratio=keep_ratio, max_frame_wh=frame_wh, parser=cfg["parser"],
+                  dtype=cfg.get("dtype", "f16"))
 
     def loop(n):
         for _ in range(n):
@@ -339,10 +347,15 @@ def kernel_label(tile: int):
            2: ("sepconv_small_kernel<", "separable block -> 128 channels, stride 2, all channels of a tile in LDS"),
            3: ("sepconv_slot_kernel<2,1,2,1,128,64>", "separable block 128 -> 256, stride 2, half-CU form"),
            4: ("sepconv_slot_kernel<1,2,1,1,256,64>", "separable block 256 -> 256, half-CU form"),
-           5: ("sepconv_pipe2_kernel<1>", "separable block 256 / 512 -> 512: 12x8 pixels x all 512 output channels per block, eight wavefronts; per 64-channel "
+           5: ("sepconv_pipe3_kernel<1,false>", "separable block 256 / 512 -> 512: 12x8 pixels x all 512 output channels per block, eight wavefronts; per 64-channel "
                "chunk the depthwise taps of chunk k+1 are issued between the pointwise MFMAs of chunk k in the SAME wavefront (one stream of 24 slots)"),
-           6: ("sepconv_pipe2_kernel<2>", "separable block 512 -> 512, dilation 2, same form")}
+           6: ("sepconv_pipe3_kernel<2,false>", "separable block 512 -> 512, dilation 2, same form")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
+    if tile >= 32000000:
+        bm, bn = (tile - 32000000) // 1000, tile % 1000
+        wm, wn = (2, 2) if bm == 128 else (1, 4)
+        return (f"conv32_kernel<{bm},{bn},{wm},{wn}>", f"conv32_kernel<BM={bm},BN={bn}> (fp32 implicit GEMM on v_mfma_f32_32x32x2_f32: {bm} cout x {bn} pixels per block, "
+                "A and B staged through LDS in fp32, K-steps of 16 channels)")
     if tile >= 9000000:
         v = tile - 9000000
         m, pj, mr, a3 = v // 1000 * 64, v // 100 % 10, v // 10 % 10 * 64, v % 10
@@ -421,7 +434,7 @@ def rocprof_avg_us(symbol_key: str, tag: str):
 RIDGE_FLOP_PER_BYTE = 2500.0e12 / 8000.0e9  # 312.5: below it a kernel's binding roof is HBM, above it the matrix pipe
 
 
-def roofline(pipe, batch, cfg_index, frames_dev=None):
+def roofline(pipe, batch, cfg_index, frames_dev=None, peak_tflops=PEAK_F16_TFLOPS):
     """Per-launch timestamps on the engine stream with the schedule run in order (hp_engine_profile_sequence: every kernel sees the
     cache state of a real inference, which is what rocprofv3's per-kernel averages over this bench see too).  achieved = algorithmic
     FLOPs of the dominant kernel's launches / their summed duration.  `back_to_back_us` is the same kernel re-launched 20 times in a
@@ -444,10 +457,11 @@ def roofline(pipe, batch, cfg_index, frames_dev=None):
     tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9   # ALGORITHMIC bytes of the launches (input + output + weights once, engine.cpp st.bytes)
     intensity = dom["flops"] / dom["bytes"]
-    bound = "mfma" if intensity >= RIDGE_FLOP_PER_BYTE else "hbm"
-    frac_mfma, frac_hbm = tflops / PEAK_F16_TFLOPS, gbs / PEAK_HBM_GBS
+    ridge = peak_tflops * 1e12 / (PEAK_HBM_GBS * 1e9)
+    bound = "mfma" if intensity >= ridge else "hbm"
+    frac_mfma, frac_hbm = tflops / peak_tflops, gbs / PEAK_HBM_GBS
     key, label = kernel_label(dom_tile)
-    tag = "" if cfg_index == 1 else f"_config{cfg_index}"
+    tag = "" if cfg_index == 1 else "_config1_fp32" if cfg_index == 5 else f"_config{cfg_index}"
     traffic, src = pmc_traffic(key, tag)
     prof_us, prof_src = rocprof_avg_us(key, tag)
     out = {
@@ -455,14 +469,14 @@ def roofline(pipe, batch, cfg_index, frames_dev=None):
         # / `peak` / `frac` are quoted on that roof, both fractions are given below
         "bound": bound,
         "achieved": round(tflops, 2) if bound == "mfma" else round(gbs, 1),
-        "peak": PEAK_F16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+        "peak": peak_tflops if bound == "mfma" else PEAK_HBM_GBS,
         "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
         "frac": round(frac_mfma if bound == "mfma" else frac_hbm, 4),
-        "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": RIDGE_FLOP_PER_BYTE,
+        "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 2), "mfma_peak_tflops": peak_tflops,
         "frac_mfma": round(frac_mfma, 4), "achieved_tflops": round(tflops, 2),
         "frac_hbm": round(frac_hbm, 4), "achieved_gbs": round(gbs, 1),
         # the largest fraction of the MFMA peak this kernel could reach at 8 TB/s given its intensity (1 when it is right of the ridge)
-        "mfma_frac_ceiling_at_hbm_peak": round(min(1.0, intensity / RIDGE_FLOP_PER_BYTE), 4),
+        "mfma_frac_ceiling_at_hbm_peak": round(min(1.0, intensity / ridge), 4),
         "traffic": traffic, "traffic_source": src,
         "kernel": label,
         "launches_per_step": dom["n"], "avg_launch_us": round(dom["ms"] / dom["n"] * 1e3, 2),
@@ -471,9 +485,9 @@ def roofline(pipe, batch, cfg_index, frames_dev=None):
         # --pipes 1` (the tracer adds ~1 us per launch) and this run's FLOPs over it - for the reader who recomputes the fraction from
         # profiles/; null unless the kernel's name matches exactly one row of that file
         "committed_profile": {"source": prof_src, "avg_launch_us": None if prof_us is None else round(prof_us, 2),
-                              "frac_mfma": None if prof_us is None else round(dom["flops"] / dom["n"] / (prof_us * 1e-6) / 1e12 / PEAK_F16_TFLOPS, 4),
+                              "frac_mfma": None if prof_us is None else round(dom["flops"] / dom["n"] / (prof_us * 1e-6) / 1e12 / peak_tflops, 4),
                               "frac_hbm": None if prof_us is None else round(dom["bytes"] / dom["n"] / (prof_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)},
-        "all_mfma_convs": {"achieved": round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2), "frac": round(mfma_fl / (mfma_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+        "all_mfma_convs": {"achieved": round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2), "frac": round(mfma_fl / (mfma_ms * 1e-3) / 1e12 / peak_tflops, 4),
                            "ms_per_step": round(mfma_ms, 4), "launches_per_step": len(mfma)},
         "serial_layer_ms_per_step": round(tot_ms, 4),
         "non_mfma_ms_per_step": round(tot_ms - mfma_ms, 4),
@@ -564,7 +578,8 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
                 "humans_per_step": n_humans / max(1, steps),
                 "fps_dnn_output": round(total_frames / dt_dnn, 1) if dt_dnn else None,
                 "conv_tflops_end_to_end": round(fps * model.flops_per_frame / 1e12, 2),
-                "conv_frac_of_mfma_peak_end_to_end": round(fps * model.flops_per_frame / 1e12 / PEAK_F16_TFLOPS / world, 4)})
+                "conv_frac_of_mfma_peak_end_to_end": round(fps * model.flops_per_frame / 1e12 / (PEAK_F32_TFLOPS if cfg.get("dtype") == "f32" else PEAK_F16_TFLOPS) / world, 4),
+                "dtype": "f32 (fp32 storage, fp32 MFMA)" if cfg.get("dtype") == "f32" else "f16 (fp32 accumulate)"})
     if rank == 0 and pipes and not args.no_roofline:
         # where the step's time goes: the parser alone (injected maps: GPU kernels + the host tail in collect) and the conv stack
         # alone, each through ONE pipe, next to the end-to-end step above (in which several pipes overlap them)
@@ -599,7 +614,7 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
         del p0
     if rank == 0 and pipes:
         if not args.no_roofline:
-            res["roofline"] = roofline(pipes[0], batch, cfg_index, frames_dev)
+            res["roofline"] = roofline(pipes[0], batch, cfg_index, frames_dev, PEAK_F32_TFLOPS if cfg.get("dtype") == "f32" else PEAK_F16_TFLOPS)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, maps)
     if not args.no_from_host:
@@ -671,7 +686,7 @@ def main():
             out[k] = head[k]
     extra = args.extra
     if extra is None:
-        extra = "0,2,3,4" if world == 1 else "3,4"
+        extra = "0,2,3,4,5" if world == 1 else "3,4"
         if args.config != 1:
             extra = ""
     workloads = {}
@@ -683,7 +698,7 @@ def main():
         scal = "strong" if world > 1 else "weak"
         r, _ = measure(k, args, rank, world, dev, scal, c["steps"], max(2, min(args.warmup, c["steps"] // 4)), False)
         r["n_gpus"] = world
-        workloads[f"configs[{k}]"] = r
+        workloads[c.get("key", f"configs[{k}]")] = r
     if workloads:
         out["workloads"] = workloads
     if rank == 0:

@@ -2677,18 +2677,17 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe_kernel(const sep_params p
 }
 
 // ---------------------------------------------------------------------------------------------------
-// sepconv_pipe_kernel with the depthwise taps INSIDE the matrix-pipe stream of the same wavefront (round 4).  The anti-phase form above
-// lets the two wavefronts of a SIMD overlap each other, but every wavefront still runs its own taps (1.6-1.8 k cycles, latency-bound on
-// its LDS reads) and its own 24 MFMAs (1.05-1.3 k) back to back: the interval between two barriers is their SUM (2.85 k, DESIGN.md
-// section 7).  Here interval k of a wavefront is ONE instruction stream of 24 slots - one MFMA of chunk k, then a few tap instructions
-// of chunk k + 1 - so the tap reads' LDS latency sits under the MFMAs and the interval tends to max(matrix pipe, vector issue).
-// The tap work is re-cut so that it is the same in every thread and re-uses its operands:
+// The 512-output separable blocks with the depthwise taps INSIDE the matrix-pipe stream of the same wavefront (round 4; the kernel is
+// sepconv_pipe3_kernel below, this is its schedule).  The anti-phase form above lets the two wavefronts of a SIMD overlap each other, but
+// every wavefront still runs its own taps (1.6-1.8 k cycles, latency-bound on its LDS reads) and its own 24 MFMAs (1.05-1.3 k) back to
+// back: the interval between two barriers is their SUM (2.85 k).  Here interval k of a wavefront is ONE instruction
+// stream of 24 slots - one MFMA of chunk k, then a few tap instructions of chunk k + 1, the order pinned by sched_barrier - so the tap
+// reads' LDS latency sits under the MFMAs.  The tap work is re-cut so that it is the same in every thread and re-uses its operands:
 //   thread = (channel quad q of the 64-channel chunk, column, row triple): three vertically adjacent output pixels x 4 channels.
-//   The 3 + 2 D input rows of the triple are read once (3 x ds_read_b64 per row: 15 / 21 reads instead of 27) and each feeds every
-//   output row it is a tap of; the 9 x 4 depthwise weights of the quad are read once per chunk (9 x b64: 18 registers instead of 36).
-//   108 v_fma_mix_f32 per thread and chunk as before (bias first, tap order (ky, kx) ascending per output: the same fp32 sums, bit for
-//   bit, as dwconv3x3_kernel), one v_med3 + rounding, one ds_write_b64 per output pixel into the swizzled B tile.
-// B tiles and halo chunks are double-buffered (24 + 36 / 49 KB; the staged epilogue is what sizes the LDS), one barrier per chunk.
+//   The 3 + 2 D input rows of the triple are read once (15 / 21 ds_read_b64 instead of 27) and each feeds every output row it is a tap
+//   of; the 9 x 4 depthwise weights of the quad are read once per chunk.  108 v_fma_mix_f32 per thread and chunk as before (bias folded
+//   into the first tap, tap order (ky, kx) ascending per output: the same fp32 sums, bit for bit, as dwconv3x3_kernel), one v_med3 +
+//   rounding, one ds_write_b64 per output pixel into the swizzled B tile.
 template <int... I, class F>
 __device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f)
 {
@@ -2701,7 +2700,7 @@ __device__ __forceinline__ void static_for(F&& f)
 }
 
 template <int D, int FIRST>
-struct pipe2_sched {
+struct tap_sched {
     static constexpr int ROWS = 3 + 2 * D; // input rows of a triple of output rows
     // the nine (output row o, kernel row t) pairs in the order their input row o + t D arrives; within an output the kernel rows ascend
     static constexpr int pair_o(int i) { return D == 1 ? (int[9]){ 0, 0, 1, 0, 1, 2, 1, 2, 2 }[i] : (int[9]){ 0, 1, 2, 0, 1, 2, 0, 1, 2 }[i]; }
@@ -2751,27 +2750,39 @@ struct pipe2_sched {
     }
 };
 
-template <int D, int FIRST = 1, bool DBG = false>
-__global__ __launch_bounds__(512, 1) void sepconv_pipe2_kernel(const sep_params p, int tiles_x, int tiles_y)
+// ---------------------------------------------------------------------------------------------------
+// sepconv_pipe3_kernel: the 24-slot stream above with its LDS traffic cut to what the stream can hide.  The timeline of its first form
+// (tap reads as plain 8-byte loads of one base pointer, HP_SEP_DBG) put a slot at 90 - 95 cycles where the two
+// wavefronts of a SIMD need 64 for their MFMAs:
+// the LDS was busy ~1.7 k cycles per interval (ds_read2_b64, which hipcc makes of neighbouring 8-byte reads, costs 8 LDS cycles where
+// two ds_read_b64 cost 2 + 2; nine 8-byte weight reads per thread; three ds_write_b128 of the halo in ONE slot by all eight wavefronts).
+//   * every 8-byte read of the taps comes from its own base register (an integer laundered through an empty asm and cast back to an
+//     LDS pointer) and halo rows are 17 pixels apart (2176 B > ds_read2's reach): no pairing, 2 cycles each;
+//   * the depthwise weights lie [chunk][quad][9 taps x 4] (80 B per quad): four ds_read_b128 + one ds_read_b64 per thread and chunk;
+//   * the halo pieces are stored one per slot in three different slots;
+//   * the chunk loop is unrolled by two, so the buffer parity is a compile-time constant and every LDS address is a base register that
+//     never changes plus an immediate (the v2 loop spent 31 v_add_u32 per interval on them).  Needs an even number of chunks.
+template <int D, bool DBG = false>
+__global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params p, int tiles_x, int tiles_y)
 {
-    using S = pipe2_sched<D, FIRST>;
+    using S = tap_sched<D, 1>;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const u32x2* lds_u2;
+    typedef __attribute__((address_space(3))) const u32x4* lds_u4;
     constexpr int NW = 8, NTHR = 512, TP = 2, TH = 12, TW = 8, NPX = TH * TW, NT = NPX / 32, CK = 64, CG = 8, KS = 4, CMAX = 512;
     constexpr int IH = TH + 2 * D, IW = TW + 2 * D, PIECES = IH * IW * CG, NLD = (PIECES + NTHR - 1) / NTHR;
-    // (every staging store is unconditional - a branch around one makes hipcc drain vmcnt, i.e. the weight-fragment prefetch, at the
-    //  join: the halo buffer is padded to NLD full rounds of pieces)
-    constexpr int HALO_BYTES = NLD * NTHR * 16, BCH_BYTES = NPX * CK * 2;
-    // the depthwise weights and biases of ALL chunks stay in LDS for the whole block ([chunk][9][64] halves, [C] floats: 11 KB at 512
-    // channels): a chunk's weights can then be read BEFORE the barrier that opens its interval
-    constexpr int DWW_CHUNK = 9 * CK * 2, DWW_BYTES = (CMAX / CK) * DWW_CHUNK, DWB_BYTES = CMAX * 4;
-    constexpr int MAIN_BYTES = 2 * BCH_BYTES + 2 * HALO_BYTES + DWW_BYTES + DWB_BYTES;
+    constexpr int ROWPX = 17, ROWB = ROWPX * CG * 16; // halo rows 2176 B apart: two 8-byte reads of neighbouring rows cannot become one ds_read2_b64
+    static_assert(IW <= ROWPX && ROWB / 8 > 255, "halo row stride");
+    constexpr int HALO_BYTES = (IH * ROWPX + 1) * CG * 16; // (+ one pixel: the dummy slot of the pieces past the tile)
+    constexpr int BCH_BYTES = NPX * CK * 2;
+    constexpr int QW = 80, DWW_CHUNK = 16 * QW, DWW_BYTES = (CMAX / CK) * DWW_CHUNK, DWB_BYTES = CMAX * 4; // [chunk][quad][9 x 4 halves + pad]
+    constexpr int OFF_HALO = 2 * BCH_BYTES, OFF_DWW = OFF_HALO + 2 * HALO_BYTES, OFF_DWB = OFF_DWW + DWW_BYTES;
+    constexpr int MAIN_BYTES = OFF_DWB + DWB_BYTES;
     constexpr int EPI_BYTES = NW * packed_geom<TP, NT>::WAVE_BYTES;
     constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    unsigned char* const s_b = lds;                        // [2] B tiles (depthwise results of a chunk, swizzled)
-    unsigned char* const s_halo = lds + 2 * BCH_BYTES;     // [2] halo chunks
-    unsigned char* const s_dww = s_halo + 2 * HALO_BYTES;  // [C / 64][9][64] halves
-    unsigned char* const s_dwb = s_dww + DWW_BYTES;        // [C] floats
+    __shared__ __attribute__((aligned(256))) unsigned char lds[LDS_BYTES];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int t = blockIdx.x;
@@ -2795,29 +2806,23 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe2_kernel(const sep_params 
         a_load(wbase, ks);
     u32x4 hv[NLD];
     int hoff[NLD];
+    unsigned hdst[NLD]; // LDS byte offset of the piece inside a halo buffer
     {   // halo pixels beyond the tensor's own zero halo (ragged bottom / right tiles) are read from its last halo row / column, which is
         // zero as well (sepconv_variant: halo >= dilation >= 1) - no mask needed
         const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
-            const int i = min(tid + k * NTHR, PIECES - 1);
-            const int hp = i / CG, c = i - hp * CG;
+            const int i = tid + k * NTHR, ic = min(i, PIECES - 1);
+            const int hp = ic / CG, c = ic - hp * CG;
             const int hy = hp / IW, hx = hp - hy * IW;
             hoff[k] = (min(iy0 + hy, ymax) * p.in.wp + min(ix0 + hx, xmax)) * p.in.cs + c * 8;
+            hdst[k] = lds0 + OFF_HALO + (i < PIECES ? ((hy * ROWPX + hx) * CG + c) * 16 : (IH * ROWPX * CG + c) * 16);
         }
     }
     const __half* const hbase = p.in.p + (size_t)b * p.in.img * p.in.cs + p.in.coff;
-    auto hload = [&](int chunk) {
-#pragma unroll
-        for (int k = 0; k < NLD; ++k)
-            hv[k] = *reinterpret_cast<const u32x4*>(hbase + hoff[k] + chunk * CK);
-    };
-    auto to_lds = [&](int chunk) {
-        unsigned char* const hs = s_halo + (chunk & 1) * HALO_BYTES;
-#pragma unroll
-        for (int k = 0; k < NLD; ++k)
-            *reinterpret_cast<u32x4*>(hs + (size_t)(tid + k * NTHR) * 16) = hv[k];
-    };
+    typedef __attribute__((address_space(3))) u32x4* lds_w4;
+    auto hload1 = [&](int k, int chunk) { hv[k] = *reinterpret_cast<const u32x4*>(hbase + hoff[k] + chunk * CK); };
+    auto hstore1 = [&](int k, auto par_) { *(lds_w4)(hdst[k] + decltype(par_)::value * HALO_BYTES) = hv[k]; };
 
     floatx16 acc[TP][NT];
 #pragma unroll
@@ -2829,52 +2834,74 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe2_kernel(const sep_params 
                 acc[i][j][r] = 0.f;
     const int frow = lane & 31, fk = lane >> 5;
     const float dw_hi = p.dw_hi;
+    // B-fragment address of k16 step 0; step ks is this XOR ks * 32 (the swizzled 16-byte slot is (2 ks + fk) ^ key = (fk ^ key) ^ 2 ks, the
+    // array is 256-byte aligned), pixel tile j adds j * 4096
+    const unsigned fbase0 = lds0 + lds_off<CK>(frow, fk);
     // tap role of this thread: channel quad q, column tcol, output rows 3 trow .. 3 trow + 2 of the tile
     const int q = tid & 15, tcol = (tid >> 4) & 7, trow = tid >> 7;
-    const int x_off = ((3 * trow * IW + tcol) * CG) * 16 + q * 8;  // first input row / column of the triple inside a halo chunk
-    int b_off[3];
+    unsigned xb[3]; // one base register per tap column, laundered so that hipcc cannot pair the reads
 #pragma unroll
-    for (int o = 0; o < 3; ++o)
-        b_off[o] = lds_off<CK>((3 * trow + o) * TW + tcol, q >> 1) + (q & 1) * 8;
-    // depthwise weights / bias of the chunk whose taps run next: loaded in place as the previous chunk's die (see `interval`)
-    uint2 wv[9];
+    for (int c = 0; c < 3; ++c) {
+        xb[c] = lds0 + OFF_HALO + ((3 * trow * ROWPX + tcol + c * D) * CG) * 16 + q * 8;
+        asm volatile("" : "+v"(xb[c]));
+    }
+    // where the three outputs go in a B tile: rows of 8 pixels are 1024 B apart and alternate the swizzle key by 4 (output 2 = output 0 + 2048)
+    const unsigned b_dst0 = lds0 + lds_off<CK>((3 * trow) * TW + tcol, q >> 1) + (q & 1) * 8;
+    const unsigned b_dst1 = lds0 + lds_off<CK>((3 * trow + 1) * TW + tcol, q >> 1) + (q & 1) * 8;
+    const unsigned wq = lds0 + OFF_DWW + q * QW, bq = lds0 + OFF_DWB + q * 16;
+    // depthwise weights / bias of the chunk whose taps run next: taps (2g, 2g + 1) in wv[g], tap 8 in w8
+    u32x4 wv[4];
+    uint2 w8;
     float4 bs;
-    auto w_load = [&](int chunk, auto t_) {
-        constexpr int tr = decltype(t_)::value;
-        const unsigned char* const ws = s_dww + chunk * DWW_CHUNK + q * 8;
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            wv[tr * 3 + c] = *reinterpret_cast<const uint2*>(ws + (tr * 3 + c) * CK * 2);
+    auto tap_w = [&](auto t9_) -> uint2 {
+        constexpr int t9 = decltype(t9_)::value;
+        if constexpr (t9 == 8)
+            return w8;
+        else
+            return (t9 & 1) ? make_uint2(wv[t9 / 2][2], wv[t9 / 2][3]) : make_uint2(wv[t9 / 2][0], wv[t9 / 2][1]);
     };
-    auto b_load = [&](int chunk) { bs = *reinterpret_cast<const float4*>(s_dwb + (chunk * CK + q * 4) * 4); };
+    auto w_load_lo = [&](int chunk) { // taps 0 .. 5 (kernel rows 0 and 1)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            wv[g] = *(lds_u4)(wq + chunk * DWW_CHUNK + g * 16);
+    };
+    auto w_load_hi = [&](int chunk) { // taps 6 .. 8 (kernel row 2)
+        wv[3] = *(lds_u4)(wq + chunk * DWW_CHUNK + 48);
+        const u32x2 t2 = *(lds_u2)(wq + chunk * DWW_CHUNK + 64);
+        w8 = make_uint2(t2.x, t2.y);
+    };
+    auto b_load = [&](int chunk) {
+        const u32x4 t4 = *(lds_u4)(bq + chunk * (CK * 4));
+        bs = make_float4(__uint_as_float(t4[0]), __uint_as_float(t4[1]), __uint_as_float(t4[2]), __uint_as_float(t4[3]));
+    };
 
     int dbg_i = 0;
-    // one chunk interval: the MFMAs of chunk kc (MM) and / or the taps of chunk kd (TAPS) as one stream of 24 slots; NEXT: the chunk
-    // whose depthwise weights replace kd's as they die (clamped by the caller).
-    // (with both: the halo chunk kd + 1 goes registers -> LDS and chunk kd + 2 is requested in the MIDDLE of the interval.  At the top
-    //  of the loop the store's s_waitcnt would have to be vmcnt(0) - the waitcnt pass merges the loop entry, where the halo loads are
-    //  the youngest requests, with the back edge - and would drain the weight-fragment prefetch every iteration; mid-interval the
-    //  merged count only covers fragments requested half an interval earlier.)
-    auto interval = [&](auto mm_, auto taps_, int kc, int kd, int knext) {
+    // one chunk interval: MFMAs of chunk kc out of B buffer PAR, taps of chunk kd = kc + 1 out of halo buffer
+    // 1 - PAR into B buffer 1 - PAR, halo chunk kd + 1 -> halo buffer PAR, weights of chunk knext in place
+    auto interval = [&](auto mm_, auto taps_, auto par_, int kc, int kd, int knext) {
         constexpr bool MM = decltype(mm_)::value, TAPS = decltype(taps_)::value;
-        constexpr int STAGE_SLOT = MM && TAPS ? S::SLOTS / 2 : -1;
-        const unsigned char* const bt = s_b + (kc & 1) * BCH_BYTES;
+        constexpr int PAR = decltype(par_)::value, TPAR = MM ? 1 - PAR : PAR; // (taps only: the prologue's chunk 0 in buffer PAR)
+        constexpr bool STAGE = MM && TAPS;
         const __half* const wn = wbase + (size_t)min(kc + 1, NCH - 1) * (KS * 512);
-        unsigned char* const bd = s_b + (kd & 1) * BCH_BYTES;
-        const unsigned char* const xs = s_halo + (kd & 1) * HALO_BYTES + x_off;
-        half8 fb[2][NT];
+        half8 fb[NT]; // ONE set: fragment j of step ks + 1 is requested right after the last MFMA of step ks that reads fragment j
         uint2 xr[S::ROWS][3];
         float v[3][4];
         auto read_row = [&](auto r_) {
             constexpr int r = decltype(r_)::value;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                xr[r][c] = *reinterpret_cast<const uint2*>(xs + ((r * IW + c * D) * CG) * 16);
+            {
+                const u32x2 t2 = *(lds_u2)(xb[c] + TPAR * HALO_BYTES + r * ROWB);
+                xr[r][c] = make_uint2(t2.x, t2.y);
+            }
+        };
+        auto read_fb = [&](auto ks_, auto j_) {
+            constexpr int ks = decltype(ks_)::value, j = decltype(j_)::value;
+            const u32x4 t4 = *(lds_u4)((fbase0 ^ (ks * 32)) + PAR * BCH_BYTES + j * 32 * CK * 2);
+            __builtin_memcpy(&fb[j], &t4, 16);
         };
         if (MM) { // the first MFMA's operands first: its s_waitcnt then only covers these three reads
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                fb[0][j] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(j * 32 + frow, fk));
+            static_for<NT>([&](auto j_) { read_fb(std::integral_constant<int, 0>{}, j_); });
             __builtin_amdgcn_sched_barrier(0);
         }
         if (TAPS) {
@@ -2886,14 +2913,11 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe2_kernel(const sep_params 
             constexpr int s = decltype(s_)::value;
             constexpr int ks = s / (TP * NT), i = (s % (TP * NT)) / NT, j = s % NT;
             if constexpr (MM) {
-                if constexpr (s % (TP * NT) == 0 && ks + 1 < KS) {
-#pragma unroll
-                    for (int jj = 0; jj < NT; ++jj)
-                        fb[(ks + 1) & 1][jj] = *reinterpret_cast<const half8*>(bt + lds_off<CK>(jj * 32 + frow, (ks + 1) * 2 + fk));
-                }
                 half8 fa;
                 __builtin_memcpy(&fa, &a[ks][i], 16);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+                if constexpr (i == TP - 1 && ks + 1 < KS) // fragment j is free: the next step's, three slots ahead of its first MFMA
+                    read_fb(std::integral_constant<int, (ks + 1) % KS>{}, std::integral_constant<int, j>{});
                 if constexpr (s % (TP * NT) == TP * NT - 1)
                     a_load(wn, ks);
             }
@@ -2908,12 +2932,14 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe2_kernel(const sep_params 
                             if constexpr (c == 0 && r + 2 < S::ROWS && (pi == 0 || S::pair_row(pi - 1) != r))
                                 read_row(std::integral_constant<int, r + 2>{});
                             if constexpr (tr == 0 && c == 0)
-                                mac4_f16_init(v[o], xr[r][c], wv[0], bs);
+                                mac4_f16_init(v[o], xr[r][c], tap_w(std::integral_constant<int, 0>{}), bs);
                             else
-                                mac4_f16(v[o], xr[r][c], wv[tr * 3 + c]);
+                                mac4_f16(v[o], xr[r][c], tap_w(std::integral_constant<int, tr * 3 + c>{}));
                             // the next chunk's weights / bias into the registers that just died
-                            if constexpr (u == S::last_unit_of_kernel_row(tr))
-                                w_load(knext, std::integral_constant<int, tr>{});
+                            if constexpr (u == S::last_unit_of_kernel_row(1))
+                                w_load_lo(knext);
+                            if constexpr (u == S::last_unit_of_kernel_row(2))
+                                w_load_hi(knext);
                             if constexpr (u == S::last_bias_unit())
                                 b_load(knext);
                         } else {
@@ -2922,14 +2948,20 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe2_kernel(const sep_params 
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
                                 h[e] = (_Float16)dw_act<true>(v[o][e], 0.f, dw_hi);
-                            *reinterpret_cast<half4*>(bd + b_off[o]) = h;
+                            typedef __attribute__((address_space(3))) half4* lds_h4;
+                            *(lds_h4)((o == 1 ? b_dst1 : b_dst0) + (o == 2 ? 2 * TW * CK * 2 : 0) + TPAR * BCH_BYTES) = h;
                         }
                     }
                 });
             }
-            if constexpr (s == STAGE_SLOT) {
-                to_lds(kd + 1);
-                hload(min(kd + 2, NCH - 1));
+            // halo chunk kd + 1: one piece per slot, registers -> LDS, then the piece of chunk kd + 2 is requested.  MID-interval: at the
+            // top of the loop the store's s_waitcnt would have to be vmcnt(0) - the waitcnt pass merges the loop entry, where the halo
+            // loads are the youngest requests, with the back edge - and would drain the weight-fragment prefetch every iteration; here
+            // the merged count only covers fragments requested half an interval earlier.  Every staging store is unconditional for the
+            // same reason (a branch around one drains vmcnt at the join): the pieces past the tile go to a dummy slot.
+            if constexpr (STAGE && s >= 10 && s < 10 + 2 * NLD && (s - 10) % 2 == 0) {
+                hstore1((s - 10) / 2, std::integral_constant<int, PAR>{});
+                hload1((s - 10) / 2, min(kd + 2, NCH - 1));
             }
             if constexpr (DBG && MM && TAPS && (s == 0 || s == 3 || s == 7 || s == 11 || s == 12 || s == 15 || s == 19 || s == 23)) {
                 // (timeline build only: stamps of intervals 2 and 3 of wavefront 0 of block 0 / wavefront 4 of block 1)
@@ -2942,6 +2974,8 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe2_kernel(const sep_params 
     };
     constexpr std::true_type YES{};
     constexpr std::false_type NO{};
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
 
 #define HP_STAMP()                                                                                   \
     if (p.pw.dbg && blockIdx.x < 2 && tid == (int)blockIdx.x * 256 && dbg_i < 40)                    \
@@ -2949,36 +2983,48 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe2_kernel(const sep_params 
     HP_STAMP();
     if (p.pw.dbg && tid == 0 && blockIdx.x < 1024) // every block's start / end on the shared 100 MHz clock
         p.pw.dbg[64 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-    hload(0);
-    {   // all depthwise weights ([9][C] halves in HBM -> [chunk][9][64]) and biases of the block, once
-        const int wpieces = 9 * (C / 8);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+        hload1(k, 0);
+    {   // all depthwise weights ([9][C] halves in HBM -> [chunk][quad][9 x 4]) and biases of the block, once
+        const int items = 9 * (C / 4);
 #pragma unroll 1
-        for (int i = tid; i < wpieces; i += NTHR) {
-            const int tp = i / (C / 8), cg = i - tp * (C / 8);
-            *reinterpret_cast<u32x4*>(s_dww + ((cg >> 3) * 9 + tp) * (CK * 2) + (cg & 7) * 16) = *reinterpret_cast<const u32x4*>(p.dw_w + (size_t)tp * C + cg * 8);
+        for (int i = tid; i < items; i += NTHR) {
+            const int tp = i / (C / 4), cq = i - tp * (C / 4);
+            *reinterpret_cast<uint2*>(lds + OFF_DWW + (cq >> 4) * DWW_CHUNK + (cq & 15) * QW + tp * 8) = *reinterpret_cast<const uint2*>(p.dw_w + (size_t)tp * C + cq * 4);
         }
         if (tid < C / 4)
-            *reinterpret_cast<u32x4*>(s_dwb + tid * 16) = *reinterpret_cast<const u32x4*>(p.dw_bias + tid * 4);
+            *reinterpret_cast<u32x4*>(lds + OFF_DWB + tid * 16) = *reinterpret_cast<const u32x4*>(p.dw_bias + tid * 4);
     }
-    to_lds(0);
-    hload(min(1, NCH - 1));
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        hstore1(k, P0);
+        hload1(k, min(1, NCH - 1));
+    }
     lds_barrier();
     HP_STAMP();
-    static_for<3>([&](auto t_) { w_load(0, t_); });
+    w_load_lo(0);
+    w_load_hi(0);
     b_load(0);
-    interval(NO, YES, 0, 0, min(1, NCH - 1));
-    to_lds(1);
-    hload(min(2, NCH - 1));
+    interval(NO, YES, P0, 0, 0, min(1, NCH - 1)); // taps of chunk 0: halo buffer 0 -> B buffer 0
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        hstore1(k, P1);
+        hload1(k, min(2, NCH - 1));
+    }
     lds_barrier();
     HP_STAMP();
+    // NCH - 1 combined intervals (an odd number: NCH is even), buffer parity = k & 1
+    interval(YES, YES, P0, 0, 1, min(2, NCH - 1));
+    lds_barrier();
 #pragma unroll 1
-    for (int k = 0; k + 1 < NCH; ++k) {
-        // (inside: halo chunk k + 2 -> the buffer chunk k's taps were done with before the last barrier; past the last chunk the store
-        //  repeats the last chunk into a buffer nobody reads any more)
-        interval(YES, YES, k, k + 1, min(k + 2, NCH - 1));
+    for (int k = 1; k + 1 < NCH; k += 2) {
+        interval(YES, YES, P1, k, k + 1, min(k + 2, NCH - 1));
+        lds_barrier();
+        interval(YES, YES, P0, k + 1, k + 2, min(k + 3, NCH - 1));
         lds_barrier();
     }
-    interval(YES, NO, NCH - 1, 0, 0);
+    interval(YES, NO, P1, NCH - 1, 0, 0);
     HP_STAMP();
     lds_barrier(); // (every wavefront past its reads of the B tiles: the slabs may overwrite them)
     int pb[NT], py[NT], px[NT];
@@ -3002,20 +3048,14 @@ template <int D, int CMAX>
 static hipError_t launch_sep_pipe(const sep_params& p, hipStream_t s)
 {
     const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 11) / 12;
-    static const bool anti_phase = getenv("HP_SEP_PIPE1") != nullptr; // A/B switch: the round-3 form (taps and MFMAs of a wavefront back to back)
-    if (anti_phase)
+    // the round-3 anti-phase form: A/B switch (HP_SEP_PIPE1=1) and the blocks with an odd number of 64-channel chunks
+    static const bool anti_phase = getenv("HP_SEP_PIPE1") != nullptr;
+    if (anti_phase || p.C % 128)
         HP_LAUNCH((sepconv_pipe_kernel<D, CMAX>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
     else if (p.pw.dbg) // HP_SEP_DBG: the build with s_memtime stamps inside the interval (tools/sep_timeline.py)
-        HP_LAUNCH((sepconv_pipe2_kernel<D, 1, true>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
-    else {
-        static const int first = getenv("HP_SEP_FIRST") ? atoi(getenv("HP_SEP_FIRST")) : 1; // A/B: slots at the head of an interval that carry no taps
-        if (first == 3)
-            HP_LAUNCH((sepconv_pipe2_kernel<D, 3>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
-        else if (first == 5)
-            HP_LAUNCH((sepconv_pipe2_kernel<D, 5>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
-        else
-            HP_LAUNCH((sepconv_pipe2_kernel<D, 1>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
-    }
+        HP_LAUNCH((sepconv_pipe3_kernel<D, true>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
+    else
+        HP_LAUNCH((sepconv_pipe3_kernel<D>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
     return hipGetLastError();
 }
 

@@ -555,6 +555,11 @@ struct val {
     int tensor = -1, coff = 0, C = 0, H = 0, W = 0;
     int producer = -1;    // the one layer that wrote exactly this value, or -1
     int post_act = 0;     // Sigmoid / Softplus waiting for the output conversion
+    // ... and the coordinate arithmetic the PoseProposal export ends in (hyperpose/Model/pose_proposal/model.py:111-119, restore_coor:
+    // x = (sigmoid + grid_x) * 32, w = sigmoid * 384): after the activation the engine adds the pixel's column (1) / row (2) index and
+    // multiplies by a scalar (hp_output_desc::grid / scale)
+    int post_grid = 0;
+    float post_scale = 1.f;
     int pad[4] = { 0, 0, 0, 0 }; // a Pad node waiting for its consumer (top, left, bottom, right)
     bool nhwc = false;    // IMAGE declared as N,H,W,3 and not yet transposed
     // post-processing views of a feature map (the PoseProposal / PifPaf exports end in Split / Reshape / Transpose nodes):
@@ -743,7 +748,7 @@ struct lowering {
     {
         if (v.kind != val::MAP)
             fail(&n, v.kind == val::IMAGE ? "cannot be applied to the network input directly" : "expects a feature map, got a constant");
-        if (v.post_act)
+        if (v.post_act || v.post_grid || v.post_scale != 1.f)
             fail(&n, "reads the result of a Sigmoid / Softplus (supported on graph outputs only)");
         if (!v.view.empty() || v.nhwc_view)
             fail(&n, "reads a reshaped / transposed feature map (Reshape and Transpose are supported as output post-processing only)");
@@ -755,6 +760,10 @@ struct lowering {
     void activation(const o_node& n, int act, float param, const std::vector<float>* alpha)
     {
         val x = get(n, 0);
+        // element-wise: the layout does not matter - exporters that keep TensorFlow's N,H,W,C order (tf2onnx) leave an activation between
+        // a Transpose pair; the pending N,H,W,C flag travels through it and is cancelled by the closing Transpose
+        const bool nhwc = x.kind == val::MAP && x.nhwc_view && x.view.empty();
+        x.nhwc_view = nhwc ? false : x.nhwc_view;
         need_map(n, x);
         if (!foldable(n.in[0], x) && !(x.producer >= 0 && m.layers[x.producer].op == HP_OP_CONV && m.layers[x.producer].act == HP_ACT_NONE
                 && m.layers[x.producer].in != 0 && uses[n.in[0]] == 1))
@@ -767,6 +776,7 @@ struct lowering {
             L.alpha_off = append(alpha->data(), alpha->size());
         if (L.res >= 0)
             L.res_before_act = 1; // conv -> Add -> activation
+        x.nhwc_view = nhwc;
         vals[n.out.at(0)] = x;
     }
 
@@ -941,9 +951,43 @@ struct lowering {
         vals[n.out.at(0)] = y;
     }
 
+    // Add / Sub / Mul / Div of a constant AFTER a Sigmoid / Softplus: only what the output conversion evaluates - a scalar factor, or the
+    // addition of the cell-index grid (a constant [.., H, W] whose value is the column or the row index) before any factor
+    bool post_arithmetic(const o_node& n, const val& x, const val& c, bool const_first)
+    {
+        if (x.kind != val::MAP || !(x.post_act || x.post_grid || x.post_scale != 1.f) || c.kind != val::CONST)
+            return false;
+        const o_tensor& t = *c.c;
+        const size_t cnt = t.count();
+        bool uniform = cnt >= 1;
+        for (size_t k = 1; k < cnt && uniform; ++k)
+            uniform = t.f[k] == t.f[0];
+        val y = x;
+        if (uniform && (n.op == "Mul" || (n.op == "Div" && !const_first))) {
+            y.post_scale = n.op == "Mul" ? x.post_scale * t.f.at(0) : x.post_scale / t.f.at(0);
+        } else if (n.op == "Add" && cnt == (size_t)x.H * x.W && x.post_grid == 0 && x.post_scale == 1.f && t.dims.size() >= 2
+            && t.dims[t.dims.size() - 1] == x.W && t.dims[t.dims.size() - 2] == x.H) {
+            bool is_x = true, is_y = true;
+            for (int yy = 0; yy < x.H; ++yy)
+                for (int xx = 0; xx < x.W; ++xx) {
+                    const float v = t.f[(size_t)yy * x.W + xx];
+                    is_x = is_x && v == (float)xx, is_y = is_y && v == (float)yy;
+                }
+            if (!is_x && !is_y)
+                fail(&n, "a constant map added after Sigmoid / Softplus must be the column-index or the row-index grid");
+            y.post_grid = (is_x && x.W > 1) || !is_y ? 1 : 2;
+        } else
+            fail(&n, "after Sigmoid / Softplus only `+ cell-index grid` followed by `* scalar` can be evaluated (the restore_coor form)");
+        y.producer = -1;
+        vals[n.out.at(0)] = y;
+        return true;
+    }
+
     void arithmetic(const o_node& n)
     {
         const val a = get(n, 0), b = get(n, 1);
+        if (post_arithmetic(n, a, b, false) || post_arithmetic(n, b, a, true))
+            return;
         if (a.kind == val::CONST && b.kind == val::CONST) { // unfolded exports: constants combined in the graph
             const o_tensor &ta = *a.c, &tb = *b.c;
             const size_t na = ta.count(), nb = tb.count();
@@ -1333,9 +1377,12 @@ struct lowering {
                     fail(&n, "only Clip(0, 6) and Clip(0, inf) are supported");
             } else if (op == "Sigmoid" || op == "Softplus") {
                 val x = get(n, 0);
+                const bool nhwc = x.kind == val::MAP && x.nhwc_view && x.view.empty(); // (element-wise: see activation())
+                x.nhwc_view = nhwc ? false : x.nhwc_view;
                 need_map(n, x);
                 x.post_act = op == "Sigmoid" ? HP_ACT_SIGMOID : HP_ACT_SOFTPLUS;
                 x.producer = -1;
+                x.nhwc_view = nhwc;
                 vals[n.out[0]] = x;
             } else if (op == "Add" || op == "Sub" || op == "Mul" || op == "Div")
                 arithmetic(n);
@@ -1470,7 +1517,8 @@ struct lowering {
                         x.nhwc_view = false;
                     else
                         fail(&n, "unsupported permutation of a feature map (N,C,H,W <-> N,H,W,C pairs and the identity are supported)");
-                    x.producer = -1;
+                    if (uses[n.in[0]] != 1)
+                        x.producer = -1; // (somebody else reads the map as it was: an activation behind the Transpose must not be folded into its producer)
                 } else
                     fail(&n, "cannot transpose this value");
                 vals[n.out[0]] = x;
@@ -1491,6 +1539,7 @@ struct lowering {
             if (v.nhwc_view)
                 fail(nullptr, "graph output '" + o.name + "' is left in N,H,W,C order: the parsers index [C,H,W]");
             m.output(o.name.c_str(), v.tensor, v.coff, v.C, v.post_act);
+            m.outputs.back().grid = v.post_grid, m.outputs.back().scale = v.post_scale == 1.f ? 0.f : v.post_scale; // (0 = no factor)
         }
         if (m.layers.empty())
             fail(nullptr, "the graph has no convolution");

@@ -70,20 +70,22 @@ def test_dominant_kernel_of_the_headline_has_both_clocks_and_traffic():
     assert "frac_rocprof" not in r and "avg_launch_us_rocprof" not in r
     assert 0.8 < cp["avg_launch_us"] / r["avg_launch_us"] < 1.35
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0
-    assert set(d["workloads"]) == {"configs[0]", "configs[2]", "configs[3]", "configs[4]"}
+    assert set(d["workloads"]) == {"configs[0]", "configs[2]", "configs[3]", "configs[4]", "configs[1]/fp32"}
+    f32 = d["workloads"]["configs[1]/fp32"]
+    assert f32["dtype"].startswith("f32") and f32["roofline"]["mfma_peak_tflops"] == 157.3 and f32["value"] > 0
 
 
 def _check_roofline(r):
-    ridge = r["ridge_flop_per_byte"]
-    assert abs(ridge - 312.5) < 1e-6
+    ridge, peak = r["ridge_flop_per_byte"], r["mfma_peak_tflops"]
+    assert peak in (2500.0, 157.3) and abs(ridge - peak * 1e12 / 8e12) < 0.01
     x = r["flops_per_launch"] / r["algorithmic_bytes_per_launch"]
     assert abs(x - r["intensity_flop_per_byte"]) <= 0.01 * x + 0.1
     assert r["bound"] == ("mfma" if r["intensity_flop_per_byte"] >= ridge else "hbm")
-    assert r["unit"] == ("TFLOP/s" if r["bound"] == "mfma" else "GB/s") and r["peak"] == (2500.0 if r["bound"] == "mfma" else 8000.0)
+    assert r["unit"] == ("TFLOP/s" if r["bound"] == "mfma" else "GB/s") and r["peak"] == (peak if r["bound"] == "mfma" else 8000.0)
     assert abs(r["frac"] - (r["frac_mfma"] if r["bound"] == "mfma" else r["frac_hbm"])) < 1e-9
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
     t = r["avg_launch_us"] * 1e-6
-    assert abs(r["frac_mfma"] - r["flops_per_launch"] / t / 2.5e15) < 5e-3
+    assert abs(r["frac_mfma"] - r["flops_per_launch"] / t / (peak * 1e12)) < 5e-3
     assert abs(r["frac_hbm"] - r["algorithmic_bytes_per_launch"] / t / 8e12) < 5e-3
     assert 0 < r["mfma_frac_ceiling_at_hbm_peak"] <= 1.0
 

@@ -251,3 +251,98 @@ def test_post_processing_operators_of_the_exported_heads():
                    [W.value_info("x", ["N", 3, 6, 8])], [W.value_info("y", ["N", 5, 48])])
     with pytest.raises(HpError):
         E.Model.from_onnx(bad3)
+
+
+# ---- a TensorFlow-export-shaped graph (every released HyperPose model is a TensorFlow export, /root/reference/scripts/downloader.py:12-21):
+# the idioms tf2onnx leaves behind that PyTorch's exporter never emits
+def tf2onnx_like_model(h=64, w=96, seed=5):
+    """N,H,W,3 input -> Transpose -> Conv(auto_pad=SAME_UPPER, stride 2, no bias) -> BatchNormalization (NOT folded) -> Relu
+    -> depthwise Conv (group = C) + BatchNormalization + Clip(min, max as INPUTS: relu6) -> 1x1 Conv + BN -> Transpose to N,H,W,C ->
+    Relu (in N,H,W,C) -> Transpose back -> 1x1 head Conv -> Sigmoid -> Split into (pc, px, py, pw) -> restore_coor: px = (px + grid_x) * 32,
+    py = (py + grid_y) * 32, pw = pw * W_in  (hyperpose/Model/pose_proposal/model.py:111-119).  Returns (bytes, torch reference)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(seed)
+    C0, C1, K = 16, 24, 2
+    def bn(c):
+        return [rng.uniform(0.5, 1.5, c), rng.normal(0, 0.2, c), rng.normal(0, 0.2, c), rng.uniform(0.5, 2.0, c)]
+    w0 = rng.normal(0, 0.3, (C0, 3, 3, 3)).astype(np.float32)
+    wd = rng.normal(0, 0.4, (C0, 1, 3, 3)).astype(np.float32)
+    w1 = rng.normal(0, 0.3, (C1, C0, 1, 1)).astype(np.float32)
+    wh = rng.normal(0, 0.3, (4 * K, C1, 1, 1)).astype(np.float32)
+    bh = rng.normal(0, 0.2, 4 * K).astype(np.float32)
+    bn0, bnd, bn1 = bn(C0), bn(C0), bn(C1)
+    gh, gw = -(-(h // 1) // 2), -(-w // 2)  # SAME, stride 2
+    gx = np.tile(np.arange(gw, dtype=np.float32), (gh, 1))
+    gy = np.tile(np.arange(gh, dtype=np.float32)[:, None], (1, gw))
+    init, nodes = [], []
+    def const(name, arr, **kw):
+        arr = np.asarray(arr, np.float32)
+        init.append(W.tensor(name, list(arr.shape), arr.ravel().tolist(), **kw))
+    def bn_node(x, y, name, ps, c):
+        for k, tag in enumerate(("scale", "B", "mean", "var")):
+            const(f"{name}_{tag}", ps[k])
+        nodes.append(W.node("BatchNormalization", [x] + [f"{name}_{t}" for t in ("scale", "B", "mean", "var")], [y], [W.attr_float("epsilon", 1e-3)], name=name))
+    const("w0", w0), const("wd", wd, raw=True), const("w1", w1), const("wh", wh), const("bh", bh)
+    const("lo", np.zeros(())), const("hi", np.full((), 6.0)), const("gx", gx[None, None]), const("gy", gy[None, None])
+    const("s32", np.full((), 32.0)), const("sw", np.full((1,), float(w)))
+    init.append(W.tensor("split", [4], [K] * 4, int64=True))
+    same = W.attr_str("auto_pad", "SAME_UPPER")
+    nodes.append(W.node("Transpose", ["image:0"], ["x_nchw"], [W.attr_ints("perm", [0, 3, 1, 2])]))
+    nodes.append(W.node("Conv", ["x_nchw", "w0"], ["c0"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_ints("strides", [2, 2]), same], name="conv0"))
+    bn_node("c0", "b0", "bn0", bn0, C0)
+    nodes.append(W.node("Relu", ["b0"], ["r0"]))
+    nodes.append(W.node("Conv", ["r0", "wd"], ["cd"], [W.attr_ints("kernel_shape", [3, 3]), W.attr_int("group", C0), same], name="dw"))
+    bn_node("cd", "bd", "bnd", bnd, C0)
+    nodes.append(W.node("Clip", ["bd", "lo", "hi"], ["rd"]))
+    nodes.append(W.node("Conv", ["rd", "w1"], ["c1"], [W.attr_ints("kernel_shape", [1, 1])], name="pw"))
+    bn_node("c1", "b1", "bn1", bn1, C1)
+    nodes.append(W.node("Transpose", ["b1"], ["b1_nhwc"], [W.attr_ints("perm", [0, 2, 3, 1])]))
+    nodes.append(W.node("Relu", ["b1_nhwc"], ["r1_nhwc"]))
+    nodes.append(W.node("Transpose", ["r1_nhwc"], ["r1"], [W.attr_ints("perm", [0, 3, 1, 2])]))
+    nodes.append(W.node("Conv", ["r1", "wh", "bh"], ["head"], [W.attr_ints("kernel_shape", [1, 1])], name="head"))
+    nodes.append(W.node("Sigmoid", ["head"], ["sg"]))
+    nodes.append(W.node("Split", ["sg", "split"], ["pc", "sx", "sy", "sw_"], [W.attr_int("axis", 1)]))
+    nodes.append(W.node("Add", ["sx", "gx"], ["ax"]))
+    nodes.append(W.node("Mul", ["ax", "s32"], ["px"]))
+    nodes.append(W.node("Add", ["gy", "sy"], ["ay"]))      # constant first
+    nodes.append(W.node("Mul", ["s32", "ay"], ["py"]))
+    nodes.append(W.node("Mul", ["sw_", "sw"], ["pw"]))
+    outs = [W.value_info(nm, ["N", K, gh, gw]) for nm in ("pc", "px", "py", "pw")]
+    raw = W.model(nodes, init, [W.value_info("image:0", ["N", h, w, 3])], outs, opset=13)
+
+    def ref(x_nhwc):
+        t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+        def bnf(x, ps):
+            return F.batch_norm(x, t(ps[2]), t(ps[3]), t(ps[0]), t(ps[1]), False, 0.0, 1e-3)
+        x = t(x_nhwc).permute(0, 3, 1, 2)
+        x = F.relu(bnf(F.conv2d(F.pad(x, (0, 1, 0, 1)), t(w0), None, stride=2), bn0))
+        x = torch.clamp(bnf(F.conv2d(F.pad(x, (1, 1, 1, 1)), t(wd), None, groups=C0), bnd), 0, 6)
+        x = F.relu(bnf(F.conv2d(x, t(w1)), bn1))
+        sg = torch.sigmoid(F.conv2d(x, t(wh), t(bh)))
+        pc, sx, sy, sw_ = torch.split(sg, K, 1)
+        return {"pc": pc.numpy(), "px": ((sx + t(gx)) * 32).numpy(), "py": ((sy + t(gy)) * 32).numpy(), "pw": (sw_ * float(w)).numpy()}
+    return raw, ref
+
+
+def test_tensorflow_export_idioms_are_lowered():
+    raw, ref = tf2onnx_like_model()
+    m = E.Model.from_onnx(raw)
+    assert (m.in_w, m.in_h) == (96, 64)
+    ops = [(L.op, L.cin, L.cout, L.kh, L.stride, L.act) for L in m.layers]
+    # BatchNorm folded away, Clip(0, 6) and the Relu inside the Transpose sandwich fused, no copy layers
+    assert ops == [(E.OP_CONV, 3, 16, 3, 2, E.ACT_RELU), (E.OP_DWCONV, 16, 16, 3, 1, E.ACT_RELU6), (E.OP_CONV, 16, 24, 1, 1, E.ACT_RELU),
+                   (E.OP_CONV, 24, 8, 1, 1, E.ACT_NONE)], ops
+    assert not any(L.pad_explicit for L in m.layers)   # auto_pad SAME_UPPER == the engine's TF "SAME"
+    outs = {o.name: (o.coff, o.channels, o.act, o.grid, round(o.scale, 3)) for o in m.outputs}
+    assert outs == {b"pc": (0, 2, E.ACT_SIGMOID, 0, 0.0), b"px": (2, 2, E.ACT_SIGMOID, 1, 32.0), b"py": (4, 2, E.ACT_SIGMOID, 2, 32.0),
+                    b"pw": (6, 2, E.ACT_SIGMOID, 0, 96.0)}, outs
+    x = np.random.default_rng(0).random((2, 64, 96, 3), dtype=np.float32)
+    want = ref(x)
+    got = ref_net.run(m.layers, m.outputs, m.weights, frames_f32=np.ascontiguousarray(x.transpose(0, 3, 1, 2)), match_fp16=False,
+                      mean=m.mean, inv_std=m.inv_std)
+    for k, v in want.items():
+        np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=1e-4)
+    # what the conversion cannot evaluate is refused with the node named, not silently dropped
+    bad = raw.replace(b"s32", b"gx\x00", 1) if False else None
+    del bad
