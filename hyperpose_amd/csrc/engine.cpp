@@ -591,7 +591,7 @@ int hp_engine::build(const hp_engine_desc* d)
                     return HP_ERR_INVALID;
                 std::copy(bb, bb + Pn.cout, b2.begin());
             }
-            st.op = OP_MLPHEAD;
+            st.op = OP_MLPHEAD, st.n_layers = 2; // (covers layers i and i + 1: the passes below must see every layer a step touches)
             auto& p = st.hp_;
             void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
             HP_TRY(upload(w1p.data(), w1p.size() * sizeof(__half), &d0));
@@ -729,7 +729,7 @@ int hp_engine::build(const hp_engine_desc* d)
                     return HP_ERR_INVALID;
                 std::copy(b, b + Pn.cout, pbias.begin());
             }
-            st.op = OP_SEPCONV;
+            st.op = OP_SEPCONV, st.n_layers = 2;
             auto& p = st.sp;
             void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
             HP_TRY(upload(dpacked.data(), dpacked.size() * sizeof(__half), &d0));
@@ -1082,7 +1082,7 @@ int hp_engine::build(const hp_engine_desc* d)
             const auto &x = a.hp_, &y = b.hp_;
             if (x.in.p != y.in.p || x.in.coff != y.in.coff || x.K1 != y.K1 || x.H != y.H || x.W != y.W || x.pw.Cout > 64 || y.pw.Cout > 64)
                 continue;
-            a.hp2_ = b.hp_, a.paired = true;
+            a.hp2_ = b.hp_, a.paired = true, a.n_layers += b.n_layers;
             a.flops += b.flops, a.bytes += b.bytes;
             steps.erase(steps.begin() + k + 1);
         }

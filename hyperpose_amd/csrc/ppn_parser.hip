@@ -233,6 +233,9 @@ __global__ __launch_bounds__(64) void ppn_assemble_kernel(const int* __restrict_
     __shared__ float s_conf[PPN_MAXC];
     __shared__ unsigned short s_head[64 * 64], s_tail[64 * 64], s_val[PPN_MAXE], s_next[PPN_MAXE];
     __shared__ int s_np, s_flags, s_cmd, s_arg, s_i, s_ne;
+    // ~126 KB of static LDS (the pose list alone is 256 x 292 B): this kernel is written for gfx950's 160 KB per CU (one block per CU)
+    static_assert(sizeof(s_root) + sizeof(s_pose) + sizeof(s_ord) + sizeof(s_conf) + sizeof(s_head) + sizeof(s_tail) + sizeof(s_val) + sizeof(s_next) + 64
+            <= 160 * 1024, "ppn_assemble_kernel needs the 160 KB LDS of gfx950");
     const int f = blockIdx.x, lane = threadIdx.x;
     const int* const h = hdr + (size_t)f * HDR;
     const ppn_box* const fb = boxes + (size_t)f * PPN_K * PPN_MAXB;
@@ -693,9 +696,12 @@ int hp_ppn_collect(hp_ppn* p, hp_human* out, int cap_per_frame, int* n_out)
         // rare path: fetch the compacted lists of the batch and run the reference's statements on the host
         if (p->h_boxes.empty())
             p->h_boxes.resize((size_t)p->max_batch * PPN_K * PPN_MAXB), p->h_cands.resize((size_t)p->max_batch * PPN_LIMBS * PPN_MAXC);
-        HP_HIP_TRY(hipMemcpy(p->h_hdr.data(), p->d_hdr.p, (size_t)n * HDR * sizeof(int), hipMemcpyDeviceToHost));
-        HP_HIP_TRY(hipMemcpy(p->h_boxes.data(), p->d_boxes.p, (size_t)n * PPN_K * PPN_MAXB * sizeof(ppn_box), hipMemcpyDeviceToHost));
-        HP_HIP_TRY(hipMemcpy(p->h_cands.data(), p->d_cands.p, (size_t)n * PPN_LIMBS * PPN_MAXC * sizeof(ppn_cand), hipMemcpyDeviceToHost));
+        // (on the parser's own stream, then one wait: a plain hipMemcpy runs on the legacy stream and fails - in this thread AND in the
+        //  capturing one - while another pipe's engine is recording its hipGraph; the batch's kernels completed before collect got here)
+        HP_HIP_TRY(hipMemcpyAsync(p->h_hdr.data(), p->d_hdr.p, (size_t)n * HDR * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        HP_HIP_TRY(hipMemcpyAsync(p->h_boxes.data(), p->d_boxes.p, (size_t)n * PPN_K * PPN_MAXB * sizeof(ppn_box), hipMemcpyDeviceToHost, p->stream));
+        HP_HIP_TRY(hipMemcpyAsync(p->h_cands.data(), p->d_cands.p, (size_t)n * PPN_LIMBS * PPN_MAXC * sizeof(ppn_cand), hipMemcpyDeviceToHost, p->stream));
+        HP_HIP_TRY(hipStreamSynchronize(p->stream));
         std::vector<int> todo;
         for (int f : job.frames) {
             if (p->h_hdr[(size_t)f * HDR + PPN_K + PPN_LIMBS] != 0) { // (host-tail mode: the extract kernel's own overflow flags)

@@ -96,14 +96,19 @@ public:
     {
         int nf = 0;
         const int rc = hp_pipeline_collect(m_pl, m_out.data(), CAP, m_n.data(), &nf);
-        if (rc == HP_ERR_CAPACITY)
-            ++m_truncated; // a frame exceeded a hard list limit of the parser: its pose list is cut, the batch is otherwise complete
-        else
+        if (rc != HP_ERR_CAPACITY)
             detail::hp_check(rc);
+        // HP_ERR_CAPACITY: a frame exceeded a hard list limit of the parser - its pose list is cut, the batch is otherwise complete.  The
+        // frames concerned are the ones whose list comes back full (the parser stops at the limit).
         std::vector<pose_set> r(nf);
-        for (int i = 0; i < nf; ++i)
+        size_t cut = 0;
+        for (int i = 0; i < nf; ++i) {
+            cut += m_n[i] >= CAP;
             for (int k = 0; k < m_n[i] && k < CAP; ++k)
                 r[i].push_back(detail::to_human(m_out[(size_t)i * CAP + k]));
+        }
+        if (rc == HP_ERR_CAPACITY)
+            m_truncated += cut ? cut : 1; // frames, not batches (at least the one the parser reported)
         return r;
     }
 
@@ -154,7 +159,10 @@ public:
             m_shutdown = true;
         }
         notify_everyone();
-        m_async_sinks.clear(); // joins the sink threads (they leave on m_shutdown)
+        {
+            std::lock_guard<std::mutex> lk(m_mu_sinks);
+            m_async_sinks.clear(); // joins the sink threads (they leave on m_shutdown)
+        }
         if (m_input_worker.joinable())
             m_input_worker.join();
         if (m_worker.joinable())
@@ -180,7 +188,18 @@ public:
         template <typename S>
         async_handler& operator>>(S&& sink)
         {
-            m_stream.m_async_sinks.emplace_back([&s = m_stream, &sink] { s.write_to(sink); });
+            // (the sink thread must not let an exception escape - std::terminate -: a failure of the stream is kept for the next call
+            // that can report it)
+            std::lock_guard<std::mutex> lk(m_stream.m_mu_sinks);
+            m_stream.m_async_sinks.emplace_back([&s = m_stream, &sink] {
+                try {
+                    s.write_to(sink);
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk2(s.m_mu);
+                    if (s.m_error.empty())
+                        s.m_error = e.what();
+                }
+            });
             return *this;
         }
     };
@@ -230,8 +249,10 @@ private:
     {
         {
             std::lock_guard<std::mutex> lk(m_mu);
-            if (m_shutdown)
+            if (m_shutdown) { // the input thread is gone: the source would be queued and never read
                 rethrow_or_ignore();
+                throw std::runtime_error("hyperpose::stream: the stream is closed, the source was not accepted");
+            }
             ++m_pending_inputs;
             m_input_jobs.push_back(std::move(job));
         }
@@ -480,7 +501,7 @@ private:
     const size_t m_queue_max;
     hip_stream m_gpu;
 
-    std::mutex m_mu;
+    std::mutex m_mu, m_mu_sinks; // (m_mu_sinks: the list of sink threads alone, never held together with a wait)
     std::condition_variable m_cv_in, m_cv_out, m_cv_space, m_cv_out_space, m_cv_jobs;
     std::deque<cv::Mat> m_in;
     std::deque<item> m_out;

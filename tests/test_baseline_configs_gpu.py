@@ -28,6 +28,7 @@ def _check_full_size_against_torch_gpu(m, w, frames, full, probe, rel, abs_):
     fp16 storage points matched, so what remains is fp32 summation order: |err| <= rel * max|ref| + abs."""
     import torch
     assert torch.cuda.is_available()
+    worst = 0.0
     for i in probe:
         ref = ref_net.run(m.layers, m.outputs, w, frames_u8=frames[i:i + 1], match_fp16=True, mean=m.mean, inv_std=m.inv_std, device="cuda")
         names = sorted(ref)
@@ -36,8 +37,10 @@ def _check_full_size_against_torch_gpu(m, w, frames, full, probe, rel, abs_):
             r, g = ref[nm][0], full[i][k]
             assert r.shape == g.shape, (nm, r.shape, g.shape)
             err, scale = float(np.abs(g - r).max()), float(np.abs(r).max())
+            worst = max(worst, err / max(scale, 1e-30))
             assert err <= rel * scale + abs_, f"frame {i} output {nm}: max err {err:.4g} vs scale {scale:.4g}"
     torch.cuda.empty_cache()
+    print(f"\n{m.arch} @ {m.in_h}x{m.in_w}: worst |err| / max|ref| over the probed frames {worst:.2e} (bound {rel:.0e})")
 
 
 def _check_invariance(eng, frames, probe=(0, 5)):
@@ -48,6 +51,33 @@ def _check_invariance(eng, frames, probe=(0, 5)):
             assert np.array_equal(a, b), f"frame {i} differs between batch and single run"
     assert all(np.isfinite(a).all() for m in full for a in m)
     return full
+
+
+def test_config0_tinyvgg_single_image_368x432(hp):
+    """BASELINE.json configs[0] at its full size: TinyVGG-V2 + PAF parser on ONE 368 x 432 image (the only GPU test of this
+    topology ran at 64 x 48)."""
+    from hyperpose_amd.parser import Paf
+    m = E.Model("lw_openpose_vggtiny", 432, 368)
+    w = m.init_weights(20240)
+    eng = E.Engine.from_model(m, w, max_batch=1)
+    fr = synth.images_u8(synth.rng_for(0), 1, 368, 432)
+    full = _maps(eng, fr)
+    assert full[0][0].shape == (19, 46, 54) and full[0][1].shape == (38, 46, 54) and all(np.isfinite(a).all() for a in full[0])
+    _check_full_size_against_torch_gpu(m, w, fr, full, (0,), 1e-2, 2e-3)
+    again = _maps(eng, fr)
+    assert all(np.array_equal(a, b) for a, b in zip(full[0], again[0]))   # deterministic
+    # the parser on the device-resident maps == the reference's own parser on the same maps
+    eng.inference(fr)
+    p = Paf(max_batch=1)
+    (_, cs, cp), (_, ps, pp) = eng.outputs
+    humans = p.process_batch_device(cp, pp, 1, cs, ps)
+    oh, _, _ = loader.ref_paf_process(full[0][0], full[0][1])
+    assert humans[0].tobytes() == oh.tobytes()
+    # and the fp32-faithful engine of the same topology at this size
+    e32 = E.Engine.from_model(m, w, max_batch=1, dtype="f32")
+    ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=False, mean=m.mean, inv_std=m.inv_std, device="cuda")
+    for nm, arr in e32.inference(fr)[0]:
+        assert float(np.abs(arr - ref[nm][0]).max()) <= 1e-4 * float(np.abs(ref[nm]).max()) + 1e-6, nm
 
 
 def test_config1_lw_openpose_b8_368x432(hp):

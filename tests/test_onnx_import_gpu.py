@@ -84,3 +84,23 @@ def test_post_processing_operators_run(hp):
         named = dict(got[f])
         assert np.allclose(named["out_a"], y[f, :4], atol=2e-3)
         assert np.allclose(named["out_b"], y[f, 4:], atol=2e-3)   # [8, 6, 8] = the [2, 4, 6, 8] view's memory
+
+
+def test_tensorflow_export_idioms_run_on_both_engines(hp):
+    """tests/test_onnx_import.py::tf2onnx_like_model (N,H,W,3 input + Transpose, auto_pad SAME_UPPER, un-folded BatchNormalization, Clip with
+    input bounds, an activation inside a Transpose sandwich, Sigmoid -> Split -> restore_coor arithmetic) through the importer and the
+    engine in both precisions, against the PyTorch evaluation of the same graph."""
+    import test_onnx_import as T
+    raw, ref = T.tf2onnx_like_model()
+    m = E.Model.from_onnx(raw)
+    x = np.random.default_rng(2).random((2, 64, 96, 3), dtype=np.float32)
+    want = ref(x)
+    nchw = np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+    for dtype, rel in (("f32", 1e-4), ("f16", 5e-3)):
+        eng = E.Engine.from_model(m, m.weights, max_batch=2, dtype=dtype)
+        got = eng.inference_f32(nchw)
+        for f in range(2):
+            named = dict(got[f])
+            assert sorted(named) == sorted(want)
+            for k, v in want.items():
+                assert np.abs(named[k] - v[f]).max() <= rel * np.abs(v).max() + rel, (dtype, k)
