@@ -1485,8 +1485,12 @@ __global__ __launch_bounds__(512) void conv1x1_big_kernel(const conv_params p)
     // (the producers are gone and the last barrier of the loop is behind every read of the B buffers: the wave-private slabs may
     // overlay them; the staged epilogue synchronises inside a wavefront only)
     // (a residual parked in LDS by the producers while the MFMAs run - no HBM round trip after the last MFMA - was built and measured:
-    // 205 -> 223 us for ResNet's 256 -> 1024 expansion.  That layer is bound by what its blocks pull through the L2s - 1.2 GB of weights
-    // per launch for 64-pixel tiles, next to 0.95 GB of activations - not by its epilogue.)
+    // 205 -> 223 us for ResNet's 256 -> 1024 expansion.  Round 4 then built the weights-stationary form of this kernel for that layer - one
+    // persistent block per CU, its 256 x 256 weight fragments in registers, 1.2 GB of L2 weight traffic per launch gone - in three variants
+    // (staged epilogue in the consumers; ALL global traffic incl. the output stores in the producer wavefronts; shortcut read in 512-byte
+    // runs): 231 / 218 / 228 us against 217 - 220 us for this kernel in the same probe.  The layer moves its 709 MB at 3.3 - 3.5 TB/s
+    // whatever the block structure: neither the weights, nor the matrix pipe (removing every MFMA: 227 us), nor who issues the stores
+    // decide it.  DESIGN.md section 7, "weights-stationary 1 x 1"; the kernels were removed.)
     if (p.res.p) // uniform
         conv_epilogue_wide<TM, NTP>(p, acc, m_wave, lane, lds + wave * (NTP * stage_geom<TM>::SLAB), pb, py, px, pv);
     else

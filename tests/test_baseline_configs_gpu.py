@@ -25,7 +25,12 @@ def _maps(eng, frames):
 def _check_full_size_against_torch_gpu(m, w, frames, full, probe, rel, abs_):
     """Oracle parity AT FULL SIZE: the probed frames of the batch against oracle/ref_net.py evaluated in fp32 by PyTorch's own GPU
     kernels (MIOpen / rocBLAS: an implementation independent of libhp_hip.so; the CPU evaluation would take minutes per frame).
-    fp16 storage points matched, so what remains is fp32 summation order: |err| <= rel * max|ref| + abs."""
+    fp16 storage points matched, so what remains is fp32 summation order and the fp16 rounding flips it causes downstream:
+    |err| <= rel * max|ref| + abs.  Measured on MI355X in round 4 (this function prints it): 2.3e-3 (configs[0]), 2.5e-3 ([1]), 2.0e-3 ([2]),
+    3.1e-3 ([3]: 53 layers, the deepest path) and 9.6e-4 ([4]) - against <= 2e-3 at the small sizes of test_engine_gpu.py.  The difference
+    is statistics, not a layer: an output map of 54 x 96 x 57 values (or 144 cells x 1 485 channels) samples the tail of the same
+    per-value error distribution 100 x more often than a 6 x 8 map, and every extra layer adds its own 2^-11 rounding flips.  The bound
+    is therefore 6e-3 for every configuration (2 x the worst observed), not the 1e-2 / 2e-2 of round 3."""
     import torch
     assert torch.cuda.is_available()
     worst = 0.0
@@ -63,7 +68,7 @@ def test_config0_tinyvgg_single_image_368x432(hp):
     fr = synth.images_u8(synth.rng_for(0), 1, 368, 432)
     full = _maps(eng, fr)
     assert full[0][0].shape == (19, 46, 54) and full[0][1].shape == (38, 46, 54) and all(np.isfinite(a).all() for a in full[0])
-    _check_full_size_against_torch_gpu(m, w, fr, full, (0,), 1e-2, 2e-3)
+    _check_full_size_against_torch_gpu(m, w, fr, full, (0,), 6e-3, 2e-3)
     again = _maps(eng, fr)
     assert all(np.array_equal(a, b) for a, b in zip(full[0], again[0]))   # deterministic
     # the parser on the device-resident maps == the reference's own parser on the same maps
@@ -87,7 +92,7 @@ def test_config1_lw_openpose_b8_368x432(hp):
     fr = synth.images_u8(synth.rng_for(1), 8, 368, 432)
     fr[3] = fr[1]
     full = _check_invariance(eng, fr)
-    _check_full_size_against_torch_gpu(m, m.init_weights(20241), fr, full, (0, 7), 1e-2, 2e-3)
+    _check_full_size_against_torch_gpu(m, m.init_weights(20241), fr, full, (0, 7), 6e-3, 2e-3)
     assert np.array_equal(full[3][0], full[1][0]) and not np.array_equal(full[2][0], full[1][0])
     # parser on the device-resident DNN output == oracle on the same maps
     eng.inference(fr)
@@ -114,7 +119,7 @@ def test_config2_openpose_vgg19_b16_432x768(hp):
     fr = synth.images_u8(synth.rng_for(2), 16, 432, 768)
     full = _check_invariance(eng, fr, probe=(0, 9))
     assert full[0][0].shape == (19, 54, 96) and full[0][1].shape == (38, 54, 96)
-    _check_full_size_against_torch_gpu(m, m.init_weights(20242), fr, full, (0, 15), 1e-2, 2e-3)
+    _check_full_size_against_torch_gpu(m, m.init_weights(20242), fr, full, (0, 15), 6e-3, 2e-3)
     eng.inference(fr)
     p = Paf(max_batch=16)
     (_, cs, cp), (_, ps, pp) = eng.outputs
@@ -140,7 +145,7 @@ def test_config3_pose_proposal_resnet50_b32_384(hp):
     fr = synth.images_u8(synth.rng_for(3), 32, 384, 384)
     full = _check_invariance(eng, fr, probe=(0, 20))
     assert [a.shape for a in full[0]] == [(18, 12, 12)] * 6 + [(17 * 81, 12, 12)]
-    _check_full_size_against_torch_gpu(m, m.init_weights(20243), fr, full, (0, 31), 2e-2, 5e-3)
+    _check_full_size_against_torch_gpu(m, m.init_weights(20243), fr, full, (0, 31), 6e-3, 2e-3)
     eng.inference(fr)
     parser = PoseProposal((384, 384), max_batch=32)
     humans = parser.process_batch([p for _, _, p in eng.outputs], on_device=True, n=32, conf_shape=(18, 12, 12), edge_shape=(17, 9, 9, 12, 12))
@@ -157,7 +162,7 @@ def test_config4_pifpaf_resnet50_b64_385(hp):
     fr = synth.images_u8(synth.rng_for(4), 64, 385, 385)
     full = _check_invariance(eng, fr, probe=(0, 40))
     assert full[0][0].shape == (171, 49, 49) and full[0][1].shape == (85, 49, 49)
-    _check_full_size_against_torch_gpu(m, m.init_weights(20244), fr, full, (0, 63), 2e-2, 5e-3)
+    _check_full_size_against_torch_gpu(m, m.init_weights(20244), fr, full, (0, 63), 6e-3, 2e-3)
     eng.inference(fr)
     parser = PifPaf(385, 385, max_batch=64)
     humans = parser.process_batch(eng.outputs[0][2], eng.outputs[1][2], on_device=True, n=64, fh=49, fw=49)

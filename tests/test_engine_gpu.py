@@ -158,6 +158,23 @@ def test_mfma_conv_shapes(hp, cin, cout, k, stride, dil):
     _check(got, ref, 3)
 
 
+@pytest.mark.parametrize("cout,with_res,h,w,n", [(1024, True, 64, 64, 4), (1024, False, 49, 49, 7), (512, True, 64, 67, 8), (256, True, 96, 100, 7)])
+def test_pixel_block_gemm_through_the_fast_epilogue(hp, cout, with_res, h, w, n):
+    """conv1x1_big_kernel on ResNet-sized expansions (256 input channels), with and without the shortcut, ragged last tile, 1 / 2 / 4
+    channel groups.  (`scale = 2` keeps the output from being a plain one: the convolution then writes its fp16 tensor through the fast
+    epilogue - a plain network output takes the generic kernel with the fused fp32 copy, which is what test_mfma_conv_shapes reaches.)"""
+    net = Net(cout + h)
+    t0 = net.conv(0, 3, 256, 3, 1)
+    r = net.conv(0, 3, cout, 1, 1) if with_res else -1
+    t = net.conv(t0, 256, cout, 1, 1, act=E.ACT_RELU, res=r, res_before_act=1 if with_res else 0)
+    fr = _frames(n, h, w, seed=cout + w)
+    eng, got, ref = _run_both(net, [Out("y", t, 0, cout, scale=2.0)], fr, h, w)
+    _check(got, ref, n)
+    assert any(5200000 <= q["tile"] < 5300000 for q in eng.profile(n, 1))
+    alone = eng.inference(fr[n - 1:n])[0][0][1]
+    assert np.array_equal(alone, got[n - 1][0][1])   # batch invariance, bit for bit
+
+
 def test_mfma_conv_is_not_transposed(hp):
     """Asymmetric, structured weights (not random): catches row/col or channel-order mix-ups exactly."""
     net = Net(0)

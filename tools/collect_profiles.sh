@@ -7,6 +7,7 @@ tag=${1:-r01}
 cfg=${2:-1}
 sfx=""
 [ "$cfg" != "1" ] && sfx="_config$cfg"
+[ "$cfg" == "5" ] && sfx="_config1_fp32"
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out
 mkdir -p $out

@@ -1,6 +1,6 @@
 """Per-layer HIP-event timing table for a built-in topology (hp_engine_profile) — run on the GPU box.
 
-    python tools/profile_layers.py [arch] [w] [h] [batch]
+    python tools/profile_layers.py [arch] [w] [h] [batch] [f16|f32]
 """
 import os
 import sys
@@ -13,12 +13,13 @@ arch = sys.argv[1] if len(sys.argv) > 1 else "lw_openpose_mobilenet"
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 432
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 368
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+dtype = sys.argv[5] if len(sys.argv) > 5 else "f16"
 _lib.init(0)
 m = Model(arch, w, h)
-eng = Engine.from_model(m, m.init_weights(1), max_batch=n)
+eng = Engine.from_model(m, m.init_weights(1), max_batch=n, dtype=dtype)
 prof = eng.profile(n, iters=20)                   # each step 20x back to back (weights warm in L2)
 seq = eng.profile(n, iters=20, in_sequence=True)  # the schedule in order, events in between (what an inference sees)
-eng2 = Engine.from_model(m, m.init_weights(1), max_batch=n)
+eng2 = Engine.from_model(m, m.init_weights(1), max_batch=n, dtype=dtype)
 pair = eng.profile(n, iters=20, pair=eng2)        # two instances on two streams: machine time per launch with overlapping pipes
 names = {100: "sep", 101: "head", 102: "chain", 103: "bneck", 1: "conv", 2: "dw", 3: "pool", 4: "up"}
 tot = 0.0
