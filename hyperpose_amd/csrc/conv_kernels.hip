@@ -1124,6 +1124,11 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(const conv_params p, i
         conv_direct_body<KS, CK, 16, NBUF>(p, lds, b, y0, x0, nchunks);
 }
 
+// (Round 4 paired the k-th 7x7 of the conf and of the paf branch of an OpenPose stage in ONE launch - 768 full + 256 half tiles: 3.5 rounds
+// for two layers instead of 2 x 2 - to recover the 1.75-of-2 round quantisation of these layers.  Measured: 240 - 249 us per pair against
+// 2 x 125 us, 1 331 vs 1 340 frames/s end to end: the CUs that idle in the half-empty second round are not lost time, the busy ones run
+// that much faster (clock / power and L2 headroom).  Removed; profiles/r04_layer_times_config2_paired_branches.txt)
+
 // split-K, second launch: the same grid without z; every wavefront adds the ksplit partial sums of the tiles it finishes (parked in its
 // own lane layout) and runs the kernel's epilogue.  A kernel boundary between the two makes the sums visible across the XCDs' L2s.
 template <int KS, int CK>
