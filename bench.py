@@ -353,7 +353,7 @@ def kernel_label(tile: int):
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
     if tile >= 32000000:
         bm, bn = (tile - 32000000) // 1000, tile % 1000
-        wm, wn = (2, 2) if bm == 128 else (1, 4)
+        wm, wn = (1, 4) if (bm, bn) == (64, 128) else (2, 2)
         return (f"conv32_kernel<{bm},{bn},{wm},{wn}>", f"conv32_kernel<BM={bm},BN={bn}> (fp32 implicit GEMM on v_mfma_f32_32x32x2_f32: {bm} cout x {bn} pixels per block, "
                 "A and B staged through LDS in fp32, K-steps of 16 channels)")
     if tile >= 9000000:

@@ -206,10 +206,22 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
     }
 }
 
+// Block tile (BM output channels x BN pixels) of a layer.  The fp32 matrix pipe is slow enough (64 cycles per MFMA) that small tiles cost
+// little per MFMA, and a layer that is one wave of 128 x 128 tiles leaves CUs idle: LW-OpenPose's 3 x 3 128 -> 128 layers at 8 x 46 x 54 pixels
+// are 156 such tiles on 256 CUs (0.38 of the fp32 MFMA peak) - as 64 x 64 tiles they are 622 blocks, several per CU.
+static void conv32_pick(const conv32_params& p, int& BM, int& BN)
+{
+    BM = p.Cout_pad % 128 == 0 ? 128 : 64, BN = 128;
+    const long blocks = (long)((p.npix + 127) / 128) * (p.Cout_pad / BM);
+    if (blocks < 448) // fewer than ~1.75 blocks per CU: quarter the tile
+        BM = 64, BN = 64;
+}
+
 int conv32_tile(const conv32_params& p)
 {
-    const int BM = p.Cout_pad % 128 == 0 ? 128 : 64;
-    return 32000000 + BM * 1000 + 128;
+    int BM, BN;
+    conv32_pick(p, BM, BN);
+    return 32000000 + BM * 1000 + BN;
 }
 
 bool set_act32(conv32_params& p)
@@ -240,12 +252,15 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
 {
     if (p.Cin % 16 || p.Cout_pad % 64 || p.npix <= 0)
         return hipErrorInvalidValue;
-    const int BM = p.Cout_pad % 128 == 0 ? 128 : 64;
-    const dim3 grid((p.npix + 127) / 128, p.Cout_pad / BM);
+    int BM, BN;
+    conv32_pick(p, BM, BN);
+    const dim3 grid((p.npix + BN - 1) / BN, p.Cout_pad / BM);
     if (BM == 128)
         HP_LAUNCH((conv32_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
-    else
+    else if (BN == 128)
         HP_LAUNCH((conv32_kernel<64, 128, 1, 4>), grid, dim3(256), 0, s, p);
+    else
+        HP_LAUNCH((conv32_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -41,6 +41,9 @@ def test_tile_code_maps_to_a_profiled_kernel(tile, tag):
         pytest.skip("no committed kernel statistics for this configuration")
     key, label = bench.kernel_label(tile)
     hits = [n for n in names if key.replace(" ", "") in n]
+    if tile < 4000000:  # the generic implicit GEMM: the tile code does not carry its K-step / epilogue template arguments, several
+        assert label and hits, (tile, key)  # instances may be in a trace - and bench.py then (rightly) quotes no committed duration
+        return
     assert label and len(hits) == 1, (tile, key, hits, sorted(names)[:5])
     us, src = bench.rocprof_avg_us(key, tag)
     assert us is not None and us > 0 and src
