@@ -1,6 +1,6 @@
 // Umbrella header, mirroring the reference's include/hyperpose/hyperpose.hpp.
 #pragma once
-#include "operator/dnn/hip_engine.hpp"
+#include "operator/dnn/tensorrt.hpp"
 #include "operator/parser/paf.hpp"
 #include "operator/parser/pifpaf.hpp"
 #include "operator/parser/proposal_network.hpp"

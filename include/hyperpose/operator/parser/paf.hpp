@@ -38,7 +38,7 @@ namespace parser {
         template <typename C>
         std::vector<human_t> process(C&& feature_map_containers) { return process(feature_map_containers[0], feature_map_containers[1]); }
 
-        // MI355X addition: n frames whose conf/paf maps are already in HBM (e.g. dnn::hip_engine outputs).
+        // MI355X addition: n frames whose conf/paf maps are already in HBM (e.g. dnn::tensorrt outputs).
         std::vector<std::vector<human_t>> process_device(int n, const float* dev_conf, const int conf_shape[3], const float* dev_paf, const int paf_shape[3])
         {
             return run(n, dev_conf, conf_shape, dev_paf, paf_shape, 1);

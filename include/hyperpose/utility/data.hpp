@@ -1,6 +1,6 @@
 // hyperpose::feature_map_t / internal_t — reference include/hyperpose/utility/data.hpp:17-67.
 // A feature_map_t owns a HOST copy (API compatibility with the reference, src/tensorrt.cpp:423-428).  The
-// MI355X fast path keeps feature maps in HBM (dnn::hip_engine::inference_device + parser::paf::process_device).
+// MI355X fast path keeps feature maps in HBM (dnn::tensorrt::inference_device + parser::paf::process_device).
 #pragma once
 #include <memory>
 #include <ostream>
