@@ -82,7 +82,7 @@ CONFIGS = {
     # storage and fp32 matrix-pipe arithmetic (HP_DTYPE_F32, conv_fp32.hip), one launch per layer - the faithful mode, reported next to the
     # fp16 headline under workloads["configs[1]/fp32"] with its own roofline against the 157 TFLOP/s fp32 MFMA peak
     5: dict(label="configs[1] with data_type::kFLOAT (fp32 storage + fp32 MFMA): Lightweight-OpenPose + PAF parser, batch 8 @ 368x432", arch="lw_openpose_mobilenet",
-            w=432, h=368, batch=8, parser="paf", pipes=2, seed=20241, steps=40, people=(1, 2, 4, 8, 16, 3, 5, 6), dtype="f32", key="configs[1]/fp32"),
+            w=432, h=368, batch=8, parser="paf", pipes=4, seed=20241, steps=40, people=(1, 2, 4, 8, 16, 3, 5, 6), dtype="f32", key="configs[1]/fp32"),
 }
 
 

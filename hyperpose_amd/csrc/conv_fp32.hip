@@ -215,6 +215,8 @@ static void conv32_pick(const conv32_params& p, int& BM, int& BN)
     const long blocks = (long)((p.npix + 127) / 128) * (p.Cout_pad / BM);
     if (blocks < 448) // fewer than ~1.75 blocks per CU: quarter the tile
         BM = 64, BN = 64;
+    else if (blocks < 1024 && BM == 128) // up to four blocks per CU: halve the tile (512 -> 512 at 8 x 46 x 54: 115 -> 100 us alone, same machine time)
+        BM = 64;
 }
 
 int conv32_tile(const conv32_params& p)
@@ -343,8 +345,75 @@ hipError_t launch_first_conv32(const first_conv32_params& p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Depthwise 3 x 3: one thread = one output pixel x 4 channels; taps in the padding read the zero halo.
-__global__ __launch_bounds__(256) void dwconv32_kernel(const dw32_params p)
+// Depthwise 3 x 3: one thread = 4 channels of one output COLUMN segment, marching down RUN output rows with the 2 D + 1 input rows it
+// needs in registers: every input value is loaded once per thread instead of once per tap row (3 loads per output at stride 1 instead
+// of 9 - the per-pixel form ran at 2.1 TB/s of its compulsory bytes, bound by the vector memory path, not by HBM).  Taps in the padding
+// read the zero halo; the tap order per output is (ky, kx) ascending as in the fp16 kernels.
+template <int S, int D>
+__global__ __launch_bounds__(256) void dwconv32_kernel(const dw32_params p, int run)
+{
+    constexpr int NR = 2 * D + 1; // input rows one output needs, from its first to its last tap row
+    const int CG = p.C / 4, segs = (p.OH + run - 1) / run;
+    const long total = (long)p.B * segs * p.OW * CG;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % CG);
+        long n = i / CG;
+        const int ox = (int)(n % p.OW);
+        n /= p.OW;
+        const int seg = (int)(n % segs), b = (int)(n / segs);
+        const int oy0 = seg * run, oy1 = min(oy0 + run, p.OH);
+        f32x4 w[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            w[t] = *reinterpret_cast<const f32x4*>(p.w + t * p.C + cg * 4);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + cg * 4);
+        // input row r of the window = tensor row oy * S - pad_t + r; three taps per row at columns ox * S - pad_l + {0, D, 2 D}
+        const float* const col0 = p.in.p + tv32_off(p.in, b, oy0 * S - p.pad_t, ox * S - p.pad_l) + cg * 4;
+        const long rstride = (long)p.in.wp * p.in.cs, cstride = (long)D * p.in.cs;
+        f32x4 x[NR][3];
+        auto load_row = [&](int r, long row) { // window slot r <- input row `row` (relative to col0)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                x[r][c] = *reinterpret_cast<const f32x4*>(col0 + row * rstride + c * cstride);
+        };
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            load_row(r, r);
+        float* op = p.out.p + tv32_off(p.out, b, oy0, ox) + cg * 4;
+        const long ostride = (long)p.out.wp * p.out.cs;
+        for (int oy = oy0; oy < oy1; ++oy) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[e] = fmaf(x[ky * D][kx][e], w[ky * 3 + kx][e], acc[e]);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = act32(acc[e], p.act, p.act_param, 0.f);
+            *reinterpret_cast<f32x4*>(op) = o;
+            op += ostride;
+            // slide the window down by S rows: keep NR - S rows, load S new ones (rows past the tensor's halo are never used: the last
+            // outputs of a segment load rows that only the NEXT output would read - clamp them to the window's last valid row)
+#pragma unroll
+            for (int r = 0; r + S < NR; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    x[r][c] = x[r + S][c];
+            if (oy + 1 < oy1) {
+#pragma unroll
+                for (int r = NR - S; r < NR; ++r)
+                    load_row(r, (long)(oy + 1 - oy0) * S + r);
+            }
+        }
+    }
+}
+
+// any other stride / dilation: one thread = one output pixel x 4 channels, nine loads per output
+__global__ __launch_bounds__(256) void dwconv32_any_kernel(const dw32_params p)
 {
     const int CG = p.C / 4;
     const long total = (long)p.B * p.OH * p.OW * CG;
@@ -378,9 +447,20 @@ hipError_t launch_dwconv32(const dw32_params& p, hipStream_t s)
 {
     if (p.C % 4)
         return hipErrorInvalidValue;
-    const long total = (long)p.B * p.OH * p.OW * (p.C / 4);
+    // rows per thread: long runs re-use more, short runs give more threads; 8 keeps > 100 k threads on the 46 x 54 maps of LW-OpenPose
+    const int run = p.OH >= 32 ? 8 : 4;
+    const long total = (long)p.B * ((p.OH + run - 1) / run) * p.OW * (p.C / 4);
     const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 32);
-    HP_LAUNCH(dwconv32_kernel, dim3(blocks), dim3(256), 0, s, p);
+    if (p.stride == 1 && p.dil == 1)
+        HP_LAUNCH((dwconv32_kernel<1, 1>), dim3(blocks), dim3(256), 0, s, p, run);
+    else if (p.stride == 2 && p.dil == 1)
+        HP_LAUNCH((dwconv32_kernel<2, 1>), dim3(blocks), dim3(256), 0, s, p, run);
+    else if (p.stride == 1 && p.dil == 2)
+        HP_LAUNCH((dwconv32_kernel<1, 2>), dim3(blocks), dim3(256), 0, s, p, run);
+    else {
+        const long px = (long)p.B * p.OH * p.OW * (p.C / 4);
+        HP_LAUNCH(dwconv32_any_kernel, dim3((int)std::min<long>((px + 255) / 256, 256 * 32)), dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
 

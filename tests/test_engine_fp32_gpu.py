@@ -90,12 +90,14 @@ def test_depthwise_pool_upsample(hp):
     d2 = net.conv(p1, 64, 64, 3, 2, op=E.OP_DWCONV, act=E.ACT_RELU6)
     p2 = net.conv(d2, 64, 64, 1, 1)
     d3 = net.conv(p2, 64, 64, 3, 1, dil=2, op=E.OP_DWCONV)
+    d3 = net.conv(d3, 64, 64, 3, 2, dil=2, op=E.OP_DWCONV)   # (stride 2 AND dilation 2: the per-pixel depthwise kernel)
+    d3 = net.conv(d3, 64, 64, 3, 1, dil=3, op=E.OP_DWCONV, act=E.ACT_LEAKY, act_param=0.1)
     mp = net.conv(d3, 64, 64, 3, 2, op=E.OP_MAXPOOL, act=E.ACT_NONE)
     mp2 = net.conv(mp, 64, 64, 2, 2, op=E.OP_MAXPOOL, act=E.ACT_NONE)
     up = net.conv(mp2, 64, 64, 0, 2, op=E.OP_UPSAMPLE, act=E.ACT_NONE)       # nearest x2
     up2 = net.conv(up, 64, 64, 1, 2, op=E.OP_UPSAMPLE, act=E.ACT_NONE)       # bilinear x2
     y = net.conv(up2, 64, 24, 3, 1, act=E.ACT_NONE)
-    _run32(net, [Out("y", y, 0, 24), Out("pooled", mp2, 0, 64), Out("up", up2, 0, 64)], _frames(2, 50, 66, seed=6), 50, 66)
+    _run32(net, [Out("y", y, 0, 24), Out("pooled", mp2, 0, 64), Out("up", up2, 0, 64)], _frames(2, 98, 130, seed=6), 98, 130)
 
 
 def test_output_post_ops(hp):
