@@ -4,6 +4,8 @@
 #define HYPERPOSE_TENSORRT_COMPAT
 #include <hyperpose/hyperpose.hpp>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 
 int main(int argc, char** argv)
@@ -77,6 +79,30 @@ int main(int argc, char** argv)
             return 9;
         if (out[0][0].shape() != std::vector<int>{ 5, 16, 12 } || out[0][1].shape() != std::vector<int>{ 6, 16, 12 })
             return 10;
+    }
+    {   // data_type (include/hyperpose/operator/dnn/tensorrt.hpp:14-21,48): the default is kFLOAT, as in the reference; kHALF is the fused
+        // fp16 engine.  Same model, same frame: the two agree to fp16 accuracy and are not the same numbers.
+        if (hp_engine_dtype(engine.handle()) != HP_DTYPE_F32)
+            return 11;
+        hp::dnn::tensorrt half_engine(hp::dnn::builtin_model{ "lw_openpose_mobilenet", {}, 7 }, cv::Size(96, 80), 4, false, hp::data_type::kHALF);
+        if (hp_engine_dtype(half_engine.handle()) != HP_DTYPE_F16)
+            return 12;
+        auto full = engine.inference({ batch[0] }), half = half_engine.inference({ batch[0] });
+        const auto &a = full[0][0], &b = half[0][0];
+        if (a.shape() != b.shape())
+            return 13;
+        size_t n = 1;
+        for (int d : a.shape())
+            n *= (size_t)d;
+        const float *x = a.view<float>(), *y = b.view<float>();
+        float scale = 0, err = 0;
+        bool same = true;
+        for (size_t k = 0; k < n; ++k) {
+            scale = std::max(scale, std::fabs(x[k])), err = std::max(err, std::fabs(x[k] - y[k]));
+            same = same && x[k] == y[k];
+        }
+        if (same || err > 2e-2f * scale + 1e-3f)
+            return 14;
     }
     bool threw = false;
     try {
