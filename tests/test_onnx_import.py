@@ -343,6 +343,34 @@ def test_tensorflow_export_idioms_are_lowered():
                       mean=m.mean, inv_std=m.inv_std)
     for k, v in want.items():
         np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=1e-4)
-    # what the conversion cannot evaluate is refused with the node named, not silently dropped
-    bad = raw.replace(b"s32", b"gx\x00", 1) if False else None
-    del bad
+
+
+def test_arithmetic_after_sigmoid_that_cannot_be_evaluated_is_refused():
+    """Only `(sigmoid + cell-index grid) * scalar` is an output post-op (hp_output_desc::grid / scale): anything else after a Sigmoid names its
+    node instead of being dropped or mis-evaluated."""
+    def model(extra_init, nodes, out):
+        init = [W.tensor("w", [4, 3, 1, 1], [0.1] * 12)] + extra_init
+        base = [W.node("Conv", ["x", "w"], ["c"], [W.attr_ints("kernel_shape", [1, 1])]), W.node("Sigmoid", ["c"], ["s"])]
+        return W.model(base + nodes, init, [W.value_info("x", ["N", 3, 6, 8])], [W.value_info(out, ["N", 4, 6, 8])], opset=13)
+    not_grid = [float(i % 5) for i in range(48)]
+    with pytest.raises(HpError, match=r"a constant map added after Sigmoid"):
+        E.Model.from_onnx(model([W.tensor("g", [1, 1, 6, 8], not_grid)], [W.node("Add", ["s", "g"], ["y"], name="addg")], "y"))
+    with pytest.raises(HpError, match=r"after Sigmoid / Softplus only"):   # per-channel factor
+        E.Model.from_onnx(model([W.tensor("v", [1, 4, 1, 1], [1.0, 2.0, 3.0, 4.0])], [W.node("Mul", ["s", "v"], ["y"], name="mulv")], "y"))
+    with pytest.raises(HpError, match=r"after Sigmoid / Softplus only"):   # the grid AFTER the factor: (s * 32) + grid is not (s + grid) * 32
+        gx = [float(i % 8) for i in range(48)]
+        E.Model.from_onnx(model([W.tensor("k", [], [32.0]), W.tensor("g", [1, 1, 6, 8], gx)],
+                                [W.node("Mul", ["s", "k"], ["m"]), W.node("Add", ["m", "g"], ["y"], name="late")], "y"))
+    with pytest.raises(HpError, match=r"Sigmoid / Softplus"):  # a convolution reading the post-processed map
+        E.Model.from_onnx(model([W.tensor("k", [], [32.0]), W.tensor("w2", [4, 4, 1, 1], [0.1] * 16)],
+                                [W.node("Mul", ["s", "k"], ["m"]), W.node("Conv", ["m", "w2"], ["y"], [W.attr_ints("kernel_shape", [1, 1])], name="conv2")], "y"))
+    # the accepted form, column grid then row grid, and Div as the inverse factor
+    gx = [float(i % 8) for i in range(48)]
+    gy = [float(i // 8) for i in range(48)]
+    ok = model([W.tensor("g", [6, 8], gy), W.tensor("k", [1], [4.0])], [W.node("Add", ["s", "g"], ["a"]), W.node("Div", ["a", "k"], ["y"])], "y")
+    m = E.Model.from_onnx(ok)
+    assert [(o.grid, round(o.scale, 4)) for o in m.outputs] == [(2, 0.25)]
+    x = np.random.default_rng(0).random((1, 3, 6, 8), dtype=np.float32)
+    want = (1 / (1 + np.exp(-(0.1 * x.sum(1, keepdims=True)))) + np.asarray(gy, np.float32).reshape(1, 1, 6, 8)) / 4.0
+    np.testing.assert_allclose(_oracle(m, x)["y"], np.repeat(want, 4, 1), rtol=1e-5, atol=1e-6)
+    del gx
