@@ -139,6 +139,8 @@ class Pipe:
     def __init__(self, cfg, model, weights, injected, batch):
         from hyperpose_amd.engine import Engine
         from hyperpose_amd import parser as P
+        from hyperpose_amd._lib import HpError
+        self._HpError = HpError
         self.kind, self.batch = cfg["parser"], batch
         self.eng = Engine.from_model(model, weights, max_batch=batch, dtype=cfg.get("dtype", "f16"))
         self.stream = self.eng.stream
@@ -186,11 +188,10 @@ class Pipe:
             self.eng_only = False
         if not self.busy:
             return 0
-        from hyperpose_amd._lib import HpError
         self.busy = False
         try:
             humans = self.par.collect()
-        except HpError as e:
+        except self._HpError as e:
             if e.code != -3:  # HP_ERR_CAPACITY: counted; anything else is a failure of the run
                 raise
             self.capacity_truncations += 1
