@@ -30,16 +30,18 @@ def _by_hand(eng, paf, frames, keep_ratio, in_w, in_h):
     return humans
 
 
-@pytest.mark.parametrize("keep_ratio", [False, True])
-def test_pipeline_equals_stages_by_hand(hp, keep_ratio):
+@pytest.mark.parametrize("keep_ratio,dtype", [(False, "f16"), (True, "f16"), (True, "f32")])
+def test_pipeline_equals_stages_by_hand(hp, keep_ratio, dtype):
+    """(dtype = "f32": the stream replicates the engine it is given WITH its precision - hp_engine_desc::dtype travels through
+    hp_pipeline_create_ex - so a data_type::kFLOAT stream equals the fp32 engine run by hand, bit for bit.)"""
     in_w, in_h = 160, 128
     m = E.Model("lw_openpose_mobilenet", in_w, in_h)
     w = m.init_weights(11)
     for L in m.layers:  # blow up the two output convolutions: random weights then give O(1) maps, peaks, limbs and humans
         if L.op == E.OP_CONV and L.cout in (19, 38) and L.out in [o.tensor for o in m.outputs]:
             w[L.w_off:L.w_off + L.cout * L.cin] *= 400.0
-    pl = Pipeline(m, w, max_batch=4, n_pipes=3, keep_ratio=keep_ratio, conf_thresh=0.05, paf_thresh=-1e9, max_frame_wh=(1280, 720))
-    eng = E.Engine.from_model(m, w, max_batch=4)
+    pl = Pipeline(m, w, max_batch=4, n_pipes=3, keep_ratio=keep_ratio, conf_thresh=0.05, paf_thresh=-1e9, max_frame_wh=(1280, 720), dtype=dtype)
+    eng = E.Engine.from_model(m, w, max_batch=4, dtype=dtype)
     paf = Paf(conf_thresh=0.05, paf_thresh=-1e9, max_batch=4)
     rng = np.random.default_rng(5)
     batches = [_frames(rng, n, k) for n, k in ((4, 0), (3, 2), (1, 5), (4, 1), (2, 3))]
