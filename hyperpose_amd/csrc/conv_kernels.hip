@@ -244,13 +244,18 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
                 for (int r = 0; r < 8; ++r)
                     rs[ps][r] = (_Float16)0.f;
         }
+        // (the slab reads of every pass before the first store: next to the store that needs it a read costs its LDS latency per pass)
+        float4 a0[G::PASSES], a1[G::PASSES];
+#pragma unroll
+        for (int ps = 0; ps < G::PASSES; ++ps) {
+            const int pix = ps * G::PPP + prow;
+            a0[ps] = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32);
+            a1[ps] = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32 + 16);
+        }
         if (clamp_only) { // relu / relu6 family without a residual: bias add + one v_med3_f32 per value
 #pragma unroll
             for (int ps = 0; ps < G::PASSES; ++ps) {
-                const int pix = ps * G::PPP + prow;
-                const float4 a0 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32);
-                const float4 a1 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32 + 16);
-                const float v[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+                const float v[8] = { a0[ps].x, a0[ps].y, a0[ps].z, a0[ps].w, a1[ps].x, a1[ps].y, a1[ps].z, a1[ps].w };
                 half8 h;
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
@@ -261,10 +266,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
         } else {
 #pragma unroll
             for (int ps = 0; ps < G::PASSES; ++ps) {
-                const int pix = ps * G::PPP + prow;
-                const float4 a0 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32);
-                const float4 a1 = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32 + 16);
-                const float v[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+                const float v[8] = { a0[ps].x, a0[ps].y, a0[ps].z, a0[ps].w, a1[ps].x, a1[ps].y, a1[ps].z, a1[ps].w };
                 half8 h;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -341,27 +343,43 @@ __device__ __forceinline__ void conv_epilogue_wide(const conv_params& p, const f
     for (int j = 0; j < TN; ++j) {
         const long* const s_ooff = reinterpret_cast<const long*>(slab + j * G::SLAB + 32 * G::ROW);
 #pragma unroll
-        for (int ps = 0; ps < G::PASSES; ++ps) {
+        for (int ps = 0; ps < G::PASSES; ++ps)
             oo[j][ps] = s_ooff[ps * G::PPP + prow];
-            if (has_res) // invalid pixels read offset 0: in bounds, result unused
+    }
+    // (the uniform choices are made around whole loop nests, never inside one: a branch per pass keeps the compiler from putting the
+    // passes' reads and residual requests in flight together)
+    if (has_res) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long* const s_ooff = reinterpret_cast<const long*>(slab + j * G::SLAB + 32 * G::ROW);
+#pragma unroll
+            for (int ps = 0; ps < G::PASSES; ++ps) // invalid pixels read offset 0: in bounds, result unused
                 rs[j][ps] = *reinterpret_cast<const half8*>(p.res.p + s_ooff[32 + ps * G::PPP + prow] + (mvalid ? mc : 0));
-            else
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int ps = 0; ps < G::PASSES; ++ps)
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
                     rs[j][ps][r] = (_Float16)0.f;
-        }
     }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    auto tile = [&](int j, auto clamp_) {
+        constexpr bool CLAMP = decltype(clamp_)::value;
         const unsigned char* const sj = slab + j * G::SLAB;
+        float4 a0[G::PASSES], a1[G::PASSES];
 #pragma unroll
         for (int ps = 0; ps < G::PASSES; ++ps) {
             const int pix = ps * G::PPP + prow;
-            const float4 a0 = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32);
-            const float4 a1 = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32 + 16);
-            const float v[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+            a0[ps] = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32);
+            a1[ps] = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32 + 16);
+        }
+#pragma unroll
+        for (int ps = 0; ps < G::PASSES; ++ps) {
+            const float v[8] = { a0[ps].x, a0[ps].y, a0[ps].z, a0[ps].w, a1[ps].x, a1[ps].y, a1[ps].z, a1[ps].w };
             half8 h;
-            if (clamp_only) {
+            if constexpr (CLAMP) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
                     h[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r] + bs[r], 0.f, hi);
@@ -381,6 +399,15 @@ __device__ __forceinline__ void conv_epilogue_wide(const conv_params& p, const f
             if (oo[j][ps] >= 0 && mvalid)
                 *reinterpret_cast<half8*>(p.out.p + oo[j][ps] + mc) = h;
         }
+    };
+    if (clamp_only) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            tile(j, std::true_type{});
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            tile(j, std::false_type{});
     }
 }
 
@@ -410,31 +437,57 @@ __device__ __forceinline__ void conv_epilogue_packed(const conv_params& p, const
     const float hi = p.act_hi;
     const bool clamp_only = !p.alpha && p.act_slope == 0.f; // uniform
     const int mq = m_wave + 4 * (lane >> 5);
+    // every bias request goes out before the first use, and the (uniform) choice of the activation is made ONCE around the whole
+    // loop nest: with the load and the choice inside it the compiler waited for each of the TM x 4 loads in turn - eight memory
+    // latencies, 2.4 of the 3.6 us the 512-channel separable block spent after its last MFMA (round 4)
+    float4 bs[TM][4];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int m = mq + i * 32 + 8 * g;
-            const float4 bs = *reinterpret_cast<const float4*>(p.bias + m);
-            float4 sl = make_float4(p.act_slope, p.act_slope, p.act_slope, p.act_slope);
-            if (p.alpha)
-                sl = *reinterpret_cast<const float4*>(p.alpha + m);
+        for (int g = 0; g < 4; ++g)
+            bs[i][g] = *reinterpret_cast<const float4*>(p.bias + mq + i * 32 + 8 * g);
+    auto put = [&](int i, int g, int j, float v0, float v1, float v2, float v3) {
+        half4 h;
+        h[0] = (_Float16)v0, h[1] = (_Float16)v1, h[2] = (_Float16)v2, h[3] = (_Float16)v3;
+        *reinterpret_cast<half4*>(slab + j * G::SLAB + (lane & 31) * G::ROW + (i * 32 + 8 * g + 4 * (lane >> 5)) * 2) = h;
+    };
+    if (clamp_only) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float v0 = acc[i][j][4 * g + 0] + bs.x, v1 = acc[i][j][4 * g + 1] + bs.y;
-                float v2 = acc[i][j][4 * g + 2] + bs.z, v3 = acc[i][j][4 * g + 3] + bs.w;
-                if (clamp_only) {
-                    v0 = __builtin_amdgcn_fmed3f(v0, 0.f, hi), v1 = __builtin_amdgcn_fmed3f(v1, 0.f, hi);
-                    v2 = __builtin_amdgcn_fmed3f(v2, 0.f, hi), v3 = __builtin_amdgcn_fmed3f(v3, 0.f, hi);
-                } else {
-                    v0 = v0 > 0.f ? fminf(v0, hi) : v0 * sl.x, v1 = v1 > 0.f ? fminf(v1, hi) : v1 * sl.y;
-                    v2 = v2 > 0.f ? fminf(v2, hi) : v2 * sl.z, v3 = v3 > 0.f ? fminf(v3, hi) : v3 * sl.w;
-                }
-                half4 h;
-                h[0] = (_Float16)v0, h[1] = (_Float16)v1, h[2] = (_Float16)v2, h[3] = (_Float16)v3;
-                *reinterpret_cast<half4*>(slab + j * G::SLAB + (lane & 31) * G::ROW + (i * 32 + 8 * g + 4 * (lane >> 5)) * 2) = h;
-            }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    put(i, g, j, __builtin_amdgcn_fmed3f(acc[i][j][4 * g + 0] + bs[i][g].x, 0.f, hi),
+                        __builtin_amdgcn_fmed3f(acc[i][j][4 * g + 1] + bs[i][g].y, 0.f, hi),
+                        __builtin_amdgcn_fmed3f(acc[i][j][4 * g + 2] + bs[i][g].z, 0.f, hi),
+                        __builtin_amdgcn_fmed3f(acc[i][j][4 * g + 3] + bs[i][g].w, 0.f, hi));
+    } else {
+        float4 sl[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                sl[i][g] = make_float4(p.act_slope, p.act_slope, p.act_slope, p.act_slope);
+        if (p.alpha) { // uniform
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    sl[i][g] = *reinterpret_cast<const float4*>(p.alpha + mq + i * 32 + 8 * g);
         }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float v0 = acc[i][j][4 * g + 0] + bs[i][g].x, v1 = acc[i][j][4 * g + 1] + bs[i][g].y;
+                    const float v2 = acc[i][j][4 * g + 2] + bs[i][g].z, v3 = acc[i][j][4 * g + 3] + bs[i][g].w;
+                    put(i, g, j, v0 > 0.f ? fminf(v0, hi) : v0 * sl[i][g].x, v1 > 0.f ? fminf(v1, hi) : v1 * sl[i][g].y,
+                        v2 > 0.f ? fminf(v2, hi) : v2 * sl[i][g].z, v3 > 0.f ? fminf(v3, hi) : v3 * sl[i][g].w);
+                }
+    }
     if (lane < 32) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -445,17 +498,22 @@ __device__ __forceinline__ void conv_epilogue_packed(const conv_params& p, const
     const int chunk = lane % G::CPP, prow = lane / G::CPP;
     const int mc = m_wave + chunk * 8;
     const bool mvalid = mc < p.Cout;
+    // (all LDS reads of a pixel tile first: a read next to the store that needs it costs its LDS latency once per pass)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const unsigned char* const sj = slab + j * G::SLAB;
+        half8 h[G::PASSES];
+        long oo[G::PASSES];
 #pragma unroll
         for (int ps = 0; ps < G::PASSES; ++ps) {
             const int pix = ps * G::PPP + prow;
-            const half8 h = *reinterpret_cast<const half8*>(sj + pix * G::ROW + chunk * 16);
-            const long oo = reinterpret_cast<const long*>(sj + 32 * G::ROW)[pix];
-            if (oo >= 0 && mvalid)
-                *reinterpret_cast<half8*>(p.out.p + oo + mc) = h;
+            h[ps] = *reinterpret_cast<const half8*>(sj + pix * G::ROW + chunk * 16);
+            oo[ps] = reinterpret_cast<const long*>(sj + 32 * G::ROW)[pix];
         }
+#pragma unroll
+        for (int ps = 0; ps < G::PASSES; ++ps)
+            if (oo[ps] >= 0 && mvalid)
+                *reinterpret_cast<half8*>(p.out.p + oo[ps] + mc) = h[ps];
     }
 }
 
@@ -2833,14 +2891,7 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params 
     auto hload1 = [&](int k, int chunk) { hv[k] = *reinterpret_cast<const u32x4*>(hbase + hoff[k] + chunk * CK); };
     auto hstore1 = [&](int k, auto par_) { *(lds_w4)(hdst[k] + decltype(par_)::value * HALO_BYTES) = hv[k]; };
 
-    floatx16 acc[TP][NT];
-#pragma unroll
-    for (int i = 0; i < TP; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[i][j][r] = 0.f;
+    floatx16 acc[TP][NT]; // (not cleared: the first k16 step of chunk 0 multiplies onto a literal zero)
     const int frow = lane & 31, fk = lane >> 5;
     const float dw_hi = p.dw_hi;
     // B-fragment address of k16 step 0; step ks is this XOR ks * 32 (the swizzled 16-byte slot is (2 ks + fk) ^ key = (fk ^ key) ^ 2 ks, the
@@ -2887,8 +2938,8 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params 
     int dbg_i = 0;
     // one chunk interval: MFMAs of chunk kc out of B buffer PAR, taps of chunk kd = kc + 1 out of halo buffer
     // 1 - PAR into B buffer 1 - PAR, halo chunk kd + 1 -> halo buffer PAR, weights of chunk knext in place
-    auto interval = [&](auto mm_, auto taps_, auto par_, int kc, int kd, int knext) {
-        constexpr bool MM = decltype(mm_)::value, TAPS = decltype(taps_)::value;
+    auto interval = [&](auto mm_, auto taps_, auto par_, int kc, int kd, int knext, auto first_) {
+        constexpr bool MM = decltype(mm_)::value, TAPS = decltype(taps_)::value, FIRST = decltype(first_)::value;
         constexpr int PAR = decltype(par_)::value, TPAR = MM ? 1 - PAR : PAR; // (taps only: the prologue's chunk 0 in buffer PAR)
         constexpr bool STAGE = MM && TAPS;
         const __half* const wn = wbase + (size_t)min(kc + 1, NCH - 1) * (KS * 512);
@@ -2924,7 +2975,10 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params 
             if constexpr (MM) {
                 half8 fa;
                 __builtin_memcpy(&fa, &a[ks][i], 16);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+                if constexpr (FIRST && ks == 0)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], floatx16{}, 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
                 if constexpr (i == TP - 1 && ks + 1 < KS) // fragment j is free: the next step's, three slots ahead of its first MFMA
                     read_fb(std::integral_constant<int, (ks + 1) % KS>{}, std::integral_constant<int, j>{});
                 if constexpr (s % (TP * NT) == TP * NT - 1)
@@ -2995,15 +3049,22 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params 
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
         hload1(k, 0);
-    {   // all depthwise weights ([9][C] halves in HBM -> [chunk][quad][9 x 4]) and biases of the block, once
-        const int items = 9 * (C / 4);
-#pragma unroll 1
-        for (int i = tid; i < items; i += NTHR) {
-            const int tp = i / (C / 4), cq = i - tp * (C / 4);
-            *reinterpret_cast<uint2*>(lds + OFF_DWW + (cq >> 4) * DWW_CHUNK + (cq & 15) * QW + tp * 8) = *reinterpret_cast<const uint2*>(p.dw_w + (size_t)tp * C + cq * 4);
+    {   // all depthwise weights ([9][C] halves in HBM -> [chunk][quad][9 x 4]) and biases of the block, once: thread cq < C / 4 takes the
+        // nine taps of channel quad cq (no index arithmetic), and every request goes out before the first store - a load -> store loop
+        // pays one memory latency per trip
+        if (tid < C / 4) { // (C / 4 is a multiple of 32 and at most 128: the first one or two wavefronts)
+            const int cq = tid;
+            uint2 dv[9];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+                dv[tp] = *reinterpret_cast<const uint2*>(p.dw_w + (size_t)tp * C + cq * 4);
+            const u32x4 bv = *reinterpret_cast<const u32x4*>(p.dw_bias + cq * 4);
+            unsigned char* const dq = lds + OFF_DWW + (cq >> 4) * DWW_CHUNK + (cq & 15) * QW;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+                *reinterpret_cast<uint2*>(dq + tp * 8) = dv[tp];
+            *reinterpret_cast<u32x4*>(lds + OFF_DWB + cq * 16) = bv;
         }
-        if (tid < C / 4)
-            *reinterpret_cast<u32x4*>(lds + OFF_DWB + tid * 16) = *reinterpret_cast<const u32x4*>(p.dw_bias + tid * 4);
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
@@ -3015,7 +3076,7 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params 
     w_load_lo(0);
     w_load_hi(0);
     b_load(0);
-    interval(NO, YES, P0, 0, 0, min(1, NCH - 1)); // taps of chunk 0: halo buffer 0 -> B buffer 0
+    interval(NO, YES, P0, 0, 0, min(1, NCH - 1), NO); // taps of chunk 0: halo buffer 0 -> B buffer 0
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         hstore1(k, P1);
@@ -3024,16 +3085,16 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params 
     lds_barrier();
     HP_STAMP();
     // NCH - 1 combined intervals (an odd number: NCH is even), buffer parity = k & 1
-    interval(YES, YES, P0, 0, 1, min(2, NCH - 1));
+    interval(YES, YES, P0, 0, 1, min(2, NCH - 1), YES);
     lds_barrier();
 #pragma unroll 1
     for (int k = 1; k + 1 < NCH; k += 2) {
-        interval(YES, YES, P1, k, k + 1, min(k + 2, NCH - 1));
+        interval(YES, YES, P1, k, k + 1, min(k + 2, NCH - 1), NO);
         lds_barrier();
-        interval(YES, YES, P0, k + 1, k + 2, min(k + 3, NCH - 1));
+        interval(YES, YES, P0, k + 1, k + 2, min(k + 3, NCH - 1), NO);
         lds_barrier();
     }
-    interval(YES, NO, P1, NCH - 1, 0, 0);
+    interval(YES, NO, P1, NCH - 1, 0, 0, NO);
     HP_STAMP();
     lds_barrier(); // (every wavefront past its reads of the B tiles: the slabs may overwrite them)
     int pb[NT], py[NT], px[NT];
