@@ -350,7 +350,9 @@ def kernel_label(tile: int):
            4: ("sepconv_slot_kernel<1,2,1,1,256,64>", "separable block 256 -> 256, half-CU form"),
            5: ("sepconv_pipe3_kernel<1,false>", "separable block 256 / 512 -> 512: 12x8 pixels x all 512 output channels per block, eight wavefronts; per 64-channel "
                "chunk the depthwise taps of chunk k+1 are issued between the pointwise MFMAs of chunk k in the SAME wavefront (one stream of 24 slots)"),
-           6: ("sepconv_pipe3_kernel<2,false>", "separable block 512 -> 512, dilation 2, same form")}
+           6: ("sepconv_pipe3_kernel<2,false>", "separable block 512 -> 512, dilation 2, same form"),
+           20: ("sepconv_pair_kernel<32,64,128>", "the stem's separable blocks 32 -> 64 and 64 -> 128 (stride 2) in one launch, the 64-channel "
+                "tensor between them in LDS only")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
     if tile >= 32000000:
         bm, bn = (tile - 32000000) // 1000, tile % 1000

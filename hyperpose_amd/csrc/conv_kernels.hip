@@ -3275,6 +3275,230 @@ static hipError_t launch_sep_small(const sep_params& p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Two consecutive separable blocks in ONE launch: block a (C0 -> C1, stride 1) and block b (C1 -> C2, stride 2) of the MobileNet
+// stem (32 -> 64 at 184 x 216, 64 -> 128 down to 92 x 108 in LW-OpenPose: block a's output is the largest tensor of the network,
+// 40.7 MB per batch of 8, written once and read once).  A block of 256 threads owns 4 x 8 output pixels of block b: the 9 x 17 pixels
+// of block a's output under them are computed in LDS and never reach HBM (1.2 x the work of block a for 61 % of the two blocks' bytes).
+//   S1  11 x 19 x C0 input halo (zero outside the image) + both depthwise weight sets -> LDS; pointwise A fragments -> registers
+//   S2  depthwise 3x3 of block a on the 153 mid pixels -> swizzled B tile [160][C0]
+//   S3  pointwise of block a: C1 / 32 row tiles x 5 pixel tiles, K = C0; bias + clamp + fp16 on the accumulators; mid pixels outside
+//       the image are block b's zero padding -> [153][C1] (+ 16 B per pixel against bank conflicts of the stride-2 reads)
+//   S4  depthwise 3x3 stride 2 of block b: one (pixel, 8 channels) per thread -> swizzled B tile [32][C1]
+//   S5  pointwise of block b: one 32-row tile per wavefront, K = C1, packed epilogue
+// Every value is computed by the same operations in the same order as sepconv_small_kernel computes it for the two blocks one after
+// the other (fp32 tap chain from the bias, one rounding to fp16 per tensor, MFMA k16 steps ascending from zero): bit-identical.
+template <int C0, int C1, int C2>
+__global__ __launch_bounds__(256) void sepconv_pair_kernel(const seppair_params p, int tiles_x, int tiles_y)
+{
+    constexpr int TH = 4, TW = 8, NO = TH * TW;
+    constexpr int MH = (TH - 1) * 2 + 3, MW = (TW - 1) * 2 + 3, NM = MH * MW; // 9 x 17 mid pixels
+    constexpr int IH = MH + 2, IW = MW + 2, NI = IH * IW;                      // 11 x 19 input pixels
+    constexpr int G0 = C0 / 8, G1 = C1 / 8, KQ1 = C0 / 16, KQ2 = C1 / 16, NPT1 = (NM + 31) / 32, RT1 = C1 / 32;
+    static_assert(NO == 32 && C2 == 128 && RT1 == 2 && 256 % G0 == 0 && NO * G1 == 256, "thread roles");
+    constexpr int NLD = (NI * G0 + 255) / 256, ITEMS1 = (NM * G0 + 255) / 256;
+    constexpr int H1_BYTES = NI * C0 * 2, B1_BYTES = NPT1 * 32 * C0 * 2;
+    constexpr int PXB2 = C1 * 2 + 16, H2_BYTES = (NM * PXB2 + 15) / 16 * 16, B2_BYTES = NO * C1 * 2;
+    constexpr int W1_BYTES = 9 * C0 * 2, BI1_BYTES = C0 * 4, W2_BYTES = 9 * C1 * 2, BI2_BYTES = C1 * 4;
+    constexpr int NWP = (W1_BYTES + BI1_BYTES + W2_BYTES + BI2_BYTES) / 16;
+    static_assert(NWP <= 256 && 4 * packed_geom<1, 1>::WAVE_BYTES <= H1_BYTES + B1_BYTES, "weight pieces / epilogue slabs");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[H1_BYTES + B1_BYTES + H2_BYTES + B2_BYTES + NWP * 16];
+    unsigned char* const s_h1 = lds;
+    unsigned char* const s_b1 = s_h1 + H1_BYTES;
+    unsigned char* const s_h2 = s_b1 + B1_BYTES;
+    unsigned char* const s_b2 = s_h2 + H2_BYTES;
+    unsigned char* const s_w1 = s_b2 + B2_BYTES;
+    unsigned char* const s_bi1 = s_w1 + W1_BYTES;
+    unsigned char* const s_w2 = s_bi1 + BI1_BYTES;
+    unsigned char* const s_bi2 = s_w2 + W2_BYTES;
+
+    const sep_params& A = p.a;
+    const sep_params& Bk = p.b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 31, fk = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int my0 = oy0 * 2 - Bk.pad_t, mx0 = ox0 * 2 - Bk.pad_l; // first mid pixel (may be -1: block b's padding)
+    const int iy0 = my0 - A.pad_t, ix0 = mx0 - A.pad_l;
+
+    // ---- S1: every request first
+    const int rt1 = wave & 1;
+    u32x4 a1[KQ1], a2[KQ2];
+#pragma unroll
+    for (int ks = 0; ks < KQ1; ++ks)
+        a1[ks] = *reinterpret_cast<const u32x4*>(A.pw.w + ((size_t)(rt1 * KQ1 + ks) * 64 + lane) * 8);
+#pragma unroll
+    for (int ks = 0; ks < KQ2; ++ks)
+        a2[ks] = *reinterpret_cast<const u32x4*>(Bk.pw.w + ((size_t)(wave * KQ2 + ks) * 64 + lane) * 8);
+    float4 bs1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        bs1[g] = *reinterpret_cast<const float4*>(A.pw.bias + rt1 * 32 + 8 * g + 4 * fk);
+    {
+        const __half* const hbase = A.in.p + (size_t)b * A.in.img * A.in.cs + A.in.coff;
+        u32x4 hv[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = min(tid + k * 256, NI * G0 - 1);
+            const int hp = i / G0, c = i - hp * G0;
+            const int hy = hp / IW, hx = hp - hy * IW;
+            const int y = iy0 + hy, x = ix0 + hx;
+            const bool ok = y >= 0 && y < A.H && x >= 0 && x < A.W;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(hbase + (size_t)(min(max(y, 0), A.H - 1) * A.in.wp + min(max(x, 0), A.W - 1)) * A.in.cs + c * 8);
+            hv[k] = v & (ok ? 0xffffffffu : 0u);
+        }
+        u32x4 wreg = u32x4{ 0, 0, 0, 0 };
+        {
+            constexpr int E1 = W1_BYTES / 16, E2 = E1 + BI1_BYTES / 16, E3 = E2 + W2_BYTES / 16;
+            const int i = min(tid, NWP - 1);
+            const unsigned char* src = i < E1 ? reinterpret_cast<const unsigned char*>(A.dw_w) + i * 16
+                : i < E2                      ? reinterpret_cast<const unsigned char*>(A.dw_bias) + (i - E1) * 16
+                : i < E3                      ? reinterpret_cast<const unsigned char*>(Bk.dw_w) + (i - E2) * 16
+                                              : reinterpret_cast<const unsigned char*>(Bk.dw_bias) + (i - E3) * 16;
+            wreg = *reinterpret_cast<const u32x4*>(src);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (tid + k * 256 < NI * G0)
+                *reinterpret_cast<u32x4*>(s_h1 + (size_t)(tid + k * 256) * 16) = hv[k];
+        if (tid < NWP)
+            *reinterpret_cast<u32x4*>(s_w1 + tid * 16) = wreg;
+    }
+    lds_barrier();
+
+    // ---- S2: depthwise taps of block a (thread = channel group tid % G0 of the pixels (tid + 256 r) / G0)
+    {
+        const int g = tid % G0;
+        const float* bsrc = reinterpret_cast<const float*>(s_bi1) + g * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
+        u32x4 wv[9];
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+            wv[t9] = *reinterpret_cast<const u32x4*>(s_w1 + (t9 * C0 + g * 8) * 2);
+        const float dw_hi = A.dw_hi;
+#pragma unroll
+        for (int r = 0; r < ITEMS1; ++r) {
+            const int pix = min((tid + r * 256) / G0, NM - 1); // (threads past the end redo the last pixel: same value to the same place)
+            const int py = pix / MW, px = pix - py * MW;
+            const unsigned char* xs = s_h1 + ((py * IW + px) * G0 + g) * 16;
+            float v[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const u32x4 x = *reinterpret_cast<const u32x4*>(xs + ((t9 / 3) * IW + (t9 % 3)) * G0 * 16);
+                mac8_f16(v, x, wv[t9]);
+            }
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                h[e] = (_Float16)dw_act<true>(v[e], 0.f, dw_hi);
+            *reinterpret_cast<half8*>(s_b1 + lds_off<C0>(pix, g)) = h;
+        }
+    }
+    lds_barrier();
+
+    // ---- S3: pointwise of block a; wavefront = row tile wave & 1, pixel tiles (wave >> 1) + 2 q
+    {
+        const float hi = A.pw.act_hi;
+#pragma unroll
+        for (int q = 0; q < (NPT1 + 1) / 2; ++q) {
+            const int pt = (wave >> 1) + 2 * q;
+            if (pt >= NPT1) // uniform per wavefront
+                break;
+            floatx16 acc;
+#pragma unroll
+            for (int ks = 0; ks < KQ1; ++ks) {
+                half8 fa;
+                __builtin_memcpy(&fa, &a1[ks], 16);
+                const half8 fb = *reinterpret_cast<const half8*>(s_b1 + lds_off<C0>(pt * 32 + frow, ks * 2 + fk));
+                acc = ks == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, floatx16{}, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0);
+            }
+            const int n = pt * 32 + frow;
+            const int my = n / MW, mx = n - my * MW;
+            const int y = my0 + my, x = mx0 + mx;
+            const bool ok = y >= 0 && y < A.OH && x >= 0 && x < A.OW;
+            if (n < NM) {
+                unsigned char* const row = s_h2 + n * PXB2 + (rt1 * 32 + 4 * fk) * 2;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 h;
+                    h[0] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc[4 * g + 0] + bs1[g].x, 0.f, hi) : 0.f);
+                    h[1] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc[4 * g + 1] + bs1[g].y, 0.f, hi) : 0.f);
+                    h[2] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc[4 * g + 2] + bs1[g].z, 0.f, hi) : 0.f);
+                    h[3] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc[4 * g + 3] + bs1[g].w, 0.f, hi) : 0.f);
+                    *reinterpret_cast<half4*>(row + 16 * g) = h;
+                }
+            }
+        }
+    }
+    lds_barrier();
+
+    // ---- S4: depthwise taps of block b, stride 2: thread = (output pixel tid / G1, channel group tid % G1)
+    {
+        const int g = tid % G1, pix = tid / G1;
+        const int py = pix / TW, px = pix - py * TW;
+        const float* bsrc = reinterpret_cast<const float*>(s_bi2) + g * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
+        const unsigned char* xs = s_h2 + ((py * 2) * MW + px * 2) * PXB2 + g * 16;
+        float v[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+            const u32x4 x = *reinterpret_cast<const u32x4*>(xs + ((t9 / 3) * MW + (t9 % 3)) * PXB2);
+            const u32x4 w = *reinterpret_cast<const u32x4*>(s_w2 + (t9 * C1 + g * 8) * 2);
+            mac8_f16(v, x, w);
+        }
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            h[e] = (_Float16)dw_act<true>(v[e], 0.f, Bk.dw_hi);
+        *reinterpret_cast<half8*>(s_b2 + lds_off<C1>(pix, g)) = h;
+    }
+    lds_barrier();
+
+    // ---- S5: pointwise of block b: row tile `wave`, the 32 output pixels, K = C1
+    floatx16 acc[1][1];
+#pragma unroll
+    for (int ks = 0; ks < KQ2; ++ks) {
+        half8 fa;
+        __builtin_memcpy(&fa, &a2[ks], 16);
+        const half8 fb = *reinterpret_cast<const half8*>(s_b2 + lds_off<C1>(frow, ks * 2 + fk));
+        acc[0][0] = ks == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, floatx16{}, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[0][0], 0, 0, 0);
+    }
+    int pb[1] = { b }, py1[1] = { oy0 + frow / TW }, px1[1] = { ox0 + frow % TW };
+    bool pv[1] = { py1[0] < Bk.OH && px1[0] < Bk.OW };
+    // (the slabs lie over the input halo and block a's B tile: every wavefront passed its reads of both two barriers ago)
+    conv_epilogue_packed<1, 1>(Bk.pw, acc, wave * 32, lane, s_h1 + wave * packed_geom<1, 1>::WAVE_BYTES, pb, py1, px1, pv);
+}
+
+// which pair kernel serves two consecutive separable blocks (0 = none: one launch per block)
+int seppair_variant(const seppair_params& p)
+{
+    const sep_params &a = p.a, &b = p.b;
+    const conv_params &qa = a.pw, &qb = b.pw;
+    if (a.C != 32 || qa.Cout != 64 || qa.Cout_pad < 64 || a.stride != 1 || a.dil != 1 || a.pad_t != 1 || a.pad_l != 1 || a.OH != a.H || a.OW != a.W)
+        return 0;
+    if (b.C != 64 || qb.Cout_pad != 128 || b.stride != 2 || b.dil != 1 || b.pad_t < 0 || b.pad_t > 1 || b.pad_l < 0 || b.pad_l > 1 || b.H != a.OH || b.W != a.OW)
+        return 0;
+    if (a.dw_slope != 0.f || b.dw_slope != 0.f || qa.alpha || qa.act_slope != 0.f || qa.res.p || qa.out_f32 || qb.out_f32 || !fast_epilogue(qb))
+        return 0;
+    if (a.in.coff % 8 || a.in.cs % 8)
+        return 0;
+    // block b reads exactly what block a writes
+    if (b.in.p != qa.out.p || b.in.coff != qa.out.coff || b.in.cs != qa.out.cs || b.in.wp != qa.out.wp || b.in.img != qa.out.img)
+        return 0;
+    return 1;
+}
+
+hipError_t launch_seppair(const seppair_params& p, hipStream_t s)
+{
+    if (seppair_variant(p) != 1)
+        return hipErrorInvalidValue;
+    const int tiles_x = (p.b.OW + 7) / 8, tiles_y = (p.b.OH + 3) / 4;
+    HP_LAUNCH((sepconv_pair_kernel<32, 64, 128>), dim3(tiles_x * tiles_y * p.b.B), dim3(256), 0, s, p, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
 // which instantiation serves (Cout_pad, stride, dilation, C); 0 = none (the engine then keeps the two launches)
 // which fused instance serves a block (0 = none: the caller keeps dwconv3x3 + a 1x1 convolution)
 int sepconv_variant_for(int C, int cout_pad, int stride, int dil, int cout)

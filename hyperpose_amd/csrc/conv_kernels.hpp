@@ -131,6 +131,14 @@ int sepconv_variant(const sep_params& p);
 int sepconv_variant_for(int C, int cout_pad, int stride, int dil, int cout = 0); // the pointer-free part of the same decision (cout: true output channels, 0 = unknown)
 hipError_t launch_sepconv(const sep_params& p, hipStream_t s);
 
+// Two consecutive separable blocks (32 -> 64 stride 1, 64 -> 128 stride 2: the MobileNet stem) in one launch, the tensor between them
+// in LDS only (sepconv_pair_kernel).  `b.in` must be `a.pw.out`.
+struct seppair_params {
+    sep_params a, b;
+};
+int seppair_variant(const seppair_params& p); // 0 = none
+hipError_t launch_seppair(const seppair_params& p, hipStream_t s);
+
 // Two chained 1x1 convolutions K1 -> 512 (relu family) -> Cout2 <= 64 in one launch (mlp_head_kernel).
 //   w1: MFMA-fragment order, half index (((m / 32) * (K1 / 16) + k / 16) * 64 + (k % 16 / 8) * 32 + m % 32) * 8 + k % 8
 //   w2: rows padded to 64; the hidden channel c = 128 w + 32 i + r32 sits at K-step 8 w + 2 i + s, lane half h, element e

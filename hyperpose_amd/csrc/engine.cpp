@@ -73,6 +73,8 @@ struct step {
     hp::dw_params dp{};
     hp::pool_params pp{};
     hp::sep_params sp{}; // op == OP_SEPCONV: depthwise layer `layer` fused with the pointwise layer `layer + 1`
+    hp::sep_params sp2{}; // ... and, when `sep_pair`, the NEXT separable block (layers `layer + 2`, `layer + 3`) in the same launch
+    bool sep_pair = false;
     hp::head_params hp_{}; // op == OP_MLPHEAD: 1x1 conv `layer` (-> 512, relu) fused with the 1x1 conv `layer + 1`
     hp::head_params hp2_{}; // ... and, when `paired`, the sibling head on the same input (layers `layer + 2`, `layer + 3`)
     bool paired = false;
@@ -1073,6 +1075,35 @@ int hp_engine::build(const hp_engine_desc* d)
                 }
         }
     }
+    // ---- the MobileNet stem's separable blocks 32 -> 64 and 64 -> 128 (stride 2) as ONE launch, the 64-channel tensor between them (the
+    // largest of the network) in LDS only (sepconv_pair_kernel).  HP_NO_SEPPAIR=1 keeps one launch per block.
+    if (!getenv("HP_NO_SEPPAIR") && !getenv("HP_NO_FUSE") && !f32) {
+        for (size_t k = 0; k + 1 < steps.size(); ++k) {
+            step &a = steps[k], &b = steps[k + 1];
+            if (a.op != OP_SEPCONV || b.op != OP_SEPCONV || a.sep_pair || b.sep_pair)
+                continue;
+            const hp_layer &Pa = layers[a.layer + 1], &Db = layers[b.layer];
+            if (Db.in != Pa.out || Db.in_coff != Pa.out_coff)
+                continue;
+            bool private_tensor = true; // nobody but block b's depthwise layer reads it and it is no network output
+            for (size_t j = 0; j < layers.size(); ++j)
+                if ((int)j != b.layer && (layers[j].in == Pa.out || layers[j].res == Pa.out))
+                    private_tensor = false;
+            for (const auto& o : outputs)
+                private_tensor = private_tensor && o.tensor != Pa.out;
+            int writers = 0;
+            for (const auto& L2 : layers)
+                writers += L2.out == Pa.out;
+            hp::seppair_params pp{ a.sp, b.sp };
+            if (!private_tensor || writers != 1 || !hp::seppair_variant(pp))
+                continue;
+            a.sp2 = b.sp, a.sep_pair = true, a.n_layers += b.n_layers;
+            a.flops += b.flops;
+            a.bytes = a.bytes + b.bytes - 2.0 * (double)a.sp.OH * a.sp.OW * Pa.cout * 2; // the tensor in between is neither written nor read
+            tensors[Pa.out]->elided = true; // allocated (pass 1) but never written
+            steps.erase(steps.begin() + k + 1);
+        }
+    }
     // sibling heads (conf / paf branch of one stage: same input, same geometry, neither reads the other) share a launch
     if (!getenv("HP_NO_PAIR_HEADS") && !f32) {
         for (size_t k = 0; k + 1 < steps.size(); ++k) {
@@ -1191,6 +1222,11 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
         }
     } else if (st.op == OP_SEPCONV) {
         st.sp.B = n, st.sp.pw.B = n, st.sp.pw.npix = n * st.sp.OH * st.sp.OW;
+        if (st.sep_pair) {
+            st.sp2.B = n, st.sp2.pw.B = n, st.sp2.pw.npix = n * st.sp2.OH * st.sp2.OW;
+            HP_HIP_TRY(hp::launch_seppair(hp::seppair_params{ st.sp, st.sp2 }, s));
+            return HP_OK;
+        }
         HP_HIP_TRY(hp::launch_sepconv(st.sp, s));
         if (dbg_sep) { // block timeline (s_memtime deltas of block 0, thread 0) of every separable block, printed per launch
             unsigned long long* dbg = nullptr;
@@ -1533,7 +1569,7 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
         HP_HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
         if (out && k < cap) {
             out[k].layer = st.layer, out[k].op = st.op;
-            out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
+            out[k].tile = st.op == OP_SEPCONV ? 4000000 + (st.sep_pair ? 20 : hp::sepconv_variant(st.sp))
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
@@ -1586,7 +1622,7 @@ int hp_engine_profile_pair(hp_engine* e, hp_engine* f, int n, int iters, hp_laye
         if (out && k < cap) {
             auto& st = sa;
             out[k].layer = st.layer, out[k].op = st.op;
-            out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
+            out[k].tile = st.op == OP_SEPCONV ? 4000000 + (st.sep_pair ? 20 : hp::sepconv_variant(st.sp))
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
@@ -1644,7 +1680,7 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
     for (auto& st : e->steps) {
         if (out && k < cap) {
             out[k].layer = st.layer, out[k].op = st.op;
-            out[k].tile = st.op == OP_SEPCONV ? 4000000 + hp::sepconv_variant(st.sp)
+            out[k].tile = st.op == OP_SEPCONV ? 4000000 + (st.sep_pair ? 20 : hp::sepconv_variant(st.sp))
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)

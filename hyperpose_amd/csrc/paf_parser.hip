@@ -202,6 +202,23 @@ __global__ __launch_bounds__(PEAK_THREADS) void paf_peaks_kernel(const float* __
     const int alive = __syncthreads_or(vmax * 1.001f >= thresh); // (also the barrier that makes the staged rows visible to every wavefront)
     if (!DUMP && alive == 0)
         return;
+    // The same bound per wavefront: its 46 columns' smoothed values and their 3 x 3 neighbourhoods are made of the samples of its own 64
+    // lanes (9 halo columns on either side = the 8-column filter radius + 1), i.e. of the source columns sx / sx1 of those lanes over the
+    // staged rows.  A strip of four wavefronts usually has people under one or two of them only.  (No barrier follows: a wavefront may leave.)
+    if (!DUMP) {
+        float wmax = 0.f;
+        for (int r = 0; r < nrows; ++r) {
+            const float v0 = s_src[r * g.Cc + sx], v1 = s_src[r * g.Cc + sx1];
+            wmax = fmaxf(wmax, fmaxf(v0, v1));
+            if (!(v0 == v0) || !(v1 == v1))
+                wmax = __builtin_huge_valf(); // a NaN source keeps the wavefront alive
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1)
+            wmax = fmaxf(wmax, __shfl_xor(wmax, d));
+        if (!(wmax * 1.001f >= thresh))
+            return;
+    }
 
     // w[j] = (R[m-16+j], R[m-15+j]): overlapping pairs of the row-filtered column, logical rows m-16 .. m+1
     f32x2 w[KSIZE];

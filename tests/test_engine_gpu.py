@@ -390,6 +390,42 @@ def test_fused_separable_block(hp, monkeypatch, c, cout, stride, dil, h, w):
             eng.debug_tensor(d, 3)  # never materialised
 
 
+@pytest.mark.parametrize("h,w,stem_stride,act", [
+    (46, 54, 1, E.ACT_RELU6),   # even map: SAME pads 0 / 1 on the stride-2 block; 23 x 27 outputs = ragged 4 x 8 tiles both ways
+    (37, 45, 1, E.ACT_RELU),    # odd map: pads 1 / 1; 19 x 23 outputs
+    (64, 96, 2, E.ACT_RELU6),   # behind a stride-2 stem, as in the network: 32 x 48 map, whole tiles
+    (9, 7, 1, E.ACT_RELU),      # smaller than one tile: everything is padding or ragged
+])
+def test_separable_pair_in_one_launch(hp, monkeypatch, h, w, stem_stride, act):
+    """sepconv_pair_kernel (32 -> 64 stride 1 and 64 -> 128 stride 2 in one launch, the tensor between them in LDS only): against the
+    oracle and bit-for-bit against one launch per block (HP_NO_SEPPAIR=1) - pixels of the tensor in between that lie outside the image
+    must act as the second block's zero padding, ragged tiles must not write outside the map."""
+    net = Net(17)
+    a = net.conv(0, 3, 32, 3, stem_stride, act=act)
+    d1 = net.conv(a, 32, 32, 3, 1, op=E.OP_DWCONV, act=act)
+    p1 = net.conv(d1, 32, 64, 1, act=act)
+    d2 = net.conv(p1, 64, 64, 3, 2, op=E.OP_DWCONV, act=act)
+    p2 = net.conv(d2, 64, 128, 1, act=act)
+    z = net.conv(p2, 128, 32, 1, act=E.ACT_NONE)  # the fused blocks must not be a network output
+    fr = _frames(3, h, w, seed=h + w)
+    outs = [Out("z", z, 0, 32)]
+    eng, got, ref = _run_both(net, outs, fr, h, w)
+    _check(got, ref, 3)
+    tiles = [p["tile"] for p in eng.profile(3, 1)]
+    assert tiles.count(4000020) == 1 and sum(4000000 <= t < 5000000 for t in tiles) == 1, tiles  # ONE launch for both blocks
+    with pytest.raises(Exception):
+        eng.debug_tensor(p1, 3)  # lives in LDS only
+    mid = eng.debug_tensor(p2, 3)
+    monkeypatch.setenv("HP_NO_SEPPAIR", "1")
+    eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 3)
+    got2 = eng2.inference(fr)
+    tiles2 = [p["tile"] for p in eng2.profile(3, 1)]
+    assert 4000020 not in tiles2 and sum(4000000 <= t < 5000000 for t in tiles2) == 2, tiles2
+    assert np.array_equal(mid, eng2.debug_tensor(p2, 3))
+    for b in range(3):
+        assert np.array_equal(got[b][0][1], got2[b][0][1])
+
+
 @pytest.mark.parametrize("variant,h,w,act", [
     ("pair", 52, 68, E.ACT_RELU),        # 13 x 17 map: ragged tiles in both directions (8 x 12 output tiles)
     ("pair_res1", 40, 100, E.ACT_RELU),  # 10 x 25: residual on the FIRST 3x3 (the CPM stage's `x + main_block(x)`, lw_openpose.py:118-121)
