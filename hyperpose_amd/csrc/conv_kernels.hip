@@ -343,43 +343,27 @@ __device__ __forceinline__ void conv_epilogue_wide(const conv_params& p, const f
     for (int j = 0; j < TN; ++j) {
         const long* const s_ooff = reinterpret_cast<const long*>(slab + j * G::SLAB + 32 * G::ROW);
 #pragma unroll
-        for (int ps = 0; ps < G::PASSES; ++ps)
+        for (int ps = 0; ps < G::PASSES; ++ps) {
             oo[j][ps] = s_ooff[ps * G::PPP + prow];
-    }
-    // (the uniform choices are made around whole loop nests, never inside one: a branch per pass keeps the compiler from putting the
-    // passes' reads and residual requests in flight together)
-    if (has_res) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const long* const s_ooff = reinterpret_cast<const long*>(slab + j * G::SLAB + 32 * G::ROW);
-#pragma unroll
-            for (int ps = 0; ps < G::PASSES; ++ps) // invalid pixels read offset 0: in bounds, result unused
+            if (has_res) // invalid pixels read offset 0: in bounds, result unused
                 rs[j][ps] = *reinterpret_cast<const half8*>(p.res.p + s_ooff[32 + ps * G::PPP + prow] + (mvalid ? mc : 0));
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int ps = 0; ps < G::PASSES; ++ps)
+            else
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
                     rs[j][ps][r] = (_Float16)0.f;
+        }
     }
-    auto tile = [&](int j, auto clamp_) {
-        constexpr bool CLAMP = decltype(clamp_)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
         const unsigned char* const sj = slab + j * G::SLAB;
-        float4 a0[G::PASSES], a1[G::PASSES];
 #pragma unroll
         for (int ps = 0; ps < G::PASSES; ++ps) {
             const int pix = ps * G::PPP + prow;
-            a0[ps] = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32);
-            a1[ps] = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32 + 16);
-        }
-#pragma unroll
-        for (int ps = 0; ps < G::PASSES; ++ps) {
-            const float v[8] = { a0[ps].x, a0[ps].y, a0[ps].z, a0[ps].w, a1[ps].x, a1[ps].y, a1[ps].z, a1[ps].w };
+            const float4 a0 = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32);
+            const float4 a1 = *reinterpret_cast<const float4*>(sj + pix * G::ROW + chunk * 32 + 16);
+            const float v[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
             half8 h;
-            if constexpr (CLAMP) {
+            if (clamp_only) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
                     h[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r] + bs[r], 0.f, hi);
@@ -399,17 +383,12 @@ __device__ __forceinline__ void conv_epilogue_wide(const conv_params& p, const f
             if (oo[j][ps] >= 0 && mvalid)
                 *reinterpret_cast<half8*>(p.out.p + oo[j][ps] + mc) = h;
         }
-    };
-    if (clamp_only) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            tile(j, std::true_type{});
-    } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            tile(j, std::false_type{});
     }
 }
+
+// (Round 4 tried this epilogue with the uniform choices hoisted around whole loop nests and every slab read of a pixel tile ahead of its
+// stores, as in conv_epilogue_staged / _packed: conv1x1_big_kernel<2,2> went from 158 to 197 registers and ResNet-50's 256 -> 1024
+// expansions from 203 to 300 us (tools/profile_layers.py, configs[4]).  Kept as it was.)
 
 // The staged epilogue with the arithmetic moved to the MFMA side of the transpose: bias, activation and the rounding to fp16 happen
 // on the accumulator registers (same operations in the same order as above, so the same bits), and the slab holds HALVES: half the
@@ -3289,7 +3268,7 @@ static hipError_t launch_sep_small(const sep_params& p, hipStream_t s)
 // Every value is computed by the same operations in the same order as sepconv_small_kernel computes it for the two blocks one after
 // the other (fp32 tap chain from the bias, one rounding to fp16 per tensor, MFMA k16 steps ascending from zero): bit-identical.
 template <int C0, int C1, int C2>
-__global__ __launch_bounds__(256) void sepconv_pair_kernel(const seppair_params p, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(256, 4) void sepconv_pair_kernel(const seppair_params p, int tiles_x, int tiles_y)
 {
     constexpr int TH = 4, TW = 8, NO = TH * TW;
     constexpr int MH = (TH - 1) * 2 + 3, MW = (TW - 1) * 2 + 3, NM = MH * MW; // 9 x 17 mid pixels
@@ -3301,13 +3280,16 @@ __global__ __launch_bounds__(256) void sepconv_pair_kernel(const seppair_params 
     constexpr int PXB2 = C1 * 2 + 16, H2_BYTES = (NM * PXB2 + 15) / 16 * 16, B2_BYTES = NO * C1 * 2;
     constexpr int W1_BYTES = 9 * C0 * 2, BI1_BYTES = C0 * 4, W2_BYTES = 9 * C1 * 2, BI2_BYTES = C1 * 4;
     constexpr int NWP = (W1_BYTES + BI1_BYTES + W2_BYTES + BI2_BYTES) / 16;
-    static_assert(NWP <= 256 && 4 * packed_geom<1, 1>::WAVE_BYTES <= H1_BYTES + B1_BYTES, "weight pieces / epilogue slabs");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[H1_BYTES + B1_BYTES + H2_BYTES + B2_BYTES + NWP * 16];
+    // LDS: region X = the input halo, then (S3 on) block a's output over it; region Y = block a's B tile, then (S4 on) block b's; each
+    // is dead when its successor is written (a barrier in between).  34 KB: four blocks per CU.
+    constexpr int X_BYTES = H1_BYTES > H2_BYTES ? H1_BYTES : H2_BYTES, Y_BYTES = B1_BYTES > B2_BYTES ? B1_BYTES : B2_BYTES;
+    static_assert(NWP <= 256 && 4 * packed_geom<1, 1>::WAVE_BYTES <= X_BYTES, "weight pieces / epilogue slabs");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X_BYTES + Y_BYTES + NWP * 16];
     unsigned char* const s_h1 = lds;
-    unsigned char* const s_b1 = s_h1 + H1_BYTES;
-    unsigned char* const s_h2 = s_b1 + B1_BYTES;
-    unsigned char* const s_b2 = s_h2 + H2_BYTES;
-    unsigned char* const s_w1 = s_b2 + B2_BYTES;
+    unsigned char* const s_h2 = lds;
+    unsigned char* const s_b1 = lds + X_BYTES;
+    unsigned char* const s_b2 = lds + X_BYTES;
+    unsigned char* const s_w1 = s_b1 + Y_BYTES;
     unsigned char* const s_bi1 = s_w1 + W1_BYTES;
     unsigned char* const s_w2 = s_bi1 + BI1_BYTES;
     unsigned char* const s_bi2 = s_w2 + W2_BYTES;
@@ -3417,17 +3399,20 @@ __global__ __launch_bounds__(256) void sepconv_pair_kernel(const seppair_params 
             const int n = pt * 32 + frow;
             const int my = n / MW, mx = n - my * MW;
             const int y = my0 + my, x = mx0 + mx;
-            const bool ok = y >= 0 && y < A.OH && x >= 0 && x < A.OW;
+            const unsigned okm = (y >= 0 && y < A.OH && x >= 0 && x < A.OW) ? 0xffffffffu : 0u;
             if (n < NM) {
                 unsigned char* const row = s_h2 + n * PXB2 + (rt1 * 32 + 4 * fk) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     half4 h;
-                    h[0] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc[4 * g + 0] + bs1[g].x, 0.f, hi) : 0.f);
-                    h[1] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc[4 * g + 1] + bs1[g].y, 0.f, hi) : 0.f);
-                    h[2] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc[4 * g + 2] + bs1[g].z, 0.f, hi) : 0.f);
-                    h[3] = (_Float16)(ok ? __builtin_amdgcn_fmed3f(acc[4 * g + 3] + bs1[g].w, 0.f, hi) : 0.f);
-                    *reinterpret_cast<half4*>(row + 16 * g) = h;
+                    h[0] = (_Float16)__builtin_amdgcn_fmed3f(acc[4 * g + 0] + bs1[g].x, 0.f, hi);
+                    h[1] = (_Float16)__builtin_amdgcn_fmed3f(acc[4 * g + 1] + bs1[g].y, 0.f, hi);
+                    h[2] = (_Float16)__builtin_amdgcn_fmed3f(acc[4 * g + 2] + bs1[g].z, 0.f, hi);
+                    h[3] = (_Float16)__builtin_amdgcn_fmed3f(acc[4 * g + 3] + bs1[g].w, 0.f, hi);
+                    uint2 u;
+                    __builtin_memcpy(&u, &h, 8);
+                    u.x &= okm, u.y &= okm; // (outside the image: + 0.0, block b's padding)
+                    *reinterpret_cast<uint2*>(row + 16 * g) = u;
                 }
             }
         }
@@ -3467,7 +3452,7 @@ __global__ __launch_bounds__(256) void sepconv_pair_kernel(const seppair_params 
     }
     int pb[1] = { b }, py1[1] = { oy0 + frow / TW }, px1[1] = { ox0 + frow % TW };
     bool pv[1] = { py1[0] < Bk.OH && px1[0] < Bk.OW };
-    // (the slabs lie over the input halo and block a's B tile: every wavefront passed its reads of both two barriers ago)
+    // (the slabs lie over region X: every wavefront passed its last reads of block a's output at the barrier above)
     conv_epilogue_packed<1, 1>(Bk.pw, acc, wave * 32, lane, s_h1 + wave * packed_geom<1, 1>::WAVE_BYTES, pb, py1, px1, pv);
 }
 

@@ -585,7 +585,8 @@ def test_lw_openpose_fused_equals_unfused(hp, monkeypatch):
     fr = _frames(2, 368, 432, seed=4)
     eng = E.Engine.from_model(m, w, max_batch=2)
     tiles = [p["tile"] for p in eng.profile(2, 1)]
-    assert sum(4000000 <= t < 5000000 for t in tiles) == 11  # every MobileNet separable block
+    assert sum(4000000 <= t < 5000000 for t in tiles) == 10  # every MobileNet separable block (the stem's first two share a launch)
+    assert tiles.count(4000020) == 1
     assert sum(6000000 <= t < 7000000 for t in tiles) == 2   # init + refinement stage: conf + paf heads share a launch
     assert sum(7000000 <= t < 8000000 for t in tiles) == 8   # CPM (2) + init stage (1) + five refinement blocks as chained launches
     got = eng.inference(fr)
