@@ -170,6 +170,11 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
             a[ks] = *reinterpret_cast<const u32x4*>(wf + (size_t)ks * 512);
     }
 
+    // An external residual (RES 1: added to S1's output, RES 2: to S2's) is requested right BEHIND the halo requests and waits in registers:
+    // requests complete in order, so one issued next to a stage's MFMA loop is older than the loop's weight-fragment ring and the loop's
+    // first s_waitcnt vmcnt exposes its whole latency (HP_CHAIN_DBG: 2.6 k of a block's 30 k ticks for RES 1, 1.7 k for RES 2), and one
+    // issued AHEAD of the halo is waited for with it (the tensor was written several launches ago: it comes from HBM, the halo from L2)
+    half4 rs1[RES == 1 ? NT1 : 1][4], rs2[RES == 2 ? NT0 : 1][4];
     // ---- the input tile + 2-pixel halo: all loads first (one round trip), then the LDS stores; pixels outside the image are zero
     {
         const tview& in = S0 ? p.c0.in : p.c1.in;
@@ -184,6 +189,27 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
             const bool ok = y >= 0 && y < H && x >= 0 && x < W;
             const u32x4 v = *reinterpret_cast<const u32x4*>(in.p + tv_off(in, b, min(max(y, 0), H - 1), min(max(x, 0), W - 1)) + c * 8);
             hv[it] = v & (ok ? 0xffffffffu : 0u);
+        }
+        if (RES == 1) {
+#pragma unroll
+            for (int j = 0; j < NT1; ++j) {
+                const int nc = min(j * 32 + fr, N1 - 1), br = nc / W1, bc = nc - br * W1;
+                const int y = y0 - 1 + br, x = x0 - 1 + bc;
+                const __half* rp = p.c1.res.p + tv_off(p.c1.res, b, min(max(y, 0), H - 1), min(max(x, 0), W - 1)) + wave * 32 + 4 * fk;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    rs1[j][g] = *reinterpret_cast<const half4*>(rp + 8 * g);
+            }
+        }
+        if (RES == 2) {
+#pragma unroll
+            for (int j = 0; j < NT0; ++j) {
+                const int n = min(j * 32 + fr, N0 - 1), br = n / TW, bc = n - br * TW;
+                const __half* rp = p.c2.res.p + tv_off(p.c2.res, b, min(y0 + br, H - 1), min(x0 + bc, W - 1)) + wave * 32 + 4 * fk;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    rs2[j][g] = *reinterpret_cast<const half4*>(rp + 8 * g);
+            }
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -265,13 +291,6 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
             const int nc = min(n, N1 - 1), br = nc / W1, bc = nc - br * W1;
             const int y = y0 - 1 + br, x = x0 - 1 + bc;
             const bool ok = y >= 0 && y < H && x >= 0 && x < W;
-            half4 rs[4];
-            if (RES == 1) {
-                const __half* rp = p.c1.res.p + tv_off(p.c1.res, b, min(max(y, 0), H - 1), min(max(x, 0), W - 1)) + wave * 32 + 4 * fk;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    rs[g] = *reinterpret_cast<const half4*>(rp + 8 * g);
-            }
             if (n < N1) {
                 unsigned char* const row = s_t2 + n * PXB + fk * 8;
                 const int key = t2_key(br, bc);
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
                     for (int r = 0; r < 4; ++r) {
                         float v = __builtin_amdgcn_fmed3f(acc[j][4 * g + r] + bs[4 * g + r], 0.f, hi);
                         if (RES == 1)
-                            v += (float)rs[g][r];
+                            v += (float)rs1[j][g][r];
                         h[r] = (_Float16)(ok ? v : 0.f);
                     }
                     *reinterpret_cast<half4*>(row + (((wave * 4 + g) ^ key) << 4)) = h;
@@ -303,17 +322,6 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
             const int n = min(j * 32 + fr, N0 - 1), br = n / TW, bc = n - br * TW; // (pad lanes of the last column tile redo its last pixel)
             pix0[j] = (br * W1 + bc) * PXB, nkey[j] = n;
         }
-        half4 rs[NT0][4];
-        if (RES == 2) { // requested before the MFMAs: 12 eight-byte loads per lane, used in the epilogue
-#pragma unroll
-            for (int j = 0; j < NT0; ++j) {
-                const int n = min(j * 32 + fr, N0 - 1), br = n / TW, bc = n - br * TW;
-                const __half* rp = p.c2.res.p + tv_off(p.c2.res, b, min(y0 + br, H - 1), min(x0 + bc, W - 1)) + wave * 32 + 4 * fk;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    rs[j][g] = *reinterpret_cast<const half4*>(rp + 8 * g);
-            }
-        }
         chain_stage<NT0, 9, W1, TW, D>(acc, a, w2, tap_stride, nullptr, s_t2, pix0, nkey, fk);
         HP_CSTAMP();
         float bs[16];
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const chain_params p
                 if (RES == 3)
                     h = *reinterpret_cast<const half4*>(at);
                 else if (RES == 2)
-                    h = rs[j][g];
+                    h = rs2[j][g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = __builtin_amdgcn_fmed3f(acc[j][4 * g + r] + bs[4 * g + r], 0.f, hi);
