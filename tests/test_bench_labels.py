@@ -25,7 +25,7 @@ def _names(tag):
 
 # (tile code as hp_engine_profile reports it, configuration whose committed summary must contain the kernel)
 CASES = [
-    (4000005, ""), (4000006, ""), (4000004, ""), (4000003, ""), (4000007, ""), (7000013, ""), (7000001, ""), (7000002, ""), (7000003, ""),
+    (4000005, ""), (4000006, ""), (4000004, ""), (4000003, ""), (4000020, ""), (4000001, ""), (7000013, ""), (7000001, ""), (7000002, ""), (7000003, ""),
     (5064192, ""), (6000128, ""), (5201002, ""), (5100192, ""),
     (6128049, "_config2"), (6256009, "_config2"), (6192049, "_config2"),
     (5202002, "_config3"), (9001311, "_config3"), (9001011, "_config3"), (9001021, "_config3"), (9002020, "_config3"), (9002021, "_config3"),
