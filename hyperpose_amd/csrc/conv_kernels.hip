@@ -1814,7 +1814,6 @@ __global__ __launch_bounds__(256) void first_conv_f16_kernel(const first_conv_pa
     for (int i = tid; i < NCOPY * IH * PITCH / 2; i += 256)
         reinterpret_cast<unsigned*>(&s_x[0][0])[i] = 0u;
     __syncthreads();
-    if constexpr (KS == 7) {
     {
         constexpr int NIT = (IH * IW + 255) / 256;
         const int c0 = p.flip_rb ? 2 : 0, c2 = p.flip_rb ? 0 : 2;
@@ -1824,9 +1823,10 @@ __global__ __launch_bounds__(256) void first_conv_f16_kernel(const first_conv_pa
             if (NCOPY == 2 && px * 3 + c >= 1)
                 s_x[NCOPY - 1][py * PITCH + px * 3 + c - 1] = v; // copy 1 [j] = copy 0 [j + 1]
         };
-        if (KS == 7 && p.in_u8) { // (the 3 x 3 stems have three passes: batching them costs more registers than it saves)
+        if (p.in_u8) {
             // all byte loads first (clamped addresses, three bytes of a pixel packed into one register): one memory round trip for the
-            // patch instead of one per pass - the patch was half of the block's time
+            // patch instead of one per pass - the patch was half of the 7 x 7 block's time, and the 3 x 3 stride-2 stem's 33 x 65 patch is nine
+            // passes (round 4: the ISA showed nine load -> wait -> convert rounds)
             unsigned raw[NIT];
             unsigned okm = 0;
 #pragma unroll
@@ -1868,39 +1868,6 @@ __global__ __launch_bounds__(256) void first_conv_f16_kernel(const first_conv_pa
                 }
             }
         }
-    }
-    } else {
-    {
-        constexpr int NIT = (IH * IW + 255) / 256;
-        const int c0 = p.flip_rb ? 2 : 0, c2 = p.flip_rb ? 0 : 2;
-#pragma unroll 4
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            if (i >= IH * IW)
-                break;
-            const int py = i / IW, px = i - py * IW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W)
-                continue; // stays zero = the convolution's padding
-            float raw[3];
-            if (p.in_u8) {
-                const uint8_t* q = p.in_u8 + (((size_t)b * p.H + iy) * p.W + ix) * 3;
-                raw[0] = (float)((double)(float)q[c0] * p.factor), raw[1] = (float)((double)(float)q[1] * p.factor),
-                raw[2] = (float)((double)(float)q[c2] * p.factor); // src/data.cpp:48
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    raw[c] = p.in_f32[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const _Float16 v = (_Float16)((raw[c] - p.mean[c]) * p.inv_std[c]);
-                s_x[0][py * PITCH + px * 3 + c] = v;
-                if (NCOPY == 2 && px * 3 + c >= 1)
-                    s_x[NCOPY - 1][py * PITCH + px * 3 + c - 1] = v; // copy 1 [j] = copy 0 [j + 1]
-            }
-        }
-    }
     }
     __syncthreads();
 
