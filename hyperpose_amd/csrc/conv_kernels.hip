@@ -404,9 +404,22 @@ struct packed_geom {
     static constexpr int WAVE_BYTES = TN * SLAB > stage_geom<TM>::SLAB ? TN * SLAB : stage_geom<TM>::SLAB;
 };
 
+// this lane's bias vectors in the order conv_epilogue_packed wants them: a caller with idle registers before its last MFMAs requests
+// them there and passes them in, so that the epilogue does not start with a memory latency
+template <int TM>
+__device__ __forceinline__ void packed_bias(const conv_params& p, int m_wave, int lane, float4 (&bs)[TM][4])
+{
+    const int mq = m_wave + 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bs[i][g] = *reinterpret_cast<const float4*>(p.bias + mq + i * 32 + 8 * g);
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_packed(const conv_params& p, const floatx16 (&acc)[TM][TN], int m_wave, int lane,
-    unsigned char* slab, const int (&pb)[TN], const int (&py)[TN], const int (&px)[TN], const bool (&pv)[TN])
+    unsigned char* slab, const int (&pb)[TN], const int (&py)[TN], const int (&px)[TN], const bool (&pv)[TN], const float4 (&bs)[TM][4])
 {
     using G = packed_geom<TM, TN>;
     if (p.res.p) { // uniform
@@ -419,12 +432,6 @@ __device__ __forceinline__ void conv_epilogue_packed(const conv_params& p, const
     // every bias request goes out before the first use, and the (uniform) choice of the activation is made ONCE around the whole
     // loop nest: with the load and the choice inside it the compiler waited for each of the TM x 4 loads in turn - eight memory
     // latencies, 2.4 of the 3.6 us the 512-channel separable block spent after its last MFMA (round 4)
-    float4 bs[TM][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bs[i][g] = *reinterpret_cast<const float4*>(p.bias + mq + i * 32 + 8 * g);
     auto put = [&](int i, int g, int j, float v0, float v1, float v2, float v3) {
         half4 h;
         h[0] = (_Float16)v0, h[1] = (_Float16)v1, h[2] = (_Float16)v2, h[3] = (_Float16)v3;
@@ -494,6 +501,15 @@ __device__ __forceinline__ void conv_epilogue_packed(const conv_params& p, const
             if (oo[ps] >= 0 && mvalid)
                 *reinterpret_cast<half8*>(p.out.p + oo[ps] + mc) = h[ps];
     }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_packed(const conv_params& p, const floatx16 (&acc)[TM][TN], int m_wave, int lane,
+    unsigned char* slab, const int (&pb)[TN], const int (&py)[TN], const int (&px)[TN], const bool (&pv)[TN])
+{
+    float4 bs[TM][4];
+    packed_bias<TM>(p, m_wave, lane, bs);
+    conv_epilogue_packed<TM, TN>(p, acc, m_wave, lane, slab, pb, py, px, pv, bs);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2775,7 +2791,7 @@ struct tap_sched {
 //   * the halo pieces are stored one per slot in three different slots;
 //   * the chunk loop is unrolled by two, so the buffer parity is a compile-time constant and every LDS address is a base register that
 //     never changes plus an immediate (the v2 loop spent 31 v_add_u32 per interval on them).  Needs an even number of chunks.
-template <int D, bool DBG = false>
+template <int D, bool DBG = false, bool TAIL = true> // TAIL: the epilogue inside the last interval (relu / relu6, no residual)
 __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params p, int tiles_x, int tiles_y)
 {
     using S = tap_sched<D, 1>;
@@ -2792,7 +2808,8 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params 
     constexpr int OFF_HALO = 2 * BCH_BYTES, OFF_DWW = OFF_HALO + 2 * HALO_BYTES, OFF_DWB = OFF_DWW + DWW_BYTES;
     constexpr int MAIN_BYTES = OFF_DWB + DWB_BYTES;
     constexpr int EPI_BYTES = NW * packed_geom<TP, NT>::WAVE_BYTES;
-    constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+    constexpr int TAIL_BYTES = OFF_HALO + NW * NT * packed_geom<TP, NT>::SLAB; // the fused tail's slabs lie behind the B tiles
+    constexpr int LDS_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) > TAIL_BYTES ? (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) : TAIL_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(256))) unsigned char lds[LDS_BYTES];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
@@ -3040,9 +3057,8 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params 
         interval(YES, YES, P0, k + 1, k + 2, min(k + 3, NCH - 1), NO);
         lds_barrier();
     }
-    interval(YES, NO, P1, NCH - 1, 0, 0, NO);
-    HP_STAMP();
-    lds_barrier(); // (every wavefront past its reads of the B tiles: the slabs may overwrite them)
+    float4 ebias[TP][4]; // the epilogue's bias vectors: requested before the last interval's MFMAs (the taps' registers are free there)
+    packed_bias<TP>(p.pw, (wave * TP) * 32, lane, ebias);
     int pb[NT], py[NT], px[NT];
     bool pv[NT];
 #pragma unroll
@@ -3053,7 +3069,79 @@ __global__ __launch_bounds__(512, 1) void sepconv_pipe3_kernel(const sep_params 
         px[j] = x0 + n % TW;
         pv[j] = py[j] < p.OH && px[j] < p.OW;
     }
-    conv_epilogue_packed<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * packed_geom<TP, NT>::WAVE_BYTES, pb, py, px, pv);
+    // The last interval has no taps to hide: with relu / relu6 and no residual (every block of the network) its vector slots take the
+    // epilogue instead.  The MFMAs run pixel tile by pixel tile (j, then k16 step, then row tile), so tile j's accumulators are final
+    // after slot 8 j + 7; bias + clamp + fp16 + the slab write of tile j - 1 (conv_epilogue_packed's arithmetic, unit = one (row tile,
+    // channel group)) sit behind the MFMAs of tile j, the global stores of tile j - 2 behind those.  The slabs lie over the halo buffers
+    // and the depthwise weights, which nobody reads any more; the B tile of the last chunk stays where it is.
+    using EG = packed_geom<TP, NT>;
+    static_assert(OFF_HALO + NW * NT * EG::SLAB <= LDS_BYTES, "the fused tail's slabs");
+    if constexpr (TAIL) {
+        unsigned char* const slab = lds + OFF_HALO + wave * (NT * EG::SLAB);
+        const float hi = p.pw.act_hi;
+        if (lane < 32) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                reinterpret_cast<long*>(slab + j * EG::SLAB + 32 * EG::ROW)[lane] = pv[j] ? tv_off(p.pw.out, pb[j], py[j], px[j]) : -1;
+        }
+        const int echunk = lane % EG::CPP, eprow = lane / EG::CPP;
+        const int emc = (wave * TP) * 32 + echunk * 8;
+        const bool emvalid = emc < p.pw.Cout;
+        half8 fbq[2]; // B fragments in MFMA order: n = j * KS + ks, two in flight
+        auto read_fbq = [&](auto n_) {
+            constexpr int n = decltype(n_)::value, j = n / KS, ks = n % KS;
+            const u32x4 t4 = *(lds_u4)((fbase0 ^ (ks * 32)) + BCH_BYTES + j * 32 * CK * 2);
+            __builtin_memcpy(&fbq[n & 1], &t4, 16);
+        };
+        auto unit = [&](auto j_, auto u_) { // bias + clamp + fp16 of accumulator registers 4 g .. 4 g + 3 of tile (i, j) -> slab j
+            constexpr int j = decltype(j_)::value, i = decltype(u_)::value / 4, g = decltype(u_)::value % 4;
+            half4 h;
+            h[0] = (_Float16)__builtin_amdgcn_fmed3f(acc[i][j][4 * g + 0] + ebias[i][g].x, 0.f, hi);
+            h[1] = (_Float16)__builtin_amdgcn_fmed3f(acc[i][j][4 * g + 1] + ebias[i][g].y, 0.f, hi);
+            h[2] = (_Float16)__builtin_amdgcn_fmed3f(acc[i][j][4 * g + 2] + ebias[i][g].z, 0.f, hi);
+            h[3] = (_Float16)__builtin_amdgcn_fmed3f(acc[i][j][4 * g + 3] + ebias[i][g].w, 0.f, hi);
+            *reinterpret_cast<half4*>(slab + j * EG::SLAB + (lane & 31) * EG::ROW + (i * 32 + 8 * g + 4 * (lane >> 5)) * 2) = h;
+        };
+        auto pass = [&](auto j_, auto ps_) { // one store pass of slab j: 8 pixels x this wavefront's 64 channels
+            constexpr int j = decltype(j_)::value, ps = decltype(ps_)::value;
+            if constexpr (ps == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's slab writes have landed (DS ops retire in order)
+                __builtin_amdgcn_wave_barrier();
+            }
+            const unsigned char* const sj = slab + j * EG::SLAB;
+            const int pix = ps * EG::PPP + eprow;
+            const half8 h = *reinterpret_cast<const half8*>(sj + pix * EG::ROW + echunk * 16);
+            const long oo = reinterpret_cast<const long*>(sj + 32 * EG::ROW)[pix];
+            if (oo >= 0 && emvalid)
+                *reinterpret_cast<half8*>(p.pw.out.p + oo + emc) = h;
+        };
+        read_fbq(std::integral_constant<int, 0>{});
+        read_fbq(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<TP * NT * KS>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            constexpr int j = s / (TP * KS), ks = (s % (TP * KS)) / TP, i = s % TP, n = j * KS + ks;
+            half8 fa;
+            __builtin_memcpy(&fa, &a[ks][i], 16);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fbq[n & 1], acc[i][j], 0, 0, 0);
+            if constexpr (i == TP - 1 && n + 2 < NT * KS) // this fragment's last reader has been issued: its register takes fragment n + 2
+                read_fbq(std::integral_constant<int, (n + 2 < NT * KS ? n + 2 : 0)>{});
+            if constexpr (j >= 1)
+                unit(std::integral_constant<int, (j >= 1 ? j - 1 : 0)>{}, std::integral_constant<int, s % (TP * KS)>{});
+            if constexpr (j >= 2 && (s % (TP * KS)) % 2 == 0)
+                pass(std::integral_constant<int, (j >= 2 ? j - 2 : 0)>{}, std::integral_constant<int, (s % (TP * KS)) / 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        HP_STAMP();
+        static_for<TP * 4>([&](auto u_) { unit(std::integral_constant<int, NT - 1>{}, u_); });
+        static_for<EG::PASSES>([&](auto ps_) { pass(std::integral_constant<int, NT - 2>{}, ps_); });
+        static_for<EG::PASSES>([&](auto ps_) { pass(std::integral_constant<int, NT - 1>{}, ps_); });
+    } else {
+        interval(YES, NO, P1, NCH - 1, 0, 0, NO);
+        HP_STAMP();
+        lds_barrier(); // (every wavefront past its reads of the B tiles: the slabs may overwrite them)
+        conv_epilogue_packed<TP, NT>(p.pw, acc, (wave * TP) * 32, lane, lds + wave * packed_geom<TP, NT>::WAVE_BYTES, pb, py, px, pv, ebias);
+    }
     HP_STAMP();
     if (p.pw.dbg && tid == 0 && blockIdx.x < 1024)
         p.pw.dbg[65 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -3068,6 +3156,8 @@ static hipError_t launch_sep_pipe(const sep_params& p, hipStream_t s)
     static const bool anti_phase = getenv("HP_SEP_PIPE1") != nullptr;
     if (anti_phase || p.C % 128)
         HP_LAUNCH((sepconv_pipe_kernel<D, CMAX>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
+    else if (p.pw.res.p || p.pw.alpha || p.pw.act_slope != 0.f) // (no block of the built-in networks: the general epilogue after the last interval)
+        HP_LAUNCH((sepconv_pipe3_kernel<D, false, false>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
     else if (p.pw.dbg) // HP_SEP_DBG: the build with s_memtime stamps inside the interval (tools/sep_timeline.py)
         HP_LAUNCH((sepconv_pipe3_kernel<D, true>), dim3(tiles_x * tiles_y * p.B), dim3(512), 0, s, p, tiles_x, tiles_y);
     else

@@ -390,6 +390,35 @@ def test_fused_separable_block(hp, monkeypatch, c, cout, stride, dil, h, w):
             eng.debug_tensor(d, 3)  # never materialised
 
 
+@pytest.mark.parametrize("c,dil,act,h,w", [
+    (512, 1, E.ACT_LEAKY, 23, 27),   # general activation: the epilogue runs after the last interval (sepconv_pipe3_kernel<.., TAIL = false>)
+    (256, 1, E.ACT_PRELU, 13, 20),
+    (512, 2, E.ACT_LEAKY, 19, 21),
+    (512, 1, E.ACT_RELU6, 25, 17),   # relu6 clamp inside the last interval (TAIL = true), ragged tiles both ways
+    (384, 1, E.ACT_RELU, 12, 8),     # six 64-channel chunks, exactly one tile
+])
+def test_512_output_separable_block_tails(hp, monkeypatch, c, dil, act, h, w):
+    """sepconv_pipe3_kernel's two tails - the epilogue inside the last interval's MFMA stream (relu / relu6) and the general one behind
+    it - against the oracle and bit-for-bit against depthwise + pointwise as two launches."""
+    net = Net(c + dil + act)
+    a = net.conv(0, 3, c, 3, 1)
+    d = net.conv(a, c, c, 3, 1, dil, op=E.OP_DWCONV, act=E.ACT_RELU6)
+    y = net.conv(d, c, 512, 1, act=act, act_param=0.1)
+    z = net.conv(y, 512, 32, 1, act=E.ACT_NONE)
+    fr = _frames(2, h, w, seed=c + h)
+    outs = [Out("z", z, 0, 32)]
+    eng, got, ref = _run_both(net, outs, fr, h, w)
+    _check(got, ref, 2)
+    assert any(t in (4000005, 4000006) for t in [p["tile"] for p in eng.profile(2, 1)])
+    mid = eng.debug_tensor(y, 2)
+    monkeypatch.setenv("HP_NO_FUSE", "1")
+    eng2 = E.Engine(net.layers, [o.c() for o in outs], net.blob(), w, h, 2)
+    got2 = eng2.inference(fr)
+    assert np.array_equal(mid, eng2.debug_tensor(y, 2))
+    for b in range(2):
+        assert np.array_equal(got[b][0][1], got2[b][0][1])
+
+
 @pytest.mark.parametrize("h,w,stem_stride,act", [
     (46, 54, 1, E.ACT_RELU6),   # even map: SAME pads 0 / 1 on the stride-2 block; 23 x 27 outputs = ragged 4 x 8 tiles both ways
     (37, 45, 1, E.ACT_RELU),    # odd map: pads 1 / 1; 19 x 23 outputs
