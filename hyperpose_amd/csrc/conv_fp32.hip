@@ -267,80 +267,114 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// First layer: Cin = 3.  Block = 256 threads = (256 / G) pixels x G groups of 8 output channels, weights in LDS.
-__global__ __launch_bounds__(256) void first_conv32_kernel(const first_conv32_params p)
+// First layer: Cin = 3.  Block = 256 threads = TH x 8 output pixels; thread = 4 horizontally adjacent pixels x 8 output channels (a
+// weight read from LDS feeds four FMAs), GP = min(G, 32) channel groups side by side, a thread loops over the groups beyond.  The
+// weights and the block's input patch - pre-processed ONCE per input pixel (src/data.cpp:21-51: x factor in double, BGR -> RGB,
+// (x - mean) / std; zero outside the image = the convolution's padding of the normalised tensor) - live in LDS; the taps run
+// branch-free in (ky, kx, c) order.  (The first form loaded and converted three bytes per tap and thread behind two bounds checks:
+// 44 us for the 184 x 216 x 32 stem of LW-OpenPose.)
+__global__ __launch_bounds__(256) void first_conv32_kernel(const first_conv32_params p, int tiles_x, int tiles_y, int TH, int GP)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_w32[]; // [KH*KW*3][Cout_pad8]
+    extern __shared__ __attribute__((aligned(16))) float s_w32[]; // [KH*KW*3][Cout_pad8], then the patch [IH][IW][3]
+    constexpr int TW = 8, PX = 4;
     const int G = (p.Cout + 7) / 8, CP = G * 8, taps = p.KH * p.KW;
+    const int IH = (TH - 1) * p.stride + p.KH, IW = (TW - 1) * p.stride + p.KW;
+    float* const s_x = s_w32 + taps * 3 * CP;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * p.stride - p.pad_t, ix0 = ox0 * p.stride - p.pad_l;
     for (int i = threadIdx.x; i < taps * 3 * CP; i += 256) {
-        const int co = i % CP, t = i / CP; // t = tap * 3 + c
-        s_w32[i] = co < p.Cout ? p.w[(size_t)co * taps * 3 + t] : 0.f;
+        const int co = i % CP, tc = i / CP; // tc = tap * 3 + c
+        s_w32[i] = co < p.Cout ? p.w[(size_t)co * taps * 3 + tc] : 0.f;
+    }
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        const int py = i / IW, px = i - py * IW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v[3] = { 0.f, 0.f, 0.f };
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            if (p.in_u8) {
+                const uint8_t* q = p.in_u8 + (((size_t)b * p.H + iy) * p.W + ix) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    v[c] = ((float)((double)q[p.flip_rb ? 2 - c : c] * p.factor) - p.mean[c]) * p.inv_std[c]; // src/data.cpp:48
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    v[c] = (p.in_f32[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix] - p.mean[c]) * p.inv_std[c];
+            }
+        }
+        s_x[i * 3] = v[0], s_x[i * 3 + 1] = v[1], s_x[i * 3 + 2] = v[2];
     }
     __syncthreads();
-    const int ppb = 256 / G;
-    const int g = threadIdx.x % G, pl = threadIdx.x / G;
-    if (pl >= ppb)
+    const int g0 = threadIdx.x % GP, slot = threadIdx.x / GP; // slot = (row of the tile, left / right half of its eight pixels)
+    if (slot >= TH * (TW / PX))
         return;
-    const int OHW = p.OH * p.OW;
-    const long npix = (long)p.B * OHW;
-    for (long n = (long)blockIdx.x * ppb + pl; n < npix; n += (long)gridDim.x * ppb) {
-        const int b = (int)(n / OHW), rem = (int)(n - (long)b * OHW);
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        float acc[8];
+    const int ly = slot / (TW / PX), lx0 = (slot % (TW / PX)) * PX;
+    const int oy = oy0 + ly;
+    if (oy >= p.OH)
+        return;
+    const bool vec_ok = ((p.out.coff | p.out.cs) & 3) == 0;
+    for (int g = g0; g < G; g += GP) {
+        float acc[PX][8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            acc[r] = (g * 8 + r < p.Cout) ? p.bias[g * 8 + r] : 0.f;
-        for (int ky = 0; ky < p.KH; ++ky) {
-            const int iy = oy * p.stride - p.pad_t + ky;
-            if (iy < 0 || iy >= p.H)
-                continue;
+        for (int r = 0; r < 8; ++r) {
+            const float bv = (g * 8 + r < p.Cout) ? p.bias[g * 8 + r] : 0.f;
+#pragma unroll
+            for (int j = 0; j < PX; ++j)
+                acc[j][r] = bv;
+        }
+        for (int ky = 0; ky < p.KH; ++ky)
             for (int kx = 0; kx < p.KW; ++kx) {
-                const int ix = ox * p.stride - p.pad_l + kx;
-                if (ix < 0 || ix >= p.W)
-                    continue;
-                float x[3];
-                if (p.in_u8) {
-                    const uint8_t* px = p.in_u8 + (((size_t)b * p.H + iy) * p.W + ix) * 3;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        x[c] = (float)((double)px[p.flip_rb ? 2 - c : c] * p.factor); // src/data.cpp:48
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        x[c] = p.in_f32[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix];
-                }
+                const float* xp = s_x + ((ly * p.stride + ky) * IW + lx0 * p.stride + kx) * 3;
                 const float* wt = s_w32 + (size_t)((ky * p.KW + kx) * 3) * CP + g * 8;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float xv = (x[c] - p.mean[c]) * p.inv_std[c];
                     const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + c * CP);
                     const f32x4 w1 = *reinterpret_cast<const f32x4*>(wt + c * CP + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[e] = fmaf(xv, w0[e], acc[e]), acc[4 + e] = fmaf(xv, w1[e], acc[4 + e]);
+                    for (int j = 0; j < PX; ++j) {
+                        const float xv = xp[j * p.stride * 3 + c]; // (a tap in the padding is 0: fma(0, w, acc) = acc, the same value as skipping it)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[j][e] = fmaf(xv, w0[e], acc[j][e]), acc[j][4 + e] = fmaf(xv, w1[e], acc[j][4 + e]);
+                    }
                 }
             }
-        }
-        float* op = p.out.p + tv32_off(p.out, b, oy, ox) + g * 8;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (g * 8 + r < p.Cout)
-                op[r] = act32(acc[r], p.act, p.act_param, 0.f);
+        for (int j = 0; j < PX; ++j) {
+            const int ox = ox0 + lx0 + j;
+            if (ox >= p.OW)
+                break;
+            float* op = p.out.p + tv32_off(p.out, b, oy, ox) + g * 8;
+            if (g * 8 + 7 < p.Cout && vec_ok) {
+                f32x4 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o0[e] = act32(acc[j][e], p.act, p.act_param, 0.f), o1[e] = act32(acc[j][4 + e], p.act, p.act_param, 0.f);
+                *reinterpret_cast<f32x4*>(op) = o0, *reinterpret_cast<f32x4*>(op + 4) = o1;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (g * 8 + r < p.Cout)
+                        op[r] = act32(acc[j][r], p.act, p.act_param, 0.f);
+            }
+        }
     }
 }
 
 hipError_t launch_first_conv32(const first_conv32_params& p, hipStream_t s)
 {
-    const int G = (p.Cout + 7) / 8;
-    if (G > 256)
-        return hipErrorInvalidValue;
-    const size_t lds = (size_t)p.KH * p.KW * 3 * G * 8 * sizeof(float);
+    const int G = (p.Cout + 7) / 8, GP = std::min(G, 32);
+    const int TH = 256 / GP / 2; // two threads (of four pixels) per row of eight
+    const int IH = (TH - 1) * p.stride + p.KH, IW = 7 * p.stride + p.KW;
+    const size_t lds = ((size_t)p.KH * p.KW * 3 * G * 8 + (size_t)IH * IW * 3) * sizeof(float);
     if (lds > 64 * 1024)
         return hipErrorInvalidValue;
-    const long npix = (long)p.B * p.OH * p.OW;
-    const int ppb = 256 / G;
-    const int blocks = (int)std::min<long>((npix + ppb - 1) / ppb, 256 * 32);
-    HP_LAUNCH(first_conv32_kernel, dim3(blocks), dim3(256), lds, s, p);
+    const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + TH - 1) / TH;
+    HP_LAUNCH(first_conv32_kernel, dim3(tiles_x * tiles_y * p.B), dim3(256), lds, s, p, tiles_x, tiles_y, TH, GP);
     return hipGetLastError();
 }
 
