@@ -13,6 +13,7 @@
 #include "conv_device.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace hp {
 
@@ -212,6 +213,13 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
 static void conv32_pick(const conv32_params& p, int& BM, int& BN)
 {
     BM = p.Cout_pad % 128 == 0 ? 128 : 64, BN = 128;
+    static const int force = getenv("HP_C32_TILE") ? atoi(getenv("HP_C32_TILE")) : 0; // A/B switch: 1 = the largest tile, 2 = 64 x 128 at most
+    if (force == 1)
+        return;
+    if (force == 2) {
+        BM = 64;
+        return;
+    }
     const long blocks = (long)((p.npix + 127) / 128) * (p.Cout_pad / BM);
     if (blocks < 448) // fewer than ~1.75 blocks per CU: quarter the tile
         BM = 64, BN = 64;
