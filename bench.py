@@ -297,24 +297,29 @@ def _host_pipeline_rate(model, weights, cfg, batch, pipes, steps, frame_wh, keep
     pl = Pipeline(model, weights, max_batch=batch, n_pipes=pipes, keep_ratio=keep_ratio, max_frame_wh=frame_wh, parser=cfg["parser"],
                   dtype=cfg.get("dtype", "f16"))
 
-    def loop(n):
+    def run(n): # n more steps; the pipes stay full (a drain after every few steps would time the fill and the drain, not the pipeline)
         for _ in range(n):
             if pl.in_flight == pl.n_pipes:
                 pl.collect()
             pl.submit_ptrs(ptrs, ws, hs, batch)
+
+    def drain():
         while pl.in_flight:
             pl.collect()
 
-    # clock ramp (0.3 s untimed), then whole multiples of `chunk` steps until at least `min_s` have been timed - independent of --steps
+    # clock ramp (0.3 s untimed, drained), then whole multiples of `chunk` steps until at least `min_s` have been timed - independent of
+    # --steps; the timed region starts with empty pipes and ends when the last result is on the host
     chunk = max(2 * pipes, 4)
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.3:
-        loop(chunk)
+        run(chunk)
+    drain()
     done = 0
     t0 = time.perf_counter()
     while done < steps or time.perf_counter() - t0 < min_s:
-        loop(chunk)
+        run(chunk)
         done += chunk
+    drain()
     dt = time.perf_counter() - t0
     pl.close()
     lib.hp_free_host(host)
