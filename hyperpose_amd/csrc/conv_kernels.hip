@@ -3638,7 +3638,8 @@ __device__ __forceinline__ void mlp_head_body(const head_params& p, int tiles_x,
     constexpr int NSLOT = 2 * NT * 4;           // float4 slots of the second GEMM's result per lane
     constexpr int RED_BYTES = 4 * NSLOT * 64 * 16; // [wave][slot][lane]
     constexpr int LDS_BYTES = X_BYTES > RED_BYTES ? X_BYTES : RED_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES + 512 * 4]; // + the first layer's 512 biases
+    float* const s_b1 = reinterpret_cast<float*>(lds + LDS_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int t = blockIdx.x;
@@ -3647,6 +3648,8 @@ __device__ __forceinline__ void mlp_head_body(const head_params& p, int tiles_x,
     const int ty = t % tiles_y, b = t / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
     const conv_params& q = p.pw;
+    // <= 32 outputs (the 19 heat-maps): the second GEMM's rows 32 .. 63 are all padding - their MFMAs and weight fragments are skipped
+    const bool two_tiles = q.Cout > 32; // uniform
     int dbg_i = 0;
 #define HP_STAMP()                                                                                                \
     if (q.dbg && blockIdx.x == 0 && tid == 0)                                                                     \
@@ -3674,12 +3677,16 @@ __device__ __forceinline__ void mlp_head_body(const head_params& p, int tiles_x,
             const int y = min(y0 + pix / TW, p.H - 1), x = min(x0 + pix % TW, p.W - 1);
             xv[k] = *reinterpret_cast<const u32x4*>(p.in.p + tv_off(p.in, b, y, x) + c * 8);
         }
+        // (the first layer's biases ride along: read from LDS after each pass instead of from L2 - a memory latency per row tile)
+        const float4 b1v = *reinterpret_cast<const float4*>(p.b1 + (tid & 127) * 4);
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int i = tid + k * 256;
             const int pix = i / (NCH * 8), c = i % (NCH * 8);
             *reinterpret_cast<u32x4*>(lds + (c >> 3) * (NPX * 128) + lds_off<64>(pix, c & 7)) = xv[k];
         }
+        if (tid < 128)
+            *reinterpret_cast<float4*>(s_b1 + tid * 4) = b1v;
     }
     floatx16 acc2[2][NT];
 #pragma unroll
@@ -3703,7 +3710,8 @@ __device__ __forceinline__ void mlp_head_body(const head_params& p, int tiles_x,
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2)
-                a2[s4][i2] = *reinterpret_cast<const u32x4*>(w2 + ((size_t)i2 * 32 + pass * 4 + s4) * 512);
+                if (i2 == 0 || two_tiles)
+                    a2[s4][i2] = *reinterpret_cast<const u32x4*>(w2 + ((size_t)i2 * 32 + pass * 4 + s4) * 512);
         // ---- GEMM1 for hidden row tiles 2 pass, 2 pass + 1 of this wavefront
         floatx16 acc[TP][NT];
 #pragma unroll
@@ -3739,7 +3747,7 @@ __device__ __forceinline__ void mlp_head_body(const head_params& p, int tiles_x,
             float bs[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.b1 + wave * 128 + (pass * TP + i) * 32 + 8 * g + 4 * fk);
+                const float4 bv = *reinterpret_cast<const float4*>(s_b1 + wave * 128 + (pass * TP + i) * 32 + 8 * g + 4 * fk);
                 bs[4 * g] = bv.x, bs[4 * g + 1] = bv.y, bs[4 * g + 2] = bv.z, bs[4 * g + 3] = bv.w;
             }
 #pragma unroll
@@ -3752,6 +3760,8 @@ __device__ __forceinline__ void mlp_head_body(const head_params& p, int tiles_x,
                         hb[j][e] = (_Float16)__builtin_amdgcn_fmed3f(acc[i][j][8 * s2 + e] + bs[8 * s2 + e], 0.f, hi1);
 #pragma unroll
                 for (int i2 = 0; i2 < 2; ++i2) {
+                    if (i2 == 1 && !two_tiles)
+                        continue;
                     half8 fa;
                     __builtin_memcpy(&fa, &a2[i * 2 + s2][i2], 16);
 #pragma unroll
