@@ -107,3 +107,16 @@ def test_pcie_inclusive_rate_and_fallback_counts_are_top_level():
     for w in d["workloads"].values():
         assert w["device_declined_frames"] >= 0 and w["capacity_truncations"] == 0 and w["frames_parsed_for_these_counts"] > 0
         assert w["device_declined_frames"] <= 0.01 * w["frames_parsed_for_these_counts"]
+
+
+def test_headline_names_the_runner_up_kernel():
+    """On configs[1] the 512-output separable block and the 128-channel chain are within a few percent of each other and swap places
+    between runs: the line carries both, each with its own roof."""
+    r = _bench_line()["roofline"]
+    ru = r["runner_up"]
+    assert ru["kernel"] and ru["kernel"] != r["kernel"] and ru["launches_per_step"] >= 1 and ru["avg_launch_us"] > 0
+    assert ru["bound"] == ("mfma" if ru["intensity_flop_per_byte"] >= r["ridge_flop_per_byte"] else "hbm")
+    assert 0 < ru["frac_mfma"] < 1 and 0 < ru["frac_hbm"] < 1
+    assert 0 < ru["share_of_serial_step"] <= r["share_of_serial_step"] < 1
+    both = (r["kernel"] + ru["kernel"])
+    assert "separable block" in both and "conv_chain_kernel" in both
