@@ -209,8 +209,11 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
     const bool clamp_only = !has_res && !p.alpha && p.act_slope == 0.f; // uniform: v > 0 ? min(v, hi) : v * 0 == med3(v, 0, hi) up to the sign of zero
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     HP_ESTAMP();
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    // The uniform choice is made ONCE, around the loop over the pixel tiles: with the residual requests and the clamp-only arithmetic in
+    // one loop body the compiler put `s_waitcnt vmcnt(0)` in front of every store pass of the clamp-only path (a request of the other
+    // path might be pending) - and vmcnt counts stores on gfx9: every pass waited for the previous pass's stores to reach L2.
+    auto tile = [&](int j, auto clamp_) {
+        constexpr bool CLAMP = decltype(clamp_)::value;
         // MFMA layout -> LDS: lane owns pixel (lane & 31), channels i*32 + 8g + 4*(lane>>5) + {0..3}
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -222,29 +225,30 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
             }
         if (lane < 32) {
             s_ooff[lane] = pv[j] ? tv_off(p.out, pb[j], py[j], px[j]) : -1;
-            s_roff[lane] = (pv[j] && has_res) ? tv_off(p.res, pb[j], py[j], px[j]) : 0;
+            if constexpr (!CLAMP)
+                s_roff[lane] = (pv[j] && has_res) ? tv_off(p.res, pb[j], py[j], px[j]) : 0;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's LDS writes have landed (DS ops retire in order)
         __builtin_amdgcn_wave_barrier();
-        HP_ESTAMP();
-        // store side: offsets, then ALL residual loads (unconditional, straight-line), then math + 16-byte stores
+        // store side: offsets, then ALL residual loads (unconditional, straight-line), then every slab row, then math + 16-byte stores
         long oo[G::PASSES];
         half8 rs[G::PASSES];
 #pragma unroll
         for (int ps = 0; ps < G::PASSES; ++ps)
             oo[ps] = s_ooff[ps * G::PPP + prow];
-        if (has_res) {
+        if constexpr (!CLAMP) {
+            if (has_res) {
 #pragma unroll
-            for (int ps = 0; ps < G::PASSES; ++ps) // invalid pixels read offset 0: in bounds, result unused
-                rs[ps] = *reinterpret_cast<const half8*>(p.res.p + s_roff[ps * G::PPP + prow] + (mvalid ? mc : 0));
-        } else {
+                for (int ps = 0; ps < G::PASSES; ++ps) // invalid pixels read offset 0: in bounds, result unused
+                    rs[ps] = *reinterpret_cast<const half8*>(p.res.p + s_roff[ps * G::PPP + prow] + (mvalid ? mc : 0));
+            } else {
 #pragma unroll
-            for (int ps = 0; ps < G::PASSES; ++ps)
+                for (int ps = 0; ps < G::PASSES; ++ps)
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    rs[ps][r] = (_Float16)0.f;
+                    for (int r = 0; r < 8; ++r)
+                        rs[ps][r] = (_Float16)0.f;
+            }
         }
-        // (the slab reads of every pass before the first store: next to the store that needs it a read costs its LDS latency per pass)
         float4 a0[G::PASSES], a1[G::PASSES];
 #pragma unroll
         for (int ps = 0; ps < G::PASSES; ++ps) {
@@ -252,22 +256,15 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
             a0[ps] = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32);
             a1[ps] = *reinterpret_cast<const float4*>(slab + pix * G::ROW + chunk * 32 + 16);
         }
-        if (clamp_only) { // relu / relu6 family without a residual: bias add + one v_med3_f32 per value
 #pragma unroll
-            for (int ps = 0; ps < G::PASSES; ++ps) {
-                const float v[8] = { a0[ps].x, a0[ps].y, a0[ps].z, a0[ps].w, a1[ps].x, a1[ps].y, a1[ps].z, a1[ps].w };
-                half8 h;
+        for (int ps = 0; ps < G::PASSES; ++ps) {
+            const float v[8] = { a0[ps].x, a0[ps].y, a0[ps].z, a0[ps].w, a1[ps].x, a1[ps].y, a1[ps].z, a1[ps].w };
+            half8 h;
+            if constexpr (CLAMP) { // relu / relu6 family without a residual: bias add + one v_med3_f32 per value
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
                     h[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r] + bs[r], 0.f, hi);
-                if (oo[ps] >= 0 && mvalid)
-                    *reinterpret_cast<half8*>(p.out.p + oo[ps] + mc) = h;
-            }
-        } else {
-#pragma unroll
-            for (int ps = 0; ps < G::PASSES; ++ps) {
-                const float v[8] = { a0[ps].x, a0[ps].y, a0[ps].z, a0[ps].w, a1[ps].x, a1[ps].y, a1[ps].z, a1[ps].w };
-                half8 h;
+            } else {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     float x = v[r] + bs[r];
@@ -279,14 +276,23 @@ __device__ __forceinline__ void conv_epilogue_staged(const conv_params& p, const
                         x += rr;
                     h[r] = (_Float16)x;
                 }
-                if (oo[ps] >= 0 && mvalid)
-                    *reinterpret_cast<half8*>(p.out.p + oo[ps] + mc) = h;
             }
+            if (oo[ps] >= 0 && mvalid)
+                *reinterpret_cast<half8*>(p.out.p + oo[ps] + mc) = h;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // slab reads done before the next pass overwrites it
         __builtin_amdgcn_wave_barrier();
-        HP_ESTAMP();
+    };
+    if (clamp_only) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            tile(j, std::true_type{});
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            tile(j, std::false_type{});
     }
+    HP_ESTAMP();
 }
 #undef HP_ESTAMP
 
