@@ -1155,6 +1155,178 @@ __device__ __forceinline__ void conv_direct_body(const conv_params& p, unsigned 
 #undef HP_DSTAMP
 }
 
+// The single-chunk form (7 x 7 / 5 x 5 x 128: OpenPose-VGG19's stage convolutions) with the wavefronts cut the other way: wavefront =
+// (pair of 32-row tiles rp, half of the six pixel tiles ph, K-half kg) - 2 x 3 MFMA tiles instead of 1 x 6.  Per k16 step it reads THREE
+// B fragments from LDS and two A fragments from L2 for its six MFMAs; the 1 x 6 cut reads six from LDS - 49 KB per step and CU, as much as
+// the LDS delivers in the 384 cycles the step's MFMAs take.  Measured (round 4, VGG19's 7 x 7 128 -> 128 at 16 x 54 x 96): 125.9 -> 123.6 us
+// per launch - halving the LDS reads buys 2 %, so the 1 x 6 cut was NOT bound by them (0.43 of the MFMA peak either way; what the loop
+// waits for is still open: DESIGN.md section 7.5).  Kept for the 2 %.
+// Same K order per output as conv_direct_body (taps ascending, this K-half's k16 steps ascending, the two halves added once): same bits.
+template <int KS, int CK>
+__device__ __forceinline__ void conv_direct_body_b(const conv_params& p, unsigned char* lds, int b, int y0, int x0)
+{
+    using G = direct_geom<KS, CK, 16, 1>;
+    constexpr int TW = 12, HPH = G::HPH, HPW = G::HPW, NT = G::NT, TM = 2, TN = NT / 2, PAD = KS / 2, TAPS = KS * KS;
+    constexpr int CHP = CK / 8, KQC = CK / 16, NS = KQC / 2;
+    constexpr int HALO_BYTES = G::HALO_BYTES, RED_BYTES = G::RED_BYTES;
+    constexpr int NIT = (HPH * HPW * CHP + 511) / 512, NPASS = (NIT + 7) / 8, PIT = (NIT + NPASS - 1) / NPASS;
+    static_assert(NT == 6 && G::K0 == TN && HPW % 2 == 0 && (CHP == 16 || CHP == 8), "tile geometry");
+    auto hkey = [](int hy, int hx) { return CHP == 16 ? ((hy * TW + hx) & 15) : (((hy * TW + hx) >> 1) & 7); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rp = wave & 1, ph = (wave >> 1) & 1, kg = wave >> 2;
+    const int m0 = blockIdx.y * 128;
+    const int KQ = p.Cin / 16;
+    const long tap_stride = (long)(p.Cout_pad / 32) * KQ * 512, row_stride = (long)KQ * 512; // halves per tap / per 32-row tile
+    const __half* wfrag = p.w + ((size_t)((m0 / 32 + rp * TM) * KQ + kg * NS) * 64 + lane) * 8;
+    u32x4 a0[TM][NS], a1[TM][NS];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            a0[i][ks] = *reinterpret_cast<const u32x4*>(wfrag + i * row_stride + (size_t)ks * 512);
+            a1[i][ks] = *reinterpret_cast<const u32x4*>(wfrag + tap_stride + i * row_stride + (size_t)ks * 512);
+        }
+    {   // halo tile: global -> registers (passes of <= 8 loads per thread) -> LDS
+        u32x4 hv[PIT];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int i = tid + (pass * PIT + it) * 512;
+                const int hp = min(i, HPH * HPW * CHP - 1) / CHP, c = i % CHP;
+                const int hy = hp / HPW, hx = hp - hy * HPW;
+                const int y = y0 + hy - PAD, x = x0 + hx - PAD;
+                const bool ok = y < p.H + PAD && x < p.W + PAD; // (y, x >= -PAD: inside the zero halo of the HBM tensor)
+                const u32x4 v = *reinterpret_cast<const u32x4*>(p.in.p + tv_off(p.in, b, min(y, p.H + PAD - 1), min(x, p.W + PAD - 1)) + c * 8);
+                hv[it] = v & (ok ? 0xffffffffu : 0u);
+            }
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int i = tid + (pass * PIT + it) * 512;
+                if (i < HPH * HPW * CHP) {
+                    const int hp = i / CHP, c = i - hp * CHP;
+                    const int hy = hp / HPW, hx = hp - hy * HPW;
+                    *reinterpret_cast<u32x4*>(lds + hp * (CK * 2) + ((c ^ hkey(hy, hx)) << 4)) = hv[it];
+                }
+            }
+        }
+    }
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+    const int fk = lane >> 5;
+    int hpo0[TN], key0[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = (ph * TN + j) * 32 + (lane & 31);
+        const int br = n / TW, bc = n - br * TW;
+        hpo0[j] = (br * HPW + bc) * (CK * 2);
+        key0[j] = br * TW + bc;
+    }
+    lds_barrier(); // the halo tile is complete
+    const int cb16 = ((kg * NS) * 2 + fk) << 4;
+    auto step_geom = [&](int tap, int (&base)[TN], int (&k16)[TN]) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int toff = (ky * HPW + kx) * (CK * 2), tkey = ky * TW + kx; // uniform
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            base[j] = hpo0[j] + toff;
+            k16[j] = (CHP == 16 ? ((key0[j] + tkey) & 15) : (((key0[j] + tkey) >> 1) & 7)) << 4;
+        }
+    };
+    half8 fb[2][TN];
+    {
+        int base[TN], k16[TN];
+        step_geom(0, base, k16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            fb[0][j] = *reinterpret_cast<const half8*>(lds + base[j] + (cb16 ^ k16[j]));
+    }
+    // one step = one tap: NS k16 steps of TM x TN MFMAs; B fragments one whole k16 step ahead (across the tap boundary too), the A
+    // fragments of tap q + 2 requested as this tap's are consumed
+#define HP_STEPB(A, Q)                                                                                            \
+    {                                                                                                             \
+        const int q_ = (Q);                                                                                       \
+        int base_[TN], k16_[TN];                                                                                  \
+        step_geom(q_, base_, k16_);                                                                               \
+        const long nxt_ = (long)min(q_ + 2, TAPS - 1) * tap_stride;                                               \
+        _Pragma("unroll") for (int ks = 0; ks < NS; ++ks)                                                         \
+        {                                                                                                         \
+            if (ks + 1 < NS) {                                                                                    \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                    \
+                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const half8*>(lds + base_[j] + ((cb16 + (ks + 1) * 32) ^ k16_[j])); \
+            } else {                                                                                              \
+                int basen_[TN], k16n_[TN];                                                                        \
+                step_geom(min(q_ + 1, TAPS - 1), basen_, k16n_);                                                  \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                    \
+                    fb[0][j] = *reinterpret_cast<const half8*>(lds + basen_[j] + (cb16 ^ k16n_[j]));              \
+            }                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                        \
+            {                                                                                                     \
+                half8 fa;                                                                                         \
+                __builtin_memcpy(&fa, &A[i][ks], 16);                                                             \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                    \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[ks & 1][j], acc[i][j], 0, 0, 0);    \
+                A[i][ks] = *reinterpret_cast<const u32x4*>(wfrag + nxt_ + i * row_stride + (size_t)ks * 512);     \
+            }                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                        \
+            {                                                                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                    \
+        }                                                                                                         \
+    }
+#pragma unroll 1
+    for (int q = 0; q + 1 < TAPS; q += 2) {
+        HP_STEPB(a0, q);
+        HP_STEPB(a1, q + 1);
+    }
+    if (TAPS & 1)
+        HP_STEPB(a0, TAPS - 1);
+#undef HP_STEPB
+
+    // ---- the K-halves meet: K-half kg finishes row tile kg of the pair and parks the other one's three tiles for its partner
+    __syncthreads(); // every wave is done with the halo tile
+    float4* const park = reinterpret_cast<float4*>(lds) + (size_t)wave * (TN * 4 * 64) + lane;
+    const float4* const take = reinterpret_cast<const float4*>(lds) + (size_t)(wave ^ 4) * (TN * 4 * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const floatx16& give = kg ? acc[0][j] : acc[1][j];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            park[(j * 4 + g4) * 64] = make_float4(give[4 * g4], give[4 * g4 + 1], give[4 * g4 + 2], give[4 * g4 + 3]);
+    }
+    __syncthreads();
+    floatx16 mine[1][TN];
+    int pb[TN], py[TN], px[TN];
+    bool pv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const floatx16& keep = kg ? acc[1][j] : acc[0][j];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 o = take[(j * 4 + g4) * 64];
+            mine[0][j][4 * g4] = keep[4 * g4] + o.x, mine[0][j][4 * g4 + 1] = keep[4 * g4 + 1] + o.y;
+            mine[0][j][4 * g4 + 2] = keep[4 * g4 + 2] + o.z, mine[0][j][4 * g4 + 3] = keep[4 * g4 + 3] + o.w;
+        }
+        const int n = (ph * TN + j) * 32 + (lane & 31);
+        const int br = n / TW, bc = n - br * TW;
+        pb[j] = b, py[j] = y0 + br, px[j] = x0 + bc;
+        pv[j] = py[j] < p.OH && px[j] < p.OW;
+    }
+    // the slabs live behind the parking area: no wave can still be reading what another overwrites
+    conv_epilogue_staged<1, TN>(p, mine, m0 + (rp * TM + kg) * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+}
+
 template <int KS, int CK, int NBUF>
 __global__ __launch_bounds__(512) void conv_direct_kernel(const conv_params p, int tiles_x, int tiles_y, int nchunks)
 {
@@ -1177,6 +1349,8 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(const conv_params p, i
     // (the two-path form of the chunk-pipelined kernels needs more than 256 registers: they always take the full tile)
     if (NBUF == 1 && p.OH - y0 <= 8) // uniform
         conv_direct_body<KS, CK, 8, NBUF>(p, lds, b, y0, x0, nchunks);
+    else if constexpr (NBUF == 1)
+        conv_direct_body_b<KS, CK>(p, lds, b, y0, x0);
     else if (NBUF == 2 && gridDim.z > 1) // split-K: gridDim.z blocks per tile, nchunks / gridDim.z chunks each
         conv_direct_body<KS, CK, 16, NBUF>(p, lds, b, y0, x0, nchunks / gridDim.z, blockIdx.z * (nchunks / gridDim.z), true);
     else
