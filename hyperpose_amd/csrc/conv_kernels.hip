@@ -1177,6 +1177,11 @@ __device__ __forceinline__ void conv_direct_body_b(const conv_params& p, unsigne
     const int rp = wave & 1, ph = (wave >> 1) & 1, kg = wave >> 2;
     const int m0 = blockIdx.y * 128;
     const int KQ = p.Cin / 16;
+    int dbg_i = 0; // tools/direct_timeline.hip: s_memtime stamps of block (0, 0) / wave 0 and of the last wave
+#define HP_DSTAMP()                                                                                               \
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && (tid == 0 || tid == 448))                                  \
+        p.dbg[(tid ? 32 : 0) + (dbg_i++)] = __builtin_amdgcn_s_memtime();
+    HP_DSTAMP();
     const long tap_stride = (long)(p.Cout_pad / 32) * KQ * 512, row_stride = (long)KQ * 512; // halves per tap / per 32-row tile
     const __half* wfrag = p.w + ((size_t)((m0 / 32 + rp * TM) * KQ + kg * NS) * 64 + lane) * 8;
     u32x4 a0[TM][NS], a1[TM][NS];
@@ -1229,7 +1234,9 @@ __device__ __forceinline__ void conv_direct_body_b(const conv_params& p, unsigne
         hpo0[j] = (br * HPW + bc) * (CK * 2);
         key0[j] = br * TW + bc;
     }
+    HP_DSTAMP();
     lds_barrier(); // the halo tile is complete
+    HP_DSTAMP();
     const int cb16 = ((kg * NS) * 2 + fk) << 4;
     auto step_geom = [&](int tap, int (&base)[TN], int (&k16)[TN]) {
         const int ky = tap / KS, kx = tap - ky * KS;
@@ -1293,6 +1300,7 @@ __device__ __forceinline__ void conv_direct_body_b(const conv_params& p, unsigne
     if (TAPS & 1)
         HP_STEPB(a0, TAPS - 1);
 #undef HP_STEPB
+    HP_DSTAMP();
 
     // ---- the K-halves meet: K-half kg finishes row tile kg of the pair and parks the other one's three tiles for its partner
     __syncthreads(); // every wave is done with the halo tile
@@ -1306,6 +1314,7 @@ __device__ __forceinline__ void conv_direct_body_b(const conv_params& p, unsigne
             park[(j * 4 + g4) * 64] = make_float4(give[4 * g4], give[4 * g4 + 1], give[4 * g4 + 2], give[4 * g4 + 3]);
     }
     __syncthreads();
+    HP_DSTAMP();
     floatx16 mine[1][TN];
     int pb[TN], py[TN], px[TN];
     bool pv[TN];
@@ -1325,6 +1334,8 @@ __device__ __forceinline__ void conv_direct_body_b(const conv_params& p, unsigne
     }
     // the slabs live behind the parking area: no wave can still be reading what another overwrites
     conv_epilogue_staged<1, TN>(p, mine, m0 + (rp * TM + kg) * 32, lane, lds + RED_BYTES + wave * stage_geom<1>::SLAB, pb, py, px, pv);
+    HP_DSTAMP();
+#undef HP_DSTAMP
 }
 
 template <int KS, int CK, int NBUF>
