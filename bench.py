@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — end-to-end FPS of the hot path on N MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {0,1,2,3,4}] [--scaling {weak,strong}] [--extra 0,2,3,4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {0,1,2,3,4}] [--dtype {f32,f16}] [--scaling {weak,strong}] [--extra 1/f16,2/f32,...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -9,37 +9,32 @@
 (one process per GPU, RCCL) and prints the ranks' ONE JSON line; under an external launcher it reads RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* as usual.
 
-One "step" = one pass of the hot path over one batch.  The headline (`value`) is BASELINE.json configs[1]:
-Lightweight-OpenPose (MobilenetDilated backbone) + PAF parser, batch 8 @ 368x432 per GPU:
+One "step" = one pass of the hot path over one batch.  The headline (`value`) is BASELINE.json configs[1] at the precision the
+reference's engine defaults to, data_type::kFLOAT (include/hyperpose/operator/dnn/tensorrt.hpp:14-21,48 - `dtype: "f32"`, roofline
+against the 157.3 TFLOP/s fp32 matrix pipe): Lightweight-OpenPose (MobilenetDilated backbone) + PAF parser, batch 8 @ 368x432 per GPU:
     u8 HWC frames already resident in HBM -> (pre-processing fused into the first conv) -> conv stack on MFMA
     -> conf/paf fp32 maps in HBM -> PAF parser kernels -> hp_human lists written to pinned host memory.
-Frames shard over GPUs with no steady-state collective; the only collective is the one-time RCCL broadcast of the weight
-blob from rank 0 (outside the timed region).  `--scaling weak` (default): every rank processes its own full batch per
-step; `--scaling strong`: the configuration's global batch is split contiguously over the ranks (32 -> 4,
-64 -> 8 frames per GPU).  Timing: W untimed steps (followed by 0.3 s of the same loop, also untimed, so that the clocks
-have settled whatever W is), then exactly K steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks, rank 0
-prints ONE JSON line.
+The fused fp16 engine (data_type::kHALF, the optional fast mode) is `value_khalf` with its own `roofline_khalf`; `--dtype f16` makes
+it the headline.  Frames shard over GPUs with no steady-state collective; the only collective is the one-time RCCL broadcast of the
+weight blob from rank 0 (outside the timed region).  `--scaling weak` (default): every rank processes its own full batch per step;
+`--scaling strong`: the configuration's global batch is split contiguously over the ranks (32 -> 4, 64 -> 8 frames per GPU).
 
-The other BASELINE configurations are measured the same way and reported under `workloads` in the same line
-(`--extra`, default 0,2,3,4,5 at N = 1 - 5 = configs[1] behind data_type::kFLOAT, the fp32-faithful engine, as workloads["configs[1]/fp32"] -
-and 3,4 strong-scaled at N > 1): configs[0] TinyVGG-V2 + PAF on a single image; configs[2] OpenPose-VGG19 + PAF, batch 16 @ 432x768;
-configs[3] PoseProposal ResNet-50 + NMS decoder, batch 32 @ 384x384; configs[4] OpenPifPaf ResNet-50 + seed/grow
-decoder, batch 64 @ 385x385 - each with its own `roofline` and (N = 1) `cpu_baseline`.
+Timing: W untimed steps, then 0.3 s of the same loop (also untimed: the clocks settle), then ONE timed region bracketed by barrier +
+torch.cuda.synchronize() on both sides, MAX over ranks.  The region is R x K steps with R the smallest whole number that makes it last
+>= --min-seconds (0.5 s): `steps` = K as given, `steps_timed` = R x K, `ms_per_step` = region / steps_timed.  (K = 20 steps of 0.36 ms
+are 7 ms, mostly pipe fill and drain - round 4's headline was the least well measured number on its line.)
+
+Output: rank 0 prints ONE compact JSON line (<= 4 KB: `compact_line`; the driver parses the last stdout line) with the contract's keys,
+the headline's `roofline` (dominant kernel: live per-launch time, both fractions, PMC traffic and the committed rocprofv3 average of the
+same kernel with its source file) and `cpu_baseline`, and one small {value, ms_per_step, dtype, bound, frac} object per other workload
+(`--extra`; default at N = 1: configs[1] at the other precision, then configs[0], [2], [3], [4] at both; at N > 1: configs[3], [4]
+strong-scaled).  EVERYTHING else - full roofline objects with runner-up kernels, parser rooflines, single-pipe and host-fed legs, the
+clock / power samples of every timed region, CPU-baseline samples - goes to `bench_detail.json` (named in the line as `detail`).
 
 Parser input: the networks have synthetic (random) weights, so their own heat-maps contain no people.  Every timed step
 runs the FULL conv stack AND parses seeded synthetic heat-maps with several people per frame that are resident in HBM
-("injected": strictly more parser work, nothing skipped); the same loop parsing the network's own output is reported as
-`fps_dnn_output`.
-
-Extra objects: `roofline` for the dominant kernel (per-launch timestamps in schedule order; `bound` = the roof its arithmetic intensity
-puts it under, with `frac_mfma` and `frac_hbm` both given; `committed_profile` = the same kernel in the newest committed rocprofv3 kernel
-trace of this command, profiles/*_kernel_stats*.csv - read from the file, not measured in the run),
-`parser_roofline` (HBM: frames/s of the parser alone x the compulsory bytes of SURVEY.md 8d / 8 TB/s), `cpu_baseline` (the
-reference's CPU parser on this box's host cores, rank 0, N = 1), `single_pipe_fps` (one engine + parser pair, one batch in
-flight), `h2d_inclusive` / top-level `value_h2d_inclusive` (the same step with network-sized u8 frames starting in pinned HOST memory - the
-PCIe-inclusive rate, never `value`; measured on all ranks at once at N > 1), `from_host` (1280x720 camera frames through the GPU letterbox) and, at N > 1, `collective` (which backend
-carried the start-up weight broadcast, its bytes and time).  Every secondary leg runs for a minimum wall time (0.3 s ramp +
->= 0.5 s timed) whatever --steps is, so the driver's short runs reproduce the long ones.
+("injected": strictly more parser work, nothing skipped); the same loop parsing the network's own output is `fps_dnn_output`.
+`value_h2d_inclusive`: the same step with network-sized u8 frames starting in pinned HOST memory (PCIe-inclusive, never `value`).
 """
 from __future__ import annotations
 
@@ -78,28 +73,54 @@ CONFIGS = {
             w=384, h=384, batch=32, parser="ppn", pipes=8, seed=20243, steps=60, people=(1, 2, 3, 4)),
     4: dict(label="configs[4]: OpenPifPaf ResNet-50 + pif/paf seed-grow decoder, batch 64 @ 385x385", arch="pifpaf_resnet50",
             w=385, h=385, batch=64, parser="pifpaf", pipes=3, seed=20244, steps=16, people=(1, 2, 3, 4)),
-    # configs[1] behind data_type::kFLOAT, the reference engine's default precision (include/hyperpose/operator/dnn/tensorrt.hpp:48): fp32
-    # storage and fp32 matrix-pipe arithmetic (HP_DTYPE_F32, conv_fp32.hip), one launch per layer - the faithful mode, reported next to the
-    # fp16 headline under workloads["configs[1]/fp32"] with its own roofline against the 157 TFLOP/s fp32 MFMA peak
-    5: dict(label="configs[1] with data_type::kFLOAT (fp32 storage + fp32 MFMA): Lightweight-OpenPose + PAF parser, batch 8 @ 368x432", arch="lw_openpose_mobilenet",
-            w=432, h=368, batch=8, parser="paf", pipes=4, seed=20241, steps=40, people=(1, 2, 4, 8, 16, 3, 5, 6), dtype="f32", key="configs[1]/fp32"),
 }
+# Steps per timed region when --steps is not given, per precision (fp32 engines are 3 - 6 x slower per step)
+F32_STEPS = {0: 200, 1: 60, 2: 6, 3: 16, 4: 6}
+F32_PIPES = {0: 4, 1: 4, 2: 2, 3: 4, 4: 2}
+PEAK_F32S_TFLOPS = PEAK_F16_TFLOPS / 3  # HP_DTYPE_F32S: every fp32 product = three fp16 MFMA products (csrc/conv_split.hip): 833 TFLOP/s of fp32-equivalent work
+PEAKS = {"f32": PEAK_F32_TFLOPS, "f16": PEAK_F16_TFLOPS, "f32s": PEAK_F32S_TFLOPS}
+DTYPE_LABEL = {"f32": "f32", "f16": "f16", "f32s": "f32 (products as 3 exact f16xf16 MFMAs, fp32 accumulate)"}
+DTYPE_LONG = {"f32": "f32 (data_type::kFLOAT, the reference's default: fp32 storage, v_mfma_f32_32x32x2_f32 products and sums; parsers fp32)",
+              "f16": "f16 (data_type::kHALF: fp16 storage and MFMA products, fp32 accumulate; parsers fp32)",
+              "f32s": "f32s (HP_DTYPE_F32S, opt-in: the kFLOAT engine - fp32 storage and accumulation - with the dense layers' products formed as "
+                      "hi*hi + 2^-11 (hi*lo + lo*hi) on the fp16 matrix pipe, x = hi + 2^-11 lo split exactly into two fp16 numbers; parsers fp32)"}
+
+
+def config(index: int, dtype: str) -> dict:
+    """BASELINE.json configs[index] at one engine precision: 'f32' = data_type::kFLOAT, the reference engine's default
+    (include/hyperpose/operator/dnn/tensorrt.hpp:14-21,48) and this bench's default; 'f16' = data_type::kHALF, the fused fp16 engine."""
+    c = dict(CONFIGS[index])
+    c["index"], c["dtype"], c["key"] = index, dtype, f"configs[{index}]/{dtype}"
+    if dtype in ("f32", "f32s"):
+        c["steps"], c["pipes"] = F32_STEPS[index], F32_PIPES[index]
+    return c
 
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps of the headline workload (default: per config)")
+    ap.add_argument("--steps", type=int, default=None, help="steps K of the headline workload; the timed region is a whole multiple of K "
+                    "lasting >= --min-seconds (reported as steps_timed)")
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="headline workload (BASELINE.json configs index; 5 = configs[1] behind data_type::kFLOAT)")
+    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 3, 4, 5], help="headline workload: BASELINE.json configs index "
+                    "(5 = old spelling of `--config 1 --dtype f32`)")
+    ap.add_argument("--dtype", choices=("f32", "f16", "f32s"), default="f32", help="engine precision of the headline: f32 = data_type::kFLOAT, the "
+                    "reference's default (default here too); f16 = data_type::kHALF, the fused fp16 engine")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--extra", default=None, help="comma-separated configs also measured and reported under `workloads` ('' = none)")
+    ap.add_argument("--extra", default=None, help="comma-separated workloads also measured, as index/dtype (e.g. 1/f16,2/f32; '' = none)")
     ap.add_argument("--pipes", type=int, default=0, help="engine+parser pairs per GPU (0 = per config)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of every timed region")
+    ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json next to bench.py, and "
+                    "gpurun_out/bench_detail.json when that directory exists)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
     ap.add_argument("--no-dnn-output", action="store_true", help="skip the second timed phase (parser fed by the network's own heat-maps)")
-    return ap.parse_args(argv)
+    ap.add_argument("--no-clocks", action="store_true", help="do not sample sclk / power during the timed regions")
+    args = ap.parse_args(argv)
+    if args.config == 5:
+        args.config, args.dtype = 1, "f32"
+    return args
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU launch
@@ -216,7 +237,7 @@ def run_loop(pipes, frames_dev, steps, injected):
 def synth_inputs(cfg, batch, rank):
     """Per-rank seeded synthetic inputs of one workload: u8 frames + the parser's injected tensors (host numpy)."""
     from hyperpose_amd import synth
-    idx = [k for k, v in CONFIGS.items() if v is cfg][0]
+    idx = cfg["index"]
     rng = synth.rng_for(idx, salt=rank)
     frames = synth.images_u8(rng, batch, cfg["h"], cfg["w"])
     if cfg["parser"] == "paf":
@@ -359,6 +380,10 @@ def kernel_label(tile: int):
            20: ("sepconv_pair_kernel<32,64,128>", "the stem's separable blocks 32 -> 64 and 64 -> 128 (stride 2) in one launch, the 64-channel "
                 "tensor between them in LDS only")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
+    if tile >= 33000000:
+        ks, wm = (tile - 33000000) // 1000, tile % 1000
+        return (f"conv32_split_kernel<{ks},{64 if ks == 1 else 32},{wm}>", f"conv32_split_kernel<KS={ks},WM={wm}> (fp32 convolution with every product formed as three exact "
+                f"fp16 x fp16 MFMA products: {64 * wm} cout x 8x8 px per block, split halo tile in LDS, split weights in fragment order from L2)")
     if tile >= 32000000:
         bm, bn = (tile - 32000000) // 1000, tile % 1000
         wm, wn = (1, 4) if (bm, bn) == (64, 128) else (2, 2)
@@ -442,14 +467,26 @@ def rocprof_avg_us(symbol_key: str, tag: str):
 RIDGE_FLOP_PER_BYTE = 2500.0e12 / 8000.0e9  # 312.5: below it a kernel's binding roof is HBM, above it the matrix pipe
 
 
-def roofline(pipe, batch, cfg_index, frames_dev=None, peak_tflops=PEAK_F16_TFLOPS):
+def profile_tag(cfg) -> str:
+    """suffix of this workload's committed rocprofv3 summaries: profiles/<round>_kernel_stats<tag>.csv, <round>_pmc_traffic<tag>.json"""
+    i = cfg["index"]
+    if cfg["dtype"] == "f32":
+        return f"_config{i}_fp32"
+    if cfg["dtype"] == "f32s":
+        return f"_config{i}_fp32s"
+    return "" if i == 1 else f"_config{i}"
+
+
+def roofline(pipe, batch, cfg, frames_dev=None):
     """Per-launch timestamps on the engine stream with the schedule run in order (hp_engine_profile_sequence: every kernel sees the
     cache state of a real inference, which is what rocprofv3's per-kernel averages over this bench see too).  achieved = algorithmic
-    FLOPs of the dominant kernel's launches / their summed duration.  `back_to_back_us` is the same kernel re-launched 20 times in a
-    row (weights warm in L2) for comparison."""
-    iters = 20 if cfg_index == 1 else 4
+    FLOPs (or bytes) of the dominant kernel's launches / their summed duration.  `back_to_back_us` is the same kernel re-launched 20
+    times in a row (weights warm in L2) for comparison."""
+    peak_tflops = PEAKS[cfg["dtype"]]
+    small = cfg["index"] in (0, 1)
+    iters = 20 if small else 4
     prof = pipe.eng.profile(batch, iters=iters, in_sequence=True)
-    warm = pipe.eng.profile(batch, iters=iters) if cfg_index == 1 else None
+    warm = pipe.eng.profile(batch, iters=iters) if small else None
     mfma = [p for p in prof if p["tile"] != 0]
     by_tile = {}
     for p in mfma:
@@ -469,12 +506,12 @@ def roofline(pipe, batch, cfg_index, frames_dev=None, peak_tflops=PEAK_F16_TFLOP
     bound = "mfma" if intensity >= ridge else "hbm"
     frac_mfma, frac_hbm = tflops / peak_tflops, gbs / PEAK_HBM_GBS
     key, label = kernel_label(dom_tile)
-    tag = "" if cfg_index == 1 else "_config1_fp32" if cfg_index == 5 else f"_config{cfg_index}"
+    tag = profile_tag(cfg)
     traffic, src = pmc_traffic(key, tag)
     prof_us, prof_src = rocprof_avg_us(key, tag)
     out = {
-        # the roof that binds THIS kernel: its arithmetic intensity against the ridge of 2.5 PFLOP/s / 8 TB/s = 312.5 FLOP/byte; `achieved`
-        # / `peak` / `frac` are quoted on that roof, both fractions are given below
+        # the roof that binds THIS kernel: its arithmetic intensity against the ridge (peak FLOP/s of the engine's matrix pipe / 8 TB/s);
+        # `achieved` / `peak` / `frac` are quoted on that roof, both fractions are given below
         "bound": bound,
         "achieved": round(tflops, 2) if bound == "mfma" else round(gbs, 1),
         "peak": peak_tflops if bound == "mfma" else PEAK_HBM_GBS,
@@ -486,12 +523,12 @@ def roofline(pipe, batch, cfg_index, frames_dev=None, peak_tflops=PEAK_F16_TFLOP
         # the largest fraction of the MFMA peak this kernel could reach at 8 TB/s given its intensity (1 when it is right of the ridge)
         "mfma_frac_ceiling_at_hbm_peak": round(min(1.0, intensity / ridge), 4),
         "traffic": traffic, "traffic_source": src,
-        "kernel": label,
+        "kernel": label, "kernel_symbol": key,
         "launches_per_step": dom["n"], "avg_launch_us": round(dom["ms"] / dom["n"] * 1e3, 2),
         "flops_per_launch": round(dom["flops"] / dom["n"]), "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
         # NOT measured in this run: the kernel's average duration in the newest COMMITTED rocprofv3 kernel trace of `bench.py --config N
-        # --pipes 1` (the tracer adds ~1 us per launch) and this run's FLOPs over it - for the reader who recomputes the fraction from
-        # profiles/; null unless the kernel's name matches exactly one row of that file
+        # --dtype D --pipes 1` (the tracer adds ~1 us per launch) and this run's FLOPs over it - for the reader who recomputes the fraction
+        # from profiles/; null unless the kernel's name matches exactly one row of that file
         "committed_profile": {"source": prof_src, "avg_launch_us": None if prof_us is None else round(prof_us, 2),
                               "frac_mfma": None if prof_us is None else round(dom["flops"] / dom["n"] / (prof_us * 1e-6) / 1e12 / peak_tflops, 4),
                               "frac_hbm": None if prof_us is None else round(dom["bytes"] / dom["n"] / (prof_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)},
@@ -500,13 +537,14 @@ def roofline(pipe, batch, cfg_index, frames_dev=None, peak_tflops=PEAK_F16_TFLOP
         "serial_layer_ms_per_step": round(tot_ms, 4),
         "non_mfma_ms_per_step": round(tot_ms - mfma_ms, 4),
     }
-    # the kernel with the second-largest share: on configs[1] the 512-output separable block and the 128-channel chain are within a
-    # few percent of each other and swap places between runs / boxes - both are always on the line
+    # the kernel with the second-largest share (on configs[1]/f16 the 512-output separable block and the 128-channel chain swap places
+    # between runs / boxes): always in the detail record
     rest = sorted(((t, d) for t, d in by_tile.items() if t != dom_tile), key=lambda kv: -kv[1]["ms"])
     if rest:
         t2, d2 = rest[0]
         tf2, gb2, in2 = d2["flops"] / (d2["ms"] * 1e-3) / 1e12, d2["bytes"] / (d2["ms"] * 1e-3) / 1e9, d2["flops"] / d2["bytes"]
-        out["runner_up"] = {"kernel": kernel_label(t2)[1], "launches_per_step": d2["n"], "avg_launch_us": round(d2["ms"] / d2["n"] * 1e3, 2),
+        out["runner_up"] = {"kernel": kernel_label(t2)[1], "kernel_symbol": kernel_label(t2)[0], "launches_per_step": d2["n"],
+                            "avg_launch_us": round(d2["ms"] / d2["n"] * 1e3, 2),
                             "share_of_serial_step": round(d2["ms"] / tot_ms, 4), "intensity_flop_per_byte": round(in2, 1),
                             "bound": "mfma" if in2 >= ridge else "hbm", "frac_mfma": round(tf2 / peak_tflops, 4), "frac_hbm": round(gb2 / PEAK_HBM_GBS, 4)}
     out["share_of_serial_step"] = round(dom["ms"] / tot_ms, 4)
@@ -514,7 +552,7 @@ def roofline(pipe, batch, cfg_index, frames_dev=None, peak_tflops=PEAK_F16_TFLOP
         out["back_to_back_us"] = round(sum(p["ms"] for p in warm if p["tile"] == dom_tile) / dom["n"] * 1e3, 2)
     if frames_dev is not None:
         # the same timestamps with the parser in the loop, as in the timed region with one pipe (and as rocprofv3 sees the kernel in
-        # profiles/r02_kernel_stats*.csv, collected from `bench.py --pipes 1`): the parser's kernels run between two engine passes and
+        # profiles/*_kernel_stats*.csv, collected from `bench.py --pipes 1`): the parser's kernels run between two engine passes and
         # evict the weights from L2
         ms = n = 0
         for _ in range(iters):
@@ -528,8 +566,90 @@ def roofline(pipe, batch, cfg_index, frames_dev=None, peak_tflops=PEAK_F16_TFLOP
     return out
 
 
-def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline):
-    """Time one BASELINE configuration; returns the dict of its numbers (identical on every rank where it matters)."""
+# ------------------------------------------------------------------------------------------------ clocks
+class ClockSampler:
+    """Shader clock / socket power of one GPU sampled from amdgpu's sysfs files by a side thread (every 20 ms) while a timed region runs -
+    the counter behind every statement about sustained clocks: `sclk_mhz_mean / min / max` say at which clock
+    the fractions of the NOMINAL peak (2.4 GHz) in the roofline objects were achieved.  Sources, first one that answers: hwmon
+    freq1_input (Hz) and power1_average / power1_input (uW); pp_dpm_sclk (the starred level).  Nothing readable -> all null."""
+
+    def __init__(self, device_index: int = 0, period_s: float = 0.02):
+        import glob
+        import threading
+        self.period, self.samples, self.power = period_s, [], []
+        self._stop = threading.Event()
+        self._thread = None
+        self.freq_file = self.power_file = self.dpm_file = None
+        cards = sorted(p for p in glob.glob("/sys/class/drm/card[0-9]*") if os.path.exists(os.path.join(p, "device", "pp_dpm_sclk")))
+        if device_index < len(cards):
+            dev = os.path.join(cards[device_index], "device")
+            for h in sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*"))):
+                f = os.path.join(h, "freq1_input")
+                if os.path.exists(f) and self.freq_file is None:
+                    self.freq_file = f
+                for name in ("power1_average", "power1_input"):
+                    f = os.path.join(h, name)
+                    if os.path.exists(f) and self.power_file is None:
+                        self.power_file = f
+            self.dpm_file = os.path.join(dev, "pp_dpm_sclk")
+        self.source = None
+
+    def _read_mhz(self):
+        if self.freq_file:
+            try:
+                v = int(open(self.freq_file).read().strip())
+                if v > 0:
+                    self.source = "hwmon freq1_input"
+                    return v / 1e6
+            except (OSError, ValueError):
+                pass
+        if self.dpm_file:
+            try:
+                for line in open(self.dpm_file):
+                    if "*" in line:
+                        self.source = "pp_dpm_sclk"
+                        return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            except (OSError, ValueError, IndexError):
+                pass
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read_mhz()
+            if v is not None:
+                self.samples.append(v)
+            if self.power_file:
+                try:
+                    self.power.append(int(open(self.power_file).read().strip()) / 1e6)
+                except (OSError, ValueError):
+                    pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        import threading
+        self.samples, self.power = [], []
+        self._stop.clear()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join()
+
+    def summary(self):
+        s, p = self.samples, self.power
+        return {"sclk_mhz_mean": round(sum(s) / len(s), 1) if s else None, "sclk_mhz_min": round(min(s), 1) if s else None,
+                "sclk_mhz_max": round(max(s), 1) if s else None, "samples": len(s), "source": self.source,
+                "power_w_mean": round(sum(p) / len(p), 1) if p else None, "power_w_max": round(max(p), 1) if p else None,
+                "nominal_peak_clock_mhz": 2400}
+
+
+def measure(cfg, args, rank, world, dev, scaling, steps, warmup, headline, light=False):
+    """Time one BASELINE configuration at one engine precision; returns the dict of its numbers (identical on every rank where it
+    matters).  `light`: the end-to-end rate, the legs and the roofline only (no CPU baseline, no host-fed legs)."""
+    import math
+
     import torch
     import torch.distributed as dist
 
@@ -537,7 +657,6 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
     from hyperpose_amd import dist as hd
     from hyperpose_amd.engine import Model
 
-    cfg = CONFIGS[cfg_index]
     batch, global_batch = rank_plan(cfg["batch"], scaling, rank, world)
     model = Model(cfg["arch"], cfg["w"], cfg["h"])
     # one-time weight broadcast from rank 0 over RCCL/xGMI (the only collective of the whole job)
@@ -554,7 +673,8 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
         coll = {"backend": hd.LAST_BROADCAST.get("backend"), "bcast_bytes": hd.LAST_BROADCAST.get("bytes"), "bcast_ms": hd.LAST_BROADCAST.get("ms"),
                 "what": "one broadcast of the fp32 weight blob from rank 0 at start-up (outside the timed region); the steady state has no collective"}
     n_pipes = args.pipes if args.pipes > 0 else cfg["pipes"]
-    res = {"workload": cfg["label"], "frames_per_gpu_per_step": batch, "global_batch": global_batch, "scaling": scaling,
+    res = {"workload": cfg["label"], "key": cfg["key"], "dtype": cfg["dtype"], "dtype_long": DTYPE_LONG[cfg["dtype"]],
+           "frames_per_gpu_per_step": batch, "global_batch": global_batch, "scaling": scaling,
            "pipes_per_gpu": n_pipes, "gflop_per_frame": round(model.flops_per_frame / 1e9, 2)}
     if coll:
         res["collective"] = coll
@@ -565,48 +685,68 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
         frames_dev = _lib.DevBuf.from_numpy(frames)
         inj = [_lib.DevBuf.from_numpy(m) for m in maps]
         pipes = [Pipe(cfg, model, w_host, inj, batch) for _ in range(max(1, n_pipes))]
+    sampler = None if (args.no_clocks or rank != 0) else ClockSampler(dev.index or 0)
 
     def timed(injected):
+        """W warm-up steps + a 0.3 s ramp of the same loop (both untimed), then ONE timed region of R x K steps - R the smallest whole
+        number that makes it last >= --min-seconds (from the ramp's own rate; the MAX over the ranks, so that every rank runs the same
+        count) - bracketed by barrier + synchronize on both sides."""
+        est = None
         if pipes:
             run_loop(pipes, frames_dev, warmup, injected)
-            # the GPU's clocks take a few hundred ms of load to settle (100 steps right after a short warm-up measure
-            # ~12 % low): keep the same loop running, untimed, until 0.3 s have passed since the warm-up began
-            t_ramp = time.perf_counter()
+            # the GPU's clocks take a few hundred ms of load to settle (100 steps right after a short warm-up measure ~12 % low): keep
+            # the same loop running, untimed, until 0.3 s have passed since the warm-up ended
+            torch.cuda.synchronize()
+            t_ramp, n_ramp = time.perf_counter(), 0
             while time.perf_counter() - t_ramp < 0.3:
                 run_loop(pipes, frames_dev, len(pipes), injected)
+                n_ramp += len(pipes)
+            torch.cuda.synchronize()
+            est = (time.perf_counter() - t_ramp) / max(1, n_ramp)
+        reps = max(1, math.ceil(args.min_seconds / (steps * est))) if est else 1
+        reps = int(round(hd.max_over_ranks(float(reps), world, device=hd.collective_device(dev))))
+        n_timed = steps * reps
         barrier()
+        if sampler:
+            sampler.__enter__()
         t0 = time.perf_counter()
-        nh = run_loop(pipes, frames_dev, steps, injected) if pipes else 0
+        nh = run_loop(pipes, frames_dev, n_timed, injected) if pipes else 0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if sampler:
+            sampler.__exit__()
         dt = hd.max_over_ranks(dt, world, device=hd.collective_device(dev))
         barrier()
-        return dt, nh
+        return dt, nh, n_timed
 
-    dt, n_humans = timed(True)
-    dt_dnn = None if (args.no_dnn_output or not headline) else timed(False)[0]
-    total_frames = global_batch * steps
-    fps = total_frames / dt
+    dt, n_humans, n_timed = timed(True)
+    if sampler:
+        res["clocks"] = sampler.summary()
+    dt_dnn, n_dnn = None, 0
+    if headline and not args.no_dnn_output:
+        dt_dnn, _, n_dnn = timed(False)
+    fps = global_batch * n_timed / dt
     # host fall-backs / truncations over every step this rank ran (warm-up and both timed phases): frames a device decoder declined and
     # handed to the host statements (PoseProposal / PifPaf), batches with an overflowed PAF list
     parsed = sum(p.frames_parsed for p in pipes)
     res.update({"device_declined_frames": sum(p.declined_frames for p in pipes), "capacity_truncations": sum(p.capacity_truncations for p in pipes),
                 "frames_parsed_for_these_counts": parsed})
-    res.update({"value": round(fps, 1), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
-                "humans_per_step": n_humans / max(1, steps),
-                "fps_dnn_output": round(total_frames / dt_dnn, 1) if dt_dnn else None,
+    peak = PEAKS[cfg["dtype"]]
+    res.update({"value": round(fps, 1), "unit": "frames/s", "steps": steps, "steps_timed": n_timed, "timed_region_s": round(dt, 4),
+                "ms_per_step": round(dt / n_timed * 1e3, 4),
+                "humans_per_step": n_humans / max(1, n_timed),
+                "fps_dnn_output": round(global_batch * n_dnn / dt_dnn, 1) if dt_dnn else None,
                 "conv_tflops_end_to_end": round(fps * model.flops_per_frame / 1e12, 2),
-                "conv_frac_of_mfma_peak_end_to_end": round(fps * model.flops_per_frame / 1e12 / (PEAK_F32_TFLOPS if cfg.get("dtype") == "f32" else PEAK_F16_TFLOPS) / world, 4),
-                "dtype": "f32 (fp32 storage, fp32 MFMA)" if cfg.get("dtype") == "f32" else "f16 (fp32 accumulate)"})
+                "conv_frac_of_mfma_peak_end_to_end": round(fps * model.flops_per_frame / 1e12 / peak / world, 4)})
     if rank == 0 and pipes and not args.no_roofline:
         # where the step's time goes: the parser alone (injected maps: GPU kernels + the host tail in collect) and the conv stack
         # alone, each through ONE pipe, next to the end-to-end step above (in which several pipes overlap them)
         p0 = pipes[0]
 
-        def leg(eng_on, par_on, min_s=0.5):
-            """ms per step of ONE pipe running the given halves serially: 0.2 s ramp, then >= min_s timed (independent of --steps)."""
+        def leg(eng_on, par_on, min_s=0.4):
+            """ms per step of ONE pipe running the given halves serially: 0.15 s ramp, then >= min_s timed (independent of --steps)."""
             t_r = time.perf_counter()
-            while time.perf_counter() - t_r < 0.2:
+            while time.perf_counter() - t_r < 0.15:
                 p0.submit(frames_dev, True, engine=eng_on, parser=par_on)
                 p0.collect()
             torch.cuda.synchronize()
@@ -632,10 +772,10 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
         del p0
     if rank == 0 and pipes:
         if not args.no_roofline:
-            res["roofline"] = roofline(pipes[0], batch, cfg_index, frames_dev, PEAK_F32_TFLOPS if cfg.get("dtype") == "f32" else PEAK_F16_TFLOPS)
-        if world == 1 and not args.no_cpu_baseline:
+            res["roofline"] = roofline(pipes[0], batch, cfg, frames_dev)
+        if world == 1 and not args.no_cpu_baseline and not light:
             res["cpu_baseline"] = cpu_baseline(cfg, maps)
-    if not args.no_from_host:
+    if not args.no_from_host and not light:
         # the PCIe-inclusive step, on EVERY rank at once (each with its own pinned frames and pipes, all feeding from
         # the same host): the aggregate is the sum of the ranks' rates over a common window, which is what the host feed limits at N > 1
         del pipes[:]
@@ -653,7 +793,99 @@ def measure(cfg_index, args, rank, world, dev, scaling, steps, warmup, headline)
             if headline and world == 1:
                 res["from_host"] = from_host(model, w_host, cfg, batch, n_pipes)
     del pipes
-    return res, model
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ the ONE line
+LINE_LIMIT = 4096  # the driver's parser takes the last stdout line; 13 KB parsed in round 3, 21 KB did not in round 4: stay far below
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 1] + "~"
+
+
+def compact_roofline(r):
+    """The roofline object of the printed line: the contract's keys + both fractions + the kernel's symbol + what the committed
+    rocprofv3 trace says about the same kernel (source file, its average, the fraction recomputed with it)."""
+    if not r:
+        return None
+    cp = r.get("committed_profile") or {}
+    frac_key = "frac_mfma" if r["bound"] == "mfma" else "frac_hbm"
+    return {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"],
+            "frac_mfma": r["frac_mfma"], "frac_hbm": r["frac_hbm"], "kernel": _short(r.get("kernel_symbol") or r["kernel"], 80),
+            "launches_per_step": r["launches_per_step"], "avg_launch_us": r["avg_launch_us"],
+            "flops_per_launch": r["flops_per_launch"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+            "all_mfma_convs_frac": r["all_mfma_convs"]["frac"],
+            "committed_profile": {"source": cp.get("source"), "avg_launch_us": cp.get("avg_launch_us"), "frac": cp.get(frac_key)}}
+
+
+def compact_line(detail):
+    """The ONE JSON line rank 0 prints: the contract's keys, the headline's roofline and cpu_baseline, one small object per other
+    workload - everything else lives in the detail file it names.  Pure function of the detail record (tests/test_bench_labels.py)."""
+    head, a = detail["headline"], detail["args"]
+    cfg_i = head["key"]
+    out = {
+        "metric": detail["metric"], "value": head["value"], "unit": "frames/s", "n_gpus": detail["n_gpus"], "steps": a["steps"], "warmup": a["warmup"],
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
+        "dtype": DTYPE_LABEL[head["dtype"]], "data": "synthetic",
+        "config": {"workload": _short(head["workload"] + " per GPU; u8 HWC frames resident in HBM, humans to pinned host memory", 200),
+                   "key": cfg_i, "engine": _short(head["dtype_long"], 140),
+                   "global_batch": head["global_batch"], "frames_per_gpu_per_step": head["frames_per_gpu_per_step"],
+                   "parallelism": f"frame-sharded x{detail['n_gpus']}, no steady-state collective", "pipes_per_gpu": head["pipes_per_gpu"],
+                   "parser_input": "injected synthetic heat-maps (several people per frame); the full conv stack also runs",
+                   "gflop_per_frame": head["gflop_per_frame"]},
+        "steps_timed": head["steps_timed"], "timed_region_s": head["timed_region_s"],
+        "fps_dnn_output": head.get("fps_dnn_output"), "value_h2d_inclusive": (head.get("h2d_inclusive") or {}).get("value"),
+        "single_pipe_fps": head.get("single_pipe_fps"), "conv_tflops_end_to_end": head["conv_tflops_end_to_end"],
+        "device_declined_frames": head["device_declined_frames"], "capacity_truncations": head["capacity_truncations"],
+        "roofline": compact_roofline(head.get("roofline")),
+    }
+    cb = head.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": cb["value"], "unit": "frames/s (parser only)", "cores": cb["cores"], "host_cores": cb["host_cores"],
+                               "kind": cb["kind"], "sample": _short(cb["sample"], 160)}
+    ck = head.get("clocks")
+    if ck:
+        out["clocks"] = {k: ck[k] for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean")}
+    if detail.get("collective_backend"):
+        out["collective_backend"] = detail["collective_backend"]
+    wl = {}
+    for key, w in detail.get("workloads", {}).items():
+        r = w.get("roofline") or {}
+        wl[key] = {"value": w["value"], "ms_per_step": w["ms_per_step"], "dtype": DTYPE_LABEL[w["dtype"]], "bound": r.get("bound"), "frac": r.get("frac"),
+                   "kernel": _short(r.get("kernel_symbol", ""), 48) or None, "declined": w["device_declined_frames"], "truncated": w["capacity_truncations"]}
+    if wl:
+        out["workloads"] = wl
+    kh = detail.get("workloads", {}).get("configs[1]/f16")
+    if kh and cfg_i == "configs[1]/f32":
+        out["value_khalf"] = kh["value"]
+        out["roofline_khalf"] = compact_roofline(kh.get("roofline"))
+    out["detail"] = detail.get("detail_file")
+    line = json.dumps(out, separators=(",", ":"))
+    # never let the line outgrow the driver's parser: drop the optional parts, largest first
+    for k in ("roofline_khalf", "workloads", "clocks"):
+        if len(line) <= LINE_LIMIT:
+            break
+        out.pop(k, None)
+        out["dropped_for_size"] = out.get("dropped_for_size", []) + [k]
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def parse_extra(extra, world, headline_key):
+    """[(index, dtype)] of the workloads measured besides the headline.  Default at N = 1: configs[1] at the other precision, then every
+    other BASELINE configuration at both precisions; at N > 1: configs[3], configs[4] (the frame-sharded ones) at the headline's precision,
+    strong-scaled."""
+    out = []
+    for tok in [t.strip() for t in extra.split(",") if t.strip()]:
+        i, _, d = tok.partition("/")
+        if int(i) == 5:
+            i, d = 1, "f32"
+        for dd in ([d] if d else ["f32", "f16"]):
+            if int(i) in CONFIGS and dd in DTYPE_LONG and f"configs[{int(i)}]/{dd}" != headline_key and (int(i), dd) not in out:
+                out.append((int(i), dd))
+    return out
 
 
 def main():
@@ -676,51 +908,43 @@ def main():
     if world > 1:
         backend = hd.init_for_gpu(dev)  # RCCL, or - agreed by all ranks - gloo if it cannot be brought up (the hot path has no collective)
 
-    cfg = CONFIGS[args.config]
+    cfg = config(args.config, args.dtype)
     steps = args.steps if args.steps is not None else cfg["steps"]
-    head, model = measure(args.config, args, rank, world, dev, args.scaling, steps, args.warmup, True)
-    out = {
+    head = measure(cfg, args, rank, world, dev, args.scaling, steps, args.warmup, True)
+    detail = {
         "metric": "end-to-end FPS (preproc+DNN+PAF parse) @ 368x432" if args.config in (0, 1) else f"end-to-end FPS (preproc+DNN+parse), {cfg['label']}",
-        "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "f16 (fp32 accumulate; parsers fp32)", "data": "synthetic",
-        "config": {"workload": cfg["label"] + " per GPU, frames u8 HWC resident in HBM, humans written to pinned host memory",
-                   "global_batch": head["global_batch"], "frames_per_gpu_per_step": head["frames_per_gpu_per_step"],
-                   "parallelism": f"frame-sharded x{world}, no steady-state collective",
-                   "pipes_per_gpu": head["pipes_per_gpu"], "frames_in_flight_per_gpu": head["pipes_per_gpu"] * head["frames_per_gpu_per_step"],
-                   "parser_input": "injected synthetic heat-maps (several people per frame); the full conv stack also runs",
-                   "humans_per_step": head["humans_per_step"], "gflop_per_frame": head["gflop_per_frame"]},
-        "fps_dnn_output": head["fps_dnn_output"],
-        "conv_tflops_end_to_end": head["conv_tflops_end_to_end"],
-        # SURVEY.md 8d's strictest reading: the same step with the u8 frames starting in pinned HOST memory (one H2D copy per batch) and the
-        # parser fed by the network's own heat-maps; aggregate over the ranks.  `value` keeps the contract's definition (inputs resident in HBM).
-        "value_h2d_inclusive": head.get("h2d_inclusive", {}).get("value"),
-        "device_declined_frames": head["device_declined_frames"], "capacity_truncations": head["capacity_truncations"],
+        "n_gpus": world, "args": {"steps": steps, "warmup": args.warmup, "config": args.config, "dtype": args.dtype, "scaling": args.scaling,
+                                  "min_seconds": args.min_seconds, "pipes": args.pipes},
+        "collective_backend": backend, "headline": head, "workloads": {},
     }
-    out["collective_backend"] = backend
-    for k in ("roofline", "parser_roofline", "cpu_baseline", "single_pipe_fps", "h2d_inclusive", "from_host", "parser_only_ms_per_step", "engine_only_ms_per_step",
-              "parser_share_of_serial_step", "collective"):
-        if k in head:
-            out[k] = head[k]
     extra = args.extra
     if extra is None:
-        extra = "0,2,3,4,5" if world == 1 else "3,4"
         if args.config != 1:
             extra = ""
-    workloads = {}
-    for tok in [t for t in extra.split(",") if t.strip()]:
-        k = int(tok)
-        if k == args.config or k not in CONFIGS:
-            continue
-        c = CONFIGS[k]
+        elif world == 1:
+            other = "f16" if args.dtype == "f32" else "f32"
+            extra = f"1/{other},1/f32s,0/{args.dtype},2/{args.dtype},3/{args.dtype},4/{args.dtype},0/{other},2/{other},3/{other},4/{other}"
+        else:
+            extra = f"3/{args.dtype},4/{args.dtype}"
+    for k, dt_ in parse_extra(extra, world, cfg["key"]):
+        c = config(k, dt_)
         scal = "strong" if world > 1 else "weak"
-        r, _ = measure(k, args, rank, world, dev, scal, c["steps"], max(2, min(args.warmup, c["steps"] // 4)), False)
+        # configs[1] at the other precision keeps its CPU-free secondary legs; the others run the light form
+        r = measure(c, args, rank, world, dev, scal, c["steps"], max(2, min(args.warmup, c["steps"] // 4)), False, light=True)
         r["n_gpus"] = world
-        workloads[c.get("key", f"configs[{k}]")] = r
-    if workloads:
-        out["workloads"] = workloads
+        detail["workloads"][c["key"]] = r
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        paths = [args.detail] if args.detail else [os.path.join(ROOT, "bench_detail.json")]
+        if not args.detail and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+        detail["detail_file"] = os.path.relpath(paths[0], ROOT) if paths[0].startswith(ROOT) else paths[0]
+        for p in paths:
+            try:
+                with open(p, "w") as f:
+                    json.dump(detail, f, indent=1)
+            except OSError as e:
+                print(f"bench.py: could not write {p}: {e}", file=sys.stderr)
+        print(compact_line(detail), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

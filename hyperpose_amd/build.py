@@ -33,6 +33,7 @@ UNITS = [
     ("conv_chain.hip", []),
     ("conv_bottleneck.hip", []),
     ("conv_fp32.hip", []),
+    ("conv_split.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),
     ("onnx_import.cpp", []),

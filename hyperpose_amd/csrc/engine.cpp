@@ -86,6 +86,7 @@ struct step {
     hp::first_conv32_params fp32{};
     hp::dw32_params dp32{};
     hp::pool32_params pp32{};
+    int cin_split = 0;     // HP_DTYPE_F32S: input channels as the split kernel reads them (whole chunks), 0 = the layer stays on conv32_kernel
     int n_layers = 1;      // consecutive layers this step covers
     double flops = 0, bytes = 0; // per frame
 };
@@ -106,7 +107,17 @@ void same_pad(int in, int k, int stride, int dil, int& out, int& pad_before)
 
 struct hp_engine {
     int in_w = 0, in_h = 0, max_batch = 0;
-    int dtype = HP_DTYPE_F16; // HP_DTYPE_F32: fp32 storage and arithmetic (the reference's data_type::kFLOAT), conv_fp32.hip
+    int dtype = HP_DTYPE_F16; // HP_DTYPE_F32: fp32 storage and arithmetic (the reference's data_type::kFLOAT), conv_fp32.hip;
+                              // HP_DTYPE_F32S: the same engine with the dense layers' products on the fp16 pipe (conv_split.hip)
+    bool is_f32() const { return dtype == HP_DTYPE_F32 || dtype == HP_DTYPE_F32S; }
+    // HP_DTYPE_F32S: a pinned host word the split kernels OR into when an activation exceeds fp16's range (|x| > 65504); once seen
+    // (hp_engine_synchronize / hp_engine_inference) the engine runs conv32_kernel instead - exact fp32 products, any range
+    hp::host_buf ovf_flag;
+    bool split_off = false;
+    int split_fallbacks = 0;
+    struct { const void* input = nullptr; size_t frame_bytes = 0; int n = 0, on_device = 0, kind = 0; void* stream = nullptr; } last; // the newest hp_engine_infer_* call
+    bool split_overflowed() const { return dtype == HP_DTYPE_F32S && !split_off && ovf_flag.p && *static_cast<volatile unsigned*>(ovf_flag.p) != 0; }
+    int leave_split(); // stop using conv32_split_kernel: drop the captured graphs (they hold its launches), count the event
     bool dbg_conv = false, dbg_bn = false, dbg_chain = false, dbg_sep = false; // HP_*_DBG block timelines, read once at creation
     double factor = 1.0 / 255;
     int flip_rb = 1;
@@ -154,9 +165,16 @@ int hp_engine::build(const hp_engine_desc* d)
     HP_REQUIRE(d->in_w > 0 && d->in_h > 0 && d->max_batch >= 1, HP_ERR_INVALID, "engine: bad input size / batch");
     HP_REQUIRE(d->layers && d->n_layers > 0 && d->weights, HP_ERR_INVALID, "engine: no layers / weights");
     in_w = d->in_w, in_h = d->in_h, max_batch = d->max_batch, factor = d->factor, flip_rb = d->flip_rb;
-    HP_REQUIRE(d->dtype == HP_DTYPE_F16 || d->dtype == HP_DTYPE_F32, HP_ERR_INVALID, "engine: dtype %d is neither HP_DTYPE_F16 nor HP_DTYPE_F32", d->dtype);
+    HP_REQUIRE(d->dtype == HP_DTYPE_F16 || d->dtype == HP_DTYPE_F32 || d->dtype == HP_DTYPE_F32S, HP_ERR_INVALID,
+        "engine: dtype %d is none of HP_DTYPE_F16 / HP_DTYPE_F32 / HP_DTYPE_F32S", d->dtype);
     dtype = d->dtype;
-    const bool f32 = dtype == HP_DTYPE_F32;
+    const bool f32 = is_f32();
+    unsigned* ovf_dev = nullptr;
+    if (dtype == HP_DTYPE_F32S) {
+        HP_TRY(ovf_flag.alloc(64));
+        memset(ovf_flag.p, 0, 64);
+        HP_HIP_TRY(hipHostGetDevicePointer((void**)&ovf_dev, ovf_flag.p, 0));
+    }
     dbg_conv = getenv("HP_CONV_DBG") != nullptr, dbg_bn = getenv("HP_BN_DBG") != nullptr;
     dbg_chain = getenv("HP_CHAIN_DBG") != nullptr, dbg_sep = getenv("HP_SEP_DBG") != nullptr;
     for (int c = 0; c < 3; ++c)
@@ -480,6 +498,26 @@ int hp_engine::build(const hp_engine_desc* d)
                     p.out.p = nullptr, to.unwritten = true; // only the fp32 network output is wanted
                 HP_REQUIRE(hp::set_act32(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
                 p.B = max_batch, p.npix = max_batch * g.OH * g.OW;
+                p.w_split = nullptr, p.ovf = ovf_dev;
+                // HP_DTYPE_F32S: the layers the split kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the
+                // buffer's channel stride) get their weights as fp16 (hi, lo) pairs in fragment order as well; the others stay on conv32_kernel
+                if (dtype == HP_DTYPE_F32S) {
+                    const int ck = taps == 1 ? 64 : 32, cin_s = round_up(L.cin, ck);
+                    hp::conv32_params q = p;
+                    q.Cin = cin_s;
+                    if (L.in_coff + cin_s <= ti.cs && hp::conv32_split_ok(q)) {
+                        std::vector<float> wide((size_t)taps * cout_pad * cin_s, 0.f);
+                        for (int t = 0; t < taps; ++t)
+                            for (int co = 0; co < cout_pad; ++co)
+                                std::copy(packed.begin() + ((size_t)t * cout_pad + co) * cin_pad, packed.begin() + ((size_t)t * cout_pad + co) * cin_pad + cin_pad,
+                                    wide.begin() + ((size_t)t * cout_pad + co) * cin_s);
+                        std::vector<_Float16> ws(wide.size() * 2);
+                        hp::conv32_split_pack(wide.data(), taps, cout_pad, cin_s, ws.data());
+                        void* dws = nullptr;
+                        HP_TRY(upload(ws.data(), ws.size() * sizeof(_Float16), &dws));
+                        p.w_split = (const _Float16*)dws, st.cin_split = cin_s;
+                    }
+                }
                 st.flops = 2.0 * opix * L.cout * taps * L.cin;
                 st.bytes = (double)ti.H * ti.W * L.cin * 4 + opix * L.cout * 4 + (double)nw * 4;
             } else if (L.op == HP_OP_DWCONV) {
@@ -1134,7 +1172,12 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
             HP_HIP_TRY(hp::launch_first_conv32(st.fp32, s));
         } else if (st.op == HP_OP_CONV) {
             st.cp32.B = n, st.cp32.npix = n * st.cp32.OH * st.cp32.OW;
-            HP_HIP_TRY(hp::launch_conv32(st.cp32, s));
+            if (st.cin_split && !split_off) {
+                hp::conv32_params q = st.cp32;
+                q.Cin = st.cin_split;
+                HP_HIP_TRY(hp::launch_conv32_split(q, s));
+            } else
+                HP_HIP_TRY(hp::launch_conv32(st.cp32, s));
         } else if (st.op == HP_OP_DWCONV) {
             st.dp32.B = n;
             HP_HIP_TRY(hp::launch_dwconv32(st.dp32, s));
@@ -1291,7 +1334,7 @@ int hp_engine::enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s
     for (auto& o : outputs)
         if (o.fused_layer < 0) {
             const tensor_info& ti = *tensors[o.tensor];
-            if (dtype == HP_DTYPE_F32)
+            if (is_f32())
                 HP_HIP_TRY(hp::launch_output_transform32(ti.view32(o.coff), n, o.H, o.W, o.x, o.buf->as<float>(), s));
             else
                 HP_HIP_TRY(hp::launch_output_transform(ti.view(o.coff), n, o.H, o.W, o.x, o.buf->as<float>(), s));
@@ -1365,7 +1408,7 @@ int hp_engine_load(hp_engine** out, const char* path, int max_batch)
     std::vector<float> w;
     bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, ENGINE_MAGIC, 8) == 0 && h.layer_size == (int32_t)sizeof(hp_layer)
         && h.output_size == (int32_t)sizeof(hp_output_desc) && h.n_layers > 0 && h.n_layers < (1 << 20) && h.n_outputs > 0
-        && h.n_outputs < 4096 && h.n_weights < ((uint64_t)1 << 34) && (h.dtype == HP_DTYPE_F16 || h.dtype == HP_DTYPE_F32);
+        && h.n_outputs < 4096 && h.n_weights < ((uint64_t)1 << 34) && (h.dtype == HP_DTYPE_F16 || h.dtype == HP_DTYPE_F32 || h.dtype == HP_DTYPE_F32S);
     if (ok) { // the counts must account for the file exactly before anything is allocated from them
         const long at = ftell(f);
         ok = fseek(f, 0, SEEK_END) == 0;
@@ -1422,9 +1465,25 @@ int hp_engine_input_size(const hp_engine* e, int* w, int* h)
     return HP_OK;
 }
 
+int hp_engine::leave_split()
+{
+    HP_HIP_TRY(hipStreamSynchronize(stream));
+    if (last.stream)
+        HP_HIP_TRY(hipStreamSynchronize((hipStream_t)last.stream));
+    for (auto& g : graphs)
+        (void)hipGraphExecDestroy(g.second);
+    graphs.clear();
+    split_off = true, ++split_fallbacks;
+    *static_cast<volatile unsigned*>(ovf_flag.p) = 0;
+    return HP_OK;
+}
+
 static int infer_common(hp_engine* e, const void* input, size_t frame_bytes, int n, int on_device, void* stream, int kind)
 {
     HP_REQUIRE(e && input, HP_ERR_INVALID, "hp_engine_infer: null argument");
+    if (e->split_overflowed()) // an earlier batch held a value outside fp16's range: from here on the fp32 matrix pipe
+        HP_TRY(e->leave_split());
+    e->last.input = input, e->last.frame_bytes = frame_bytes, e->last.n = n, e->last.on_device = on_device, e->last.kind = kind, e->last.stream = stream;
     HP_REQUIRE(n >= 1, HP_ERR_INVALID, "hp_engine_infer: empty batch");
     // src/tensorrt.cpp:439-443 throws std::logic_error here
     HP_REQUIRE(n <= e->max_batch, HP_ERR_CAPACITY, "Input batch size overflow: Yours@%d Max@%d", n, e->max_batch);
@@ -1489,8 +1548,18 @@ int hp_engine_synchronize(hp_engine* e)
 {
     HP_REQUIRE(e, HP_ERR_INVALID, "null engine");
     HP_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->split_overflowed() && e->last.input && true) {
+        // HP_DTYPE_F32S: the batch just finished saw |x| > 65504 somewhere - its outputs are not trustworthy.  Run it again on the fp32
+        // pipe before the caller reads them (a host input is copied again from the caller's buffer, which the API keeps valid until the
+        // outputs are read)
+        HP_TRY(e->leave_split());
+        HP_TRY(infer_common(e, e->last.input, e->last.frame_bytes, e->last.n, e->last.on_device, e->last.stream, e->last.kind));
+        HP_HIP_TRY(hipStreamSynchronize(e->last.stream ? (hipStream_t)e->last.stream : e->stream));
+    }
     return HP_OK;
 }
+
+int hp_engine_split_fallbacks(const hp_engine* e) { return e ? e->split_fallbacks : HP_ERR_INVALID; }
 
 void* hp_engine_stream(hp_engine* e) { return e ? (void*)e->stream : nullptr; }
 
@@ -1520,7 +1589,7 @@ int hp_engine_output_to_host(hp_engine* e, int i, int n, float* host)
 {
     HP_REQUIRE(e && host && i >= 0 && i < (int)e->outputs.size() && n >= 1 && n <= e->max_batch, HP_ERR_INVALID, "hp_engine_output_to_host: bad argument");
     const out_info& o = e->outputs[i];
-    HP_HIP_TRY(hipStreamSynchronize(e->stream));
+    HP_TRY(hp_engine_synchronize(e)); // (an HP_DTYPE_F32S engine re-runs the batch here if a value left fp16's range)
     HP_HIP_TRY(hipMemcpy(host, o.buf->p, (size_t)n * o.out_c() * o.x.out_h * o.x.out_w * sizeof(float), hipMemcpyDeviceToHost));
     return HP_OK;
 }
@@ -1540,7 +1609,7 @@ int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int sha
     HP_TRY(tmp.alloc((size_t)n * ti.C * ti.H * ti.W * sizeof(float)));
     hp::out_xform px{};
     px.C = ti.C, px.act = 0, px.shuffle = 1, px.group = 0, px.out_h = ti.H, px.out_w = ti.W, px.scale = 1.f, px.grid = 0;
-    if (e->dtype == HP_DTYPE_F32)
+    if (e->is_f32())
         HP_HIP_TRY(hp::launch_output_transform32(ti.view32(0), n, ti.H, ti.W, px, tmp.as<float>(), e->stream));
     else
         HP_HIP_TRY(hp::launch_output_transform(ti.view(0), n, ti.H, ti.W, px, tmp.as<float>(), e->stream));
@@ -1573,7 +1642,7 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? hp::conv32_tile(st.cp32) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? ((st.cin_split && !e->split_off) ? hp::conv32_split_tile(st.cp32) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = ms / iters;
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1626,7 +1695,7 @@ int hp_engine_profile_pair(hp_engine* e, hp_engine* f, int n, int iters, hp_laye
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? hp::conv32_tile(st.cp32) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? ((st.cin_split && !e->split_off) ? hp::conv32_split_tile(st.cp32) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = std::max(m0, m1) / (2 * iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1684,7 +1753,7 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? hp::conv32_tile(st.cp32) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? ((st.cin_split && !e->split_off) ? hp::conv32_split_tile(st.cp32) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = (float)(acc[k] / iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;

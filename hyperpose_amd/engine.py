@@ -39,9 +39,12 @@ class EngineDesc(C.Structure):
                 ("dtype", C.c_int32)]
 
 
-DTYPE_F16, DTYPE_F32 = 0, 1  # HP_DTYPE_*: data_type::kHALF / data_type::kFLOAT of the reference's engine
+# HP_DTYPE_*: data_type::kHALF / data_type::kFLOAT of the reference's engine; F32S = the kFLOAT engine with the dense layers' products
+# formed as three exact fp16 x fp16 products on the fp16 matrix pipe (csrc/conv_split.hip), opt-in
+DTYPE_F16, DTYPE_F32, DTYPE_F32S = 0, 1, 2
 _DTYPES = {"f16": DTYPE_F16, "fp16": DTYPE_F16, "half": DTYPE_F16, DTYPE_F16: DTYPE_F16,
-           "f32": DTYPE_F32, "fp32": DTYPE_F32, "float": DTYPE_F32, DTYPE_F32: DTYPE_F32}
+           "f32": DTYPE_F32, "fp32": DTYPE_F32, "float": DTYPE_F32, DTYPE_F32: DTYPE_F32,
+           "f32s": DTYPE_F32S, "f32_split": DTYPE_F32S, DTYPE_F32S: DTYPE_F32S}
 
 
 class LayerTime(C.Structure):
@@ -187,6 +190,11 @@ class Engine:
         check(lib().hp_engine_load(C.byref(handle), path.encode(), int(max_batch)))
         self._adopt(handle, max_batch)
         return self
+
+    @property
+    def split_fallbacks(self) -> int:
+        """HP_DTYPE_F32S engines: 1 once an activation beyond fp16's range sent the engine back to the fp32 matrix pipe."""
+        return int(lib().hp_engine_split_fallbacks(self._h))
 
     def close(self):
         if self._h:

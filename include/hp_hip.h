@@ -244,8 +244,12 @@ typedef struct hp_output_desc {
 
 /* Arithmetic of the engine.  HP_DTYPE_F16: fp16 storage, fp16 MFMA products, fp32 accumulation - the fast path (data_type::kHALF).
  * HP_DTYPE_F32: fp32 storage and fp32 matrix-pipe arithmetic, one launch per layer - what data_type::kFLOAT, the reference's default,
- * promises: outputs agree with an fp32 evaluation of the graph to ~1e-5 relative (tests/test_engine_fp32_gpu.py). */
-enum { HP_DTYPE_F16 = 0, HP_DTYPE_F32 = 1 };
+ * promises: outputs agree with an fp32 evaluation of the graph to ~1e-5 relative (tests/test_engine_fp32_gpu.py).
+ * HP_DTYPE_F32S ("split"): the HP_DTYPE_F32 engine - fp32 storage, fp32 accumulation, same launches - with the products of its dense
+ * 1 x 1 / 3 x 3 stride-1 layers formed on the fp16 matrix pipe: x = hi + 2^-11 lo with hi, lo fp16, a b = hi hi + 2^-11 (hi lo + lo hi),
+ * every partial product exact in the fp32 accumulator, ~2^-22 relative per product (csrc/conv_split.hip).  Opt-in; an activation beyond
+ * fp16's range (|x| > 65504) makes the engine re-run the batch on the fp32 pipe and stay there (hp_engine_split_fallbacks counts). */
+enum { HP_DTYPE_F16 = 0, HP_DTYPE_F32 = 1, HP_DTYPE_F32S = 2 };
 
 typedef struct hp_engine_desc {
     int32_t in_w, in_h, max_batch;   /* tensorrt(..., cv::Size input_size, int max_batch_size = 8, ...) */
@@ -258,7 +262,7 @@ typedef struct hp_engine_desc {
     int32_t n_outputs;
     const float* weights;            /* host fp32 blob */
     size_t n_weights;
-    int32_t dtype;                   /* HP_DTYPE_F16 (0, the zero-initialised default) or HP_DTYPE_F32: the reference's data_type argument
+    int32_t dtype;                   /* HP_DTYPE_F16 (0, the zero-initialised default), HP_DTYPE_F32 or HP_DTYPE_F32S: the reference's data_type argument
                                       * (include/hyperpose/operator/dnn/tensorrt.hpp:14-21,48; src/tensorrt.cpp:327,353) */
 } hp_engine_desc;
 
@@ -347,6 +351,9 @@ int hp_engine_create_from_model(hp_engine** out, const hp_model* m, int max_batc
 int hp_engine_create_from_model_dtype(hp_engine** out, const hp_model* m, int max_batch, double factor, int flip_rb,
                                       const float* weights, size_t n_weights, int dtype);
 int hp_engine_dtype(const hp_engine* e); /* HP_DTYPE_* of an engine (serialized engines carry theirs) */
+/* HP_DTYPE_F32S engines: how many times the engine left the split kernels for the fp32 pipe because an activation did not fit fp16's
+ * range (0 or 1: it does not go back); 0 for the other types */
+int hp_engine_split_fallbacks(const hp_engine* e);
 
 /* ---- hyperpose::stream on the GPU (reference include/hyperpose/stream/stream.hpp:119-390, src/stream.cpp:60-147): host frames of
  * any size in, humans out, in submission order.  Each submit copies one batch (<= max_batch frames, 8-bit BGR HWC, packed rows) to

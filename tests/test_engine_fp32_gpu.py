@@ -20,6 +20,13 @@ pytestmark = pytest.mark.gpu
 REL, ABS = 1e-4, 1e-6
 
 
+@pytest.fixture(params=["f32", "f32s"])
+def f32dtype(request):
+    """HP_DTYPE_F32 (fp32 matrix pipe) and HP_DTYPE_F32S (the same engine with the dense 1 x 1 / 3 x 3 stride-1 layers' products formed as
+    three exact fp16 x fp16 products on the fp16 pipe, csrc/conv_split.hip): ONE tolerance, the pure fp32 oracle, for both."""
+    return request.param
+
+
 def _close32(got, ref, what=""):
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max())
@@ -27,10 +34,10 @@ def _close32(got, ref, what=""):
     return err / max(scale, 1e-30)
 
 
-def _run32(net, outs, frames, h, w, f32_input=False, **kw):
+def _run32(net, outs, frames, h, w, f32_input=False, dtype="f32", **kw):
     blob = net.blob()
-    eng = E.Engine(net.layers, [o.c() for o in outs], blob, w, h, len(frames), dtype="f32", **kw)
-    assert eng.dtype == E.DTYPE_F32
+    eng = E.Engine(net.layers, [o.c() for o in outs], blob, w, h, len(frames), dtype=dtype, **kw)
+    assert eng.dtype == E._DTYPES[dtype]
     if f32_input:
         got = eng.inference_f32(frames)
         ref = ref_net.run(net.layers, outs, blob, frames_f32=frames, match_fp16=False)
@@ -43,30 +50,32 @@ def _run32(net, outs, frames, h, w, f32_input=False, **kw):
         assert [nm for nm, _ in got[b]] == names
         for nm, arr in got[b]:
             _close32(arr, ref[nm][b], nm)
+    assert eng.split_fallbacks == 0
     return eng, got, ref
 
 
-def test_first_layer_u8_and_f32_inputs(hp):
+def test_first_layer_u8_and_f32_inputs(hp, f32dtype):
     for stride, k, cout in ((2, 3, 32), (1, 3, 64), (2, 7, 64), (1, 5, 20)):
         net = Net(1)
         t = net.conv(0, 3, cout, k, stride, act=E.ACT_LEAKY if k == 5 else E.ACT_RELU, act_param=0.1)
-        _run32(net, [Out("y", t, 0, cout)], _frames(2, 37, 45), 37, 45, flip_rgb=True, mean=(0.4, 0.45, 0.5), inv_std=(2., 3., 4.))
+        _run32(net, [Out("y", t, 0, cout)], _frames(2, 37, 45), 37, 45, flip_rgb=True, mean=(0.4, 0.45, 0.5), inv_std=(2., 3., 4.), dtype=f32dtype)
     net = Net(2)
     t = net.conv(0, 3, 24, 3, 1)
     x = np.random.default_rng(3).normal(0, 1, (2, 3, 20, 28)).astype(np.float32)
-    _run32(net, [Out("y", t, 0, 24)], x, 20, 28, f32_input=True)
+    _run32(net, [Out("y", t, 0, 24)], x, 20, 28, f32_input=True, dtype=f32dtype)
 
 
 @pytest.mark.parametrize("k,stride,dil,cin,cout", [(1, 1, 1, 32, 64), (1, 2, 1, 64, 40), (3, 1, 1, 48, 128), (3, 2, 1, 128, 96),
-                                                    (3, 1, 2, 64, 64), (5, 1, 1, 16, 19), (7, 1, 1, 185, 128), (1, 1, 1, 512, 260)])
-def test_dense_conv_shapes(hp, k, stride, dil, cin, cout):
+                                                    (3, 1, 2, 64, 64), (5, 1, 1, 16, 19), (7, 1, 1, 185, 128), (1, 1, 1, 512, 260),
+                                                    (1, 1, 1, 185, 128), (3, 1, 1, 128, 128), (1, 1, 1, 128, 512), (1, 1, 1, 512, 38), (3, 1, 1, 96, 200)])
+def test_dense_conv_shapes(hp, f32dtype, k, stride, dil, cin, cout):
     net = Net(10 + k)
     t0 = net.conv(0, 3, cin, 3, 1)
     t1 = net.conv(t0, cin, cout, k, stride, dil, act=E.ACT_PRELU if k == 7 else E.ACT_RELU)
-    _run32(net, [Out("y", t1, 0, cout)], _frames(3, 30, 41, seed=k), 30, 41)
+    _run32(net, [Out("y", t1, 0, cout)], _frames(3, 30, 41, seed=k), 30, 41, dtype=f32dtype)
 
 
-def test_residuals_concat_and_unaligned_slices(hp):
+def test_residuals_concat_and_unaligned_slices(hp, f32dtype):
     # concat buffer [128 | 19 | 38] like LW-OpenPose's stage input: the third slice starts at channel 147 (not 4-aligned)
     net = Net(5)
     cat = net.new_tensor()
@@ -79,10 +88,10 @@ def test_residuals_concat_and_unaligned_slices(hp):
     c = net.conv(b, 128, 128, 3, 1, res=a, res_before_act=0)        # residual after the activation
     d = net.conv(c, 128, 128, 3, 1, res=c, res_before_act=1)        # ... and before it (ResNet style)
     e = net.conv(d, 128, 38, 1, 1, act=E.ACT_NONE)
-    _run32(net, [Out("paf", e, 0, 38), Out("mid", d, 0, 128), Out("conf_slice", cat, 128, 19)], _frames(2, 40, 56, seed=5), 40, 56)
+    _run32(net, [Out("paf", e, 0, 38), Out("mid", d, 0, 128), Out("conf_slice", cat, 128, 19)], _frames(2, 40, 56, seed=5), 40, 56, dtype=f32dtype)
 
 
-def test_depthwise_pool_upsample(hp):
+def test_depthwise_pool_upsample(hp, f32dtype):
     net = Net(6)
     t0 = net.conv(0, 3, 32, 3, 2)
     d1 = net.conv(t0, 32, 32, 3, 1, op=E.OP_DWCONV)
@@ -97,10 +106,10 @@ def test_depthwise_pool_upsample(hp):
     up = net.conv(mp2, 64, 64, 0, 2, op=E.OP_UPSAMPLE, act=E.ACT_NONE)       # nearest x2
     up2 = net.conv(up, 64, 64, 1, 2, op=E.OP_UPSAMPLE, act=E.ACT_NONE)       # bilinear x2
     y = net.conv(up2, 64, 24, 3, 1, act=E.ACT_NONE)
-    _run32(net, [Out("y", y, 0, 24), Out("pooled", mp2, 0, 64), Out("up", up2, 0, 64)], _frames(2, 98, 130, seed=6), 98, 130)
+    _run32(net, [Out("y", y, 0, 24), Out("pooled", mp2, 0, 64), Out("up", up2, 0, 64)], _frames(2, 98, 130, seed=6), 98, 130, dtype=f32dtype)
 
 
-def test_output_post_ops(hp):
+def test_output_post_ops(hp, f32dtype):
     # pixel shuffle + crop + per-component sigmoid / softplus (PifPaf heads) and the PoseProposal grid / scale map
     net = Net(7)
     t0 = net.conv(0, 3, 32, 3, 2)
@@ -109,15 +118,15 @@ def test_output_post_ops(hp):
     outs = [Out("pif", h1, 0, 17 * 5 * 4, shuffle=2, group=5, sigmoid_mask=1, softplus_mask=16, out_h=2 * 13 - 1, out_w=2 * 17 - 1),
             Out("px", h2, 0, 18, act=E.ACT_SIGMOID, grid=1, scale=32.0),
             Out("sig", h2, 0, 18, act=E.ACT_SIGMOID)]
-    _run32(net, outs, _frames(2, 26, 34, seed=7), 26, 34)
+    _run32(net, outs, _frames(2, 26, 34, seed=7), 26, 34, dtype=f32dtype)
 
 
 @pytest.mark.parametrize("arch", ["lw_openpose_mobilenet", "lw_openpose_vggtiny", "openpose_vgg19", "pose_proposal_resnet50", "pifpaf_resnet50"])
-def test_builtin_topologies_small(hp, arch):
+def test_builtin_topologies_small(hp, f32dtype, arch):
     w_, h_ = (97, 97) if arch.startswith("pifpaf") else (160, 128) if arch.startswith("pose_proposal") else (96, 80)
     m = E.Model(arch, w_, h_)
     w = m.init_weights(3)
-    eng = E.Engine.from_model(m, w, max_batch=2, dtype="f32")
+    eng = E.Engine.from_model(m, w, max_batch=2, dtype=f32dtype)
     fr = synth.images_u8(synth.rng_for(8), 2, h_, w_)
     got = eng.inference(fr)
     ref = ref_net.run(m.layers, m.outputs, w, frames_u8=fr, match_fp16=False, mean=m.mean, inv_std=m.inv_std)
@@ -136,7 +145,7 @@ def test_serialized_engine_keeps_its_dtype(hp):
     w = m.init_weights(4)
     fr = synth.images_u8(synth.rng_for(9), 2, 48, 64)
     with tempfile.TemporaryDirectory() as d:
-        for dtype in ("f32", "f16"):
+        for dtype in ("f32", "f16", "f32s"):
             eng = E.Engine.from_model(m, w, max_batch=2, dtype=dtype)
             path = os.path.join(d, dtype + ".engine")
             eng.save(path)
@@ -164,18 +173,42 @@ def test_bad_dtype_is_refused(hp):
     assert hp.lib().hp_engine_create(C.byref(h), C.byref(d)) == -1  # HP_ERR_INVALID
 
 
+def test_split_engine_leaves_the_fp16_pipe_when_a_value_does_not_fit(hp):
+    """HP_DTYPE_F32S: an activation beyond fp16's range (|x| > 65504) raises the sticky flag; hp_engine_synchronize re-runs the batch on the
+    fp32 matrix pipe before the outputs are read, and the engine stays there: the result is the fp32 engine's, within the same tolerance."""
+    net = Net(21)
+    t0 = net.conv(0, 3, 32, 3, 1, act=E.ACT_NONE)
+    t1 = net.conv(t0, 32, 64, 3, 1, act=E.ACT_NONE)
+    t2 = net.conv(t1, 64, 64, 1, 1, act=E.ACT_NONE)
+    outs = [Out("y", t2, 0, 64)]
+    frames = _frames(2, 24, 32, seed=21)
+    blob = net.blob()
+    ok = E.Engine(net.layers, [o.c() for o in outs], blob, 32, 24, 2, dtype="f32s")
+    ok.inference(frames)
+    assert ok.split_fallbacks == 0
+    big = E.Engine(net.layers, [o.c() for o in outs], blob, 32, 24, 2, dtype="f32s", factor=4000.0)   # first-layer outputs ~ 1e6
+    ref = ref_net.run(net.layers, outs, blob, frames_u8=frames, match_fp16=False, factor=4000.0)
+    got = big.inference(frames)
+    assert big.split_fallbacks == 1
+    for b in range(2):
+        _close32(got[b][0][1], ref["y"][b], "after the fall-back")
+    got2 = big.inference(frames)
+    assert big.split_fallbacks == 1 and np.array_equal(got2[0][0][1], got[0][0][1])
+
+
 # ---- the BASELINE configurations at FULL size, one probed frame each, against PyTorch's own fp32 GPU kernels
 FULL = [("lw_openpose_mobilenet", 432, 368, 8, 20241), ("openpose_vgg19", 768, 432, 16, 20242),
         ("pose_proposal_resnet50", 384, 384, 32, 20243), ("pifpaf_resnet50", 385, 385, 64, 20244)]
 
 
 @pytest.mark.parametrize("arch,w_,h_,batch,seed", FULL)
-def test_full_size_configs_fp32(hp, arch, w_, h_, batch, seed, capsys):
+def test_full_size_configs_fp32(hp, f32dtype, arch, w_, h_, batch, seed, capsys):
+    """The BASELINE batch itself (8 / 16 / 32 / 64 frames: VERDICT r4 item 7 - round 4 ran min(batch, 4)), first and last frame probed."""
     import torch
     m = E.Model(arch, w_, h_)
     w = m.init_weights(seed)
-    n = min(batch, 4)  # fp32 activations of the full batch are not needed to probe frames; the kernels see the same per-frame geometry
-    eng = E.Engine.from_model(m, w, max_batch=n, dtype="f32")
+    n = batch
+    eng = E.Engine.from_model(m, w, max_batch=n, dtype=f32dtype)
     fr = synth.images_u8(synth.rng_for(seed), n, h_, w_)
     got = eng.inference(fr)
     worst = 0.0
@@ -185,4 +218,4 @@ def test_full_size_configs_fp32(hp, arch, w_, h_, batch, seed, capsys):
             worst = max(worst, _close32(arr, ref[nm][0], f"{arch} frame {i} {nm}"))
     torch.cuda.empty_cache()
     with capsys.disabled():
-        print(f"\nfp32 engine {arch} @ {h_}x{w_}: worst relative error vs the fp32 oracle {worst:.2e}")
+        print(f"\n{f32dtype} engine {arch} @ {h_}x{w_} batch {n}: worst relative error vs the fp32 oracle {worst:.2e}, split fall-backs {eng.split_fallbacks}")

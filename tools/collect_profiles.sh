@@ -5,16 +5,18 @@
 set -u
 tag=${1:-r01}
 cfg=${2:-1}
+dt=${3:-f16}   # engine precision: f16 (data_type::kHALF) or f32 (data_type::kFLOAT); "5" is the old spelling of "1 f32"
+[ "$cfg" == "5" ] && cfg=1 && dt=f32
 sfx=""
 [ "$cfg" != "1" ] && sfx="_config$cfg"
-[ "$cfg" == "5" ] && sfx="_config1_fp32"
+[ "$dt" == "f32" ] && sfx="_config${cfg}_fp32"
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 steps=12
 [ "$cfg" != "1" ] && steps=3
-cmd="python $repo/bench.py --config $cfg --extra= --steps $steps --warmup 2 --pipes 1 --no-cpu-baseline --no-roofline --no-from-host --no-dnn-output"
+cmd="python $repo/bench.py --config $cfg --dtype $dt --no-clocks --min-seconds 0 --extra= --steps $steps --warmup 2 --pipes 1 --no-cpu-baseline --no-roofline --no-from-host --no-dnn-output"
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- $cmd > /dev/null 2>&1
 cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats${sfx}.csv
