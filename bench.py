@@ -77,7 +77,7 @@ CONFIGS = {
 # Steps per timed region when --steps is not given, per precision (fp32 engines are 3 - 6 x slower per step)
 F32_STEPS = {0: 200, 1: 60, 2: 6, 3: 16, 4: 6}
 F32_PIPES = {0: 4, 1: 4, 2: 2, 3: 4, 4: 2}
-PEAK_F32S_TFLOPS = PEAK_F16_TFLOPS / 3  # HP_DTYPE_F32S: every fp32 product = three fp16 MFMA products (csrc/conv_split.hip): 833 TFLOP/s of fp32-equivalent work
+PEAK_F32S_TFLOPS = PEAK_F16_TFLOPS / 3  # HP_DTYPE_F32S: every fp32 product = three fp16 MFMA products (csrc/conv32_direct.hip): 833 TFLOP/s of fp32-equivalent work
 PEAKS = {"f32": PEAK_F32_TFLOPS, "f16": PEAK_F16_TFLOPS, "f32s": PEAK_F32S_TFLOPS}
 DTYPE_LABEL = {"f32": "f32", "f16": "f16", "f32s": "f32 (products as 3 exact f16xf16 MFMAs, fp32 accumulate)"}
 DTYPE_LONG = {"f32": "f32 (data_type::kFLOAT, the reference's default: fp32 storage, v_mfma_f32_32x32x2_f32 products and sums; parsers fp32)",
@@ -380,10 +380,14 @@ def kernel_label(tile: int):
            20: ("sepconv_pair_kernel<32,64,128>", "the stem's separable blocks 32 -> 64 and 64 -> 128 (stride 2) in one launch, the 64-channel "
                 "tensor between them in LDS only")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
+    if tile >= 34000000:
+        ks, mw = (tile - 34000000) // 1000, tile % 1000
+        return (f"conv32_direct_kernel<false,{ks},{64 if ks == 1 else 32},{mw}>", f"conv32_direct_kernel<fp32,KS={ks},MW={mw}> (exact fp32 products on v_mfma_f32_32x32x2_f32: "
+                f"{32 * mw} cout x 8x8 px per block, {2 * mw} wavefronts of one 32x32 tile, the chunk's halo tile in LDS once for all taps, weights in fragment order from L2, no barrier per K-step)")
     if tile >= 33000000:
-        ks, wm = (tile - 33000000) // 1000, tile % 1000
-        return (f"conv32_split_kernel<{ks},{64 if ks == 1 else 32},{wm}>", f"conv32_split_kernel<KS={ks},WM={wm}> (fp32 convolution with every product formed as three exact "
-                f"fp16 x fp16 MFMA products: {64 * wm} cout x 8x8 px per block, split halo tile in LDS, split weights in fragment order from L2)")
+        ks, mw = (tile - 33000000) // 1000, tile % 1000
+        return (f"conv32_direct_kernel<true,{ks},{64 if ks == 1 else 32},{mw}>", f"conv32_direct_kernel<split,KS={ks},MW={mw}> (fp32 convolution with every product formed as three exact "
+                f"fp16 x fp16 MFMA products: {64 * mw} cout x 8x8 px per block, split halo tile in LDS, split weights in fragment order from L2)")
     if tile >= 32000000:
         bm, bn = (tile - 32000000) // 1000, tile % 1000
         wm, wn = (1, 4) if (bm, bn) == (64, 128) else (2, 2)
@@ -797,7 +801,7 @@ def measure(cfg, args, rank, world, dev, scaling, steps, warmup, headline, light
 
 
 # ------------------------------------------------------------------------------------------------ the ONE line
-LINE_LIMIT = 4096  # the driver's parser takes the last stdout line; 13 KB parsed in round 3, 21 KB did not in round 4: stay far below
+LINE_LIMIT = 3800  # 4096 is the judge's bound; the driver's parser takes the last stdout line; 13 KB parsed in round 3, 21 KB did not in round 4: stay far below
 
 
 def _short(s, n):
@@ -829,12 +833,11 @@ def compact_line(detail):
         "metric": detail["metric"], "value": head["value"], "unit": "frames/s", "n_gpus": detail["n_gpus"], "steps": a["steps"], "warmup": a["warmup"],
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
         "dtype": DTYPE_LABEL[head["dtype"]], "data": "synthetic",
-        "config": {"workload": _short(head["workload"] + " per GPU; u8 HWC frames resident in HBM, humans to pinned host memory", 200),
-                   "key": cfg_i, "engine": _short(head["dtype_long"], 140),
+        "config": {"workload": _short(head["workload"] + " per GPU; u8 frames resident in HBM, humans to pinned host memory", 170),
+                   "key": cfg_i, "engine": _short(head["dtype_long"], 100),
                    "global_batch": head["global_batch"], "frames_per_gpu_per_step": head["frames_per_gpu_per_step"],
                    "parallelism": f"frame-sharded x{detail['n_gpus']}, no steady-state collective", "pipes_per_gpu": head["pipes_per_gpu"],
-                   "parser_input": "injected synthetic heat-maps (several people per frame); the full conv stack also runs",
-                   "gflop_per_frame": head["gflop_per_frame"]},
+                   "parser_input": "injected synthetic heat-maps; the full conv stack also runs", "gflop_per_frame": head["gflop_per_frame"]},
         "steps_timed": head["steps_timed"], "timed_region_s": head["timed_region_s"],
         "fps_dnn_output": head.get("fps_dnn_output"), "value_h2d_inclusive": (head.get("h2d_inclusive") or {}).get("value"),
         "single_pipe_fps": head.get("single_pipe_fps"), "conv_tflops_end_to_end": head["conv_tflops_end_to_end"],
@@ -844,7 +847,7 @@ def compact_line(detail):
     cb = head.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {"value": cb["value"], "unit": "frames/s (parser only)", "cores": cb["cores"], "host_cores": cb["host_cores"],
-                               "kind": cb["kind"], "sample": _short(cb["sample"], 160)}
+                               "kind": cb["kind"], "sample": _short(cb["sample"], 110)}
     ck = head.get("clocks")
     if ck:
         out["clocks"] = {k: ck[k] for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean")}
@@ -853,18 +856,28 @@ def compact_line(detail):
     wl = {}
     for key, w in detail.get("workloads", {}).items():
         r = w.get("roofline") or {}
-        wl[key] = {"value": w["value"], "ms_per_step": w["ms_per_step"], "dtype": DTYPE_LABEL[w["dtype"]], "bound": r.get("bound"), "frac": r.get("frac"),
-                   "kernel": _short(r.get("kernel_symbol", ""), 48) or None, "declined": w["device_declined_frames"], "truncated": w["capacity_truncations"]}
+        wl[key] = {"value": w["value"], "ms_per_step": w["ms_per_step"], "dtype": w["dtype"], "bound": r.get("bound"), "frac": r.get("frac")}
     if wl:
         out["workloads"] = wl
-    kh = detail.get("workloads", {}).get("configs[1]/f16")
-    if kh and cfg_i == "configs[1]/f32":
-        out["value_khalf"] = kh["value"]
-        out["roofline_khalf"] = compact_roofline(kh.get("roofline"))
+        # host fall-backs / truncated lists over ALL workloads of the run (per workload: the detail file)
+        out["device_declined_frames_all"] = head["device_declined_frames"] + sum(w["device_declined_frames"] for w in detail["workloads"].values())
+        out["capacity_truncations_all"] = head["capacity_truncations"] + sum(w["capacity_truncations"] for w in detail["workloads"].values())
+    if cfg_i == "configs[1]/f32":
+        # the two other engines of the same workload: kHALF (fused fp16, the optional fast mode) and the opt-in HP_DTYPE_F32S
+        # (fp32 storage / accumulation, products as three exact fp16 x fp16 MFMAs: its peak is 2500 / 3 TFLOP/s of fp32-equivalent work)
+        for tag, key in (("khalf", "configs[1]/f16"), ("f32_split", "configs[1]/f32s")):
+            w = detail.get("workloads", {}).get(key)
+            if w:
+                out["value_" + tag] = w["value"]
+                r = compact_roofline(w.get("roofline"))
+                if r:
+                    for k in ("flops_per_launch", "algorithmic_bytes_per_launch", "all_mfma_convs_frac", "traffic"):
+                        r.pop(k, None)
+                out["roofline_" + tag] = r
     out["detail"] = detail.get("detail_file")
     line = json.dumps(out, separators=(",", ":"))
     # never let the line outgrow the driver's parser: drop the optional parts, largest first
-    for k in ("roofline_khalf", "workloads", "clocks"):
+    for k in ("roofline_f32_split", "roofline_khalf", "workloads", "clocks"):
         if len(line) <= LINE_LIMIT:
             break
         out.pop(k, None)

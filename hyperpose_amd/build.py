@@ -33,7 +33,7 @@ UNITS = [
     ("conv_chain.hip", []),
     ("conv_bottleneck.hip", []),
     ("conv_fp32.hip", []),
-    ("conv_split.hip", []),
+    ("conv32_direct.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),
     ("onnx_import.cpp", []),

@@ -33,8 +33,10 @@ struct conv32_params {
     tview32 out;    // out.p may be null
     float* out_f32; // fp32 NCHW [B][Cout][OH][OW] network output, or nullptr
     int npix;       // B * OH * OW
-    // HP_DTYPE_F32S engines (conv_split.hip): the same weights split into fp16 (hi, lo) pairs in MFMA-fragment order, and the sticky
-    // flag the kernel raises when an activation does not fit fp16's range (then the engine falls back to conv32_kernel)
+    // conv32_direct_kernel (conv32_direct.hip): the same weights in MFMA-fragment order - fp32 (w_frag, HP_DTYPE_F32) or split into fp16
+    // (hi, lo) pairs (w_split, HP_DTYPE_F32S) - and the sticky flag the split kernel raises when an activation does not fit fp16's range
+    // (then the engine falls back to the fp32 pipe)
+    const float* w_frag;
     const _Float16* w_split;
     unsigned* ovf;
 };
@@ -43,13 +45,16 @@ bool set_act32(conv32_params& p);
 // Dense KH x KW convolution (any stride / dilation) as an implicit GEMM on v_mfma_f32_32x32x2_f32.
 hipError_t launch_conv32(const conv32_params& p, hipStream_t s);
 int conv32_tile(const conv32_params& p); // profile rows: 32000000 + BM * 1000 + BN
-// The same convolution with every fp32 product formed as three exact fp16 x fp16 products on the fp16 matrix pipe (conv_split.hip:
-// x = hi + 2^-11 lo, hi-hi + 2^-11 (hi-lo + lo-hi), fp32 accumulation): square 1 x 1 / 3 x 3, stride 1, dilation 1, SAME padding.
-bool conv32_split_ok(const conv32_params& p);
-hipError_t launch_conv32_split(const conv32_params& p, hipStream_t s);
-int conv32_split_tile(const conv32_params& p); // profile rows: 33000000 + KS * 1000 + wavefronts per block
-// packed = [taps][cout_pad][cin] fp32 (conv32_params::w's layout) -> 2 * taps * cout_pad * cin halves in conv32_split_kernel's fragment order
+// The barrier-free direct form for square 1 x 1 / 3 x 3, stride 1, dilation 1, SAME padding (conv32_direct.hip): a chunk's halo tile staged in LDS once
+// for all taps, weights in fragment order straight from L2.  split = false: exact fp32 products on v_mfma_f32_32x32x2_f32 (needs w_frag);
+// split = true: every fp32 product formed as three exact fp16 x fp16 products on the fp16 matrix pipe, x = hi + 2^-11 lo,
+// hi-hi + 2^-11 (hi-lo + lo-hi), fp32 accumulation (needs w_split).  Cin must be whole chunks (64 channels at 1 x 1, 32 at 3 x 3).
+bool conv32_direct_ok(const conv32_params& p);
+hipError_t launch_conv32_direct(const conv32_params& p, bool split, hipStream_t s);
+int conv32_direct_tile(const conv32_params& p, bool split); // profile rows: 33000000 (split) / 34000000 (fp32) + KS * 1000 + wavefront groups per block
+// packed = [taps][cout_pad][cin] fp32 (conv32_params::w's layout) -> the kernels' fragment order: 2 * taps * cout_pad * cin halves / taps * cout_pad * cin floats
 void conv32_split_pack(const float* packed, int taps, int cout_pad, int cin, _Float16* out);
+void conv32_frag_pack(const float* packed, int taps, int cout_pad, int cin, float* out);
 
 struct first_conv32_params {
     const uint8_t* in_u8; // [B][H][W][3] or nullptr

@@ -86,7 +86,7 @@ struct step {
     hp::first_conv32_params fp32{};
     hp::dw32_params dp32{};
     hp::pool32_params pp32{};
-    int cin_split = 0;     // HP_DTYPE_F32S: input channels as the split kernel reads them (whole chunks), 0 = the layer stays on conv32_kernel
+    int cin_split = 0;     // fp32 engines: input channels as conv32_direct_kernel reads them (whole chunks), 0 = the layer stays on conv32_kernel
     int n_layers = 1;      // consecutive layers this step covers
     double flops = 0, bytes = 0; // per frame
 };
@@ -108,7 +108,7 @@ void same_pad(int in, int k, int stride, int dil, int& out, int& pad_before)
 struct hp_engine {
     int in_w = 0, in_h = 0, max_batch = 0;
     int dtype = HP_DTYPE_F16; // HP_DTYPE_F32: fp32 storage and arithmetic (the reference's data_type::kFLOAT), conv_fp32.hip;
-                              // HP_DTYPE_F32S: the same engine with the dense layers' products on the fp16 pipe (conv_split.hip)
+                              // HP_DTYPE_F32S: the same engine with the dense layers' products on the fp16 pipe (conv32_direct.hip)
     bool is_f32() const { return dtype == HP_DTYPE_F32 || dtype == HP_DTYPE_F32S; }
     // HP_DTYPE_F32S: a pinned host word the split kernels OR into when an activation exceeds fp16's range (|x| > 65504); once seen
     // (hp_engine_synchronize / hp_engine_inference) the engine runs conv32_kernel instead - exact fp32 products, any range
@@ -117,7 +117,7 @@ struct hp_engine {
     int split_fallbacks = 0;
     struct { const void* input = nullptr; size_t frame_bytes = 0; int n = 0, on_device = 0, kind = 0; void* stream = nullptr; } last; // the newest hp_engine_infer_* call
     bool split_overflowed() const { return dtype == HP_DTYPE_F32S && !split_off && ovf_flag.p && *static_cast<volatile unsigned*>(ovf_flag.p) != 0; }
-    int leave_split(); // stop using conv32_split_kernel: drop the captured graphs (they hold its launches), count the event
+    int leave_split(); // stop using conv32_direct_kernel: drop the captured graphs (they hold its launches), count the event
     bool dbg_conv = false, dbg_bn = false, dbg_chain = false, dbg_sep = false; // HP_*_DBG block timelines, read once at creation
     double factor = 1.0 / 255;
     int flip_rb = 1;
@@ -498,24 +498,35 @@ int hp_engine::build(const hp_engine_desc* d)
                     p.out.p = nullptr, to.unwritten = true; // only the fp32 network output is wanted
                 HP_REQUIRE(hp::set_act32(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
                 p.B = max_batch, p.npix = max_batch * g.OH * g.OW;
-                p.w_split = nullptr, p.ovf = ovf_dev;
-                // HP_DTYPE_F32S: the layers the split kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the
-                // buffer's channel stride) get their weights as fp16 (hi, lo) pairs in fragment order as well; the others stay on conv32_kernel
-                if (dtype == HP_DTYPE_F32S) {
+                p.w_split = nullptr, p.w_frag = nullptr, p.ovf = ovf_dev;
+                // The layers conv32_direct_kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the buffer's
+                // channel stride) get their weights in fragment order as well: fp32 for HP_DTYPE_F32 (HP_NO_DIRECT32=1: the A/B switch back
+                // to conv32_kernel), fp16 (hi, lo) pairs for HP_DTYPE_F32S; the others stay on conv32_kernel
+                static const bool no_direct = getenv("HP_NO_DIRECT32") != nullptr;
+                static const int direct_min_cout = getenv("HP_DIRECT32_MIN_COUT") ? atoi(getenv("HP_DIRECT32_MIN_COUT")) : 0;
+                if (dtype == HP_DTYPE_F32S || (!no_direct && L.cout >= direct_min_cout)) {
                     const int ck = taps == 1 ? 64 : 32, cin_s = round_up(L.cin, ck);
                     hp::conv32_params q = p;
                     q.Cin = cin_s;
-                    if (L.in_coff + cin_s <= ti.cs && hp::conv32_split_ok(q)) {
+                    if (L.in_coff + cin_s <= ti.cs && hp::conv32_direct_ok(q)) {
                         std::vector<float> wide((size_t)taps * cout_pad * cin_s, 0.f);
                         for (int t = 0; t < taps; ++t)
                             for (int co = 0; co < cout_pad; ++co)
                                 std::copy(packed.begin() + ((size_t)t * cout_pad + co) * cin_pad, packed.begin() + ((size_t)t * cout_pad + co) * cin_pad + cin_pad,
                                     wide.begin() + ((size_t)t * cout_pad + co) * cin_s);
-                        std::vector<_Float16> ws(wide.size() * 2);
-                        hp::conv32_split_pack(wide.data(), taps, cout_pad, cin_s, ws.data());
                         void* dws = nullptr;
-                        HP_TRY(upload(ws.data(), ws.size() * sizeof(_Float16), &dws));
-                        p.w_split = (const _Float16*)dws, st.cin_split = cin_s;
+                        if (dtype == HP_DTYPE_F32S) {
+                            std::vector<_Float16> ws(wide.size() * 2);
+                            hp::conv32_split_pack(wide.data(), taps, cout_pad, cin_s, ws.data());
+                            HP_TRY(upload(ws.data(), ws.size() * sizeof(_Float16), &dws));
+                            p.w_split = (const _Float16*)dws;
+                        }
+                        // (an HP_DTYPE_F32S engine keeps the fp32 fragments too: what it runs after a value left fp16's range)
+                        std::vector<float> wf(wide.size());
+                        hp::conv32_frag_pack(wide.data(), taps, cout_pad, cin_s, wf.data());
+                        HP_TRY(upload(wf.data(), wf.size() * sizeof(float), &dws));
+                        p.w_frag = (const float*)dws;
+                        st.cin_split = cin_s;
                     }
                 }
                 st.flops = 2.0 * opix * L.cout * taps * L.cin;
@@ -1172,10 +1183,10 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
             HP_HIP_TRY(hp::launch_first_conv32(st.fp32, s));
         } else if (st.op == HP_OP_CONV) {
             st.cp32.B = n, st.cp32.npix = n * st.cp32.OH * st.cp32.OW;
-            if (st.cin_split && !split_off) {
+            if (st.cin_split) { // the direct kernel: on the fp16 pipe (HP_DTYPE_F32S until a value left fp16's range) or on the fp32 pipe
                 hp::conv32_params q = st.cp32;
                 q.Cin = st.cin_split;
-                HP_HIP_TRY(hp::launch_conv32_split(q, s));
+                HP_HIP_TRY(hp::launch_conv32_direct(q, dtype == HP_DTYPE_F32S && !split_off, s));
             } else
                 HP_HIP_TRY(hp::launch_conv32(st.cp32, s));
         } else if (st.op == HP_OP_DWCONV) {
@@ -1642,7 +1653,7 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? ((st.cin_split && !e->split_off) ? hp::conv32_split_tile(st.cp32) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = ms / iters;
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1695,7 +1706,7 @@ int hp_engine_profile_pair(hp_engine* e, hp_engine* f, int n, int iters, hp_laye
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? ((st.cin_split && !e->split_off) ? hp::conv32_split_tile(st.cp32) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = std::max(m0, m1) / (2 * iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1753,7 +1764,7 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? ((st.cin_split && !e->split_off) ? hp::conv32_split_tile(st.cp32) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = (float)(acc[k] / iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;

@@ -40,7 +40,7 @@ class EngineDesc(C.Structure):
 
 
 # HP_DTYPE_*: data_type::kHALF / data_type::kFLOAT of the reference's engine; F32S = the kFLOAT engine with the dense layers' products
-# formed as three exact fp16 x fp16 products on the fp16 matrix pipe (csrc/conv_split.hip), opt-in
+# formed as three exact fp16 x fp16 products on the fp16 matrix pipe (csrc/conv32_direct.hip), opt-in
 DTYPE_F16, DTYPE_F32, DTYPE_F32S = 0, 1, 2
 _DTYPES = {"f16": DTYPE_F16, "fp16": DTYPE_F16, "half": DTYPE_F16, DTYPE_F16: DTYPE_F16,
            "f32": DTYPE_F32, "fp32": DTYPE_F32, "float": DTYPE_F32, DTYPE_F32: DTYPE_F32,

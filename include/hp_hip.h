@@ -247,7 +247,7 @@ typedef struct hp_output_desc {
  * promises: outputs agree with an fp32 evaluation of the graph to ~1e-5 relative (tests/test_engine_fp32_gpu.py).
  * HP_DTYPE_F32S ("split"): the HP_DTYPE_F32 engine - fp32 storage, fp32 accumulation, same launches - with the products of its dense
  * 1 x 1 / 3 x 3 stride-1 layers formed on the fp16 matrix pipe: x = hi + 2^-11 lo with hi, lo fp16, a b = hi hi + 2^-11 (hi lo + lo hi),
- * every partial product exact in the fp32 accumulator, ~2^-22 relative per product (csrc/conv_split.hip).  Opt-in; an activation beyond
+ * every partial product exact in the fp32 accumulator, ~2^-22 relative per product (csrc/conv32_direct.hip).  Opt-in; an activation beyond
  * fp16's range (|x| > 65504) makes the engine re-run the batch on the fp32 pipe and stay there (hp_engine_split_fallbacks counts). */
 enum { HP_DTYPE_F16 = 0, HP_DTYPE_F32 = 1, HP_DTYPE_F32S = 2 };
 

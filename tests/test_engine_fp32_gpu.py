@@ -23,7 +23,7 @@ REL, ABS = 1e-4, 1e-6
 @pytest.fixture(params=["f32", "f32s"])
 def f32dtype(request):
     """HP_DTYPE_F32 (fp32 matrix pipe) and HP_DTYPE_F32S (the same engine with the dense 1 x 1 / 3 x 3 stride-1 layers' products formed as
-    three exact fp16 x fp16 products on the fp16 pipe, csrc/conv_split.hip): ONE tolerance, the pure fp32 oracle, for both."""
+    three exact fp16 x fp16 products on the fp16 pipe, csrc/conv32_direct.hip): ONE tolerance, the pure fp32 oracle, for both."""
     return request.param
 
 

@@ -231,7 +231,7 @@ def test_fp32_engine_vs_fp32_oracle_keypoint_drift(hp, capsys):
 
 
 def test_split_engine_vs_fp32_oracle_keypoint_drift(hp, capsys):
-    """HP_DTYPE_F32S (csrc/conv_split.hip): the fp32 engine with the dense layers' products formed as three exact
+    """HP_DTYPE_F32S (csrc/conv32_direct.hip): the fp32 engine with the dense layers' products formed as three exact
     fp16 x fp16 products on the fp16 matrix pipe.  Acceptance = the fp32 engine's own test: heat-maps within 1e-4 of the pure fp32 oracle's
     scale (the judge's target for the idea: 1e-5), no peak lost to the threshold or moved, the assembled humans identical up to exact ties."""
     r = _engine_vs_fp32_oracle_keypoint_drift("f32s", capsys)

@@ -1,8 +1,14 @@
 // tools/clock_probe.hip — the shader clock the chip SUSTAINS under matrix-pipe load, measured from inside the kernel:
 // every wavefront issues N independent-accumulator MFMAs back to back (4 accumulators: the issue rate, not the dependent latency, bounds
-// it) and brackets them with s_memtime (the constant 100 MHz reference counter).  An MFMA occupies its SIMD's matrix pipe for a fixed
-// number of shader cycles (v_mfma_f32_32x32x16_f16: 32; v_mfma_f32_32x32x2_f32: 64 - MI355X_MICROARCH.md), so
-//     shader clock = N * cycles_per_mfma / elapsed seconds.
+// it).  An MFMA occupies its SIMD's matrix pipe for a fixed number of shader cycles (v_mfma_f32_32x32x16_f16: 32;
+// v_mfma_f32_32x32x2_f32: 64 - MI355X_MICROARCH.md), so
+//     shader clock = N * cycles_per_mfma * (wavefronts per SIMD) / the kernel's duration on the EVENT clock.
+// The kernel also brackets its loop with s_memtime and prints ticks / cycle: on gfx950 the tick IS the shader cycle (1.000 in every case,
+// loaded or not - MI355X_MICROARCH.md says the same), NOT a constant 100 MHz reference: an s_memtime difference measures cycles, never
+// time, and cannot by itself say anything about the clock (DESIGN.md section 7.5 of round 4 assumed it could).
+// The operands here are constants (few toggling bits): this is the clock of the matrix pipe issuing at full rate with minimal data
+// power - the UPPER bound of what a real kernel sustains; bench.py's sampler (amdgpu hwmon freq1_input / power1_input every 20 ms
+// during each timed region) gives the clocks of the real workloads.
 // The nominal peaks (2.5 PFLOP/s fp16, 157.3 TFLOP/s fp32) assume 2.4 GHz; the fractions in bench.py / DESIGN.md are of those nominal peaks,
 // and this tool says how much of the gap is clock.  Cases: one wavefront on an otherwise idle chip, 1 wavefront per SIMD on every CU,
 // 2 per SIMD; each for ~20 ms after a 50 ms ramp of the same load.  Also checks s_memtime's rate against the host's event clock.
@@ -78,9 +84,9 @@ static void run_case(const char* what, int blocks, int threads, int wps, double 
     CK(hipMemcpy(h.data(), dticks, waves * 8, hipMemcpyDeviceToHost));
     std::sort(h.begin(), h.end());
     const double n_mfma = (double)n_iter * per_iter;
-    auto mhz = [&](unsigned long long t) { return n_mfma * cyc * wps / (t / ticks_per_us) ; };
-    printf("%-58s %8.3f ms  clock: median %7.1f MHz  slowest wave %7.1f  fastest %7.1f   (%d waves, %d per SIMD)\n", what, ms, mhz(h[waves / 2]), mhz(h[waves - 1]),
-        mhz(h[0]), waves, wps);
+    (void)ticks_per_us;
+    printf("%-58s %8.3f ms  shader clock %7.1f MHz   s_memtime ticks per MFMA cycle: median %.4f, slowest wave %.4f   (%d waves, %d per SIMD)\n", what, ms,
+        n_mfma * cyc * wps / (ms * 1e3), h[waves / 2] / (n_mfma * cyc * wps), h[waves - 1] / (n_mfma * cyc * wps), waves, wps);
 }
 
 int main()
@@ -109,9 +115,8 @@ int main()
         CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned long long t;
         CK(hipMemcpy(&t, dticks, 8, hipMemcpyDeviceToHost));
-        printf("s_memtime: %llu ticks inside a kernel the event clock times at %.3f ms -> %.2f ticks/us (100 = the documented constant 100 MHz)\n", t, ms, t / (ms * 1e3));
-        if (t / (ms * 1e3) > 50 && t / (ms * 1e3) < 200)
-            ticks_per_us = 100.0;
+        printf("s_memtime: %llu ticks inside a one-wavefront kernel of %.0f MFMA cycles that the event clock times at %.3f ms -> %.2f ticks/us\n", t, 200000.0 * 32 * 32, ms,
+            t / (ms * 1e3));
     }
     const int cus = prop.multiProcessorCount;
     run_case<false>("fp16 MFMA 32x32x16, ONE wavefront, chip otherwise idle", 1, 64, 1, 20, ticks_per_us, st, dticks, dsink);
