@@ -585,8 +585,16 @@ class ClockSampler:
         self._thread = None
         self.freq_file = self.power_file = self.dpm_file = None
         cards = sorted(p for p in glob.glob("/sys/class/drm/card[0-9]*") if os.path.exists(os.path.join(p, "device", "pp_dpm_sclk")))
-        if device_index < len(cards):
+        # the sysfs card of HIP device `device_index`: by PCI address (a box exposes ONE of its GPUs to the process, and card0 is rarely it)
+        self.pci = self._pci_bus_id(device_index)
+        dev = None
+        if self.pci:
+            for c in cards:
+                if os.path.basename(os.path.realpath(os.path.join(c, "device"))).lower() == self.pci.lower():
+                    dev = os.path.join(c, "device")
+        elif device_index < len(cards) and device_index >= 0:
             dev = os.path.join(cards[device_index], "device")
+        if dev:
             for h in sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*"))):
                 f = os.path.join(h, "freq1_input")
                 if os.path.exists(f) and self.freq_file is None:
@@ -597,6 +605,22 @@ class ClockSampler:
                         self.power_file = f
             self.dpm_file = os.path.join(dev, "pp_dpm_sclk")
         self.source = None
+
+    @staticmethod
+    def _pci_bus_id(device_index):
+        """'0000:05:00.0' of a HIP device (hipDeviceGetPCIBusId through the runtime libhp_hip.so already loaded), or None."""
+        import ctypes
+        if device_index < 0:
+            return None
+        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+            try:
+                hip = ctypes.CDLL(name)
+                buf = ctypes.create_string_buffer(64)
+                if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+                    return buf.value.decode().strip() or None
+            except (OSError, AttributeError):
+                continue
+        return None
 
     def _read_mhz(self):
         if self.freq_file:
@@ -646,7 +670,7 @@ class ClockSampler:
         return {"sclk_mhz_mean": round(sum(s) / len(s), 1) if s else None, "sclk_mhz_min": round(min(s), 1) if s else None,
                 "sclk_mhz_max": round(max(s), 1) if s else None, "samples": len(s), "source": self.source,
                 "power_w_mean": round(sum(p) / len(p), 1) if p else None, "power_w_max": round(max(p), 1) if p else None,
-                "nominal_peak_clock_mhz": 2400}
+                "nominal_peak_clock_mhz": 2400, "pci": self.pci}
 
 
 def measure(cfg, args, rank, world, dev, scaling, steps, warmup, headline, light=False):

@@ -50,7 +50,7 @@ __device__ __forceinline__ long tvd_off(const tview32& t, int b, int y, int x)
     return ((long)b * t.img + (long)y * t.wp + x) * t.cs + t.coff;
 }
 
-template <bool SPLIT, int KS, int CK>
+template <bool SPLIT, int KS, int CK, int MW>
 struct direct32_geom {
     static constexpr int HP = 8 + KS - 1;                          // halo tile is HP x HP pixels
     static constexpr int PBU = CK / 4 + 1;                         // 16-byte units per halo pixel: CK elements of 4 bytes + one unit of padding (odd)
@@ -61,19 +61,23 @@ struct direct32_geom {
     static constexpr int QUADS = HP * HP * QPP;                    // ... per chunk
     static constexpr int KQ = SPLIT ? CK / 16 : CK / 8;            // steps per tap: 32 bytes of a pixel row each
     static constexpr int SPC = KS * KS * KQ;                       // steps per chunk
-    static constexpr int RING = SPC % 3 == 0 ? 3 : 4;              // A-fragment ring: the step in use + two in flight
+    static constexpr int RING = SPC % 3 == 0 ? 3 : (SPLIT ? 2 : 4); // A-fragment ring: the step in use + one or two in flight
+    static constexpr int AHEAD = RING - 1;                         // steps between an A fragment's request and its use
+    // chunks in flight between HBM and LDS (registers): a 1 x 1 layer's chunk is only KQ steps of MFMAs - far shorter than an HBM round trip
+    // under load - and Little's law asks for ~40 KB in flight per CU to stream at the rate the layer needs; a 3 x 3 chunk covers its successor
+    static constexpr int DEPTH = KS == 1 ? (SPLIT && MW < 4 ? 2 : 3) : 1; // (fewer threads share a tile's staging when MW < 4: 16 quads per thread and chunk at MW = 1)
     static_assert(SPC % RING == 0 && SPC % 2 == 0, "ring / double buffer periods");
 };
 
 } // namespace
 
 template <bool SPLIT, int KS, int CK, int MW>
-__global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW) void conv32_direct_kernel(const conv32_params p, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 : 2) void conv32_direct_kernel(const conv32_params p, int tiles_x, int tiles_y)
 {
-    using G = direct32_geom<SPLIT, KS, CK>;
+    using G = direct32_geom<SPLIT, KS, CK, MW>;
     constexpr int TM = SPLIT ? 2 : 1, TN = SPLIT ? 2 : 1, NWN = 2 / TN, NT = 64 * MW * NWN, NACC = SPLIT ? 2 : 1;
     constexpr int NFA = SPLIT ? 2 * TM : TM; // A fragments (16 bytes per lane each) of one step
-    constexpr int HP = G::HP, RP = G::RP, PB = G::PB, KQ = G::KQ, SPC = G::SPC, RING = G::RING;
+    constexpr int HP = G::HP, RP = G::RP, PB = G::PB, KQ = G::KQ, SPC = G::SPC, RING = G::RING, AHEAD = G::AHEAD, DEPTH = G::DEPTH;
     constexpr int NQ = (G::QUADS + NT - 1) / NT; // float4 per thread and chunk
     __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
 
@@ -104,18 +108,18 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW) void conv32_direct_kern
         goff[i] = tvd_off(p.in, b, min(y, ymax), min(x, xmax)) + c4 * 4;
         soff[i] = hy * RP + hx * PB + (SPLIT ? c4 * 8 : c4 * 16);
     }
-    f32x4 stage[NQ];
-    auto gload = [&](int c) {
+    f32x4 stage[DEPTH][NQ]; // stage[0] = the chunk about to be written to LDS, stage[d] = d chunks later
+    auto gload = [&](int d, int c) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
-            stage[i] = *reinterpret_cast<const f32x4*>(p.in.p + goff[i] + c * CK);
+            stage[d][i] = *reinterpret_cast<const f32x4*>(p.in.p + goff[i] + min(c, nch - 1) * CK);
     };
     unsigned ovf = 0;
     auto to_lds = [&]() {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             if (i * NT + tid < G::QUADS) {
-                f32x4 x = stage[i];
+                f32x4 x = stage[0][i];
                 if (!qok[i])
                     x = f32x4{ 0.f, 0.f, 0.f, 0.f };
                 if constexpr (SPLIT) {
@@ -166,17 +170,24 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW) void conv32_direct_kern
     for (int j = 0; j < TN; ++j)
         bbase[j] = (4 * (wn * TN + j) + (n >> 3)) * RP + (n & 7) * PB + fk * 16;
 
-    gload(0);
-    aload(0, 0);
-    aload(1, 1);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        gload(d, d);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        aload(a, a);
     int s = 0; // global step index
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
         if (c)
             lds_barrier(); // every wavefront is done reading the previous chunk's tile
         to_lds();
-        if (c + 1 < nch)
-            gload(c + 1);
+#pragma unroll
+        for (int d = 0; d + 1 < DEPTH; ++d)
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                stage[d][i] = stage[d + 1][i];
+        gload(DEPTH - 1, c + DEPTH); // (past the last chunk: a harmless re-read of it)
         lds_barrier();
         u32x4 fb[2][TN][NACC]; // [buffer][n tile][SPLIT: hi | lo]
 #pragma unroll
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW) void conv32_direct_kern
                         fb[cur ^ 1][j][a] = *reinterpret_cast<const u32x4*>(lds + bbase[j] + toff + a * CK * 2);
             }
             const int slot = st % RING; // (SPC % RING == 0: the ring position is a compile-time function of st in every chunk)
-            aload((st + 2) % RING, s + 2);
+            aload((st + AHEAD) % RING, s + AHEAD);
             if constexpr (SPLIT) {
                 // hi-hi first (independent accumulators), then the two cross products of every tile
 #pragma unroll
@@ -335,7 +346,7 @@ static int direct_mw(const conv32_params& p, bool split)
     for (int mw : { 4, 2, 1 }) {
         if (force && mw != force)
             continue;
-        if (groups % mw == 0 && (force || mw == 1 || tiles * (groups / mw) >= (split ? 512 : 640)))
+        if (groups % mw == 0 && (force || mw == 1 || tiles * (groups / mw) >= (split ? 256 : 640)))
             return mw;
     }
     return 1;

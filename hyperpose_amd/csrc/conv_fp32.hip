@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
     // epilogue: lane (n, h) of a 32 x 32 tile holds rows (r & 3) + 8 (r >> 2) + 4 h of column n: four consecutive channels per r >> 2
     const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
     const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
-    const float pre = p.res_before_act ? 1.f : 0.f, post = 1.f - pre; // (the residual is 0 when there is none)
+    const bool res_pre = p.res.p && p.res_before_act, res_post = p.res.p && !p.res_before_act; // (selected with branches: 0 * Inf would be NaN)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + frow;
@@ -180,9 +180,13 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
                         sl = *reinterpret_cast<const f32x4*>(p.alpha + m);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = acc[i][j][4 * q + e] + bs[e] + pre * rr[e];
+                        float x = acc[i][j][4 * q + e] + bs[e];
+                        if (res_pre)
+                            x += rr[e];
                         x = x > 0.f ? fminf(x, p.act_hi) : x * sl[e];
-                        v[e] = x + post * rr[e];
+                        if (res_post)
+                            x += rr[e];
+                        v[e] = x;
                     }
                     if (p.out.p) {
                         if (full && out_vec) {

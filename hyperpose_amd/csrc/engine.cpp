@@ -502,9 +502,12 @@ int hp_engine::build(const hp_engine_desc* d)
                 // The layers conv32_direct_kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the buffer's
                 // channel stride) get their weights in fragment order as well: fp32 for HP_DTYPE_F32 (HP_NO_DIRECT32=1: the A/B switch back
                 // to conv32_kernel), fp16 (hi, lo) pairs for HP_DTYPE_F32S; the others stay on conv32_kernel
+                // fp32 pipe, measured per layer of LW-OpenPose @ 8 x 46 x 54 (machine time with a second stream, conv32_kernel -> direct): 3 x 3 128 -> 128
+                // 52.0 -> 48.2 us (72 -> 58 alone), 1 x 1 512 -> 128 26.2 -> 24.2, 512 -> 19 / 38 18.2 / 18.9 -> 16.9 / 17.4, 128 -> 256 18.5 -> 17.0; but
+                // 512 -> 512 88.3 -> 90.5, 128 -> 512 25.9 -> 27.8: wide 1 x 1 layers stay on conv32_kernel (HP_DIRECT32_MAX_1X1 moves the limit)
                 static const bool no_direct = getenv("HP_NO_DIRECT32") != nullptr;
-                static const int direct_min_cout = getenv("HP_DIRECT32_MIN_COUT") ? atoi(getenv("HP_DIRECT32_MIN_COUT")) : 0;
-                if (dtype == HP_DTYPE_F32S || (!no_direct && L.cout >= direct_min_cout)) {
+                static const int direct_max_1x1 = getenv("HP_DIRECT32_MAX_1X1") ? atoi(getenv("HP_DIRECT32_MAX_1X1")) : 256;
+                if (dtype == HP_DTYPE_F32S || (!no_direct && (taps > 1 || cout_pad <= direct_max_1x1))) {
                     const int ck = taps == 1 ? 64 : 32, cin_s = round_up(L.cin, ck);
                     hp::conv32_params q = p;
                     q.Cin = cin_s;
@@ -534,6 +537,9 @@ int hp_engine::build(const hp_engine_desc* d)
             } else if (L.op == HP_OP_DWCONV) {
                 HP_REQUIRE(L.kh == 3 && L.kw == 3, HP_ERR_INVALID, "layer %zu: depthwise kernels are 3x3", i);
                 HP_REQUIRE(L.cin % 4 == 0 && L.in_coff % 4 == 0 && L.out_coff % 4 == 0, HP_ERR_INVALID, "layer %zu: depthwise needs 4-aligned channels", i);
+                // (the fp16 path refuses the same set, set_act: a PReLU here would silently run as ReLU - there are no slopes in dw32_params)
+                HP_REQUIRE(L.act != HP_ACT_PRELU && L.act != HP_ACT_SIGMOID && L.act != HP_ACT_SOFTPLUS && L.res < 0, HP_ERR_INVALID,
+                    "layer %zu: activation %d / a residual on a depthwise layer is not supported", i, L.act);
                 const float* w = blob(L.w_off, (size_t)L.cin * 9, "weights", i);
                 std::vector<float> bias;
                 if (!w || !padded(L.b_off, L.cin, L.cin, "bias", bias))
@@ -1417,7 +1423,14 @@ int hp_engine_load(hp_engine** out, const char* path, int max_batch)
     std::vector<hp_layer> layers;
     std::vector<hp_output_desc> outs;
     std::vector<float> w;
-    bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, ENGINE_MAGIC, 8) == 0 && h.layer_size == (int32_t)sizeof(hp_layer)
+    // an HPENG001 file (before data_type was honoured) is an 002 file without the trailing (dtype, reserved) pair, and its engine was fp16
+    constexpr size_t HDR_001 = offsetof(engine_file_header, dtype);
+    bool ok = fread(&h, HDR_001, 1, f) == 1;
+    if (ok && memcmp(h.magic, "HPENG001", 8) == 0)
+        memcpy(h.magic, ENGINE_MAGIC, 8), h.dtype = HP_DTYPE_F16, h.reserved = 0;
+    else
+        ok = ok && fread(reinterpret_cast<char*>(&h) + HDR_001, sizeof(h) - HDR_001, 1, f) == 1;
+    ok = ok && memcmp(h.magic, ENGINE_MAGIC, 8) == 0 && h.layer_size == (int32_t)sizeof(hp_layer)
         && h.output_size == (int32_t)sizeof(hp_output_desc) && h.n_layers > 0 && h.n_layers < (1 << 20) && h.n_outputs > 0
         && h.n_outputs < 4096 && h.n_weights < ((uint64_t)1 << 34) && (h.dtype == HP_DTYPE_F16 || h.dtype == HP_DTYPE_F32 || h.dtype == HP_DTYPE_F32S);
     if (ok) { // the counts must account for the file exactly before anything is allocated from them

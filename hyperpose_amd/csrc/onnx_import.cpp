@@ -1539,6 +1539,10 @@ struct lowering {
             if (v.nhwc_view)
                 fail(nullptr, "graph output '" + o.name + "' is left in N,H,W,C order: the parsers index [C,H,W]");
             m.output(o.name.c_str(), v.tensor, v.coff, v.C, v.post_act);
+            // (hp_output_desc::scale = 0 means "no factor": a graph that really multiplies its output by 0 - or by a non-finite constant -
+            // cannot be expressed and is refused rather than silently losing the factor)
+            if (v.post_scale == 0.f || !std::isfinite(v.post_scale))
+                fail(nullptr, "graph output '" + o.name + "' is scaled by " + std::to_string(v.post_scale) + ": not representable as an output post-op");
             m.outputs.back().grid = v.post_grid, m.outputs.back().scale = v.post_scale == 1.f ? 0.f : v.post_scale; // (0 = no factor)
         }
         if (m.layers.empty())

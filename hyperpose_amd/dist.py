@@ -75,7 +75,12 @@ def init_for_gpu(device, probe: bool = True, probe_timeout_s: float = 45.0):
         ok, why = 0, "a rank asked for gloo (HP_DIST_BACKEND) or cannot load RCCL"
     else:
         # a failed collective must surface as an exception on the ranks that wait for it, not as the watchdog aborting the process
-        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        # (for the PROBE only: the variable is restored below, and the group that carries the data collectives - weight broadcast, timing
+        # reductions - is created afterwards with torch's normal error handling and its default 10-minute timeout, so a peer that dies
+        # later makes the others fail at that timeout instead of hanging in synchronize().  work.wait(timeout) blocking the CPU needs
+        # torch >= 2.6; this image has 2.10.)
+        prev = os.environ.get("TORCH_NCCL_ASYNC_ERROR_HANDLING")
+        os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = "0"
         wait = datetime.timedelta(seconds=probe_timeout_s)
         try:
             group = dist.new_group(backend="nccl", timeout=wait)
@@ -88,9 +93,18 @@ def init_for_gpu(device, probe: bool = True, probe_timeout_s: float = 45.0):
                 raise RuntimeError(f"probe all-reduce returned {t.item()}")
         except Exception as e:  # noqa: BLE001 - any failure of the GPU backend takes the same way out
             ok, why = 0, f"{type(e).__name__}: {e}"
+        finally:
+            if prev is None:
+                os.environ.pop("TORCH_NCCL_ASYNC_ERROR_HANDLING", None)
+            else:
+                os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = prev
     flag = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo: round 2, the agreement
     if int(flag.item()) == 1:
+        try:  # every rank got here with a working RCCL: the data collectives' own group (collective call, same order on all ranks)
+            group = dist.new_group(backend="nccl")
+        except Exception:  # noqa: BLE001 - keep the probe's group rather than fail after the agreement
+            pass
         _GROUP, _COLLECTIVE_DEVICE, _BACKEND = group, device, "nccl"
     else:
         if why:

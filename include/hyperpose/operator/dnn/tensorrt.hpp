@@ -119,6 +119,11 @@ namespace dnn {
                 fatal(hp_last_error());
         }
 
+        /// The builtin_model constructor (an addition of this library) took (model, size, batch, keep_ratio, factor, flip_rgb) before it learned
+        /// `dtype`; data_type(int) is implicit - as in the reference - so that old positional call would still compile, with factor truncated
+        /// into a data_type.  A floating-point argument in the dtype position is a compile error instead.
+        tensorrt(const builtin_model&, cv::Size, int, bool, double, bool = true) = delete;
+
         tensorrt(const tensorrt&) = delete;
         tensorrt& operator=(const tensorrt&) = delete;
         ~tensorrt()

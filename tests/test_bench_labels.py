@@ -207,7 +207,7 @@ def test_clock_samples_are_recorded_next_to_the_fractions():
 def test_clock_sampler_reads_its_sources(tmp_path):
     """ClockSampler against a fake sysfs tree: hwmon freq1_input (Hz) first, pp_dpm_sclk's starred level otherwise."""
     import time
-    s = bench.ClockSampler(device_index=99)
+    s = bench.ClockSampler(device_index=-1)
     assert s.freq_file is None and s._read_mhz() is None
     f = tmp_path / "freq1_input"
     f.write_text("2100000000\n")

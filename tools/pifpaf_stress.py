@@ -1,5 +1,5 @@
 """Soak test of the PifPaf device decoder against the host tail on random synthetic maps (run on the GPU box):
-    PYTHONPATH=. python tools/pifpaf_stress.py [batches]
+    PYTHONPATH=. python tools/pifpaf_stress.py [batches] [max people per frame, default 24]
 Prints the number of frames compared, how many the device decoder handed back to the host tail, and any mismatch."""
 import os
 import sys
@@ -10,6 +10,7 @@ from hyperpose_amd import synth
 from hyperpose_amd.parser import PifPaf
 
 n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+max_people = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 B = 32
 os.environ["HP_PIFPAF_HOST_TAIL"] = "0"
 dev = PifPaf(385, 385, 0.05, max_batch=B, cap_per_frame=256)
@@ -18,7 +19,7 @@ host = PifPaf(385, 385, 0.05, max_batch=B, cap_per_frame=256)
 rng = np.random.default_rng(20244)
 frames = fell = humans = bad = 0
 for it in range(n_batches):
-    people = tuple(int(v) for v in rng.integers(0, 24, 8))
+    people = tuple(int(v) for v in rng.integers(max_people // 2 if max_people > 24 else 0, max_people + 1, 8))
     noise = float(rng.choice([0.02, 0.1, 0.2, 0.28]))
     paf, pif = synth.pifpaf_maps(np.random.default_rng(1000 + it), B, people=people, noise=noise)
     a, b = dev.process_batch(paf, pif), host.process_batch(paf, pif)
