@@ -502,11 +502,12 @@ int hp_engine::build(const hp_engine_desc* d)
                 // The layers conv32_direct_kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the buffer's
                 // channel stride) get their weights in fragment order as well: fp32 for HP_DTYPE_F32 (HP_NO_DIRECT32=1: the A/B switch back
                 // to conv32_kernel), fp16 (hi, lo) pairs for HP_DTYPE_F32S; the others stay on conv32_kernel
-                // fp32 pipe, measured per layer of LW-OpenPose @ 8 x 46 x 54 (machine time with a second stream, conv32_kernel -> direct): 3 x 3 128 -> 128
-                // 52.0 -> 48.2 us (72 -> 58 alone), 1 x 1 512 -> 128 26.2 -> 24.2, 512 -> 19 / 38 18.2 / 18.9 -> 16.9 / 17.4, 128 -> 256 18.5 -> 17.0; but
-                // 512 -> 512 88.3 -> 90.5, 128 -> 512 25.9 -> 27.8: wide 1 x 1 layers stay on conv32_kernel (HP_DIRECT32_MAX_1X1 moves the limit)
+                // fp32 pipe, measured per layer of LW-OpenPose @ 8 x 46 x 54 (conv32_kernel -> direct, us alone | with a second stream): 3 x 3 128 -> 128
+                // 72.2 -> 58.7 | 52.6 -> 48.9; the 1 x 1 heads 512 -> 19 / 38 27.9 / 29.3 -> 26.1 / 27.4 | 18.8 / 19.6 -> 17.9 / 18.2; every wider 1 x 1
+                // layer within +-3 % or worse (64 -> 128 22.9 -> 29.0 paired, 512 -> 512 100 -> 100 alone): 1 x 1 layers wider than 64 padded outputs
+                // stay on conv32_kernel (HP_DIRECT32_MAX_1X1 moves the limit, HP_NO_DIRECT32=1 is the A/B switch)
                 static const bool no_direct = getenv("HP_NO_DIRECT32") != nullptr;
-                static const int direct_max_1x1 = getenv("HP_DIRECT32_MAX_1X1") ? atoi(getenv("HP_DIRECT32_MAX_1X1")) : 256;
+                static const int direct_max_1x1 = getenv("HP_DIRECT32_MAX_1X1") ? atoi(getenv("HP_DIRECT32_MAX_1X1")) : 64;
                 if (dtype == HP_DTYPE_F32S || (!no_direct && (taps > 1 || cout_pad <= direct_max_1x1))) {
                     const int ck = taps == 1 ? 64 : 32, cin_s = round_up(L.cin, ck);
                     hp::conv32_params q = p;

@@ -348,6 +348,7 @@ __global__ void pp_offsets_kernel(int n, int seed_cap, long long arena_cap, int*
         long long sz = (long long)h[0] * 5;
         for (int l = 0; l < 2 * NB; ++l)
             sz += (long long)h[1 + l] * 9;
+        h[42] = (int)sz; // what the frame needs (hp_pifpaf_collect grows the arena by it and parses the batch again)
         if (off + sz > arena_cap) { // the frame's lists do not fit: it is reported, not packed
             h[40] |= 2;
             sz = 0;
@@ -1501,6 +1502,8 @@ struct hp_pifpaf {
     hp::dev_buf cells, ncells, seeds, lists, hdr, total, in_paf, in_pif;
     hp::host_buf h_hdr, h_arena; // the pack kernel writes the dense arena straight into pinned host memory
     size_t arena_cap = 0;        // floats
+    int arena_growths = 0;       // times hp_pifpaf_collect enlarged the arena and parsed a batch again (the reference's vectors just grow)
+    struct { int n = 0, fh = 0, fw = 0; const float *paf = nullptr, *pif = nullptr; hipStream_t s = nullptr; } last; // the batch in flight, on the device
     std::vector<occupancy> occ;  // one per pool worker
     int pending = 0;
     // device decoder (pp_decode_kernel); HP_PIFPAF_HOST_TAIL=1 keeps every frame on the host tail
@@ -1602,6 +1605,7 @@ static int pifpaf_launch(hp_pifpaf* p, int n, const float* paf, const float* pif
         HP_HIP_TRY(hipMemcpyAsync(p->in_pif.p, pif, ib * n, hipMemcpyHostToDevice, s));
         dpaf = p->in_paf.as<float>(), dpif = p->in_pif.as<float>();
     }
+    p->last.n = n, p->last.fh = fh, p->last.fw = fw, p->last.paf = dpaf, p->last.pif = dpif, p->last.s = s;
     HP_HIP_TRY(hipMemsetAsync(p->hdr.p, 0, (size_t)n * HDR * sizeof(int), s));
     hipLaunchKernelGGL(pp_cells_kernel, dim3(NK, n), dim3(64), 0, s, dpif, p->g, p->cells.as<pp_cell>(), p->ncells.as<int>());
     hipLaunchKernelGGL(pp_seeds_kernel, dim3(NK, n), dim3(64), 0, s, dpif, p->g, p->cells.as<pp_cell>(), p->ncells.as<int>(), p->seeds.as<pp_seed>(),
@@ -1676,6 +1680,29 @@ int hp_pifpaf_collect(hp_pifpaf* p, hp_human* out, int cap_per_frame, int* n_out
     const int n = p->pending;
     p->pending = 0;
     HP_HIP_TRY(hipEventSynchronize(p->done));
+    // The reference's lists are std::vectors (openpifpaf_postprocessor.cpp:764-851).  The pinned arena that carries the frames the host tail
+    // decodes starts at a size that fits ordinary frames; when a frame's lists did not fit (h[40] & 2) it grows to what the batch needs
+    // (h[42] per frame, + 25 %) - at most the size at which no list can overflow - and the batch is parsed again from the inputs, which
+    // the API keeps valid until collect returns (device inputs) or which were copied to the parser's own buffers (host inputs).
+    for (int round = 0; round < 4; ++round) {
+        size_t need = 0;
+        bool over = false;
+        for (int f = 0; f < n; ++f) {
+            const int* h = p->h_hdr.as<int>() + (size_t)f * HDR;
+            over |= (h[40] & 2) != 0;
+            if (!h[41])
+                need += (size_t)h[42];
+        }
+        const size_t HW = (size_t)p->g.H * p->g.W, cap_max = (size_t)p->max_batch * HW * (NK * 5 + NB * 2 * 9);
+        if (!over || p->arena_cap >= cap_max)
+            break;
+        const size_t cap = std::min(cap_max, std::max(p->arena_cap * 2, need + need / 4));
+        HP_TRY(p->h_arena.alloc(cap * sizeof(float)));
+        p->arena_cap = cap, ++p->arena_growths;
+        HP_TRY(pifpaf_launch(p, p->last.n, p->last.paf, p->last.pif, p->last.fh, p->last.fw, 1, p->last.s));
+        p->pending = 0;
+        HP_HIP_TRY(hipEventSynchronize(p->done));
+    }
     p->last_flags.assign(n, -1);
     if (p->device_decode)
         std::copy_n(p->h_counts.as<int>() + p->max_batch, n, p->last_flags.begin());

@@ -7,8 +7,7 @@ mkdir -p $out
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/clock_probe.hip -o /tmp/clock_probe && timeout 120 /tmp/clock_probe > $out/${name}_clock_probe.txt 2>&1
 timeout 900 python -m pytest tests/test_engine_fp32_gpu.py tests/test_pipeline_gpu.py -q -m gpu -x 2>&1 | tail -15 > $out/${name}_pytest_fp32.txt
 timeout 300 python tools/profile_layers.py lw_openpose_mobilenet 432 368 8 f32 > $out/${name}_layers_f32.txt 2>&1
-PYTHONPATH=. timeout 300 python tools/pifpaf_stress.py 6 64 > $out/${name}_pifpaf_stress64.txt 2>&1
-HP_NO_DIRECT32=1 timeout 300 python tools/profile_layers.py lw_openpose_mobilenet 432 368 8 f32 > $out/${name}_layers_f32_nodirect.txt 2>&1
+PYTHONPATH=. timeout 300 python tools/pifpaf_stress.py 4 64 > $out/${name}_pifpaf_stress64.txt 2>&1
 timeout 300 python tools/profile_layers.py lw_openpose_mobilenet 432 368 8 f32s > $out/${name}_layers_f32s.txt 2>&1
 timeout 600 python bench.py --steps 20 --warmup 5 --extra 1/f16,1/f32s > $out/${name}_bench.json 2> $out/${name}_bench.err
 cp bench_detail.json $out/${name}_bench_detail.json 2>/dev/null
