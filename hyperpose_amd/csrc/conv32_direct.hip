@@ -32,6 +32,7 @@
 //            into registers, two steps ahead, never through LDS.
 #include "conv_fp32.hpp"
 
+#include "conv32_epilogue.hpp"
 #include "conv_device.hpp"
 
 #include <algorithm>
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
     constexpr int NFA = SPLIT ? 2 * TM : TM; // A fragments (16 bytes per lane each) of one step
     constexpr int HP = G::HP, RP = G::RP, PB = G::PB, KQ = G::KQ, SPC = G::SPC, RING = G::RING, AHEAD = G::AHEAD, DEPTH = G::DEPTH;
     constexpr int NQ = (G::QUADS + NT - 1) / NT; // float4 per thread and chunk
-    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
+    constexpr int SLABS = MW * NWN * rows_geom<TM>::SLAB_BYTES; // the epilogue's transposition slabs lie over the (then dead) halo tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES > SLABS ? G::LDS_BYTES : SLABS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
@@ -90,6 +92,11 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
     const int y0 = ty * 8, x0 = tx * 8;
     const int MT = p.Cout_pad / 32, mt0 = (blockIdx.y * MW + wm) * TM;
     const int nch = p.Cin / CK;
+    int dbg_i = 0;
+#define HP_STAMP()                                                     \
+    if (p.dbg && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0)       \
+        p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
 
     // ---- staging geometry: quad q of a chunk = (halo pixel q / QPP, channels 4 (q % QPP) ..)
     long goff[NQ];
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
                 stage[d][i] = stage[d + 1][i];
         gload(DEPTH - 1, c + DEPTH); // (past the last chunk: a harmless re-read of it)
         lds_barrier();
+        HP_STAMP();
         u32x4 fb[2][TN][NACC]; // [buffer][n tile][SPLIT: hi | lo]
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -255,11 +263,36 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
             __builtin_amdgcn_sched_barrier(0); // nothing crosses a step boundary: the reads above belong to LATER steps and must stay here
             ++s;
         }
+        HP_STAMP();
     }
     if (SPLIT && ovf && p.ovf)
         atomicOr(p.ovf, 1u);
 
-    // ---- epilogue: lane (n, fk) of a 32 x 32 tile holds rows (r & 3) + 8 (r >> 2) + 4 fk of column n: four consecutive channels per r >> 2
+    // ---- epilogue
+    if (!p.out_f32) {
+        // NHWC output only (every layer but the network's heads): row-major through a private LDS slab (conv32_epilogue.hpp)
+        lds_barrier(); // every wavefront is done with the halo tile the slabs lie over
+        float* const slab = reinterpret_cast<float*>(lds) + wave * (rows_geom<TM>::SLAB_BYTES / 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            floatx16 fin[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    fin[i][r] = SPLIT ? __builtin_fmaf(acc[i][j][NACC - 1][r], 1.f / 2048.f, acc[i][j][0][r]) : acc[i][j][0][r];
+            const int ty0 = y0 + 4 * (wn * TN + j);
+            conv32_store_rows<TM>(p, fin, slab, lane, mt0 * 32, [&](int r, bool& ok, long& ooff, long& roff) {
+                const int oy = ty0 + (r >> 3), ox = x0 + (r & 7);
+                ok = oy < p.OH && ox < p.OW;
+                const int oyc = min(oy, p.OH - 1), oxc = min(ox, p.OW - 1);
+                ooff = tvd_off(p.out, b, oyc, oxc);
+                roff = p.res.p ? tvd_off(p.res, b, oyc, oxc) : 0;
+            });
+        }
+    } else {
+    // the network's heads (fp32 NCHW for the parsers, runs along x): lane (n, fk) of a 32 x 32 tile holds rows (r & 3) + 8 (r >> 2) + 4 fk of
+    // column n, four consecutive channels per r >> 2
     const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
     const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
     const int OHW = p.OH * p.OW;
@@ -326,6 +359,9 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
             }
         }
     }
+    }
+    HP_STAMP();
+#undef HP_STAMP
 }
 
 // Which layers the direct kernels take: square 1 x 1 / 3 x 3, stride 1, dilation 1, SAME padding, channel slice readable in whole chunks

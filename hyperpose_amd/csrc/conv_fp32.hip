@@ -10,6 +10,7 @@
 // Activations keep the zero-halo NHWC layout of the fp16 path with 4-byte elements.
 #include "conv_fp32.hpp"
 
+#include "conv32_epilogue.hpp"
 #include "conv_device.hpp"
 
 #include <algorithm>
@@ -61,8 +62,11 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
     constexpr int BK = 16, LDR = 20;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NA = BM / 64, NB = BN / 64;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && NA >= 1 && NB >= 1, "tile");
-    __shared__ __attribute__((aligned(16))) float sA[2][BM * LDR];
-    __shared__ __attribute__((aligned(16))) float sB[2][BN * LDR];
+    // [2][BM * LDR] A tiles, then [2][BN * LDR] B tiles; the epilogue's transposition slabs (conv32_epilogue.hpp) lie over them afterwards
+    constexpr int AB_BYTES = 2 * (BM + BN) * LDR * 4, SLABS = 4 * rows_geom<TM>::SLAB_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[AB_BYTES > SLABS ? AB_BYTES : SLABS];
+    float (*const sA)[BM * LDR] = reinterpret_cast<float (*)[BM * LDR]>(lds_raw);
+    float (*const sB)[BN * LDR] = reinterpret_cast<float (*)[BN * LDR]>(lds_raw + 2 * BM * LDR * 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -141,7 +145,32 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
         lds_barrier();
     }
 
-    // epilogue: lane (n, h) of a 32 x 32 tile holds rows (r & 3) + 8 (r >> 2) + 4 h of column n: four consecutive channels per r >> 2
+    // epilogue
+    if (!p.out_f32) {
+        // NHWC output only (every layer but the network's heads): row-major through a private LDS slab (conv32_epilogue.hpp)
+        lds_barrier(); // every wavefront is done with the last K-step's tiles the slabs lie over
+        float* const slab = reinterpret_cast<float*>(lds_raw) + wave * (rows_geom<TM>::SLAB_BYTES / 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            floatx16 fin[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fin[i] = acc[i][j];
+            const int nb = n0 + (wn * TN + j) * 32;
+            conv32_store_rows<TM>(p, fin, slab, lane, m0 + wm * TM * 32, [&](int r, bool& ok, long& ooff, long& roff) {
+                const int n = nb + r;
+                ok = n < p.npix;
+                const int nc = min(n, p.npix - 1);
+                const int b = nc / OHW, rem = nc - b * OHW;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                ooff = tv32_off(p.out, b, oy, ox);
+                roff = p.res.p ? tv32_off(p.res, b, oy, ox) : 0;
+            });
+        }
+        return;
+    }
+    // the network's heads (fp32 NCHW for the parsers, runs along x): lane (n, h) of a 32 x 32 tile holds rows (r & 3) + 8 (r >> 2) + 4 h of
+    // column n, four consecutive channels per r >> 2
     const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
     const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
     const bool res_pre = p.res.p && p.res_before_act, res_post = p.res.p && !p.res_before_act; // (selected with branches: 0 * Inf would be NaN)

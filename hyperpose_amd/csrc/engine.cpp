@@ -498,7 +498,7 @@ int hp_engine::build(const hp_engine_desc* d)
                     p.out.p = nullptr, to.unwritten = true; // only the fp32 network output is wanted
                 HP_REQUIRE(hp::set_act32(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
                 p.B = max_batch, p.npix = max_batch * g.OH * g.OW;
-                p.w_split = nullptr, p.w_frag = nullptr, p.ovf = ovf_dev;
+                p.w_split = nullptr, p.w_frag = nullptr, p.ovf = ovf_dev, p.dbg = nullptr;
                 // The layers conv32_direct_kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the buffer's
                 // channel stride) get their weights in fragment order as well: fp32 for HP_DTYPE_F32 (HP_NO_DIRECT32=1: the A/B switch back
                 // to conv32_kernel), fp16 (hi, lo) pairs for HP_DTYPE_F32S; the others stay on conv32_kernel
@@ -1194,6 +1194,23 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
                 hp::conv32_params q = st.cp32;
                 q.Cin = st.cin_split;
                 HP_HIP_TRY(hp::launch_conv32_direct(q, dtype == HP_DTYPE_F32S && !split_off, s));
+                static const bool dbg_direct = getenv("HP_DIRECT_DBG") != nullptr;
+                if (dbg_direct) { // block timeline (s_memtime = shader cycles, block (1, 0), thread 0), printed per launch
+                    unsigned long long* dbg = nullptr;
+                    HP_HIP_TRY(hipMalloc(&dbg, 64 * 8));
+                    HP_HIP_TRY(hipMemset(dbg, 0, 64 * 8));
+                    q.dbg = dbg;
+                    HP_HIP_TRY(hp::launch_conv32_direct(q, dtype == HP_DTYPE_F32S && !split_off, s));
+                    HP_HIP_TRY(hipStreamSynchronize(s));
+                    unsigned long long h[64];
+                    HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "direct layer %d %dx%d %d->%d tile %d cycles [start | staged, multiplied per chunk | stored]:", st.layer, q.KH, q.KW, q.Cin, q.Cout,
+                        hp::conv32_direct_tile(q, dtype == HP_DTYPE_F32S && !split_off));
+                    for (int i = 1; i < 64 && h[i]; ++i)
+                        fprintf(stderr, " %llu", h[i] - h[i - 1]);
+                    fprintf(stderr, "\n");
+                    (void)hipFree(dbg);
+                }
             } else
                 HP_HIP_TRY(hp::launch_conv32(st.cp32, s));
         } else if (st.op == HP_OP_DWCONV) {
