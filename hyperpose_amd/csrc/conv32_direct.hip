@@ -66,14 +66,14 @@ struct direct32_geom {
     static constexpr int AHEAD = RING - 1;                         // steps between an A fragment's request and its use
     // chunks in flight between HBM and LDS (registers): a 1 x 1 layer's chunk is only KQ steps of MFMAs - far shorter than an HBM round trip
     // under load - and Little's law asks for ~40 KB in flight per CU to stream at the rate the layer needs; a 3 x 3 chunk covers its successor
-    static constexpr int DEPTH = KS == 1 ? (SPLIT ? 2 : 3) : 1; // (the split kernel's 128 accumulator registers leave room for two chunks at 2 wavefronts per SIMD)
+    static constexpr int DEPTH = KS == 1 ? (SPLIT && MW < 4 ? 2 : 3) : 1; // (fewer threads share a tile's staging when MW < 4: 16 quads per thread and chunk at MW = 1)
     static_assert(SPC % RING == 0 && SPC % 2 == 0, "ring / double buffer periods");
 };
 
 } // namespace
 
 template <bool SPLIT, int KS, int CK, int MW>
-__global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && (MW < 4 || KS == 3)) ? 1 : 2) void conv32_direct_kernel(const conv32_params p, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 : 2) void conv32_direct_kernel(const conv32_params p, int tiles_x, int tiles_y)
 {
     using G = direct32_geom<SPLIT, KS, CK, MW>;
     constexpr int TM = SPLIT ? 2 : 1, TN = SPLIT ? 2 : 1, NWN = 2 / TN, NT = 64 * MW * NWN, NACC = SPLIT ? 2 : 1;
@@ -81,8 +81,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && (MW < 4 || KS
     constexpr int HP = G::HP, RP = G::RP, PB = G::PB, KQ = G::KQ, SPC = G::SPC, RING = G::RING, AHEAD = G::AHEAD, DEPTH = G::DEPTH;
     constexpr int NQ = (G::QUADS + NT - 1) / NT; // float4 per thread and chunk
     constexpr int SLABS = MW * NWN * rows_geom<TM>::SLAB_BYTES; // the epilogue's transposition slabs lie over the (then dead) halo tile
-    // two tile buffers: chunk c + 1 is converted and written into one (inside the MFMA shadows of chunk c's steps) while chunk c is read from the other
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::LDS_BYTES > SLABS ? 2 * G::LDS_BYTES : SLABS];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES > SLABS ? G::LDS_BYTES : SLABS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
@@ -123,32 +122,27 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && (MW < 4 || KS
             stage[d][i] = *reinterpret_cast<const f32x4*>(p.in.p + goff[i] + min(c, nch - 1) * CK);
     };
     unsigned ovf = 0;
-    auto quad_to_lds = [&](int i, int boff) { // quad i of the chunk in stage[0] -> tile buffer at byte offset boff
-        if (i * NT + tid < G::QUADS) {
-            f32x4 x = stage[0][i];
-            if (!qok[i])
-                x = f32x4{ 0.f, 0.f, 0.f, 0.f };
-            if constexpr (SPLIT) {
-                _Float16 h[4], l[4];
+    auto to_lds = [&]() {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    h[e] = (_Float16)x[e];
-                    l[e] = (_Float16)((x[e] - (float)h[e]) * 2048.f);
-                    ovf |= __builtin_fabsf(x[e]) > 65504.f;
-                }
-                *reinterpret_cast<half4v*>(lds + boff + soff[i]) = half4v{ h[0], h[1], h[2], h[3] };
-                *reinterpret_cast<half4v*>(lds + boff + soff[i] + CK * 2) = half4v{ l[0], l[1], l[2], l[3] };
-            } else
-                *reinterpret_cast<f32x4*>(lds + boff + soff[i]) = x;
+        for (int i = 0; i < NQ; ++i) {
+            if (i * NT + tid < G::QUADS) {
+                f32x4 x = stage[0][i];
+                if (!qok[i])
+                    x = f32x4{ 0.f, 0.f, 0.f, 0.f };
+                if constexpr (SPLIT) {
+                    _Float16 h[4], l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = (_Float16)x[e];
+                        l[e] = (_Float16)((x[e] - (float)h[e]) * 2048.f);
+                        ovf |= __builtin_fabsf(x[e]) > 65504.f;
+                    }
+                    *reinterpret_cast<half4v*>(lds + soff[i]) = half4v{ h[0], h[1], h[2], h[3] };
+                    *reinterpret_cast<half4v*>(lds + soff[i] + CK * 2) = half4v{ l[0], l[1], l[2], l[3] };
+                } else
+                    *reinterpret_cast<f32x4*>(lds + soff[i]) = x;
+            }
         }
-    };
-    auto shift_and_load = [&](int c_next) { // stage[0] consumed: the chunks behind it move up, chunk c_next is requested into the last slot
-#pragma unroll
-        for (int d = 0; d + 1 < DEPTH; ++d)
-#pragma unroll
-            for (int i = 0; i < NQ; ++i)
-                stage[d][i] = stage[d + 1][i];
-        gload(DEPTH - 1, c_next); // (past the last chunk: a harmless re-read of it)
     };
 
     // ---- A fragments: steps run (chunk, tap, step of the tap) in packing order; a step's fragments of this wavefront are contiguous
@@ -189,24 +183,26 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && (MW < 4 || KS
 #pragma unroll
     for (int a = 0; a < AHEAD; ++a)
         aload(a, a);
-    // chunk 0 -> buffer 0 (the only staging that is not hidden)
-#pragma unroll
-    for (int i = 0; i < NQ; ++i)
-        quad_to_lds(i, 0);
-    shift_and_load(DEPTH);
-    lds_barrier();
-    HP_STAMP();
     int s = 0; // global step index
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
-        const int rb = (c & 1) * G::LDS_BYTES, wb = G::LDS_BYTES - rb; // this chunk's tile / the buffer chunk c + 1 is written into
-        const unsigned char* const tile = lds + rb;
+        if (c)
+            lds_barrier(); // every wavefront is done reading the previous chunk's tile
+        to_lds();
+#pragma unroll
+        for (int d = 0; d + 1 < DEPTH; ++d)
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                stage[d][i] = stage[d + 1][i];
+        gload(DEPTH - 1, c + DEPTH); // (past the last chunk: a harmless re-read of it)
+        lds_barrier();
+        HP_STAMP();
         u32x4 fb[2][TN][NACC]; // [buffer][n tile][SPLIT: hi | lo]
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int a = 0; a < NACC; ++a)
-                fb[0][j][a] = *reinterpret_cast<const u32x4*>(tile + bbase[j] + a * CK * 2);
+                fb[0][j][a] = *reinterpret_cast<const u32x4*>(lds + bbase[j] + a * CK * 2);
 #pragma unroll
         for (int st = 0; st < SPC; ++st) { // st = tap * KQ + step of the tap (the packing order of the weights)
             const int cur = st & 1;
@@ -218,16 +214,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && (MW < 4 || KS
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int a = 0; a < NACC; ++a)
-                        fb[cur ^ 1][j][a] = *reinterpret_cast<const u32x4*>(tile + bbase[j] + toff + a * CK * 2);
+                        fb[cur ^ 1][j][a] = *reinterpret_cast<const u32x4*>(lds + bbase[j] + toff + a * CK * 2);
             }
             const int slot = st % RING; // (SPC % RING == 0: the ring position is a compile-time function of st in every chunk)
             aload((st + AHEAD) % RING, s + AHEAD);
-            // the next chunk's quads assigned to this step: converted and written to the other buffer beside this step's MFMAs (the last
-            // chunk stages a harmless copy of itself: no branch, one scheduling region per step)
-#pragma unroll
-            for (int i = 0; i < NQ; ++i)
-                if (i * SPC / NQ == st)
-                    quad_to_lds(i, wb);
             if constexpr (SPLIT) {
                 // hi-hi first (independent accumulators), then the two cross products of every tile
 #pragma unroll
@@ -273,9 +263,6 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && (MW < 4 || KS
             __builtin_amdgcn_sched_barrier(0); // nothing crosses a step boundary: the reads above belong to LATER steps and must stay here
             ++s;
         }
-        HP_STAMP();
-        shift_and_load(c + 1 + DEPTH);
-        lds_barrier(); // chunk c + 1 is complete in its buffer, and every wavefront is done reading chunk c's
         HP_STAMP();
     }
     if (SPLIT && ovf && p.ovf)
