@@ -66,7 +66,7 @@ struct direct32_geom {
     static constexpr int AHEAD = RING - 1;                         // steps between an A fragment's request and its use
     // chunks in flight between HBM and LDS (registers): a 1 x 1 layer's chunk is only KQ steps of MFMAs - far shorter than an HBM round trip
     // under load - and Little's law asks for ~40 KB in flight per CU to stream at the rate the layer needs; a 3 x 3 chunk covers its successor
-    static constexpr int DEPTH = KS == 1 ? (SPLIT && MW < 4 ? 2 : 3) : 1; // (fewer threads share a tile's staging when MW < 4: 16 quads per thread and chunk at MW = 1)
+    static constexpr int DEPTH = KS == 1 ? (SPLIT && (MW < 4 || MW == 8) ? 2 : 3) : 1; // (fewer threads share a tile's staging when MW < 4: 16 quads per thread and chunk at MW = 1)
     static_assert(SPC % RING == 0 && SPC % 2 == 0, "ring / double buffer periods");
 };
 
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
         atomicOr(p.ovf, 1u);
 
     // ---- epilogue
-    if (!p.out_f32) {
+    if (!p.out_f32 && !p.lane_epilogue) {
         // NHWC output only (every layer but the network's heads): row-major through a private LDS slab (conv32_epilogue.hpp)
         lds_barrier(); // every wavefront is done with the halo tile the slabs lie over
         float* const slab = reinterpret_cast<float*>(lds) + wave * (rows_geom<TM>::SLAB_BYTES / 4);
@@ -379,8 +379,11 @@ static int direct_mw(const conv32_params& p, bool split)
     const int groups = p.Cout_pad / (split ? 64 : 32);
     const long tiles = (long)p.B * ((p.OH + 7) / 8) * ((p.OW + 7) / 8);
     static const int force = getenv("HP_DIRECT_MW") ? atoi(getenv("HP_DIRECT_MW")) : 0;
-    for (int mw : { 4, 2, 1 }) {
-        if (force && mw != force)
+    for (int mw : { 8, 4, 2, 1 }) {
+        if (mw == 8 && (!split || p.KH != 1))
+            continue; // (8 wavefronts of 64 channels: the split 1 x 1 layers with 512 outputs read their input tile once)
+        static const int mw_max = getenv("HP_DIRECT_MW_MAX") ? atoi(getenv("HP_DIRECT_MW_MAX")) : 8;
+        if ((force && mw != force) || mw > mw_max)
             continue;
         if (groups % mw == 0 && (force || mw == 1 || tiles * (groups / mw) >= (split ? 256 : 640)))
             return mw;
@@ -442,6 +445,7 @@ hipError_t launch_conv32_direct(const conv32_params& p, bool split, hipStream_t 
     HP_DIRECT_CASE(true, 1, 64, 1)
     HP_DIRECT_CASE(true, 1, 64, 2)
     HP_DIRECT_CASE(true, 1, 64, 4)
+    HP_DIRECT_CASE(true, 1, 64, 8)
     HP_DIRECT_CASE(true, 3, 32, 1)
     HP_DIRECT_CASE(true, 3, 32, 2)
     HP_DIRECT_CASE(true, 3, 32, 4)

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
     }
 
     // epilogue
-    if (!p.out_f32) {
+    if (!p.out_f32 && !p.lane_epilogue) {
         // NHWC output only (every layer but the network's heads): row-major through a private LDS slab (conv32_epilogue.hpp)
         lds_barrier(); // every wavefront is done with the last K-step's tiles the slabs lie over
         float* const slab = reinterpret_cast<float*>(lds_raw) + wave * (rows_geom<TM>::SLAB_BYTES / 4);

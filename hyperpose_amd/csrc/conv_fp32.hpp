@@ -39,6 +39,7 @@ struct conv32_params {
     const float* w_frag;
     const _Float16* w_split;
     unsigned* ovf;
+    int lane_epilogue; // HP_LANE_EPILOGUE=1 (A/B switch): store from the accumulators' lane = pixel layout instead of whole pixel rows (conv32_epilogue.hpp)
     unsigned long long* dbg; // HP_DIRECT_DBG: s_memtime stamps (shader cycles) of block (0, 0)'s thread 0 - start, chunk staged, chunk multiplied, ..., stored
 };
 // fills act_slope / act_hi from act / act_param; false for activations the epilogue does not evaluate (sigmoid / softplus are output post-ops)

@@ -499,6 +499,8 @@ int hp_engine::build(const hp_engine_desc* d)
                 HP_REQUIRE(hp::set_act32(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
                 p.B = max_batch, p.npix = max_batch * g.OH * g.OW;
                 p.w_split = nullptr, p.w_frag = nullptr, p.ovf = ovf_dev, p.dbg = nullptr;
+                static const int lane_epi = getenv("HP_LANE_EPILOGUE") ? atoi(getenv("HP_LANE_EPILOGUE")) : 0;
+                p.lane_epilogue = lane_epi;
                 // The layers conv32_direct_kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the buffer's
                 // channel stride) get their weights in fragment order as well: fp32 for HP_DTYPE_F32 (HP_NO_DIRECT32=1: the A/B switch back
                 // to conv32_kernel), fp16 (hi, lo) pairs for HP_DTYPE_F32S; the others stay on conv32_kernel
