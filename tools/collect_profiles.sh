@@ -10,12 +10,14 @@ dt=${3:-f16}   # engine precision: f16 (data_type::kHALF) or f32 (data_type::kFL
 sfx=""
 [ "$cfg" != "1" ] && sfx="_config$cfg"
 [ "$dt" == "f32" ] && sfx="_config${cfg}_fp32"
+[ "$dt" == "f32s" ] && sfx="_config${cfg}_fp32s"
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 steps=12
-[ "$cfg" != "1" ] && steps=3
+[ "$cfg" != "1" ] && [ "$cfg" != "0" ] && steps=3
+[ "$dt" != "f16" ] && [ "$cfg" != "1" ] && [ "$cfg" != "0" ] && steps=2
 cmd="python $repo/bench.py --config $cfg --dtype $dt --no-clocks --min-seconds 0 --extra= --steps $steps --warmup 2 --pipes 1 --no-cpu-baseline --no-roofline --no-from-host --no-dnn-output"
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- $cmd > /dev/null 2>&1

@@ -1,5 +1,5 @@
 """How the end-to-end step time of bench.py's headline splits when several pipes overlap: ms per step for 1..8 pipes with the
-engine only, the parser only, and both (same Pipe objects and loop as bench.py).  Usage: python tools/pipe_sweep.py [config]"""
+engine only, the parser only, and both (same Pipe objects and loop as bench.py).  Usage: python tools/pipe_sweep.py [config] [f16|f32|f32s]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import bench
@@ -9,7 +9,7 @@ from hyperpose_amd.engine import Model
 
 def main():
     idx = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-    cfg = bench.CONFIGS[idx]
+    cfg = bench.config(idx, sys.argv[2] if len(sys.argv) > 2 else "f16")
     _lib.init(0)
     batch = cfg["batch"]
     model = Model(cfg["arch"], cfg["w"], cfg["h"])

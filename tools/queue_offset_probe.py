@@ -10,7 +10,7 @@ torch.cuda.set_device(0); _lib.init(0)
 lib = _lib.lib()
 # k dummy streams shift the runtime's round-robin queue assignment
 dummies = [torch.cuda.Stream() for _ in range(k)]
-cfg = bench.CONFIGS[1]
+cfg = bench.config(1, "f16")
 model = Model(cfg["arch"], cfg["w"], cfg["h"]); w = model.init_weights(1)
 frames, maps = bench.synth_inputs(cfg, 8, 0)
 fd = _lib.DevBuf.from_numpy(frames); inj = [_lib.DevBuf.from_numpy(m) for m in maps]
