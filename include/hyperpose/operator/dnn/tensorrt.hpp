@@ -17,6 +17,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../../hp_hip.h"
@@ -122,7 +123,8 @@ namespace dnn {
         /// The builtin_model constructor (an addition of this library) took (model, size, batch, keep_ratio, factor, flip_rgb) before it learned
         /// `dtype`; data_type(int) is implicit - as in the reference - so that old positional call would still compile, with factor truncated
         /// into a data_type.  A floating-point argument in the dtype position is a compile error instead.
-        tensorrt(const builtin_model&, cv::Size, int, bool, double, bool = true) = delete;
+        template <class F, class = typename std::enable_if<std::is_floating_point<F>::value>::type>
+        tensorrt(const builtin_model&, cv::Size, int, bool, F, bool = true) = delete;
 
         tensorrt(const tensorrt&) = delete;
         tensorrt& operator=(const tensorrt&) = delete;
