@@ -380,13 +380,17 @@ def kernel_label(tile: int):
            20: ("sepconv_pair_kernel<32,64,128>", "the stem's separable blocks 32 -> 64 and 64 -> 128 (stride 2) in one launch, the 64-channel "
                 "tensor between them in LDS only")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
+    if tile >= 33000000 and (tile // 100000) % 10:  # a depthwise 3 x 3 fused in front of the 1 x 1 layer
+        split, dil, mw = tile < 34000000, (tile // 100000) % 10, tile % 1000
+        return (f"conv32_direct_kernel<{'true' if split else 'false'},1,64,{mw},{dil}>", f"conv32_direct_kernel<{'split' if split else 'fp32'},KS=1,MW={mw},DWD={dil}> (separable block in one launch: "
+                f"the depthwise 3x3 (dilation {dil}) computed from its input tile in LDS straight into the tile the 1x1 layer's MFMAs read; {(64 if split else 32) * mw} cout x 8x8 px per block)")
     if tile >= 34000000:
         ks, mw = (tile - 34000000) // 1000, tile % 1000
-        return (f"conv32_direct_kernel<false,{ks},{64 if ks == 1 else 32},{mw}>", f"conv32_direct_kernel<fp32,KS={ks},MW={mw}> (exact fp32 products on v_mfma_f32_32x32x2_f32: "
+        return (f"conv32_direct_kernel<false,{ks},{64 if ks == 1 else 32},{mw},0>", f"conv32_direct_kernel<fp32,KS={ks},MW={mw}> (exact fp32 products on v_mfma_f32_32x32x2_f32: "
                 f"{32 * mw} cout x 8x8 px per block, {2 * mw} wavefronts of one 32x32 tile, the chunk's halo tile in LDS once for all taps, weights in fragment order from L2, no barrier per K-step)")
     if tile >= 33000000:
         ks, mw = (tile - 33000000) // 1000, tile % 1000
-        return (f"conv32_direct_kernel<true,{ks},{64 if ks == 1 else 32},{mw}>", f"conv32_direct_kernel<split,KS={ks},MW={mw}> (fp32 convolution with every product formed as three exact "
+        return (f"conv32_direct_kernel<true,{ks},{64 if ks == 1 else 32},{mw},0>", f"conv32_direct_kernel<split,KS={ks},MW={mw}> (fp32 convolution with every product formed as three exact "
                 f"fp16 x fp16 MFMA products: {64 * mw} cout x 8x8 px per block, split halo tile in LDS, split weights in fragment order from L2)")
     if tile >= 32000000:
         bm, bn = (tile - 32000000) // 1000, tile % 1000

@@ -51,7 +51,7 @@ __device__ __forceinline__ long tvd_off(const tview32& t, int b, int y, int x)
     return ((long)b * t.img + (long)y * t.wp + x) * t.cs + t.coff;
 }
 
-template <bool SPLIT, int KS, int CK, int MW>
+template <bool SPLIT, int KS, int CK, int MW, int DWD = 0>
 struct direct32_geom {
     static constexpr int HP = 8 + KS - 1;                          // halo tile is HP x HP pixels
     static constexpr int PBU = CK / 4 + 1;                         // 16-byte units per halo pixel: CK elements of 4 bytes + one unit of padding (odd)
@@ -59,29 +59,41 @@ struct direct32_geom {
     static constexpr int RP = ((HP * PBU + 7) / 16 * 16 + 8) * 16; // pixel-row pitch in bytes: >= HP pixels, = 8 mod 16 units
     static constexpr int LDS_BYTES = HP * RP;
     static constexpr int QPP = CK / 4;                             // float4 quads per pixel
-    static constexpr int QUADS = HP * HP * QPP;                    // ... per chunk
+    // DWD > 0 (a depthwise 3 x 3 of dilation DWD fused in front of the 1 x 1, KS = 1): the chunk's DEPTHWISE input - (8 + 2 DWD)^2 pixels x CK
+    // fp32 channels in pixel rows of PB bytes - is what arrives from HBM, into a second LDS tile behind the first; the depthwise outputs are
+    // computed from it into the first tile, which the MFMAs read as before.  The depthwise weights and biases of ALL chunks ([9][C] + [C]
+    // floats) sit behind that, loaded once per block.
+    static constexpr int XP = DWD ? 8 + 2 * DWD : HP;              // staged tile is XP x XP pixels
+    static constexpr int XT_BYTES = DWD ? XP * XP * PB : 0;
+    static constexpr int QUADS = XP * XP * QPP;                    // float4 quads staged per chunk
+    static constexpr int TM = SPLIT ? 2 : 1, TN = SPLIT ? 2 : 1, NWN = 2 / TN; // MFMA tiles per wavefront; wavefronts side by side over the pixels
+    static constexpr int SLABS = MW * NWN * (32 * (TM * 32 + 4) * 4); // the epilogue's transposition slabs (rows_geom<TM>::SLAB_BYTES per wavefront) lie over the dead tiles
+    static constexpr int TILES_BYTES = LDS_BYTES + XT_BYTES;
+    static constexpr int DWW_OFF = TILES_BYTES > SLABS ? TILES_BYTES : SLABS; // dynamic LDS: this + 40 bytes per depthwise channel (DWD)
     static constexpr int KQ = SPLIT ? CK / 16 : CK / 8;            // steps per tap: 32 bytes of a pixel row each
     static constexpr int SPC = KS * KS * KQ;                       // steps per chunk
     static constexpr int RING = SPC % 3 == 0 ? 3 : (SPLIT ? 2 : 4); // A-fragment ring: the step in use + one or two in flight
     static constexpr int AHEAD = RING - 1;                         // steps between an A fragment's request and its use
     // chunks in flight between HBM and LDS (registers): a 1 x 1 layer's chunk is only KQ steps of MFMAs - far shorter than an HBM round trip
     // under load - and Little's law asks for ~40 KB in flight per CU to stream at the rate the layer needs; a 3 x 3 chunk covers its successor
-    static constexpr int DEPTH = KS == 1 ? (SPLIT && (MW < 4 || MW == 8) ? 2 : 3) : 1; // (fewer threads share a tile's staging when MW < 4: 16 quads per thread and chunk at MW = 1)
+    static constexpr int DEPTH = KS != 1 ? 1 : DWD ? (SPLIT && MW == 8 ? 1 : 2) : (SPLIT && (MW < 4 || MW == 8) ? 2 : 3); // (fewer threads share a tile's staging when MW < 4: 16 quads per thread and chunk at MW = 1)
     static_assert(SPC % RING == 0 && SPC % 2 == 0, "ring / double buffer periods");
 };
 
 } // namespace
 
-template <bool SPLIT, int KS, int CK, int MW>
-__global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 : 2) void conv32_direct_kernel(const conv32_params p, int tiles_x, int tiles_y)
+template <bool SPLIT, int KS, int CK, int MW, int DWD = 0>
+__global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && (MW < 4 || (DWD && MW == 4))) ? 1 : 2) void conv32_direct_kernel(const conv32_params p, int tiles_x, int tiles_y)
 {
-    using G = direct32_geom<SPLIT, KS, CK, MW>;
-    constexpr int TM = SPLIT ? 2 : 1, TN = SPLIT ? 2 : 1, NWN = 2 / TN, NT = 64 * MW * NWN, NACC = SPLIT ? 2 : 1;
+    static_assert(DWD == 0 || KS == 1, "a fused depthwise layer feeds a 1 x 1 convolution");
+    using G = direct32_geom<SPLIT, KS, CK, MW, DWD>;
+    constexpr int TM = G::TM, TN = G::TN, NWN = G::NWN, NT = 64 * MW * NWN, NACC = SPLIT ? 2 : 1;
+    static_assert(G::SLABS == MW * NWN * rows_geom<TM>::SLAB_BYTES, "slab size");
     constexpr int NFA = SPLIT ? 2 * TM : TM; // A fragments (16 bytes per lane each) of one step
-    constexpr int HP = G::HP, RP = G::RP, PB = G::PB, KQ = G::KQ, SPC = G::SPC, RING = G::RING, AHEAD = G::AHEAD, DEPTH = G::DEPTH;
+    constexpr int RP = G::RP, PB = G::PB, KQ = G::KQ, SPC = G::SPC, RING = G::RING, AHEAD = G::AHEAD, DEPTH = G::DEPTH;
     constexpr int NQ = (G::QUADS + NT - 1) / NT; // float4 per thread and chunk
-    constexpr int SLABS = MW * NWN * rows_geom<TM>::SLAB_BYTES; // the epilogue's transposition slabs lie over the (then dead) halo tile
-    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES > SLABS ? G::LDS_BYTES : SLABS];
+    constexpr int XT_OFF = G::LDS_BYTES, XP = G::XP, DWW_OFF = G::DWW_OFF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[]; // G::DWW_OFF bytes (+ 40 bytes per depthwise channel when DWD)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
@@ -106,14 +118,15 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
     for (int i = 0; i < NQ; ++i) {
         const int q = tid + i * NT;
         const int hp = min(q, G::QUADS - 1) / G::QPP, c4 = q % G::QPP;
-        const int hy = hp / HP, hx = hp - hy * HP;
+        const int hy = hp / XP, hx = hp - hy * XP;
         // (the tensor's zero halo covers the padding rows / columns below and right of the image too; pixels of a ragged last tile
         // beyond it are clamped to it and zeroed - they only feed output pixels that are never stored)
-        const int y = y0 + hy - p.pad_t, x = x0 + hx - p.pad_l;
-        const int ymax = p.H - 1 + (KS - 1 - p.pad_t), xmax = p.W - 1 + (KS - 1 - p.pad_l);
+        const int pt = DWD ? DWD : p.pad_t, pl = DWD ? DWD : p.pad_l, reach = DWD ? 2 * DWD : KS - 1;
+        const int y = y0 + hy - pt, x = x0 + hx - pl;
+        const int ymax = p.H - 1 + (reach - pt), xmax = p.W - 1 + (reach - pl);
         qok[i] = y <= ymax && x <= xmax && q < G::QUADS;
         goff[i] = tvd_off(p.in, b, min(y, ymax), min(x, xmax)) + c4 * 4;
-        soff[i] = hy * RP + hx * PB + (SPLIT ? c4 * 8 : c4 * 16);
+        soff[i] = DWD ? XT_OFF + hp * PB + c4 * 16 : hy * RP + hx * PB + (SPLIT ? c4 * 8 : c4 * 16);
     }
     f32x4 stage[DEPTH][NQ]; // stage[0] = the chunk about to be written to LDS, stage[d] = d chunks later
     auto gload = [&](int d, int c) {
@@ -129,7 +142,9 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
                 f32x4 x = stage[0][i];
                 if (!qok[i])
                     x = f32x4{ 0.f, 0.f, 0.f, 0.f };
-                if constexpr (SPLIT) {
+                if constexpr (DWD != 0) {
+                    *reinterpret_cast<f32x4*>(lds + soff[i]) = x; // the depthwise input, as it is
+                } else if constexpr (SPLIT) {
                     _Float16 h[4], l[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -144,6 +159,57 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
             }
         }
     };
+
+    // ---- fused depthwise 3 x 3 (DWD > 0): the chunk's 64 pixels x CK channels from the staged input tile into the MFMAs' tile.  Quad q =
+    // (pixel q / QPP, channels 4 (q % QPP) ..): a thread's channel quad is the same for all its pixels; taps in (ky, kx) order, fmaf, bias
+    // first - dwconv32_kernel's arithmetic, so fusing does not change a bit of the depthwise result
+    auto dw_compute = [&](int c) {
+        if constexpr (DWD != 0) {
+            constexpr int OQ = 64 * G::QPP;
+            const float* const dww = reinterpret_cast<const float*>(lds + DWW_OFF);
+#pragma unroll 1
+            for (int i = 0; i < (OQ + NT - 1) / NT; ++i) { // (one quad at a time: nine tile reads + nine weight reads live, not 4 x that)
+                const int q = tid + i * NT;
+                if (q < OQ) {
+                    const int px = q / G::QPP, c4 = q % G::QPP, oy = px >> 3, ox = px & 7;
+                    const int ch = c * CK + c4 * 4;
+                    f32x4 a = *reinterpret_cast<const f32x4*>(dww + 9 * p.Cin + ch);
+                    const unsigned char* const xt = lds + XT_OFF + (oy * XP + ox) * PB + c4 * 16;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const f32x4 x = *reinterpret_cast<const f32x4*>(xt + (ky * DWD * XP + kx * DWD) * PB);
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(dww + (ky * 3 + kx) * p.Cin + ch);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                a[e] = __builtin_fmaf(x[e], w[e], a[e]);
+                        }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        a[e] = a[e] > 0.f ? fminf(a[e], p.dw_hi) : a[e] * p.dw_slope;
+                    unsigned char* const dst = lds + oy * RP + ox * PB;
+                    if constexpr (SPLIT) {
+                        _Float16 h[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            h[e] = (_Float16)a[e];
+                            l[e] = (_Float16)((a[e] - (float)h[e]) * 2048.f);
+                            ovf |= __builtin_fabsf(a[e]) > 65504.f;
+                        }
+                        *reinterpret_cast<half4v*>(dst + c4 * 8) = half4v{ h[0], h[1], h[2], h[3] };
+                        *reinterpret_cast<half4v*>(dst + c4 * 8 + CK * 2) = half4v{ l[0], l[1], l[2], l[3] };
+                    } else
+                        *reinterpret_cast<f32x4*>(dst + c4 * 16) = a;
+                }
+            }
+        }
+    };
+    if constexpr (DWD != 0) { // the depthwise weights and biases of every chunk: [9][C] + [C] floats, once per block (the first barrier covers them)
+        float* const dww = reinterpret_cast<float*>(lds + DWW_OFF);
+        for (int i = tid; i < 10 * p.Cin / 4; i += NT)
+            *reinterpret_cast<f32x4*>(dww + i * 4) = *reinterpret_cast<const f32x4*>(p.dw_w + i * 4);
+    }
 
     // ---- A fragments: steps run (chunk, tap, step of the tap) in packing order; a step's fragments of this wavefront are contiguous
     constexpr int FRAG = SPLIT ? 512 : 256;             // elements (halves / floats) of one 1 KB fragment
@@ -186,7 +252,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
     int s = 0; // global step index
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
-        if (c)
+        if (c && DWD == 0)
             lds_barrier(); // every wavefront is done reading the previous chunk's tile
         to_lds();
 #pragma unroll
@@ -196,6 +262,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && MW < 4) ? 1 :
                 stage[d][i] = stage[d + 1][i];
         gload(DEPTH - 1, c + DEPTH); // (past the last chunk: a harmless re-read of it)
         lds_barrier();
+        if constexpr (DWD != 0) { // (that barrier: the depthwise input tile is complete AND every wavefront has left the previous chunk's MFMAs)
+            dw_compute(c);
+            lds_barrier();
+        }
         HP_STAMP();
         u32x4 fb[2][TN][NACC]; // [buffer][n tile][SPLIT: hi | lo]
 #pragma unroll
@@ -391,7 +461,7 @@ static int direct_mw(const conv32_params& p, bool split)
     return 1;
 }
 
-int conv32_direct_tile(const conv32_params& p, bool split) { return (split ? 33000000 : 34000000) + p.KH * 1000 + direct_mw(p, split); }
+int conv32_direct_tile(const conv32_params& p, bool split) { return (split ? 33000000 : 34000000) + (p.dw_w ? 100000 * p.dw_dil : 0) + p.KH * 1000 + direct_mw(p, split); }
 
 // Host side: the packed fp32 matrix [tap][Cout_pad][Cin] (conv32_params::w's layout) in the kernels' fragment order.
 //   split: [chunk][tap][k16][32-row tile][hi | lo][lane][8 halves]      (2 * taps * cout_pad * cin halves)
@@ -431,30 +501,65 @@ void conv32_frag_pack(const float* packed, int taps, int cout_pad, int cin, floa
                 }
 }
 
+// The depthwise-fused forms that are compiled: dilation 1 | 2; split: 2 / 4 / 8 wavefronts of 64 channels, fp32: 2 / 4 wavefront pairs of 32.
+bool conv32_dw_fusable(const conv32_params& p, bool split, int dil)
+{
+    if (!conv32_direct_ok(p) || p.KH != 1 || (dil != 1 && dil != 2))
+        return false;
+    const int mw = direct_mw(p, split);
+    return split ? (mw == 2 || mw == 4 || (mw == 8 && dil == 1)) : (mw == 2 || mw == 4); // (8 wavefronts at dilation 2: 68 spilled registers - not compiled)
+}
+
+template <bool SPLIT, int KS, int CK, int MW, int DWD>
+static hipError_t launch_direct_case(const conv32_params& p, dim3 grid, int tiles_x, int tiles_y, hipStream_t s)
+{
+    using G = direct32_geom<SPLIT, KS, CK, MW, DWD>;
+    const size_t lds = (size_t)G::DWW_OFF + (DWD ? (size_t)40 * p.Cin : 0);
+    if (lds > 160 * 1024)
+        return hipErrorInvalidValue;
+    static size_t granted = 0; // (per instantiation: the largest dynamic LDS size the runtime has been told about)
+    if (lds > 64 * 1024 && lds > granted) {
+        const hipError_t e = hipFuncSetAttribute((const void*)conv32_direct_kernel<SPLIT, KS, CK, MW, DWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        granted = lds;
+    }
+    HP_LAUNCH((conv32_direct_kernel<SPLIT, KS, CK, MW, DWD>), grid, dim3((SPLIT ? 64 : 128) * MW), lds, s, p, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv32_direct(const conv32_params& p, bool split, hipStream_t s)
 {
     if (!conv32_direct_ok(p) || !(split ? (const void*)p.w_split : (const void*)p.w_frag) || p.npix <= 0)
         return hipErrorInvalidValue;
     const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 7) / 8, mw = direct_mw(p, split);
     const dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / ((split ? 64 : 32) * mw));
-#define HP_DIRECT_CASE(SPLIT_, KS_, CK_, MW_)                                                                                        \
-    if (split == SPLIT_ && p.KH == KS_ && mw == MW_) {                                                                               \
-        HP_LAUNCH((conv32_direct_kernel<SPLIT_, KS_, CK_, MW_>), grid, dim3((SPLIT_ ? 64 : 128) * MW_), 0, s, p, tiles_x, tiles_y); \
-        return hipGetLastError();                                                                                                    \
-    }
-    HP_DIRECT_CASE(true, 1, 64, 1)
-    HP_DIRECT_CASE(true, 1, 64, 2)
-    HP_DIRECT_CASE(true, 1, 64, 4)
-    HP_DIRECT_CASE(true, 1, 64, 8)
-    HP_DIRECT_CASE(true, 3, 32, 1)
-    HP_DIRECT_CASE(true, 3, 32, 2)
-    HP_DIRECT_CASE(true, 3, 32, 4)
-    HP_DIRECT_CASE(false, 1, 64, 1)
-    HP_DIRECT_CASE(false, 1, 64, 2)
-    HP_DIRECT_CASE(false, 1, 64, 4)
-    HP_DIRECT_CASE(false, 3, 32, 1)
-    HP_DIRECT_CASE(false, 3, 32, 2)
-    HP_DIRECT_CASE(false, 3, 32, 4)
+    const int dwd = p.dw_w ? p.dw_dil : 0;
+#define HP_DIRECT_CASE(SPLIT_, KS_, CK_, MW_, DWD_)                                                               \
+    if (split == SPLIT_ && p.KH == KS_ && mw == MW_ && dwd == DWD_)                                               \
+        return launch_direct_case<SPLIT_, KS_, CK_, MW_, DWD_>(p, grid, tiles_x, tiles_y, s);
+    HP_DIRECT_CASE(true, 1, 64, 1, 0)
+    HP_DIRECT_CASE(true, 1, 64, 2, 0)
+    HP_DIRECT_CASE(true, 1, 64, 4, 0)
+    HP_DIRECT_CASE(true, 1, 64, 8, 0)
+    HP_DIRECT_CASE(true, 3, 32, 1, 0)
+    HP_DIRECT_CASE(true, 3, 32, 2, 0)
+    HP_DIRECT_CASE(true, 3, 32, 4, 0)
+    HP_DIRECT_CASE(false, 1, 64, 1, 0)
+    HP_DIRECT_CASE(false, 1, 64, 2, 0)
+    HP_DIRECT_CASE(false, 1, 64, 4, 0)
+    HP_DIRECT_CASE(false, 3, 32, 1, 0)
+    HP_DIRECT_CASE(false, 3, 32, 2, 0)
+    HP_DIRECT_CASE(false, 3, 32, 4, 0)
+    HP_DIRECT_CASE(true, 1, 64, 2, 1)
+    HP_DIRECT_CASE(true, 1, 64, 4, 1)
+    HP_DIRECT_CASE(true, 1, 64, 8, 1)
+    HP_DIRECT_CASE(true, 1, 64, 2, 2)
+    HP_DIRECT_CASE(true, 1, 64, 4, 2)
+    HP_DIRECT_CASE(false, 1, 64, 2, 1)
+    HP_DIRECT_CASE(false, 1, 64, 4, 1)
+    HP_DIRECT_CASE(false, 1, 64, 2, 2)
+    HP_DIRECT_CASE(false, 1, 64, 4, 2)
 #undef HP_DIRECT_CASE
     return hipErrorInvalidValue;
 }

@@ -39,6 +39,11 @@ struct conv32_params {
     const float* w_frag;
     const _Float16* w_split;
     unsigned* ovf;
+    // a depthwise 3 x 3 (stride 1, dilation dw_dil = 1 | 2, SAME padding) fused in front of this 1 x 1 convolution (conv32_direct_kernel's DWD
+    // forms): `in` is then the DEPTHWISE layer's input; dw_w = [9][Cin] tap-major weights followed by [Cin] biases; y = v > 0 ? min(v, dw_hi) : v * dw_slope
+    const float* dw_w;
+    int dw_dil;
+    float dw_slope, dw_hi;
     int lane_epilogue; // HP_LANE_EPILOGUE=1 (A/B switch): store from the accumulators' lane = pixel layout instead of whole pixel rows (conv32_epilogue.hpp)
     unsigned long long* dbg; // HP_DIRECT_DBG: s_memtime stamps (shader cycles) of block (0, 0)'s thread 0 - start, chunk staged, chunk multiplied, ..., stored
 };
@@ -53,7 +58,9 @@ int conv32_tile(const conv32_params& p); // profile rows: 32000000 + BM * 1000 +
 // hi-hi + 2^-11 (hi-lo + lo-hi), fp32 accumulation (needs w_split).  Cin must be whole chunks (64 channels at 1 x 1, 32 at 3 x 3).
 bool conv32_direct_ok(const conv32_params& p);
 hipError_t launch_conv32_direct(const conv32_params& p, bool split, hipStream_t s);
-int conv32_direct_tile(const conv32_params& p, bool split); // profile rows: 33000000 (split) / 34000000 (fp32) + KS * 1000 + wavefront groups per block
+int conv32_direct_tile(const conv32_params& p, bool split); // profile rows: 33000000 (split) / 34000000 (fp32) + 100000 * fused depthwise dilation + KS * 1000 + wavefront groups per block
+// whether the 1 x 1 layer p can take a depthwise 3 x 3 of dilation `dil` in front of it in the same launch (p.dw_w etc. not yet set)
+bool conv32_dw_fusable(const conv32_params& p, bool split, int dil);
 // packed = [taps][cout_pad][cin] fp32 (conv32_params::w's layout) -> the kernels' fragment order: 2 * taps * cout_pad * cin halves / taps * cout_pad * cin floats
 void conv32_split_pack(const float* packed, int taps, int cout_pad, int cin, _Float16* out);
 void conv32_frag_pack(const float* packed, int taps, int cout_pad, int cin, float* out);

@@ -303,6 +303,43 @@ int hp_engine::build(const hp_engine_desc* d)
             tensors[A.out]->elided = true;
         }
     }
+    // ---- fp32 engines: the same pairing for conv32_direct_kernel's depthwise-fused forms (stride 1, dilation 1 | 2, whole 64-channel chunks;
+    // whether the 1 x 1 half takes them is decided where its parameters are known: pass 2).  HP_NO_FUSE=1 / HP_NO_FUSE32=1 keep two launches.
+    std::vector<char> fuse32_with_next(layers.size(), 0);
+    if (f32 && !getenv("HP_NO_FUSE") && !getenv("HP_NO_FUSE32")) {
+        for (size_t i = 0; i + 1 < layers.size(); ++i) {
+            const hp_layer &A = layers[i], &Bn = layers[i + 1];
+            if (A.op != HP_OP_DWCONV || A.kh != 3 || A.kw != 3 || A.in == 0 || A.out_coff != 0 || A.in_coff % 4 || A.stride != 1 || (A.dil != 1 && A.dil != 2)
+                || A.cin % 64 || A.res >= 0)
+                continue;
+            if (A.act != HP_ACT_NONE && A.act != HP_ACT_RELU && A.act != HP_ACT_RELU6 && A.act != HP_ACT_LEAKY)
+                continue;
+            if (Bn.op != HP_OP_CONV || Bn.kh != 1 || Bn.kw != 1 || Bn.stride != 1 || Bn.in != A.out || Bn.in_coff != 0 || Bn.cin != A.cout || Bn.out == A.out
+                || Bn.res == A.out)
+                continue;
+            if (tensors[A.out]->C != A.cout || geos[i].OH != tensors[A.in]->H || geos[i].OW != tensors[A.in]->W || geos[i].pt != A.dil || geos[i].pl != A.dil
+                || geos[i + 1].OH != geos[i].OH || geos[i + 1].OW != geos[i].OW || geos[i + 1].pt || geos[i + 1].pl)
+                continue; // TF-SAME geometry of a stride-1 3 x 3: the map keeps its size, the padding is the dilation; the 1 x 1 half does not pad
+            bool sole = true;
+            for (size_t j = 0; j < layers.size(); ++j)
+                if (j != i + 1 && (layers[j].in == A.out || layers[j].res == A.out || (j != i && layers[j].out == A.out)))
+                    sole = false;
+            for (int o = 0; o < d->n_outputs; ++o)
+                if (d->outputs[o].tensor == A.out)
+                    sole = false;
+            if (!sole)
+                continue;
+            // the 1 x 1 half as pass 2 will describe it, to ask the kernel family whether a fused form exists for its size
+            hp::conv32_params q{};
+            q.B = max_batch, q.H = q.OH = geos[i].OH, q.W = q.OW = geos[i].OW, q.Cin = Bn.cin, q.Cout = Bn.cout, q.Cout_pad = round_up(Bn.cout, 64);
+            q.KH = q.KW = 1, q.stride = 1, q.dil = 1, q.pad_t = q.pad_l = 0, q.npix = max_batch * q.OH * q.OW;
+            // (an HP_DTYPE_F32S engine must also be able to run the block on the fp32 pipe: where it goes when a value leaves fp16's range)
+            if (!hp::conv32_dw_fusable(q, false, A.dil) || (dtype == HP_DTYPE_F32S && !hp::conv32_dw_fusable(q, true, A.dil)))
+                continue;
+            fuse32_with_next[i] = 1;
+            tensors[A.out]->elided = true;
+        }
+    }
     // ---- two-layer heads: 1x1 K1 -> 512 (relu) whose only consumer is the next layer, a 1x1 512 -> <= 64 channels
     std::vector<char> head_with_next(layers.size(), 0);
     if (!getenv("HP_NO_FUSE") && !f32) {
@@ -423,6 +460,9 @@ int hp_engine::build(const hp_engine_desc* d)
         if (f32) {
             // ---- HP_DTYPE_F32: one fp32 launch per layer (conv_fp32.hip), weights uploaded as they are
             st.f32 = true;
+            if (fuse32_with_next[i]) // the depthwise half of a fused separable block: described at the 1 x 1 layer that follows
+                continue;
+            const bool dw_in_front = i > 0 && fuse32_with_next[i - 1];
             auto padded = [&](int64_t off, int n, int n_pad, const char* what, std::vector<float>& v) -> bool {
                 v.assign(n_pad, 0.f);
                 if (off < 0)
@@ -457,8 +497,11 @@ int hp_engine::build(const hp_engine_desc* d)
                 st.bytes = (double)ti.H * ti.W * 3 + opix * L.cout * 4 + nw * 4;
             } else if (L.op == HP_OP_CONV) {
                 const int cin_pad = round_up(L.cin, 16), cout_pad = round_up(L.cout, 64), taps = L.kh * L.kw;
-                HP_REQUIRE(L.in_coff % 4 == 0 && L.in_coff + cin_pad <= ti.cs, HP_ERR_INVALID,
-                    "layer %zu: channel slice [%d,+%d) not 4-aligned / exceeds the padded stride %d", i, L.in_coff, cin_pad, ti.cs);
+                // (behind a fused depthwise layer the tensor this layer "reads" is never materialised: what the kernel reads is the depthwise input)
+                const tensor_info& tsrc = dw_in_front ? *tensors[layers[i - 1].in] : ti;
+                const int src_coff = dw_in_front ? layers[i - 1].in_coff : L.in_coff;
+                HP_REQUIRE(src_coff % 4 == 0 && src_coff + cin_pad <= tsrc.cs, HP_ERR_INVALID,
+                    "layer %zu: channel slice [%d,+%d) not 4-aligned / exceeds the padded stride %d", i, src_coff, cin_pad, tsrc.cs);
                 const size_t nw = (size_t)L.cout * taps * L.cin;
                 const float* w = blob(L.w_off, nw, "weights", i);
                 std::vector<float> bias, alpha;
@@ -485,6 +528,27 @@ int hp_engine::build(const hp_engine_desc* d)
                 p.in = ti.view32(L.in_coff);
                 p.H = ti.H, p.W = ti.W, p.OH = g.OH, p.OW = g.OW, p.Cin = cin_pad, p.Cout = L.cout, p.Cout_pad = cout_pad;
                 p.KH = L.kh, p.KW = L.kw, p.stride = L.stride, p.dil = L.dil, p.pad_t = g.pt, p.pad_l = g.pl;
+                p.dw_w = nullptr, p.dw_dil = 0, p.dw_slope = 1.f, p.dw_hi = __builtin_huge_valf();
+                if (dw_in_front) { // conv32_direct_kernel's fused form: `in` is the depthwise layer's input, its weights ride along as [9][C] + [C]
+                    const hp_layer& D = layers[i - 1];
+                    const float* dwf = blob(D.w_off, (size_t)D.cin * 9, "weights", i - 1);
+                    std::vector<float> dbias;
+                    if (!dwf || !padded(D.b_off, D.cin, D.cin, "bias", dbias))
+                        return HP_ERR_INVALID;
+                    std::vector<float> dpack((size_t)10 * D.cin);
+                    for (int c = 0; c < D.cin; ++c) {
+                        for (int t = 0; t < 9; ++t)
+                            dpack[(size_t)t * D.cin + c] = dwf[(size_t)c * 9 + t];
+                        dpack[(size_t)9 * D.cin + c] = dbias[c];
+                    }
+                    void* ddw = nullptr;
+                    HP_TRY(upload(dpack.data(), dpack.size() * sizeof(float), &ddw));
+                    p.dw_w = (const float*)ddw, p.dw_dil = D.dil;
+                    p.dw_slope = D.act == HP_ACT_NONE ? 1.f : D.act == HP_ACT_LEAKY ? D.act_param : 0.f;
+                    p.dw_hi = D.act == HP_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+                    p.in = tensors[D.in]->view32(D.in_coff);
+                    st.layer = (int)i - 1, st.n_layers = 2;
+                }
                 p.act = L.act, p.act_param = L.act_param;
                 p.res = hp::tview32{ nullptr, 0, 0, 0, 0 }, p.res_before_act = L.res_before_act;
                 if (L.res >= 0)
@@ -510,11 +574,13 @@ int hp_engine::build(const hp_engine_desc* d)
                 // stay on conv32_kernel (HP_DIRECT32_MAX_1X1 moves the limit, HP_NO_DIRECT32=1 is the A/B switch)
                 static const bool no_direct = getenv("HP_NO_DIRECT32") != nullptr;
                 static const int direct_max_1x1 = getenv("HP_DIRECT32_MAX_1X1") ? atoi(getenv("HP_DIRECT32_MAX_1X1")) : 64;
-                if (dtype == HP_DTYPE_F32S || (!no_direct && (taps > 1 || cout_pad <= direct_max_1x1))) {
+                if (dtype == HP_DTYPE_F32S || dw_in_front || (!no_direct && (taps > 1 || cout_pad <= direct_max_1x1))) {
                     const int ck = taps == 1 ? 64 : 32, cin_s = round_up(L.cin, ck);
                     hp::conv32_params q = p;
                     q.Cin = cin_s;
-                    if (L.in_coff + cin_s <= ti.cs && hp::conv32_direct_ok(q)) {
+                    HP_REQUIRE(!dw_in_front || (src_coff + cin_s <= tsrc.cs && hp::conv32_direct_ok(q)), HP_ERR_STATE,
+                        "layer %zu: fused behind a depthwise layer but not a direct-kernel layer (engine bug)", i);
+                    if (src_coff + cin_s <= tsrc.cs && hp::conv32_direct_ok(q)) {
                         std::vector<float> wide((size_t)taps * cout_pad * cin_s, 0.f);
                         for (int t = 0; t < taps; ++t)
                             for (int co = 0; co < cout_pad; ++co)
@@ -537,6 +603,8 @@ int hp_engine::build(const hp_engine_desc* d)
                 }
                 st.flops = 2.0 * opix * L.cout * taps * L.cin;
                 st.bytes = (double)ti.H * ti.W * L.cin * 4 + opix * L.cout * 4 + (double)nw * 4;
+                if (dw_in_front) // + the depthwise taps; the tensor between the two layers costs no bytes any more
+                    st.flops += 2.0 * opix * L.cin * 9, st.bytes += (double)L.cin * 10 * 4;
             } else if (L.op == HP_OP_DWCONV) {
                 HP_REQUIRE(L.kh == 3 && L.kw == 3, HP_ERR_INVALID, "layer %zu: depthwise kernels are 3x3", i);
                 HP_REQUIRE(L.cin % 4 == 0 && L.in_coff % 4 == 0 && L.out_coff % 4 == 0, HP_ERR_INVALID, "layer %zu: depthwise needs 4-aligned channels", i);

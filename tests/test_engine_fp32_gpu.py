@@ -109,6 +109,34 @@ def test_depthwise_pool_upsample(hp, f32dtype):
     _run32(net, [Out("y", y, 0, 24), Out("pooled", mp2, 0, 64), Out("up", up2, 0, 64)], _frames(2, 98, 130, seed=6), 98, 130, dtype=f32dtype)
 
 
+@pytest.mark.parametrize("c,cout,dil,dact,h,w", [(64, 128, 1, E.ACT_RELU6, 30, 41), (128, 256, 1, E.ACT_RELU, 23, 17), (256, 512, 2, E.ACT_RELU6, 19, 26),
+                                                    (512, 512, 1, E.ACT_RELU6, 16, 24), (64, 64, 2, E.ACT_LEAKY, 11, 9), (192, 128, 1, E.ACT_NONE, 8, 8)])
+def test_fused_separable_blocks(hp, f32dtype, c, cout, dil, dact, h, w, monkeypatch):
+    """depthwise 3 x 3 (stride 1, dilation 1 | 2) + 1 x 1 in ONE launch (conv32_direct_kernel's DWD forms): against the oracle, and
+    against the two-launch schedule (HP_NO_FUSE32=1) - the depthwise arithmetic is the same fmaf chain, so on the fp32 pipe the two schedules
+    differ only where the 1 x 1 layer's kernel differs (summation order)."""
+    def build(seed=31):
+        net = Net(seed)
+        t0 = net.conv(0, 3, c, 3, 1)
+        d1 = net.conv(t0, c, c, 3, 1, dil, op=E.OP_DWCONV, act=dact, act_param=0.1)
+        p1 = net.conv(d1, c, cout, 1, 1, act=E.ACT_RELU)
+        d2 = net.conv(p1, cout, cout, 3, 1, 1, op=E.OP_DWCONV, act=E.ACT_RELU6)
+        p2 = net.conv(d2, cout, 64, 1, 1, act=E.ACT_NONE, res=-1 if cout != 64 else p1)   # a residual on the 1 x 1 half where shapes allow
+        return net, [Out("y", p2, 0, 64), Out("mid", p1, 0, cout)]
+    frames = _frames(2, h, w, seed=c + dil)
+    net, outs = build()
+    eng, got, ref = _run32(net, outs, frames, h, w, dtype=f32dtype)
+    fused = [p for p in eng.profile(2, iters=1) if p["tile"] // 100000 % 10 in (1, 2) and p["tile"] >= 33000000]
+    assert len(fused) == 2, [p["tile"] for p in eng.profile(2, iters=1)]
+    monkeypatch.setenv("HP_NO_FUSE32", "1")
+    net2, outs2 = build()
+    eng2, got2, _ = _run32(net2, outs2, frames, h, w, dtype=f32dtype)
+    assert not [p for p in eng2.profile(2, iters=1) if p["tile"] // 100000 % 10 in (1, 2) and p["tile"] >= 33000000]
+    for b in range(2):
+        for (nm, a), (_, bq) in zip(got[b], got2[b]):
+            assert np.abs(a - bq).max() <= 2e-5 * np.abs(bq).max() + 1e-6, nm
+
+
 def test_output_post_ops(hp, f32dtype):
     # pixel shuffle + crop + per-component sigmoid / softplus (PifPaf heads) and the PoseProposal grid / scale map
     net = Net(7)
