@@ -339,7 +339,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * MW : 128 * MW, (SPLIT && (MW < 4 || (D
         atomicOr(p.ovf, 1u);
 
     // ---- epilogue
-    if (!p.out_f32 && !p.lane_epilogue) {
+    if (!p.out_f32 && p.lane_epilogue <= 0) {
         // NHWC output only (every layer but the network's heads): row-major through a private LDS slab (conv32_epilogue.hpp)
         lds_barrier(); // every wavefront is done with the halo tile the slabs lie over
         float* const slab = reinterpret_cast<float*>(lds) + wave * (rows_geom<TM>::SLAB_BYTES / 4);
@@ -444,22 +444,27 @@ bool conv32_direct_ok(const conv32_params& p)
 
 // Wavefront groups per block.  All wavefronts of a block share one 8 x 8 pixel tile, so more of them amortise the tile's staging over more
 // output channels - but a layer needs enough blocks for 256 CUs.  SPLIT: MW wavefronts of 64 channels; fp32: MW x 2 wavefronts, 32 MW channels.
-static int direct_mw(const conv32_params& p, bool split)
+// dwd = dilation of a depthwise 3 x 3 fused in front (0: none).  The fused forms exist for 2 / 4 (and, split at dilation 1, 8) groups only: a
+// fused layer takes the largest of those that still leaves enough blocks, 2 at least; 0 = no fused form fits (odd group count).
+static int direct_mw(const conv32_params& p, bool split, int dwd)
 {
     const int groups = p.Cout_pad / (split ? 64 : 32);
     const long tiles = (long)p.B * ((p.OH + 7) / 8) * ((p.OW + 7) / 8);
     static const int force = getenv("HP_DIRECT_MW") ? atoi(getenv("HP_DIRECT_MW")) : 0;
+    static const int mw_max = getenv("HP_DIRECT_MW_MAX") ? atoi(getenv("HP_DIRECT_MW_MAX")) : 8;
     for (int mw : { 8, 4, 2, 1 }) {
-        if (mw == 8 && (!split || p.KH != 1))
-            continue; // (8 wavefronts of 64 channels: the split 1 x 1 layers with 512 outputs read their input tile once)
-        static const int mw_max = getenv("HP_DIRECT_MW_MAX") ? atoi(getenv("HP_DIRECT_MW_MAX")) : 8;
+        if (mw == 8 && (!split || p.KH != 1 || dwd == 2))
+            continue; // (8 wavefronts of 64 channels: the split 1 x 1 layers with 512 outputs read their input tile once; behind a depthwise layer of dilation 2: 68 spilled registers - not compiled)
+        if (dwd && mw == 1)
+            break;
         if ((force && mw != force) || mw > mw_max)
             continue;
-        if (groups % mw == 0 && (force || mw == 1 || tiles * (groups / mw) >= (split ? 256 : 640)))
+        if (groups % mw == 0 && (force || mw == 1 || (dwd && mw == 2) || tiles * (groups / mw) >= (split ? 256 : 640)))
             return mw;
     }
-    return 1;
+    return dwd ? 0 : 1;
 }
+static int direct_mw(const conv32_params& p, bool split) { return direct_mw(p, split, p.dw_w ? p.dw_dil : 0); }
 
 int conv32_direct_tile(const conv32_params& p, bool split) { return (split ? 33000000 : 34000000) + (p.dw_w ? 100000 * p.dw_dil : 0) + p.KH * 1000 + direct_mw(p, split); }
 
@@ -504,10 +509,7 @@ void conv32_frag_pack(const float* packed, int taps, int cout_pad, int cin, floa
 // The depthwise-fused forms that are compiled: dilation 1 | 2; split: 2 / 4 / 8 wavefronts of 64 channels, fp32: 2 / 4 wavefront pairs of 32.
 bool conv32_dw_fusable(const conv32_params& p, bool split, int dil)
 {
-    if (!conv32_direct_ok(p) || p.KH != 1 || (dil != 1 && dil != 2))
-        return false;
-    const int mw = direct_mw(p, split);
-    return split ? (mw == 2 || mw == 4 || (mw == 8 && dil == 1)) : (mw == 2 || mw == 4); // (8 wavefronts at dilation 2: 68 spilled registers - not compiled)
+    return conv32_direct_ok(p) && p.KH == 1 && (dil == 1 || dil == 2) && direct_mw(p, split, dil) != 0;
 }
 
 template <bool SPLIT, int KS, int CK, int MW, int DWD>

@@ -56,7 +56,10 @@ __device__ __forceinline__ long tv32_off(const tview32& t, int b, int y, int x)
 // K order inside a group of 8 channels: lane (row, h) reads channels [4h, 4h + 4) of its row with one ds_read_b128 and feeds element e
 // to MFMA e, i.e. MFMA e multiplies channels {e, 4 + e} - A and B use the same permutation, so the sum over the 8 channels is complete.
 // LDS rows are 20 floats (80 B): the 16 lanes of a ds_read_b128 service group then touch 64 distinct banks.
-template <int BM, int BN, int WM, int WN>
+// ROWS = the row-major epilogue (NHWC output only); !ROWS = the lane = pixel epilogue (the network's heads; HP_LANE_EPILOGUE=1: every layer).
+// A template parameter, not a branch: with both epilogues in one body the kernel carries the register peak of the larger one into every
+// launch (conv32_kernel<64, 128>: 92 registers with the lane form alone, 140 - 184 with both) and the store-bound 1 x 1 layers lose a block per CU.
+template <int BM, int BN, int WM, int WN, bool ROWS>
 __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
 {
     constexpr int BK = 16, LDR = 20;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
     }
 
     // epilogue
-    if (!p.out_f32 && !p.lane_epilogue) {
+    if constexpr (ROWS) {
         // NHWC output only (every layer but the network's heads): row-major through a private LDS slab (conv32_epilogue.hpp)
         lds_barrier(); // every wavefront is done with the last K-step's tiles the slabs lie over
         float* const slab = reinterpret_cast<float*>(lds_raw) + wave * (rows_geom<TM>::SLAB_BYTES / 4);
@@ -167,8 +170,7 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
                 roff = p.res.p ? tv32_off(p.res, b, oy, ox) : 0;
             });
         }
-        return;
-    }
+    } else {
     // the network's heads (fp32 NCHW for the parsers, runs along x): lane (n, h) of a 32 x 32 tile holds rows (r & 3) + 8 (r >> 2) + 4 h of
     // column n, four consecutive channels per r >> 2
     const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
             }
         }
     }
+    }
 }
 
 // Block tile (BM output channels x BN pixels) of a layer.  The fp32 matrix pipe is slow enough (64 cycles per MFMA) that small tiles cost
@@ -298,12 +301,25 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
     int BM, BN;
     conv32_pick(p, BM, BN);
     const dim3 grid((p.npix + BN - 1) / BN, p.Cout_pad / BM);
-    if (BM == 128)
-        HP_LAUNCH((conv32_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
-    else if (BN == 128)
-        HP_LAUNCH((conv32_kernel<64, 128, 1, 4>), grid, dim3(256), 0, s, p);
-    else
-        HP_LAUNCH((conv32_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, p);
+    // The row-major epilogue pays on the 64-pixel tile only.  Measured per layer of LW-OpenPose @ 8 x 46 x 54 (us alone | with a second
+    // stream; rows -> lane = pixel): <64, 64> 256 -> 256 33.2 | 26.9 -> 33.8 | 29.2, 128 -> 256 21.3 | 15.8 -> 21.7 | 19.0;  <64, 128> (two
+    // channel tiles per wavefront: eight pixel rows of 256 B in flight per lane group) 128 -> 512 61.5 | 40.3 -> 35.1 | 27.4, 32 -> 64 at
+    // 184 x 216 59.2 | 46.6 -> 36.0 | 29.6, 512 -> 512 129 | 93 -> 106 | 94 (gpurun_out s2, round 5).  HP_LANE_EPILOGUE=1: lane form everywhere,
+    // HP_LANE_EPILOGUE=-1: row form everywhere.
+    const bool rows = !p.out_f32 && (p.lane_epilogue < 0 || (p.lane_epilogue == 0 && BN == 64));
+#define HP_C32_CASE(BM_, BN_, WM_, WN_)                                                    \
+    if (rows)                                                                              \
+        HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, true>), grid, dim3(256), 0, s, p);    \
+    else                                                                                   \
+        HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, s, p);
+    if (BM == 128) {
+        HP_C32_CASE(128, 128, 2, 2)
+    } else if (BN == 128) {
+        HP_C32_CASE(64, 128, 1, 4)
+    } else {
+        HP_C32_CASE(64, 64, 2, 2)
+    }
+#undef HP_C32_CASE
     return hipGetLastError();
 }
 

@@ -44,7 +44,7 @@ struct conv32_params {
     const float* dw_w;
     int dw_dil;
     float dw_slope, dw_hi;
-    int lane_epilogue; // HP_LANE_EPILOGUE=1 (A/B switch): store from the accumulators' lane = pixel layout instead of whole pixel rows (conv32_epilogue.hpp)
+    int lane_epilogue; // HP_LANE_EPILOGUE (A/B switch): 0 = per kernel (launch_conv32: rows on the 64-pixel tile; direct kernels: rows), 1 = the accumulators' lane = pixel layout everywhere, -1 = whole pixel rows everywhere (conv32_epilogue.hpp)
     unsigned long long* dbg; // HP_DIRECT_DBG: s_memtime stamps (shader cycles) of block (0, 0)'s thread 0 - start, chunk staged, chunk multiplied, ..., stored
 };
 // fills act_slope / act_hi from act / act_param; false for activations the epilogue does not evaluate (sigmoid / softplus are output post-ops)

@@ -305,8 +305,12 @@ int hp_engine::build(const hp_engine_desc* d)
     }
     // ---- fp32 engines: the same pairing for conv32_direct_kernel's depthwise-fused forms (stride 1, dilation 1 | 2, whole 64-channel chunks;
     // whether the 1 x 1 half takes them is decided where its parameters are known: pass 2).  HP_NO_FUSE=1 / HP_NO_FUSE32=1 keep two launches.
+    // Default: HP_DTYPE_F32S only.  Measured on LW-OpenPose @ 8 x 46 x 54 (us per batch alone | with a second stream, fused -> two launches):
+    // split 1528 | 1077 -> 1514 | 1079 (nothing lost, one 40 MB tensor per block not allocated); fp32 pipe 2880 | 2294 -> 2671 | 1984: the fused
+    // form computes the depthwise tile once per 128-channel block of the 1 x 1 layer (4 x at 512 outputs) between two barriers, the MFMA pipe
+    // idle meanwhile - 194 us for dw + 512 -> 512 against 24.5 + 100.  HP_FUSE32=1 fuses on the fp32 pipe too (tests).
     std::vector<char> fuse32_with_next(layers.size(), 0);
-    if (f32 && !getenv("HP_NO_FUSE") && !getenv("HP_NO_FUSE32")) {
+    if (f32 && !getenv("HP_NO_FUSE") && !getenv("HP_NO_FUSE32") && (dtype == HP_DTYPE_F32S || getenv("HP_FUSE32"))) {
         for (size_t i = 0; i + 1 < layers.size(); ++i) {
             const hp_layer &A = layers[i], &Bn = layers[i + 1];
             if (A.op != HP_OP_DWCONV || A.kh != 3 || A.kw != 3 || A.in == 0 || A.out_coff != 0 || A.in_coff % 4 || A.stride != 1 || (A.dil != 1 && A.dil != 2)
