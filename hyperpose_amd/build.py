@@ -34,6 +34,7 @@ UNITS = [
     ("conv_bottleneck.hip", []),
     ("conv_fp32.hip", []),
     ("conv32_direct.hip", []),
+    ("conv32_winograd.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),
     ("onnx_import.cpp", []),

@@ -1,0 +1,326 @@
+// conv32_winograd.hip — the 3 x 3, stride-1 convolutions of the fp32 engine (HP_DTYPE_F32, data_type::kFLOAT) in Winograd's minimal form
+// F(2 x 2, 3 x 3) on the fp32 matrix pipe (interface: conv_fp32.hpp).
+//
+// The fp32 pipe (v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD, 157 TFLOP/s) is the bound of every dense fp32 layer here, so the lever left is the
+// number of multiplications.  For a 2 x 2 output tile and a 3 x 3 filter (Lavin & Gray; what cuDNN / TensorRT pick for fp32 3 x 3 layers - the
+// reference's engine, src/tensorrt.cpp:327-353, leaves the choice to the TensorRT builder):
+//        Y = At [ (G g Gt) . (Bt d B) ] A            d: the 4 x 4 input patch, g: the filter, ".": element-wise, summed over input channels
+//        Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]    G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]    At = [1 1 1 0; 0 1 -1 -1]
+// i.e. 16 multiplications per tile and channel pair instead of 36: the sum over input channels is 16 independent matrix products
+//        M[pos][cout][tile] = sum_c U[pos][cout][c] V[pos][c][tile]          U = G g Gt (host, once),  V = Bt d B (per launch, in LDS)
+// - 2.25 x fewer MFMA cycles than the direct form.  Input and output transforms are additions only; U's factors 1/2 and 1/4 are exact in binary
+// and U is rounded to fp32 once on the host (computed in double).  The products and sums of the 16 matrix products are exact fp32 FMAs on the
+// matrix pipe like everywhere else in this engine; what changes against the direct form is the order of summation and the cancellation inside the
+// transforms - measured against the pure fp32 oracle in tests/test_engine_fp32_gpu.py (same 1e-4 bound as every fp32 kernel; DESIGN.md 7 has the
+// measured figures).
+//
+// Kernel shape (MW = wavefronts per block, 4 by default):
+//   block   = 16 x 8 output pixels = 8 x 4 Winograd tiles (two N = 16 column tiles of the MFMA) x 16 MW output channels; a wavefront = ONE
+//             16-row MFMA tile of channels x 32 tiles x 16 positions = 128 accumulator registers.  MW = 4: two blocks per CU - one block's
+//             transform phases and epilogue run under the other's MFMAs; MW = 8 (HP_WINO_MW=8): one block of two wavefronts per SIMD per
+//             CU, the staging / transform of a pixel tile shared by 128 channels - 44.6 us alone against 46.3 for a 128 -> 128 layer at
+//             8 x 46 x 54, but 31.5 against 28.8 with a second stream (its phases are in step inside the one block).
+//             (The first form - 32 channels x 16 tiles per wavefront - read 2 KB of A per eight MFMAs: 68 us alone.)
+//   K loop  = chunks of 16 input channels.  The chunk's 18 x 10 halo patch arrives from HBM as fp32 (requested one chunk ahead, into
+//             registers), goes to LDS, is transformed cooperatively (a wavefront = ONE row of Bt d B for 16 tiles, lane = (tile, 4-channel
+//             quad): 8 LDS reads, 8 vector additions, 4 LDS writes) into V[pos][tile][16 channels]; two barriers per chunk;
+//   MFMA    = per position one step of 16 channels: lane (row / tile, kq) holds channels 4 kq .. 4 kq + 3 of its row (A, 1 KB from L2 in
+//             fragment order, six steps ahead) / tile (B, two ds_read_b128 from V) and feeds element e to MFMA e - 8 MFMAs of 32 cycles per step;
+//   output  = At M A per lane from its own registers (lane (tile, kq) holds channels 4 kq + r at all 16 positions), written into a slab the
+//             block shares ([128 pixels][16 MW channels]), then the row-major epilogue of conv32_epilogue.hpp: whole pixel rows.
+// Block timeline (tools/direct_timeline.py f32; shader cycles, MW = 4): start 3.0 k | per chunk: staged 0.7 - 1.1 k, transformed 1.9 - 2.5 k,
+// multiplied 4.9 - 7.0 k (4.1 k of MFMA issue per wavefront; the SIMD is shared with the other block's wavefront) | output 15.6 k.
+#include "conv_fp32.hpp"
+
+#include "conv32_epilogue.hpp"
+#include "conv_device.hpp"
+
+#include <cstdlib>
+#include <vector>
+
+namespace hp {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WCK = 16;                        // input channels per chunk
+constexpr int HALO_H = 18, HALO_W = 10;        // halo patch of the 16 x 8 pixel tile
+constexpr int RAW_Q = HALO_H * HALO_W * 4;     // 720 float4 quads (64 bytes per pixel)
+constexpr int RAW_PB = WCK * 4;
+constexpr int VP = 24 * 4;                     // V row (one tile, 16 channels) pitch in bytes: 24 floats - the transform's ds_write_b128 and the MFMA's ds_read_b128 are conflict-free
+constexpr int VPOS = 32 * VP, VBUF = 16 * VPOS; // one position (32 tiles), all 16 positions: 49152 bytes
+
+template <int MW>
+struct wino_geom {
+    static constexpr int NT = 64 * MW;
+    static constexpr int NQ = (RAW_Q + NT - 1) / NT;  // quads per thread and chunk
+    static constexpr int RAW_BYTES = NQ * NT * 16;    // + room for the surplus threads' (discarded) quads: the store to LDS has no branch
+    static constexpr int NI = 8 / MW;                 // transform items (row of Bt d B, half of the tiles) per wavefront and chunk
+    static constexpr int TMS = MW / 2;                // the block's output slab: [128 pixel rows][16 MW channels + 4] = rows_geom<TMS>
+    static constexpr int SLAB_PITCH = rows_geom<TMS>::PITCH, SLAB_BYTES = 128 * SLAB_PITCH * 4;
+    static constexpr int LDS_BYTES = RAW_BYTES + (VBUF > SLAB_BYTES ? VBUF : SLAB_BYTES); // MW = 4: 61440 (two blocks per CU), MW = 8: 83968 (one)
+};
+
+__device__ __forceinline__ long tvw_off(const tview32& t, int b, int y, int x)
+{
+    return ((long)b * t.img + (long)y * t.wp + x) * t.cs + t.coff;
+}
+
+} // namespace
+
+template <int MW>
+__global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kernel(const conv32_params p, int tiles_x, int tiles_y)
+{
+    using G = wino_geom<MW>;
+    constexpr int NT = G::NT, NQ = G::NQ, SLAB_PITCH = G::SLAB_PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[]; // G::LDS_BYTES
+    unsigned char* const raw = lds;
+    unsigned char* const vb = lds + G::RAW_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * 16, x0 = tx * 8;
+    const int MT = p.Cout_pad / 16, mt = blockIdx.y * MW + wave;
+    const int nch = p.Cin / WCK;
+    int dbg_i = 0;
+#define HP_STAMP()                                                     \
+    if (p.dbg && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0)       \
+        p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
+    if (p.dbg && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0)
+        p.dbg[119] = __builtin_readcyclecounter(), p.dbg[120] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- staging geometry: quad q of a chunk = (halo pixel q / 4, channels 4 (q % 4) ..); halo pixel (hy, hx) = image pixel (y0 - 1 + hy, x0 - 1 + hx).
+    // The tensor's zero halo is the convolution's padding; pixels further out (ragged last tiles, the fourth patch row / column of an odd-sized
+    // map) are clamped to it and zeroed - they only feed outputs that are never stored
+    long goff[NQ];
+    bool qok[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = min(tid + i * NT, RAW_Q - 1);
+        const int hp = q >> 2, c4 = q & 3;
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        qok[i] = y <= p.H && x <= p.W;
+        goff[i] = tvw_off(p.in, b, min(y, p.H), min(x, p.W)) + c4 * 4;
+    }
+    f32x4 stage[NQ];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+            stage[i] = *reinterpret_cast<const f32x4*>(p.in.p + goff[i] + min(c, nch - 1) * WCK);
+    };
+    auto to_lds = [&]() { // (no branch: with one, hipcc drains EVERY load in flight - the A fragments of the next steps too - before the first store)
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+            *reinterpret_cast<f32x4*>(raw + (tid + i * NT) * 16) = qok[i] ? stage[i] : f32x4{ 0.f, 0.f, 0.f, 0.f };
+    };
+    // ---- input transform: item of a wavefront = (row i of Bt d B, 16 of the 32 tiles); lane (tile, quad) like the MFMA's B read.  Row i of
+    // T = Bt d combines two patch rows; V[i][.] = T[i][.] B
+    auto transform = [&]() {
+#pragma unroll
+        for (int k = 0; k < G::NI; ++k) {
+            const int item = wave + k * MW, i = item >> 1;
+            const int quad = lane >> 4, tile = (item & 1) * 16 + (lane & 15);
+            const int ra = i == 0 ? 0 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
+            const float sg = i == 1 ? 1.f : -1.f;
+            const unsigned char* const src = raw + ((2 * (tile >> 2)) * HALO_W + 2 * (tile & 3)) * RAW_PB + quad * 16;
+            f32x4 T[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src + (ra * HALO_W + j) * RAW_PB);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(src + (rb * HALO_W + j) * RAW_PB);
+                T[j] = a + sg * bq; // (an exact sign change, then one rounded addition)
+            }
+            unsigned char* const dst = vb + (i * 4) * VPOS + tile * VP + quad * 16;
+            *reinterpret_cast<f32x4*>(dst) = T[0] - T[2];
+            *reinterpret_cast<f32x4*>(dst + VPOS) = T[1] + T[2];
+            *reinterpret_cast<f32x4*>(dst + 2 * VPOS) = T[2] - T[1];
+            *reinterpret_cast<f32x4*>(dst + 3 * VPOS) = T[1] - T[3];
+        }
+    };
+
+    // ---- A fragments: [chunk][pos][16-row tile][lane][4 floats]; step s = chunk * 16 + pos
+    const long step_stride = (long)MT * 256;
+    const float* const wp = p.w_wino + (long)mt * 256 + lane * 4;
+    const int nsteps = nch * 16;
+    constexpr int RING = 8, AHEAD = 6;
+    f32x4 fa[RING];
+    auto aload = [&](int slot, int s) { fa[slot] = *reinterpret_cast<const f32x4*>(wp + (long)min(s, nsteps - 1) * step_stride); };
+
+    f32x4 acc[16][2]; // [position][column tile: tile rows 0 - 3 | 4 - 7 of the block]
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        acc[i][0] = acc[i][1] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+
+    const int btile = lane & 15, kq = lane >> 4;
+    const unsigned char* const vsrc = vb + btile * VP + kq * 16;
+
+    gload(0);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        aload(a, a);
+    int s = 0;
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        to_lds();     // (the previous chunk's transform is behind every wavefront: its second barrier)
+        gload(c + 1); // (past the last chunk: a harmless re-read of it)
+        lds_barrier(); // the patch is complete AND every wavefront has left the previous chunk's MFMAs: V may be overwritten
+        HP_STAMP();
+        transform();
+        lds_barrier();
+        HP_STAMP();
+        f32x4 fb[2][2];
+        fb[0][0] = *reinterpret_cast<const f32x4*>(vsrc);
+        fb[0][1] = *reinterpret_cast<const f32x4*>(vsrc + 16 * VP);
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            const int cur = pos & 1, npos = pos + 1 < 16 ? pos + 1 : pos;
+            fb[cur ^ 1][0] = *reinterpret_cast<const f32x4*>(vsrc + npos * VPOS);
+            fb[cur ^ 1][1] = *reinterpret_cast<const f32x4*>(vsrc + npos * VPOS + 16 * VP);
+            aload((pos + AHEAD) % RING, s + AHEAD); // (16 % RING == 0: the ring position is a compile-time function of pos)
+            const int slot = pos % RING;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][e], fb[cur][0][e], acc[pos][0], 0, 0, 0);
+                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][e], fb[cur][1][e], acc[pos][1], 0, 0, 0);
+            }
+            // issue order of a step: MFMA, LDS read, MFMA, LDS read (the next position's B), MFMA, L2 read (A six steps ahead), 5 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ++s;
+        }
+        HP_STAMP();
+    }
+
+    // ---- output transform Y = At M A, per lane: tile 16 nt + (lane & 15), channels 16 wave + 4 kq + r; then whole pixel rows through the
+    // block's slab.  Slab row (a * 2 + bb) * 32 + tile = output pixel (2 tile_y + a, 2 tile_x + bb) of the block's 16 x 8
+    lds_barrier(); // every wavefront is done with V, which the slab lies over (MW = 8: and beyond)
+    float* const slab = reinterpret_cast<float*>(vb);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        f32x4 S[2][4]; // At M: S[0][j] = M0j + M1j + M2j, S[1][j] = M1j - M2j - M3j
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            S[0][j] = acc[j][nt] + acc[4 + j][nt] + acc[8 + j][nt];
+            S[1][j] = acc[4 + j][nt] - acc[8 + j][nt] - acc[12 + j][nt];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const f32x4 y0v = S[a][0] + S[a][1] + S[a][2], y1v = S[a][1] - S[a][2] - S[a][3];
+            *reinterpret_cast<f32x4*>(slab + ((a * 2 + 0) * 32 + nt * 16 + btile) * SLAB_PITCH + wave * 16 + kq * 4) = y0v;
+            *reinterpret_cast<f32x4*>(slab + ((a * 2 + 1) * 32 + nt * 16 + btile) * SLAB_PITCH + wave * 16 + kq * 4) = y1v;
+        }
+    }
+    lds_barrier(); // the slab holds all 16 MW channels of the block's 128 pixels; wavefront w stores rows (128 / MW) w ..
+    constexpr int RPW = 128 / MW;
+    conv32_drain_rows<G::TMS, RPW>(p, slab + wave * RPW * SLAB_PITCH, lane, blockIdx.y * 16 * MW, [&](int r, bool& ok, long& ooff, long& roff) {
+        const int rr = wave * RPW + r, ab = rr >> 5, tile = rr & 31;
+        const int oy = y0 + 2 * (tile >> 2) + (ab >> 1), ox = x0 + 2 * (tile & 3) + (ab & 1);
+        ok = oy < p.OH && ox < p.OW;
+        const int oyc = min(oy, p.OH - 1), oxc = min(ox, p.OW - 1);
+        ooff = tvw_off(p.out, b, oyc, oxc);
+        roff = p.res.p ? tvw_off(p.res, b, oyc, oxc) : 0;
+    });
+    HP_STAMP();
+#undef HP_STAMP
+    if (p.dbg && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0) // slots 119 - 122: the shader clock and the constant 100 MHz clock at the start / end
+        p.dbg[121] = __builtin_readcyclecounter(), p.dbg[122] = __builtin_amdgcn_s_memrealtime();
+}
+
+// 3 x 3, stride 1, dilation 1, SAME padding, input slice readable in whole 16-channel chunks, NHWC output only (a network head keeps the
+// direct kernel's lane = pixel epilogue for its NCHW copy)
+bool conv32_winograd_ok(const conv32_params& p)
+{
+    return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil == 1 && p.Cin % WCK == 0 && p.Cout_pad % 64 == 0 && p.OH == p.H && p.OW == p.W && p.pad_t == 1
+        && p.pad_l == 1 && !p.out_f32 && p.out.p;
+}
+
+// Wavefronts (16-channel MFMA tiles) per block: 4 (two blocks per CU); HP_WINO_MW=8 where the channel count allows: see "Kernel shape"
+static int winograd_mw(const conv32_params& p)
+{
+    static const int force = getenv("HP_WINO_MW") ? atoi(getenv("HP_WINO_MW")) : 0;
+    return (force == 8 && p.Cout_pad % 128 == 0) ? 8 : 4;
+}
+
+int conv32_winograd_tile(const conv32_params& p) { return 35000000 + 3000 + winograd_mw(p); }
+
+// MFMA work of one launch (what the roofline fraction of this kernel is computed from): 16 products per tile and channel pair
+double conv32_winograd_flops(const conv32_params& p)
+{
+    return 2.0 * 16 * (double)p.B * ((p.OH + 1) / 2) * ((p.OW + 1) / 2) * p.Cout * p.Cin;
+}
+
+// packed = [9 taps][cout_pad][cin] fp32 (conv32_params::w's layout) -> U = G g Gt in fragment order [chunk][pos][16-row tile][lane][4 floats]
+// (16 * cout_pad * cin floats); lane (row, kq) = channels chunk * 16 + 4 kq + {0..3}.  U is formed in double and rounded to fp32 once.
+void conv32_winograd_pack(const float* packed, int cout_pad, int cin, float* out)
+{
+    static const double G[4][3] = { { 1, 0, 0 }, { .5, .5, .5 }, { .5, -.5, .5 }, { 0, 0, 1 } };
+    const int nch = cin / WCK, MT = cout_pad / 16;
+    std::vector<double> U((size_t)16 * cout_pad * cin);
+    for (int m = 0; m < cout_pad; ++m)
+        for (int k = 0; k < cin; ++k) {
+            double g[3][3], Gg[4][3];
+            for (int t = 0; t < 9; ++t)
+                g[t / 3][t % 3] = packed[((size_t)t * cout_pad + m) * cin + k];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 3; ++j)
+                    Gg[i][j] = G[i][0] * g[0][j] + G[i][1] * g[1][j] + G[i][2] * g[2][j];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
+                    U[((size_t)(i * 4 + j) * cout_pad + m) * cin + k] = Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2];
+        }
+    for (int c = 0; c < nch; ++c)
+        for (int pos = 0; pos < 16; ++pos)
+            for (int mt = 0; mt < MT; ++mt) {
+                float* dst = out + (((size_t)c * 16 + pos) * MT + mt) * 256;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = mt * 16 + (lane & 15), k = c * WCK + (lane >> 4) * 4 + e;
+                        dst[lane * 4 + e] = (float)U[((size_t)pos * cout_pad + m) * cin + k];
+                    }
+            }
+}
+
+template <int MW>
+static hipError_t launch_wino_case(const conv32_params& q, dim3 grid, int tiles_x, int tiles_y, hipStream_t s)
+{
+    constexpr int lds = wino_geom<MW>::LDS_BYTES;
+    static bool granted = false;
+    if (lds > 64 * 1024 && !granted) {
+        const hipError_t e = hipFuncSetAttribute((const void*)conv32_winograd_kernel<MW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess)
+            return e;
+        granted = true;
+    }
+    HP_LAUNCH((conv32_winograd_kernel<MW>), grid, dim3(64 * MW), lds, s, q, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv32_winograd(const conv32_params& p, hipStream_t s)
+{
+    if (!conv32_winograd_ok(p) || !p.w_wino || p.npix <= 0)
+        return hipErrorInvalidValue;
+    const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 15) / 16, mw = winograd_mw(p);
+    const dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / (16 * mw));
+    return mw == 8 ? launch_wino_case<8>(p, grid, tiles_x, tiles_y, s) : launch_wino_case<4>(p, grid, tiles_x, tiles_y, s);
+}
+
+hipError_t conv32_winograd_occupancy(const conv32_params& p, int* blocks_per_cu)
+{
+    if (winograd_mw(p) == 8)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, conv32_winograd_kernel<8>, 512, wino_geom<8>::LDS_BYTES);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, conv32_winograd_kernel<4>, 256, wino_geom<4>::LDS_BYTES);
+}
+
+} // namespace hp

@@ -39,6 +39,8 @@ struct conv32_params {
     const float* w_frag;
     const _Float16* w_split;
     unsigned* ovf;
+    // conv32_winograd_kernel (conv32_winograd.hip, HP_DTYPE_F32 only): U = G g Gt of a 3 x 3 stride-1 layer in MFMA-fragment order, or nullptr
+    const float* w_wino;
     // a depthwise 3 x 3 (stride 1, dilation dw_dil = 1 | 2, SAME padding) fused in front of this 1 x 1 convolution (conv32_direct_kernel's DWD
     // forms): `in` is then the DEPTHWISE layer's input; dw_w = [9][Cin] tap-major weights followed by [Cin] biases; y = v > 0 ? min(v, dw_hi) : v * dw_slope
     const float* dw_w;
@@ -64,6 +66,15 @@ bool conv32_dw_fusable(const conv32_params& p, bool split, int dil);
 // packed = [taps][cout_pad][cin] fp32 (conv32_params::w's layout) -> the kernels' fragment order: 2 * taps * cout_pad * cin halves / taps * cout_pad * cin floats
 void conv32_split_pack(const float* packed, int taps, int cout_pad, int cin, _Float16* out);
 void conv32_frag_pack(const float* packed, int taps, int cout_pad, int cin, float* out);
+
+// Winograd F(2 x 2, 3 x 3) on the fp32 matrix pipe for 3 x 3, stride 1, dilation 1, SAME-padded layers with an NHWC output (conv32_winograd.hip):
+// 16 instead of 36 MFMA products per output tile and channel pair.  Needs w_wino (conv32_winograd_pack of the packed matrix).
+bool conv32_winograd_ok(const conv32_params& p);
+hipError_t launch_conv32_winograd(const conv32_params& p, hipStream_t s);
+hipError_t conv32_winograd_occupancy(const conv32_params& p, int* blocks_per_cu); // what the runtime grants this launch's kernel
+int conv32_winograd_tile(const conv32_params& p);     // profile rows: 35000000 + 3000 + wavefronts per block
+double conv32_winograd_flops(const conv32_params& p); // the MFMA work of one launch: 2 * 16 * tiles * Cout * Cin
+void conv32_winograd_pack(const float* packed, int cout_pad, int cin, float* out); // [9][cout_pad][cin] -> 16 * cout_pad * cin floats
 
 struct first_conv32_params {
     const uint8_t* in_u8; // [B][H][W][3] or nullptr

@@ -86,6 +86,7 @@ struct step {
     hp::first_conv32_params fp32{};
     hp::dw32_params dp32{};
     hp::pool32_params pp32{};
+    bool wino = false;     // HP_DTYPE_F32: a 3 x 3 stride-1 layer on conv32_winograd_kernel (cp32.w_wino)
     int cin_split = 0;     // fp32 engines: input channels as conv32_direct_kernel reads them (whole chunks), 0 = the layer stays on conv32_kernel
     int n_layers = 1;      // consecutive layers this step covers
     double flops = 0, bytes = 0; // per frame
@@ -566,7 +567,7 @@ int hp_engine::build(const hp_engine_desc* d)
                     p.out.p = nullptr, to.unwritten = true; // only the fp32 network output is wanted
                 HP_REQUIRE(hp::set_act32(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
                 p.B = max_batch, p.npix = max_batch * g.OH * g.OW;
-                p.w_split = nullptr, p.w_frag = nullptr, p.ovf = ovf_dev, p.dbg = nullptr;
+                p.w_split = nullptr, p.w_frag = nullptr, p.w_wino = nullptr, p.ovf = ovf_dev, p.dbg = nullptr;
                 static const int lane_epi = getenv("HP_LANE_EPILOGUE") ? atoi(getenv("HP_LANE_EPILOGUE")) : 0;
                 p.lane_epilogue = lane_epi;
                 // The layers conv32_direct_kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the buffer's
@@ -607,6 +608,19 @@ int hp_engine::build(const hp_engine_desc* d)
                 }
                 st.flops = 2.0 * opix * L.cout * taps * L.cin;
                 st.bytes = (double)ti.H * ti.W * L.cin * 4 + opix * L.cout * 4 + (double)nw * 4;
+                // HP_DTYPE_F32: 3 x 3 stride-1 layers in Winograd's F(2 x 2, 3 x 3) form - 16 MFMA products per 2 x 2 output tile and channel pair
+                // instead of 36 (conv32_winograd.hip; HP_NO_WINOGRAD32=1 is the A/B switch back to the direct kernel).  The step's `flops` are then the
+                // MFMA work actually issued (what the roofline fraction of this kernel must be computed from), not the direct form's count.
+                if (dtype == HP_DTYPE_F32 && !dw_in_front && !getenv("HP_NO_WINOGRAD32") && hp::conv32_winograd_ok(p)) {
+                    std::vector<float> wu((size_t)16 * cout_pad * cin_pad);
+                    hp::conv32_winograd_pack(packed.data(), cout_pad, cin_pad, wu.data());
+                    void* dwu = nullptr;
+                    HP_TRY(upload(wu.data(), wu.size() * sizeof(float), &dwu));
+                    p.w_wino = (const float*)dwu;
+                    st.wino = true;
+                    st.flops = 2.0 * 16 * ((g.OH + 1) / 2) * ((g.OW + 1) / 2) * (double)L.cout * L.cin;
+                    st.bytes += (double)nw * 4 * (16.0 / 9 - 1);
+                }
                 if (dw_in_front) // + the depthwise taps; the tensor between the two layers costs no bytes any more
                     st.flops += 2.0 * opix * L.cin * 9, st.bytes += (double)L.cin * 10 * 4;
             } else if (L.op == HP_OP_DWCONV) {
@@ -1264,7 +1278,29 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
             HP_HIP_TRY(hp::launch_first_conv32(st.fp32, s));
         } else if (st.op == HP_OP_CONV) {
             st.cp32.B = n, st.cp32.npix = n * st.cp32.OH * st.cp32.OW;
-            if (st.cin_split) { // the direct kernel: on the fp16 pipe (HP_DTYPE_F32S until a value left fp16's range) or on the fp32 pipe
+            if (st.wino) {
+                HP_HIP_TRY(hp::launch_conv32_winograd(st.cp32, s));
+                static const bool dbg_wino = getenv("HP_DIRECT_DBG") != nullptr;
+                if (dbg_wino) { // block timeline (s_memtime = shader cycles, block (1, 0), thread 0), printed per launch
+                    unsigned long long* dbg = nullptr;
+                    HP_HIP_TRY(hipMalloc(&dbg, 128 * 8));
+                    HP_HIP_TRY(hipMemset(dbg, 0, 128 * 8));
+                    hp::conv32_params q = st.cp32;
+                    q.dbg = dbg;
+                    HP_HIP_TRY(hp::launch_conv32_winograd(q, s));
+                    HP_HIP_TRY(hipStreamSynchronize(s));
+                    unsigned long long h[128];
+                    HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "winograd layer %d %d->%d tile %d cycles [start | staged, transformed, multiplied per chunk | stored]:", st.layer, q.Cin, q.Cout,
+                        hp::conv32_winograd_tile(q));
+                    for (int i = 1; i < 119 && h[i]; ++i)
+                        fprintf(stderr, " %llu", h[i] - h[i - 1]);
+                    int occ = 0;
+                    (void)hp::conv32_winograd_occupancy(q, &occ);
+                    fprintf(stderr, " | s_memtime ticks %llu in %llu ticks of the 100 MHz clock; blocks per CU %d\n", h[121] - h[119], h[122] - h[120], occ);
+                    (void)hipFree(dbg);
+                }
+            } else if (st.cin_split) { // the direct kernel: on the fp16 pipe (HP_DTYPE_F32S until a value left fp16's range) or on the fp32 pipe
                 hp::conv32_params q = st.cp32;
                 q.Cin = st.cin_split;
                 HP_HIP_TRY(hp::launch_conv32_direct(q, dtype == HP_DTYPE_F32S && !split_off, s));
@@ -1758,7 +1794,7 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.wino ? hp::conv32_winograd_tile(st.cp32) : st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = ms / iters;
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1811,7 +1847,7 @@ int hp_engine_profile_pair(hp_engine* e, hp_engine* f, int n, int iters, hp_laye
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.wino ? hp::conv32_winograd_tile(st.cp32) : st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = std::max(m0, m1) / (2 * iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1869,7 +1905,7 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.wino ? hp::conv32_winograd_tile(st.cp32) : st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = (float)(acc[k] / iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
