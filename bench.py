@@ -380,11 +380,16 @@ def kernel_label(tile: int):
            20: ("sepconv_pair_kernel<32,64,128>", "the stem's separable blocks 32 -> 64 and 64 -> 128 (stride 2) in one launch, the 64-channel "
                 "tensor between them in LDS only")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
-    if tile >= 33000000 and (tile // 100000) % 10:  # a depthwise 3 x 3 fused in front of the 1 x 1 layer
+    if tile >= 35000000:
+        mw = tile % 1000
+        return (f"conv32_winograd_kernel<{mw}>", f"conv32_winograd_kernel<MW={mw}> (fp32 3x3 stride-1 convolution in Winograd's F(2x2,3x3) form on v_mfma_f32_16x16x4_f32: 16 MFMA "
+                f"products per output tile and channel pair instead of 36; {16 * mw} cout x 16x8 px per block, input transform through LDS, U = G g Gt in fragment order from L2; "
+                "flops = the MFMA work issued)")
+    if 35000000 > tile >= 33000000 and (tile // 100000) % 10:  # a depthwise 3 x 3 fused in front of the 1 x 1 layer
         split, dil, mw = tile < 34000000, (tile // 100000) % 10, tile % 1000
         return (f"conv32_direct_kernel<{'true' if split else 'false'},1,64,{mw},{dil}>", f"conv32_direct_kernel<{'split' if split else 'fp32'},KS=1,MW={mw},DWD={dil}> (separable block in one launch: "
                 f"the depthwise 3x3 (dilation {dil}) computed from its input tile in LDS straight into the tile the 1x1 layer's MFMAs read; {(64 if split else 32) * mw} cout x 8x8 px per block)")
-    if tile >= 34000000:
+    if 35000000 > tile >= 34000000:
         ks, mw = (tile - 34000000) // 1000, tile % 1000
         return (f"conv32_direct_kernel<false,{ks},{64 if ks == 1 else 32},{mw},0>", f"conv32_direct_kernel<fp32,KS={ks},MW={mw}> (exact fp32 products on v_mfma_f32_32x32x2_f32: "
                 f"{32 * mw} cout x 8x8 px per block, {2 * mw} wavefronts of one 32x32 tile, the chunk's halo tile in LDS once for all taps, weights in fragment order from L2, no barrier per K-step)")
@@ -393,10 +398,12 @@ def kernel_label(tile: int):
         return (f"conv32_direct_kernel<true,{ks},{64 if ks == 1 else 32},{mw},0>", f"conv32_direct_kernel<split,KS={ks},MW={mw}> (fp32 convolution with every product formed as three exact "
                 f"fp16 x fp16 MFMA products: {64 * mw} cout x 8x8 px per block, split halo tile in LDS, split weights in fragment order from L2)")
     if tile >= 32000000:
-        bm, bn = (tile - 32000000) // 1000, tile % 1000
+        v = tile - 32000000
+        rows, v = v >= 400000, v % 400000
+        bm, bn = v // 1000, v % 1000
         wm, wn = (1, 4) if (bm, bn) == (64, 128) else (2, 2)
-        return (f"conv32_kernel<{bm},{bn},{wm},{wn}>", f"conv32_kernel<BM={bm},BN={bn}> (fp32 implicit GEMM on v_mfma_f32_32x32x2_f32: {bm} cout x {bn} pixels per block, "
-                "A and B staged through LDS in fp32, K-steps of 16 channels)")
+        return (f"conv32_kernel<{bm},{bn},{wm},{wn},{'true' if rows else 'false'}>", f"conv32_kernel<BM={bm},BN={bn}> (fp32 implicit GEMM on v_mfma_f32_32x32x2_f32: {bm} cout x {bn} pixels per block, "
+                f"A and B staged through LDS in fp32, K-steps of 16 channels, {'row-major' if rows else 'lane = pixel'} epilogue)")
     if tile >= 9000000:
         v = tile - 9000000
         m, pj, mr, a3 = v // 1000 * 64, v // 100 % 10, v // 10 % 10 * 64, v % 10
@@ -534,6 +541,9 @@ def roofline(pipe, batch, cfg, frames_dev=None):
         "kernel": label, "kernel_symbol": key,
         "launches_per_step": dom["n"], "avg_launch_us": round(dom["ms"] / dom["n"] * 1e3, 2),
         "flops_per_launch": round(dom["flops"] / dom["n"]), "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
+        # a Winograd F(2x2,3x3) kernel issues 16 MFMA products where the layer's algorithmic (direct-form) count has 36: `frac` above is of the
+        # ALGORITHMIC flops (the contract's definition; it may pass what the pipe could do in direct form), this is the pipe's own utilisation
+        **({"frac_mfma_issued": round(frac_mfma * 16 / 36, 4), "mfma_issued_flops_per_launch": round(dom["flops"] / dom["n"] * 16 / 36)} if dom_tile >= 35000000 else {}),
         # NOT measured in this run: the kernel's average duration in the newest COMMITTED rocprofv3 kernel trace of `bench.py --config N
         # --dtype D --pipes 1` (the tracer adds ~1 us per launch) and this run's FLOPs over it - for the reader who recomputes the fraction
         # from profiles/; null unless the kernel's name matches exactly one row of that file
@@ -790,6 +800,9 @@ def measure(cfg, args, rank, world, dev, scaling, steps, warmup, headline, light
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n * 1e3
 
+        db = p0.eng.device_bytes   # HBM one engine holds for this batch (activations with halos, weights in every packed form, fp32 outputs)
+        res["engine_hbm_mb"] = {k: round(v / 2 ** 20, 1) for k, v in db.items()}
+        res["engine_hbm_mb"]["all_pipes_total"] = round(db["total"] * len(pipes) / 2 ** 20, 1)
         res["parser_only_ms_per_step"] = round(leg(False, True), 4)
         res["engine_only_ms_per_step"] = round(leg(True, False), 4)
         res["parser_share_of_serial_step"] = round(res["parser_only_ms_per_step"] / (res["parser_only_ms_per_step"] + res["engine_only_ms_per_step"]), 4)
@@ -849,6 +862,8 @@ def compact_roofline(r):
             "launches_per_step": r["launches_per_step"], "avg_launch_us": r["avg_launch_us"],
             "flops_per_launch": r["flops_per_launch"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
             "all_mfma_convs_frac": r["all_mfma_convs"]["frac"],
+            **({"frac_mfma_issued": r["frac_mfma_issued"], "note": "Winograd F(2x2,3x3): frac = algorithmic (direct-form) flops / time / peak; frac_mfma_issued = the 16/36 of them the pipe executes"}
+               if "frac_mfma_issued" in r else {}),
             "committed_profile": {"source": cp.get("source"), "avg_launch_us": cp.get("avg_launch_us"), "frac": cp.get(frac_key)}}
 
 

@@ -60,7 +60,7 @@ SYMBOLS = [
     "hp_engine_output", "hp_engine_output_to_host", "hp_engine_debug_tensor", "hp_engine_profile", "hp_engine_profile_sequence", "hp_engine_profile_pair", "hp_model_build", "hp_model_from_onnx", "hp_model_from_onnx_file", "hp_model_weights",
     "hp_model_input_size",
     "hp_model_destroy", "hp_model_archs", "hp_model_layers", "hp_model_outputs", "hp_model_num_weights",
-    "hp_model_preproc", "hp_model_flops_per_frame", "hp_model_init_weights", "hp_engine_create_from_model", "hp_engine_create_from_model_dtype", "hp_engine_dtype", "hp_engine_split_fallbacks", "hp_engine_save", "hp_engine_load", "hp_pipeline_create", "hp_pipeline_create_ex", "hp_pipeline_destroy", "hp_pipeline_submit", "hp_pipeline_collect", "hp_pipeline_in_flight",
+    "hp_model_preproc", "hp_model_flops_per_frame", "hp_model_init_weights", "hp_engine_create_from_model", "hp_engine_create_from_model_dtype", "hp_engine_dtype", "hp_engine_split_fallbacks", "hp_engine_device_bytes", "hp_engine_save", "hp_engine_load", "hp_pipeline_create", "hp_pipeline_create_ex", "hp_pipeline_destroy", "hp_pipeline_submit", "hp_pipeline_collect", "hp_pipeline_in_flight",
 ]
 
 

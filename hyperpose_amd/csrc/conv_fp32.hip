@@ -263,11 +263,21 @@ static void conv32_pick(const conv32_params& p, int& BM, int& BN)
         BM = 64;
 }
 
+static bool conv32_rows(const conv32_params& p, int BN)
+{
+    // The row-major epilogue pays on the 64-pixel tile only.  Measured per layer of LW-OpenPose @ 8 x 46 x 54 (us alone | with a second
+    // stream; rows -> lane = pixel): <64, 64> 256 -> 256 33.2 | 26.9 -> 33.8 | 29.2, 128 -> 256 21.3 | 15.8 -> 21.7 | 19.0;  <64, 128> (two
+    // channel tiles per wavefront: eight pixel rows of 256 B in flight per lane group) 128 -> 512 61.5 | 40.3 -> 35.1 | 27.4, 32 -> 64 at
+    // 184 x 216 59.2 | 46.6 -> 36.0 | 29.6, 512 -> 512 129 | 93 -> 106 | 94 (profiles/r05_ab_layers_f32_*_epilogue.txt).
+    // HP_LANE_EPILOGUE=1: lane form everywhere, HP_LANE_EPILOGUE=-1: row form everywhere.
+    return !p.out_f32 && (p.lane_epilogue < 0 || (p.lane_epilogue == 0 && BN == 64));
+}
+
 int conv32_tile(const conv32_params& p)
 {
     int BM, BN;
     conv32_pick(p, BM, BN);
-    return 32000000 + BM * 1000 + BN;
+    return 32000000 + (conv32_rows(p, BN) ? 400000 : 0) + BM * 1000 + BN;
 }
 
 bool set_act32(conv32_params& p)
@@ -301,12 +311,7 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
     int BM, BN;
     conv32_pick(p, BM, BN);
     const dim3 grid((p.npix + BN - 1) / BN, p.Cout_pad / BM);
-    // The row-major epilogue pays on the 64-pixel tile only.  Measured per layer of LW-OpenPose @ 8 x 46 x 54 (us alone | with a second
-    // stream; rows -> lane = pixel): <64, 64> 256 -> 256 33.2 | 26.9 -> 33.8 | 29.2, 128 -> 256 21.3 | 15.8 -> 21.7 | 19.0;  <64, 128> (two
-    // channel tiles per wavefront: eight pixel rows of 256 B in flight per lane group) 128 -> 512 61.5 | 40.3 -> 35.1 | 27.4, 32 -> 64 at
-    // 184 x 216 59.2 | 46.6 -> 36.0 | 29.6, 512 -> 512 129 | 93 -> 106 | 94 (gpurun_out s2, round 5).  HP_LANE_EPILOGUE=1: lane form everywhere,
-    // HP_LANE_EPILOGUE=-1: row form everywhere.
-    const bool rows = !p.out_f32 && (p.lane_epilogue < 0 || (p.lane_epilogue == 0 && BN == 64));
+    const bool rows = conv32_rows(p, BN);
 #define HP_C32_CASE(BM_, BN_, WM_, WN_)                                                    \
     if (rows)                                                                              \
         HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, true>), grid, dim3(256), 0, s, p);    \

@@ -609,8 +609,8 @@ int hp_engine::build(const hp_engine_desc* d)
                 st.flops = 2.0 * opix * L.cout * taps * L.cin;
                 st.bytes = (double)ti.H * ti.W * L.cin * 4 + opix * L.cout * 4 + (double)nw * 4;
                 // HP_DTYPE_F32: 3 x 3 stride-1 layers in Winograd's F(2 x 2, 3 x 3) form - 16 MFMA products per 2 x 2 output tile and channel pair
-                // instead of 36 (conv32_winograd.hip; HP_NO_WINOGRAD32=1 is the A/B switch back to the direct kernel).  The step's `flops` are then the
-                // MFMA work actually issued (what the roofline fraction of this kernel must be computed from), not the direct form's count.
+                // instead of 36 (conv32_winograd.hip; HP_NO_WINOGRAD32=1 is the A/B switch back to the direct kernel).  The step's `flops` stay the
+                // layer's ALGORITHMIC count (the direct form's 2 * 9 * Cin * Cout per pixel); the MFMA work issued is 16 / 36 of it (bench.py reports both).
                 if (dtype == HP_DTYPE_F32 && !dw_in_front && !getenv("HP_NO_WINOGRAD32") && hp::conv32_winograd_ok(p)) {
                     std::vector<float> wu((size_t)16 * cout_pad * cin_pad);
                     hp::conv32_winograd_pack(packed.data(), cout_pad, cin_pad, wu.data());
@@ -618,7 +618,6 @@ int hp_engine::build(const hp_engine_desc* d)
                     HP_TRY(upload(wu.data(), wu.size() * sizeof(float), &dwu));
                     p.w_wino = (const float*)dwu;
                     st.wino = true;
-                    st.flops = 2.0 * 16 * ((g.OH + 1) / 2) * ((g.OW + 1) / 2) * (double)L.cout * L.cin;
                     st.bytes += (double)nw * 4 * (16.0 / 9 - 1);
                 }
                 if (dw_in_front) // + the depthwise taps; the tensor between the two layers costs no bytes any more
@@ -1712,6 +1711,21 @@ int hp_engine_synchronize(hp_engine* e)
 }
 
 int hp_engine_split_fallbacks(const hp_engine* e) { return e ? e->split_fallbacks : HP_ERR_INVALID; }
+
+int hp_engine_device_bytes(const hp_engine* e, uint64_t bytes[3])
+{
+    HP_REQUIRE(e && bytes, HP_ERR_INVALID, "hp_engine_device_bytes: null argument");
+    bytes[0] = bytes[1] = bytes[2] = 0;
+    for (const auto& t : e->tensors)
+        if (t)
+            bytes[0] += t->buf.bytes;
+    for (const auto& w : e->weight_bufs)
+        bytes[1] += w->bytes;
+    for (const auto& o : e->outputs)
+        if (o.buf)
+            bytes[2] += o.buf->bytes;
+    return HP_OK;
+}
 
 void* hp_engine_stream(hp_engine* e) { return e ? (void*)e->stream : nullptr; }
 

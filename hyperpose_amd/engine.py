@@ -121,6 +121,13 @@ class Model:
                                           C.c_size_t(blob.size)))
         return blob
 
+    @property
+    def device_bytes(self) -> dict:
+        """HBM the engine holds for its max_batch (hp_engine_device_bytes): activation tensors, packed weights, fp32 network outputs."""
+        b = (C.c_uint64 * 3)()
+        check(lib().hp_engine_device_bytes(self._h, b))
+        return {"activations": int(b[0]), "weights": int(b[1]), "outputs": int(b[2]), "total": int(b[0] + b[1] + b[2])}
+
     def close(self):
         if self._h:
             lib().hp_model_destroy(self._h)

@@ -354,6 +354,9 @@ int hp_engine_dtype(const hp_engine* e); /* HP_DTYPE_* of an engine (serialized 
 /* HP_DTYPE_F32S engines: how many times the engine left the split kernels for the fp32 pipe because an activation did not fit fp16's
  * range (0 or 1: it does not go back); 0 for the other types */
 int hp_engine_split_fallbacks(const hp_engine* e);
+/* HBM the engine holds for its max_batch, in bytes: bytes[0] activation tensors (with their zero halos), bytes[1] packed weights in every
+ * form its kernels read (fragment orders, the Winograd U matrices of an HP_DTYPE_F32 engine ...), bytes[2] the fp32 NCHW network outputs */
+int hp_engine_device_bytes(const hp_engine* e, uint64_t bytes[3]);
 
 /* ---- hyperpose::stream on the GPU (reference include/hyperpose/stream/stream.hpp:119-390, src/stream.cpp:60-147): host frames of
  * any size in, humans out, in submission order.  Each submit copies one batch (<= max_batch frames, 8-bit BGR HWC, packed rows) to
