@@ -79,19 +79,26 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     unsigned char* const vb = lds + G::RAW_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int t = blockIdx.x;
+    // XCD-aware block order (1-D grid): block id -> XCD id % 8; the NG channel groups of one pixel tile are ids b, b + 8, .. - back to back on one
+    // XCD, whose L2 then serves the tile's halo patch NG - 1 times (conv_fp32.hip has the measurement behind this)
+    const int NG = p.Cout_pad / (16 * MW), ntiles = tiles_x * tiles_y * p.B;
+    const int bj = blockIdx.x >> 3, by = bj % NG;
+    int t = (bj / NG) * 8 + (blockIdx.x & 7);
+    if (t >= ntiles)
+        return; // (the grid is padded to whole groups of eight pixel tiles)
+    const int bx = t;
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y, b = t / tiles_y;
     const int y0 = ty * 16, x0 = tx * 8;
-    const int MT = p.Cout_pad / 16, mt = blockIdx.y * MW + wave;
+    const int MT = p.Cout_pad / 16, mt = by * MW + wave;
     const int nch = p.Cin / WCK;
     int dbg_i = 0;
 #define HP_STAMP()                                                     \
-    if (p.dbg && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0)       \
+    if (p.dbg && bx == 1 && by == 0 && tid == 0)       \
         p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
     HP_STAMP();
-    if (p.dbg && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0)
+    if (p.dbg && bx == 1 && by == 0 && tid == 0)
         p.dbg[119] = __builtin_readcyclecounter(), p.dbg[120] = __builtin_amdgcn_s_memrealtime();
 
     // ---- staging geometry: quad q of a chunk = (halo pixel q / 4, channels 4 (q % 4) ..); halo pixel (hy, hx) = image pixel (y0 - 1 + hy, x0 - 1 + hx).
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     }
     lds_barrier(); // the slab holds all 16 MW channels of the block's 128 pixels; wavefront w stores rows (128 / MW) w ..
     constexpr int RPW = 128 / MW;
-    conv32_drain_rows<G::TMS, RPW>(p, slab + wave * RPW * SLAB_PITCH, lane, blockIdx.y * 16 * MW, [&](int r, bool& ok, long& ooff, long& roff) {
+    conv32_drain_rows<G::TMS, RPW>(p, slab + wave * RPW * SLAB_PITCH, lane, by * 16 * MW, [&](int r, bool& ok, long& ooff, long& roff) {
         const int rr = wave * RPW + r, ab = rr >> 5, tile = rr & 31;
         const int oy = y0 + 2 * (tile >> 2) + (ab >> 1), ox = x0 + 2 * (tile & 3) + (ab & 1);
         ok = oy < p.OH && ox < p.OW;
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     });
     HP_STAMP();
 #undef HP_STAMP
-    if (p.dbg && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0) // slots 119 - 122: the shader clock and the constant 100 MHz clock at the start / end
+    if (p.dbg && bx == 1 && by == 0 && tid == 0) // slots 119 - 122: the shader clock and the constant 100 MHz clock at the start / end
         p.dbg[121] = __builtin_readcyclecounter(), p.dbg[122] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -312,7 +319,7 @@ hipError_t launch_conv32_winograd(const conv32_params& p, hipStream_t s)
     if (!conv32_winograd_ok(p) || !p.w_wino || p.npix <= 0)
         return hipErrorInvalidValue;
     const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 15) / 16, mw = winograd_mw(p);
-    const dim3 grid(tiles_x * tiles_y * p.B, p.Cout_pad / (16 * mw));
+    const dim3 grid((tiles_x * tiles_y * p.B + 7) / 8 * 8 * (p.Cout_pad / (16 * mw))); // XCD-aware 1-D order: see the kernel
     return mw == 8 ? launch_wino_case<8>(p, grid, tiles_x, tiles_y, s) : launch_wino_case<4>(p, grid, tiles_x, tiles_y, s);
 }
 

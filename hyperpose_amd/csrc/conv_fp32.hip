@@ -73,7 +73,16 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // XCD-aware block order (1-D grid).  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md, workgroup dispatch) and every XCD
+    // has its own L2: the G = Cout_pad / BM blocks that read the SAME pixel tile are b, b + 8, .., b + 8 (G - 1) - dispatched back to back to
+    // one XCD, so the tile comes from HBM once and from that L2 G - 1 times.  (With blockIdx.y = channel group the whole input streamed past
+    // once per group: conv32_kernel<64, 128> on 512 -> 512 at 8 x 46 x 54 moved 213 MB per launch against 76 MB algorithmic, rocprofv3
+    // FETCH_SIZE / WRITE_SIZE.)
+    const int G = p.Cout_pad / BM, nx = (p.npix + BN - 1) / BN;
+    const int bj = blockIdx.x >> 3, ptile = (bj / G) * 8 + (blockIdx.x & 7);
+    if (ptile >= nx)
+        return; // (the grid is padded to whole groups of eight pixel tiles)
+    const int n0 = ptile * BN, m0 = (bj % G) * BM;
     const int lrow = tid >> 2, lchunk = (tid & 3) * 4;
     const int OHW = p.OH * p.OW, kc = p.Cin / BK, steps = p.KH * p.KW * kc;
 
@@ -310,7 +319,7 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
         return hipErrorInvalidValue;
     int BM, BN;
     conv32_pick(p, BM, BN);
-    const dim3 grid((p.npix + BN - 1) / BN, p.Cout_pad / BM);
+    const dim3 grid(((p.npix + BN - 1) / BN + 7) / 8 * 8 * (p.Cout_pad / BM)); // XCD-aware 1-D order: see conv32_kernel
     const bool rows = conv32_rows(p, BN);
 #define HP_C32_CASE(BM_, BN_, WM_, WN_)                                                    \
     if (rows)                                                                              \

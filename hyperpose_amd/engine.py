@@ -121,13 +121,6 @@ class Model:
                                           C.c_size_t(blob.size)))
         return blob
 
-    @property
-    def device_bytes(self) -> dict:
-        """HBM the engine holds for its max_batch (hp_engine_device_bytes): activation tensors, packed weights, fp32 network outputs."""
-        b = (C.c_uint64 * 3)()
-        check(lib().hp_engine_device_bytes(self._h, b))
-        return {"activations": int(b[0]), "weights": int(b[1]), "outputs": int(b[2]), "total": int(b[0] + b[1] + b[2])}
-
     def close(self):
         if self._h:
             lib().hp_model_destroy(self._h)
@@ -202,6 +195,13 @@ class Engine:
     def split_fallbacks(self) -> int:
         """HP_DTYPE_F32S engines: 1 once an activation beyond fp16's range sent the engine back to the fp32 matrix pipe."""
         return int(lib().hp_engine_split_fallbacks(self._h))
+
+    @property
+    def device_bytes(self) -> dict:
+        """HBM the engine holds for its max_batch (hp_engine_device_bytes): activation tensors, packed weights, fp32 network outputs."""
+        b = (C.c_uint64 * 3)()
+        check(lib().hp_engine_device_bytes(self._h, b))
+        return {"activations": int(b[0]), "weights": int(b[1]), "outputs": int(b[2]), "total": int(b[0] + b[1] + b[2])}
 
     def close(self):
         if self._h:
