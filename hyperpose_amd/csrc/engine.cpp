@@ -306,10 +306,14 @@ int hp_engine::build(const hp_engine_desc* d)
     }
     // ---- fp32 engines: the same pairing for conv32_direct_kernel's depthwise-fused forms (stride 1, dilation 1 | 2, whole 64-channel chunks;
     // whether the 1 x 1 half takes them is decided where its parameters are known: pass 2).  HP_NO_FUSE=1 / HP_NO_FUSE32=1 keep two launches.
-    // Default: HP_DTYPE_F32S only.  Measured on LW-OpenPose @ 8 x 46 x 54 (us per batch alone | with a second stream, fused -> two launches):
-    // split 1528 | 1077 -> 1514 | 1079 (nothing lost, one 40 MB tensor per block not allocated); fp32 pipe 2880 | 2294 -> 2671 | 1984: the fused
-    // form computes the depthwise tile once per 128-channel block of the 1 x 1 layer (4 x at 512 outputs) between two barriers, the MFMA pipe
-    // idle meanwhile - 194 us for dw + 512 -> 512 against 24.5 + 100.  HP_FUSE32=1 fuses on the fp32 pipe too (tests).
+    // Default: HP_DTYPE_F32S only (HP_FUSE32=1 fuses on the fp32 pipe too: tests).  Measured on LW-OpenPose @ 8 x 46 x 54, us per batch alone |
+    // with a second stream, fused -> two launches: split 1528 | 1077 -> 1514 | 1079 (nothing lost, one 40 MB tensor per block not allocated);
+    // fp32 pipe 2880 | 2294 -> 2671 | 1984: conv32_direct_kernel's fused forms compute the depthwise tile once per 128-channel block of the 1 x 1
+    // layer (4 x at 512 outputs) between two barriers, the MFMA pipe idle meanwhile - 194 us for dw + 512 -> 512 against 24.5 + 100.  A second
+    // attempt in round 5 - one block per pixel tile owning ALL 512 outputs (eight wavefronts, 16-channel chunks double-buffered, the depthwise
+    // reads hidden under the chunk's 32 MFMAs, one barrier per chunk) - computed the depthwise tile once and still ran 161 us alone / 108 with
+    // a second stream against 125 / 107 for the two launches (profiles/r05_ab_layers_f32_sep_kernel.txt): one block of eight wavefronts per CU
+    // moves in step with its own barrier, where conv32_kernel's four independent blocks per CU fill each other's gaps.  Not adopted, removed.
     std::vector<char> fuse32_with_next(layers.size(), 0);
     if (f32 && !getenv("HP_NO_FUSE") && !getenv("HP_NO_FUSE32") && (dtype == HP_DTYPE_F32S || getenv("HP_FUSE32"))) {
         for (size_t i = 0; i + 1 < layers.size(); ++i) {
