@@ -21,15 +21,18 @@
 //             CU, the staging / transform of a pixel tile shared by 128 channels - 44.6 us alone against 46.3 for a 128 -> 128 layer at
 //             8 x 46 x 54, but 31.5 against 28.8 with a second stream (its phases are in step inside the one block).
 //             (The first form - 32 channels x 16 tiles per wavefront - read 2 KB of A per eight MFMAs: 68 us alone.)
-//   K loop  = chunks of 16 input channels.  The chunk's 18 x 10 halo patch arrives from HBM as fp32 (requested one chunk ahead, into
+//   K loop  = chunks of 16 input channels.  The chunk's 18 x 10 halo patch arrives from HBM as fp32 (requested two chunks ahead, into
 //             registers), goes to LDS, is transformed cooperatively (a wavefront = ONE row of Bt d B for 16 tiles, lane = (tile, 4-channel
-//             quad): 8 LDS reads, 8 vector additions, 4 LDS writes) into V[pos][tile][16 channels]; two barriers per chunk;
+//             quad): 8 LDS reads, 8 vector additions, 4 LDS writes) into V[pos][tile][16 channels].  MW = 4 (PIPE): two V buffers, the
+//             transform of chunk c + 1 cut into 16 pieces that sit inside the 16 MFMA steps of chunk c (46.6 -> 44.3 us alone, 28.9 -> 27.0
+//             with a second stream; HP_WINO_PIPE=0 is the A/B switch back); MW = 8: one buffer, the transform between two barriers;
 //   MFMA    = per position one step of 16 channels: lane (row / tile, kq) holds channels 4 kq .. 4 kq + 3 of its row (A, 1 KB from L2 in
 //             fragment order, six steps ahead) / tile (B, two ds_read_b128 from V) and feeds element e to MFMA e - 8 MFMAs of 32 cycles per step;
 //   output  = At M A per lane from its own registers (lane (tile, kq) holds channels 4 kq + r at all 16 positions), written into a slab the
 //             block shares ([128 pixels][16 MW channels]), then the row-major epilogue of conv32_epilogue.hpp: whole pixel rows.
-// Block timeline (tools/direct_timeline.py f32; shader cycles, MW = 4): start 3.0 k | per chunk: staged 0.7 - 1.1 k, transformed 1.9 - 2.5 k,
-// multiplied 4.9 - 7.0 k (4.1 k of MFMA issue per wavefront; the SIMD is shared with the other block's wavefront) | output 15.6 k.
+// Block timeline (tools/direct_timeline.py f32; shader cycles at 2.2 GHz, MW = 4, PIPE, 128 -> 128 at 8 x 46 x 54, two blocks per CU): start +
+// chunk 0's transform 5.7 k | per chunk: patch stored 0.6 - 1.2 k, multiplied 7.4 - 8.0 k (8.2 k = the pipe's time for the two blocks' 2 x 128
+// MFMAs per SIMD: the loop is at the pipe's rate) | output transform + stores 17 k.  89 k cycles per block of which 2 x 32.8 k are MFMA issue.
 #include "conv_fp32.hpp"
 
 #include "conv32_epilogue.hpp"
@@ -60,6 +63,10 @@ struct wino_geom {
     static constexpr int TMS = MW / 2;                // the block's output slab: [128 pixel rows][16 MW channels + 4] = rows_geom<TMS>
     static constexpr int SLAB_PITCH = rows_geom<TMS>::PITCH, SLAB_BYTES = 128 * SLAB_PITCH * 4;
     static constexpr int LDS_BYTES = RAW_BYTES + (VBUF > SLAB_BYTES ? VBUF : SLAB_BYTES); // MW = 4: 61440 (two blocks per CU), MW = 8: 83968 (one)
+    // the pipelined form (MW = 4): two V buffers without padding - 64 bytes per tile, the 16-byte quad index XOR-ed with a function of the
+    // tile so that the transform's ds_write_b128 and the MFMA's ds_read_b128 (same lane -> (tile, quad) map) stay conflict-free
+    static constexpr int PVPOS = 32 * 64, PVBUF = 16 * PVPOS;                       // 32768 bytes per buffer
+    static constexpr int PLDS_BYTES = RAW_BYTES + (2 * PVBUF > SLAB_BYTES ? 2 * PVBUF : SLAB_BYTES); // 12288 + 65536 = 77824: two blocks per CU
 };
 
 __device__ __forceinline__ long tvw_off(const tview32& t, int b, int y, int x)
@@ -69,9 +76,11 @@ __device__ __forceinline__ long tvw_off(const tview32& t, int b, int y, int x)
 
 } // namespace
 
-template <int MW>
+// PIPE: the input transform of chunk c + 1 runs inside the MFMA steps of chunk c (two V buffers): see "K loop" above
+template <int MW, bool PIPE>
 __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kernel(const conv32_params p, int tiles_x, int tiles_y)
 {
+    static_assert(!PIPE || MW == 4, "the pipelined form is the four-wavefront one");
     using G = wino_geom<MW>;
     constexpr int NT = G::NT, NQ = G::NQ, SLAB_PITCH = G::SLAB_PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[]; // G::LDS_BYTES
@@ -143,11 +152,35 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
                 const f32x4 bq = *reinterpret_cast<const f32x4*>(src + (rb * HALO_W + j) * RAW_PB);
                 T[j] = a + sg * bq; // (an exact sign change, then one rounded addition)
             }
-            unsigned char* const dst = vb + (i * 4) * VPOS + tile * VP + quad * 16;
+            constexpr int PS = PIPE ? G::PVPOS : VPOS;
+            unsigned char* const dst = PIPE ? vb + (i * 4) * PS + tile * 64 + ((quad ^ ((4 - (tile >> 2)) & 3)) * 16) : vb + (i * 4) * PS + tile * VP + quad * 16;
             *reinterpret_cast<f32x4*>(dst) = T[0] - T[2];
-            *reinterpret_cast<f32x4*>(dst + VPOS) = T[1] + T[2];
-            *reinterpret_cast<f32x4*>(dst + 2 * VPOS) = T[2] - T[1];
-            *reinterpret_cast<f32x4*>(dst + 3 * VPOS) = T[1] - T[3];
+            *reinterpret_cast<f32x4*>(dst + PS) = T[1] + T[2];
+            *reinterpret_cast<f32x4*>(dst + 2 * PS) = T[2] - T[1];
+            *reinterpret_cast<f32x4*>(dst + 3 * PS) = T[1] - T[3];
+        }
+    };
+    // the same transform in pieces, one per MFMA step (PIPE): item k = 0 in steps 0 - 7, k = 1 in steps 8 - 15 of the PREVIOUS chunk's
+    // multiplication: steps 0 - 3 read a column pair each, step 4 forms T, steps 4 - 7 form and store one position each
+    f32x4 ta[4], tb[4];
+    auto transform_piece = [&](int pos, int buf) {
+        const int k = pos >> 3, ps = pos & 7;
+        const int item = wave + k * MW, i = item >> 1;
+        const int quad = lane >> 4, tile = (item & 1) * 16 + (lane & 15);
+        const int ra = i == 0 ? 0 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
+        const unsigned char* const src = raw + ((2 * (tile >> 2)) * HALO_W + 2 * (tile & 3)) * RAW_PB + quad * 16;
+        if (ps < 4) {
+            ta[ps] = *reinterpret_cast<const f32x4*>(src + (ra * HALO_W + ps) * RAW_PB);
+            tb[ps] = *reinterpret_cast<const f32x4*>(src + (rb * HALO_W + ps) * RAW_PB);
+        } else {
+            if (ps == 4) {
+                const float sg = i == 1 ? 1.f : -1.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    ta[j] = ta[j] + sg * tb[j];
+            }
+            unsigned char* const dst = vb + buf * G::PVBUF + (i * 4 + (ps - 4)) * G::PVPOS + tile * 64 + ((quad ^ ((4 - (tile >> 2)) & 3)) * 16);
+            *reinterpret_cast<f32x4*>(dst) = ps == 4 ? ta[0] - ta[2] : ps == 5 ? ta[1] + ta[2] : ps == 6 ? ta[2] - ta[1] : ta[1] - ta[3];
         }
     };
 
@@ -155,7 +188,7 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     const long step_stride = (long)MT * 256;
     const float* const wp = p.w_wino + (long)mt * 256 + lane * 4;
     const int nsteps = nch * 16;
-    constexpr int RING = 8, AHEAD = 6;
+    constexpr int RING = PIPE ? 4 : 8, AHEAD = PIPE ? 3 : 6; // (PIPE: the transform's eight patch quads want the registers)
     f32x4 fa[RING];
     auto aload = [&](int slot, int s) { fa[slot] = *reinterpret_cast<const f32x4*>(wp + (long)min(s, nsteps - 1) * step_stride); };
 
@@ -165,30 +198,42 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
         acc[i][0] = acc[i][1] = f32x4{ 0.f, 0.f, 0.f, 0.f };
 
     const int btile = lane & 15, kq = lane >> 4;
-    const unsigned char* const vsrc = vb + btile * VP + kq * 16;
+    const unsigned char* const vsrc = PIPE ? vb + btile * 64 + ((kq ^ ((4 - (btile >> 2)) & 3)) * 16) : vb + btile * VP + kq * 16;
+    constexpr int BPOS = PIPE ? G::PVPOS : VPOS, BNT = PIPE ? 16 * 64 : 16 * VP; // B fragment strides: position, second column tile
 
     gload(0);
 #pragma unroll
     for (int a = 0; a < AHEAD; ++a)
         aload(a, a);
+    if constexpr (PIPE) { // chunk 0's transform is the one that nothing hides
+        to_lds();
+        gload(1);
+        lds_barrier();
+        transform();
+    }
     int s = 0;
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
-        to_lds();     // (the previous chunk's transform is behind every wavefront: its second barrier)
-        gload(c + 1); // (past the last chunk: a harmless re-read of it)
-        lds_barrier(); // the patch is complete AND every wavefront has left the previous chunk's MFMAs: V may be overwritten
+        if constexpr (PIPE)
+            lds_barrier(); // V[c & 1] is complete and every wavefront has left the patch (transform c) and V[(c + 1) & 1] (chunk c - 1's MFMAs)
+        to_lds();     // PIPE: chunk c + 1's patch; else chunk c's (the previous chunk's transform is behind every wavefront: its second barrier)
+        gload(PIPE ? c + 2 : c + 1); // (past the last chunk: a harmless re-read of it)
+        lds_barrier(); // the patch is complete (!PIPE: AND every wavefront has left the previous chunk's MFMAs: V may be overwritten)
         HP_STAMP();
-        transform();
-        lds_barrier();
-        HP_STAMP();
+        if constexpr (!PIPE) {
+            transform();
+            lds_barrier();
+            HP_STAMP();
+        }
+        const unsigned char* const vcur = vsrc + (PIPE ? (c & 1) * G::PVBUF : 0);
         f32x4 fb[2][2];
-        fb[0][0] = *reinterpret_cast<const f32x4*>(vsrc);
-        fb[0][1] = *reinterpret_cast<const f32x4*>(vsrc + 16 * VP);
+        fb[0][0] = *reinterpret_cast<const f32x4*>(vcur);
+        fb[0][1] = *reinterpret_cast<const f32x4*>(vcur + BNT);
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos) {
             const int cur = pos & 1, npos = pos + 1 < 16 ? pos + 1 : pos;
-            fb[cur ^ 1][0] = *reinterpret_cast<const f32x4*>(vsrc + npos * VPOS);
-            fb[cur ^ 1][1] = *reinterpret_cast<const f32x4*>(vsrc + npos * VPOS + 16 * VP);
+            fb[cur ^ 1][0] = *reinterpret_cast<const f32x4*>(vcur + npos * BPOS);
+            fb[cur ^ 1][1] = *reinterpret_cast<const f32x4*>(vcur + npos * BPOS + BNT);
             aload((pos + AHEAD) % RING, s + AHEAD); // (16 % RING == 0: the ring position is a compile-time function of pos)
             const int slot = pos % RING;
 #pragma unroll
@@ -196,7 +241,10 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
                 acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][e], fb[cur][0][e], acc[pos][0], 0, 0, 0);
                 acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][e], fb[cur][1][e], acc[pos][1], 0, 0, 0);
             }
-            // issue order of a step: MFMA, LDS read, MFMA, LDS read (the next position's B), MFMA, L2 read (A six steps ahead), 5 MFMAs
+            if constexpr (PIPE)
+                transform_piece(pos, (c + 1) & 1); // chunk c + 1's transform, one piece per step, under this step's MFMAs
+            // issue order of a step: MFMA, LDS read, MFMA, LDS read (the next position's B), MFMA, L2 read (A some steps ahead), 5 MFMAs
+            // (the transform's piece - two LDS reads, or a few additions and one LDS write - goes wherever hipcc finds room between them)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -299,19 +347,25 @@ void conv32_winograd_pack(const float* packed, int cout_pad, int cin, float* out
             }
 }
 
-template <int MW>
+template <int MW, bool PIPE>
 static hipError_t launch_wino_case(const conv32_params& q, dim3 grid, int tiles_x, int tiles_y, hipStream_t s)
 {
-    constexpr int lds = wino_geom<MW>::LDS_BYTES;
+    constexpr int lds = PIPE ? wino_geom<MW>::PLDS_BYTES : wino_geom<MW>::LDS_BYTES;
     static bool granted = false;
     if (lds > 64 * 1024 && !granted) {
-        const hipError_t e = hipFuncSetAttribute((const void*)conv32_winograd_kernel<MW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t e = hipFuncSetAttribute((const void*)conv32_winograd_kernel<MW, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess)
             return e;
         granted = true;
     }
-    HP_LAUNCH((conv32_winograd_kernel<MW>), grid, dim3(64 * MW), lds, s, q, tiles_x, tiles_y);
+    HP_LAUNCH((conv32_winograd_kernel<MW, PIPE>), grid, dim3(64 * MW), lds, s, q, tiles_x, tiles_y);
     return hipGetLastError();
+}
+
+static bool winograd_pipe() // HP_WINO_PIPE=0: the A/B switch back to the form with the transform between two barriers
+{
+    static const bool off = getenv("HP_WINO_PIPE") && atoi(getenv("HP_WINO_PIPE")) == 0;
+    return !off;
 }
 
 hipError_t launch_conv32_winograd(const conv32_params& p, hipStream_t s)
@@ -320,14 +374,18 @@ hipError_t launch_conv32_winograd(const conv32_params& p, hipStream_t s)
         return hipErrorInvalidValue;
     const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 15) / 16, mw = winograd_mw(p);
     const dim3 grid((tiles_x * tiles_y * p.B + 7) / 8 * 8 * (p.Cout_pad / (16 * mw))); // XCD-aware 1-D order: see the kernel
-    return mw == 8 ? launch_wino_case<8>(p, grid, tiles_x, tiles_y, s) : launch_wino_case<4>(p, grid, tiles_x, tiles_y, s);
+    if (mw == 8)
+        return launch_wino_case<8, false>(p, grid, tiles_x, tiles_y, s);
+    return winograd_pipe() ? launch_wino_case<4, true>(p, grid, tiles_x, tiles_y, s) : launch_wino_case<4, false>(p, grid, tiles_x, tiles_y, s);
 }
 
 hipError_t conv32_winograd_occupancy(const conv32_params& p, int* blocks_per_cu)
 {
     if (winograd_mw(p) == 8)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, conv32_winograd_kernel<8>, 512, wino_geom<8>::LDS_BYTES);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, conv32_winograd_kernel<4>, 256, wino_geom<4>::LDS_BYTES);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, conv32_winograd_kernel<8, false>, 512, wino_geom<8>::LDS_BYTES);
+    if (winograd_pipe())
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, conv32_winograd_kernel<4, true>, 256, wino_geom<4>::PLDS_BYTES);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, conv32_winograd_kernel<4, false>, 256, wino_geom<4>::LDS_BYTES);
 }
 
 } // namespace hp

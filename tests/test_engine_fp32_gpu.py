@@ -140,6 +140,37 @@ def test_fused_separable_blocks(hp, f32dtype, c, cout, dil, dact, h, w, monkeypa
             assert np.abs(a - bq).max() <= 2e-5 * np.abs(bq).max() + 1e-6, nm
 
 
+@pytest.mark.parametrize("cin,cout,h,w,act", [(16, 64, 23, 17, E.ACT_RELU), (48, 200, 31, 41, E.ACT_LEAKY), (128, 128, 16, 8, E.ACT_NONE),
+                                                 (64, 96, 9, 33, E.ACT_PRELU), (256, 64, 25, 25, E.ACT_RELU6)])
+def test_winograd_3x3_layers(hp, cin, cout, h, w, act, monkeypatch):
+    """HP_DTYPE_F32: interior 3 x 3 stride-1 layers run in Winograd's F(2 x 2, 3 x 3) form (conv32_winograd.hip): odd map sizes (the fourth
+    patch row / column beyond the halo), ragged 16 x 8 pixel tiles, channel counts that are not whole 64-channel groups, every epilogue
+    (slopes, clamp, residual before / after the activation) - against the oracle at the engine's one tolerance, against the direct kernel
+    (HP_NO_WINOGRAD32=1) at 2e-5 of scale, and bit-for-bit batch invariance."""
+    def build():
+        net = Net(40 + cin)
+        t0 = net.conv(0, 3, cin, 3, 1)
+        a = net.conv(t0, cin, cout, 3, 1, act=act, act_param=0.2)
+        b = net.conv(a, cout, cout, 3, 1, res=a, res_before_act=0, act=E.ACT_RELU)
+        c = net.conv(b, cout, cout, 3, 1, res=b, res_before_act=1, act=act, act_param=0.2)
+        y = net.conv(c, cout, 24, 1, 1, act=E.ACT_NONE)
+        return net, [Out("y", y, 0, 24)]
+    frames = _frames(3, h, w, seed=cin + h)
+    net, outs = build()
+    eng, got, _ = _run32(net, outs, frames, h, w, dtype="f32")
+    assert sum(p["tile"] // 1000 == 35003 for p in eng.profile(3, iters=1)) == 3
+    alone = eng.inference(frames[2:3])[0]
+    for (_, a1), (_, a3) in zip(alone, got[2]):
+        assert np.array_equal(a1, a3)
+    monkeypatch.setenv("HP_NO_WINOGRAD32", "1")
+    net2, outs2 = build()
+    eng2, got2, _ = _run32(net2, outs2, frames, h, w, dtype="f32")
+    assert not [p for p in eng2.profile(3, iters=1) if p["tile"] // 1000 == 35003]
+    for b in range(3):
+        for (nm, x), (_, yv) in zip(got[b], got2[b]):
+            assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
+
+
 def test_output_post_ops(hp, f32dtype):
     # pixel shuffle + crop + per-component sigmoid / softplus (PifPaf heads) and the PoseProposal grid / scale map
     net = Net(7)
