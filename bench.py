@@ -380,6 +380,10 @@ def kernel_label(tile: int):
            20: ("sepconv_pair_kernel<32,64,128>", "the stem's separable blocks 32 -> 64 and 64 -> 128 (stride 2) in one launch, the 64-channel "
                 "tensor between them in LDS only")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
+    if tile >= 37000000:
+        hid, c2 = (tile - 37000000) // 100, tile % 100
+        return (f"conv32_head_kernel<{1 if c2 <= 32 else 2}>", f"conv32_head_kernel (fp32 two-layer head in one launch: 1x1 128 -> {hid} relu -> 1x1 {hid} -> {c2}, 32 pixels per block, "
+                "the hidden tile's accumulator registers are the second layer's B operand)")
     if tile >= 35000000:
         mw = tile % 1000
         return (f"conv32_winograd_kernel<{mw}>", f"conv32_winograd_kernel<MW={mw}> (fp32 3x3 stride-1 convolution in Winograd's F(2x2,3x3) form on v_mfma_f32_16x16x4_f32: 16 MFMA "
@@ -543,7 +547,7 @@ def roofline(pipe, batch, cfg, frames_dev=None):
         "flops_per_launch": round(dom["flops"] / dom["n"]), "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
         # a Winograd F(2x2,3x3) kernel issues 16 MFMA products where the layer's algorithmic (direct-form) count has 36: `frac` above is of the
         # ALGORITHMIC flops (the contract's definition; it may pass what the pipe could do in direct form), this is the pipe's own utilisation
-        **({"frac_mfma_issued": round(frac_mfma * 16 / 36, 4), "mfma_issued_flops_per_launch": round(dom["flops"] / dom["n"] * 16 / 36)} if dom_tile >= 35000000 else {}),
+        **({"frac_mfma_issued": round(frac_mfma * 16 / 36, 4), "mfma_issued_flops_per_launch": round(dom["flops"] / dom["n"] * 16 / 36)} if 37000000 > dom_tile >= 35000000 else {}),
         # NOT measured in this run: the kernel's average duration in the newest COMMITTED rocprofv3 kernel trace of `bench.py --config N
         # --dtype D --pipes 1` (the tracer adds ~1 us per launch) and this run's FLOPs over it - for the reader who recomputes the fraction
         # from profiles/; null unless the kernel's name matches exactly one row of that file

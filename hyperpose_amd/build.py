@@ -35,6 +35,7 @@ UNITS = [
     ("conv_fp32.hip", []),
     ("conv32_direct.hip", []),
     ("conv32_winograd.hip", []),
+    ("conv32_head.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),
     ("onnx_import.cpp", []),

@@ -76,6 +76,21 @@ int conv32_winograd_tile(const conv32_params& p);     // profile rows: 35000000 
 double conv32_winograd_flops(const conv32_params& p); // the MFMA work of one launch: 2 * 16 * tiles * Cout * Cin
 void conv32_winograd_pack(const float* packed, int cout_pad, int cin, float* out); // [9][cout_pad][cin] -> 16 * cout_pad * cin floats
 
+// The two-layer heads of an HP_DTYPE_F32 engine in one launch (conv32_head.hip): 1 x 1 128 -> HID (ReLU family) -> 1 x 1 HID -> C2 <= 64, the
+// hidden tensor in registers.  `q` = the SECOND layer's conv32_params (bias, activation, out, out_f32, Cout = C2, OH / OW / npix) with q.in = the
+// FIRST layer's input view; `h` = what the first layer adds.
+struct head32_hidden {
+    const float* w1_frag; // conv32_frag_pack of the first layer's [1][HID][128] matrix
+    const float* bias1;   // [HID]
+    const float* w2_frag; // conv32_head_pack of the second layer's [32 tm2][HID] matrix (zero rows in the padding), tm2 = C2 <= 32 ? 1 : 2
+    float slope1, hi1;    // hidden activation: y = v > 0 ? min(v, hi1) : v * slope1
+    int HID;
+};
+bool conv32_head_ok(int k1, int hid, int c2);
+hipError_t launch_conv32_head(const conv32_params& q, const head32_hidden& h, hipStream_t s);
+int conv32_head_tile(int hid, int c2); // profile rows: 37000000 + 100 * HID + C2
+void conv32_head_pack(const float* w2, int tm2, int hid, float* out);
+
 struct first_conv32_params {
     const uint8_t* in_u8; // [B][H][W][3] or nullptr
     const float* in_f32;  // [B][3][H][W] or nullptr

@@ -87,6 +87,8 @@ struct step {
     hp::dw32_params dp32{};
     hp::pool32_params pp32{};
     bool wino = false;     // HP_DTYPE_F32: a 3 x 3 stride-1 layer on conv32_winograd_kernel (cp32.w_wino)
+    bool head32 = false;   // HP_DTYPE_F32: 1 x 1 128 -> HID -> 1 x 1 HID -> C2 in one launch (conv32_head.hip): cp32 = the second layer's epilogue, hh = the first layer
+    hp::head32_hidden hh{};
     int cin_split = 0;     // fp32 engines: input channels as conv32_direct_kernel reads them (whole chunks), 0 = the layer stays on conv32_kernel
     int n_layers = 1;      // consecutive layers this step covers
     double flops = 0, bytes = 0; // per frame
@@ -380,6 +382,38 @@ int hp_engine::build(const hp_engine_desc* d)
             tensors[A.out]->elided = true;
         }
     }
+    // ---- HP_DTYPE_F32: the same two-layer heads for conv32_head_kernel (1 x 1 128 -> HID, ReLU family, sole consumer a 1 x 1 HID -> <= 64
+    // channels; the hidden tensor stays in registers).  HP_NO_FUSE=1 / HP_NO_HEAD32=1 keep two launches.
+    std::vector<char> head32_with_next(layers.size(), 0);
+    if (dtype == HP_DTYPE_F32 && !getenv("HP_NO_FUSE") && !getenv("HP_NO_HEAD32")) {
+        for (size_t i = 0; i + 1 < layers.size(); ++i) {
+            const hp_layer &A = layers[i], &Bn = layers[i + 1];
+            if (A.op != HP_OP_CONV || A.kh != 1 || A.kw != 1 || A.stride != 1 || A.in == 0 || A.res >= 0 || A.out_coff != 0 || A.in_coff % 4
+                || (A.act != HP_ACT_NONE && A.act != HP_ACT_RELU && A.act != HP_ACT_RELU6 && A.act != HP_ACT_LEAKY))
+                continue;
+            if (Bn.op != HP_OP_CONV || Bn.kh != 1 || Bn.kw != 1 || Bn.stride != 1 || Bn.in != A.out || Bn.in_coff != 0 || Bn.cin != A.cout || Bn.res >= 0
+                || Bn.out == A.out || Bn.act == HP_ACT_SIGMOID || Bn.act == HP_ACT_SOFTPLUS)
+                continue;
+            if (tensors[A.out]->C != A.cout || !hp::conv32_head_ok(A.cin, A.cout, Bn.cout) || A.in_coff + A.cin > round_up(tensors[A.in]->C, 32))
+                continue;
+            if (geos[i].OH != tensors[A.in]->H || geos[i].OW != tensors[A.in]->W || geos[i].pt || geos[i].pl || geos[i + 1].OH != geos[i].OH
+                || geos[i + 1].OW != geos[i].OW || geos[i + 1].pt || geos[i + 1].pl)
+                continue; // a padded 1x1 (ONNX pads) changes the map size: the fused head assumes it does not
+            if ((i > 0 && fuse32_with_next[i - 1]) || fuse32_with_next[i])
+                continue;
+            bool sole = true;
+            for (size_t j = 0; j < layers.size(); ++j)
+                if (j != i + 1 && (layers[j].in == A.out || layers[j].res == A.out || (j != i && layers[j].out == A.out)))
+                    sole = false;
+            for (int o = 0; o < d->n_outputs; ++o)
+                if (d->outputs[o].tensor == A.out)
+                    sole = false;
+            if (!sole)
+                continue;
+            head32_with_next[i] = 1;
+            tensors[A.out]->elided = true;
+        }
+    }
     for (size_t t = 1; t < tensors.size(); ++t) {
         tensor_info& ti = *tensors[t];
         if (!ti.defined || ti.elided)
@@ -469,9 +503,10 @@ int hp_engine::build(const hp_engine_desc* d)
         if (f32) {
             // ---- HP_DTYPE_F32: one fp32 launch per layer (conv_fp32.hip), weights uploaded as they are
             st.f32 = true;
-            if (fuse32_with_next[i]) // the depthwise half of a fused separable block: described at the 1 x 1 layer that follows
+            if (fuse32_with_next[i] || head32_with_next[i]) // the first half of a fused pair: described at the 1 x 1 layer that follows
                 continue;
             const bool dw_in_front = i > 0 && fuse32_with_next[i - 1];
+            const bool head_in_front = i > 0 && head32_with_next[i - 1];
             auto padded = [&](int64_t off, int n, int n_pad, const char* what, std::vector<float>& v) -> bool {
                 v.assign(n_pad, 0.f);
                 if (off < 0)
@@ -507,9 +542,9 @@ int hp_engine::build(const hp_engine_desc* d)
             } else if (L.op == HP_OP_CONV) {
                 const int cin_pad = round_up(L.cin, 16), cout_pad = round_up(L.cout, 64), taps = L.kh * L.kw;
                 // (behind a fused depthwise layer the tensor this layer "reads" is never materialised: what the kernel reads is the depthwise input)
-                const tensor_info& tsrc = dw_in_front ? *tensors[layers[i - 1].in] : ti;
-                const int src_coff = dw_in_front ? layers[i - 1].in_coff : L.in_coff;
-                HP_REQUIRE(src_coff % 4 == 0 && src_coff + cin_pad <= tsrc.cs, HP_ERR_INVALID,
+                const tensor_info& tsrc = (dw_in_front || head_in_front) ? *tensors[layers[i - 1].in] : ti;
+                const int src_coff = (dw_in_front || head_in_front) ? layers[i - 1].in_coff : L.in_coff;
+                HP_REQUIRE(src_coff % 4 == 0 && src_coff + (head_in_front ? layers[i - 1].cin : cin_pad) <= tsrc.cs, HP_ERR_INVALID,
                     "layer %zu: channel slice [%d,+%d) not 4-aligned / exceeds the padded stride %d", i, src_coff, cin_pad, tsrc.cs);
                 const size_t nw = (size_t)L.cout * taps * L.cin;
                 const float* w = blob(L.w_off, nw, "weights", i);
@@ -626,6 +661,32 @@ int hp_engine::build(const hp_engine_desc* d)
                 }
                 if (dw_in_front) // + the depthwise taps; the tensor between the two layers costs no bytes any more
                     st.flops += 2.0 * opix * L.cin * 9, st.bytes += (double)L.cin * 10 * 4;
+                if (head_in_front) { // conv32_head_kernel: this layer's epilogue + the hidden layer in front of it
+                    const hp_layer& A = layers[i - 1];
+                    const size_t nwa = (size_t)A.cout * A.cin;
+                    const float* wa = blob(A.w_off, nwa, "weights", i - 1);
+                    std::vector<float> biasa;
+                    if (!wa || !padded(A.b_off, A.cout, A.cout, "bias", biasa))
+                        return HP_ERR_INVALID;
+                    std::vector<float> w1f(nwa), w2p((size_t)cout_pad * L.cin, 0.f), w2f;
+                    hp::conv32_frag_pack(wa, 1, A.cout, A.cin, w1f.data()); // ([1][HID][128] is the blob's own layout: HID rows of 128)
+                    const int tm2 = L.cout <= 32 ? 1 : 2;
+                    std::copy(w, w + nw, w2p.begin()); // [cout][HID] rows, zero rows up to 32 tm2
+                    w2f.resize((size_t)32 * tm2 * L.cin);
+                    hp::conv32_head_pack(w2p.data(), tm2, L.cin, w2f.data());
+                    void *d1 = nullptr, *db1 = nullptr, *d2 = nullptr;
+                    HP_TRY(upload(w1f.data(), w1f.size() * sizeof(float), &d1));
+                    HP_TRY(upload(biasa.data(), biasa.size() * sizeof(float), &db1));
+                    HP_TRY(upload(w2f.data(), w2f.size() * sizeof(float), &d2));
+                    st.hh.w1_frag = (const float*)d1, st.hh.bias1 = (const float*)db1, st.hh.w2_frag = (const float*)d2, st.hh.HID = A.cout;
+                    st.hh.slope1 = A.act == HP_ACT_NONE ? 1.f : A.act == HP_ACT_LEAKY ? A.act_param : 0.f;
+                    st.hh.hi1 = A.act == HP_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+                    p.in = tsrc.view32(src_coff);
+                    st.head32 = true, st.wino = false, st.cin_split = 0;
+                    st.layer = (int)i - 1, st.n_layers = 2;
+                    st.flops = 2.0 * opix * ((double)A.cout * A.cin + (double)L.cout * L.cin);
+                    st.bytes = (double)tsrc.H * tsrc.W * A.cin * 4 + opix * L.cout * 4 + (double)(nwa + nw) * 4;
+                }
             } else if (L.op == HP_OP_DWCONV) {
                 HP_REQUIRE(L.kh == 3 && L.kw == 3, HP_ERR_INVALID, "layer %zu: depthwise kernels are 3x3", i);
                 HP_REQUIRE(L.cin % 4 == 0 && L.in_coff % 4 == 0 && L.out_coff % 4 == 0, HP_ERR_INVALID, "layer %zu: depthwise needs 4-aligned channels", i);
@@ -1281,7 +1342,9 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
             HP_HIP_TRY(hp::launch_first_conv32(st.fp32, s));
         } else if (st.op == HP_OP_CONV) {
             st.cp32.B = n, st.cp32.npix = n * st.cp32.OH * st.cp32.OW;
-            if (st.wino) {
+            if (st.head32) {
+                HP_HIP_TRY(hp::launch_conv32_head(st.cp32, st.hh, s));
+            } else if (st.wino) {
                 HP_HIP_TRY(hp::launch_conv32_winograd(st.cp32, s));
                 static const bool dbg_wino = getenv("HP_DIRECT_DBG") != nullptr;
                 if (dbg_wino) { // block timeline (s_memtime = shader cycles, block (1, 0), thread 0), printed per launch
@@ -1812,7 +1875,7 @@ int hp_engine_profile(hp_engine* e, int n, int iters, hp_layer_time* out, int ca
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.wino ? hp::conv32_winograd_tile(st.cp32) : st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.head32 ? hp::conv32_head_tile(st.hh.HID, st.cp32.Cout) : st.wino ? hp::conv32_winograd_tile(st.cp32) : st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = ms / iters;
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1865,7 +1928,7 @@ int hp_engine_profile_pair(hp_engine* e, hp_engine* f, int n, int iters, hp_laye
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.wino ? hp::conv32_winograd_tile(st.cp32) : st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.head32 ? hp::conv32_head_tile(st.hh.HID, st.cp32.Cout) : st.wino ? hp::conv32_winograd_tile(st.cp32) : st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = std::max(m0, m1) / (2 * iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;
@@ -1923,7 +1986,7 @@ int hp_engine_profile_sequence(hp_engine* e, int n, int iters, hp_layer_time* ou
                 : st.op == OP_MLPHEAD        ? 6000000 + st.hp_.K1
                 : st.op == OP_CHAIN          ? 7000000 + hp::conv_chain_variant(st.ch)
                 : st.op == OP_BNECK          ? 9000000 + hp::bottleneck_variant(st.bn)
-                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.wino ? hp::conv32_winograd_tile(st.cp32) : st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
+                : (st.op == HP_OP_CONV && !st.first) ? (st.f32 ? (st.head32 ? hp::conv32_head_tile(st.hh.HID, st.cp32.Cout) : st.wino ? hp::conv32_winograd_tile(st.cp32) : st.cin_split ? hp::conv32_direct_tile(st.cp32, e->dtype == HP_DTYPE_F32S && !e->split_off) : hp::conv32_tile(st.cp32)) : hp::conv_mfma_tile(st.cp))
                                                     : 0;
             out[k].ms = (float)(acc[k] / iters);
             out[k].flops = st.flops * n, out[k].bytes = st.bytes * n;

@@ -171,6 +171,44 @@ def test_winograd_3x3_layers(hp, cin, cout, h, w, act, monkeypatch):
             assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
 
 
+@pytest.mark.parametrize("hid,h,w,act1", [(512, 23, 27, E.ACT_RELU), (256, 9, 13, E.ACT_RELU6), (128, 16, 32, E.ACT_LEAKY)])
+def test_fused_two_layer_heads(hp, hid, h, w, act1, monkeypatch):
+    """HP_DTYPE_F32: 1 x 1 128 -> HID -> 1 x 1 HID -> 19 | 38 | 64 in ONE launch (conv32_head.hip), the hidden tile's accumulator registers
+    used as the second layer's B operand.  LW-OpenPose's stage layout: both heads write slices of the next stage's concat buffer (the
+    second one at channel 147: not 4-aligned) AND are network outputs; a 64-channel head with PReLU feeds a further layer.  Against the
+    oracle at the engine's tolerance, against the two-launch schedule (HP_NO_HEAD32=1) at 2e-5 of scale, batch invariance bit for bit."""
+    def build():
+        net = Net(60 + hid)
+        cat = net.new_tensor()
+        t0 = net.conv(0, 3, 32, 3, 1)
+        net.conv(t0, 32, 128, 3, 1, out=cat, out_coff=0)
+        trunk = net.conv(cat, 128, 128, 1, 1, in_coff=0)
+        a = net.conv(trunk, 128, hid, 1, 1, act=act1, act_param=0.1)
+        net.conv(a, hid, 19, 1, 1, out=cat, out_coff=128, act=E.ACT_NONE)
+        b = net.conv(trunk, 128, hid, 1, 1, act=act1, act_param=0.1)
+        net.conv(b, hid, 38, 1, 1, out=cat, out_coff=147, act=E.ACT_NONE)
+        c = net.conv(cat, 128, hid, 1, 1, act=E.ACT_RELU)
+        d = net.conv(c, hid, 64, 1, 1, act=E.ACT_PRELU)
+        nxt = net.conv(cat, 185, 128, 1, 1)
+        y = net.conv(nxt, 128, 24, 3, 1, act=E.ACT_NONE)
+        z = net.conv(d, 64, 16, 1, 1, act=E.ACT_NONE)
+        return net, [Out("conf", cat, 128, 19), Out("paf", cat, 147, 38), Out("y", y, 0, 24), Out("z", z, 0, 16)]
+    frames = _frames(3, h, w, seed=hid + h)
+    net, outs = build()
+    eng, got, _ = _run32(net, outs, frames, h, w, dtype="f32")
+    assert sum(p["tile"] // 1000000 == 37 for p in eng.profile(3, iters=1)) == 3
+    alone = eng.inference(frames[2:3])[0]
+    for (_, a1), (_, a3) in zip(alone, got[2]):
+        assert np.array_equal(a1, a3)
+    monkeypatch.setenv("HP_NO_HEAD32", "1")
+    net2, outs2 = build()
+    eng2, got2, _ = _run32(net2, outs2, frames, h, w, dtype="f32")
+    assert not [p for p in eng2.profile(3, iters=1) if p["tile"] // 1000000 == 37]
+    for b in range(3):
+        for (nm, x), (_, yv) in zip(got[b], got2[b]):
+            assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
+
+
 def test_output_post_ops(hp, f32dtype):
     # pixel shuffle + crop + per-component sigmoid / softplus (PifPaf heads) and the PoseProposal grid / scale map
     net = Net(7)
