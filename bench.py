@@ -386,7 +386,7 @@ def kernel_label(tile: int):
                 "the hidden tile's accumulator registers are the second layer's B operand)")
     if tile >= 35000000:
         mw = tile % 1000
-        return (f"conv32_winograd_kernel<{mw}>", f"conv32_winograd_kernel<MW={mw}> (fp32 3x3 stride-1 convolution in Winograd's F(2x2,3x3) form on v_mfma_f32_16x16x4_f32: 16 MFMA "
+        return (f"conv32_winograd_kernel<{mw},{'true' if mw == 4 else 'false'}>", f"conv32_winograd_kernel<MW={mw}> (fp32 3x3 stride-1 convolution in Winograd's F(2x2,3x3) form on v_mfma_f32_16x16x4_f32: 16 MFMA "
                 f"products per output tile and channel pair instead of 36; {16 * mw} cout x 16x8 px per block, input transform through LDS, U = G g Gt in fragment order from L2; "
                 "flops = the MFMA work issued)")
     if 35000000 > tile >= 33000000 and (tile // 100000) % 10:  # a depthwise 3 x 3 fused in front of the 1 x 1 layer
