@@ -261,6 +261,7 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     // ---- output transform Y = At M A, per lane: tile 16 nt + (lane & 15), channels 16 wave + 4 kq + r; then whole pixel rows through the
     // block's slab.  Slab row (a * 2 + bb) * 32 + tile = output pixel (2 tile_y + a, 2 tile_x + bb) of the block's 16 x 8
     lds_barrier(); // every wavefront is done with V, which the slab lies over (MW = 8: and beyond)
+    HP_STAMP();
     float* const slab = reinterpret_cast<float*>(vb);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -277,7 +278,9 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
             *reinterpret_cast<f32x4*>(slab + ((a * 2 + 1) * 32 + nt * 16 + btile) * SLAB_PITCH + wave * 16 + kq * 4) = y1v;
         }
     }
+    HP_STAMP();
     lds_barrier(); // the slab holds all 16 MW channels of the block's 128 pixels; wavefront w stores rows (128 / MW) w ..
+    HP_STAMP();
     constexpr int RPW = 128 / MW;
     conv32_drain_rows<G::TMS, RPW>(p, slab + wave * RPW * SLAB_PITCH, lane, by * 16 * MW, [&](int r, bool& ok, long& ooff, long& roff) {
         const int rr = wave * RPW + r, ab = rr >> 5, tile = rr & 31;

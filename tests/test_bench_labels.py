@@ -31,6 +31,10 @@ CASES = [
     (5202002, "_config3"), (9001311, "_config3"), (9001011, "_config3"), (9001021, "_config3"), (9002020, "_config3"), (9002021, "_config3"),
     (9002041, "_config3"), (6512009, "_config3"),
     (5202002, "_config4"), (9001311, "_config4"), (9002021, "_config4"), (128128, "_config4"),
+    # the fp32 engine (round 5): Winograd, the fused heads, both epilogue forms of conv32_kernel, the direct kernel of the narrow heads' fall-back
+    (35003004, "_config1_fp32"), (37051219, "_config1_fp32"), (37051238, "_config1_fp32"), (32064128, "_config1_fp32"), (32464064, "_config1_fp32"),
+    (35003004, "_config2_fp32"), (32064128, "_config2_fp32"), (32128128, "_config3_fp32"), (32128128, "_config4_fp32"),
+    (33003002, "_config1_fp32s"), (33001008, "_config1_fp32s"), (33101008, "_config1_fp32s"),
 ]
 
 
