@@ -454,17 +454,26 @@ hipError_t launch_first_conv32(const first_conv32_params& p, hipStream_t s)
 // needs in registers: every input value is loaded once per thread instead of once per tap row (3 loads per output at stride 1 instead
 // of 9 - the per-pixel form ran at 2.1 TB/s of its compulsory bytes, bound by the vector memory path, not by HBM).  Taps in the padding
 // read the zero halo; the tap order per output is (ky, kx) ascending as in the fp16 kernels.
-template <int S, int D>
+// PX = 2 (stride 1): a thread owns TWO output columns D apart - their windows share two of three tap columns, so a row of the window is
+// four loads for two outputs instead of six (1.5 + 1 requests of the vector memory path per output instead of 3 + 1: that path, not HBM,
+// bounds the kernel - 512 channels at 8 x 46 x 54 ran at 3.3 TB/s of its compulsory bytes).  Each output is the same chain of fmaf as before.
+template <int S, int D, int PX>
 __global__ __launch_bounds__(256) void dwconv32_kernel(const dw32_params p, int run)
 {
+    static_assert(PX == 1 || (PX == 2 && S == 1), "column pairs share taps at stride 1 only");
     constexpr int NR = 2 * D + 1; // input rows one output needs, from its first to its last tap row
+    constexpr int NC = 2 + PX;    // tap columns of a window row: offsets 0, D, 2 D (, 3 D)
     const int CG = p.C / 4, segs = (p.OH + run - 1) / run;
-    const long total = (long)p.B * segs * p.OW * CG;
+    const int ncol = PX == 1 ? p.OW : (p.OW + 2 * D - 1) / (2 * D) * D; // column slots: PX = 2 pairs columns (j, j + D) inside groups of 2 D
+    const long total = (long)p.B * segs * ncol * CG;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int cg = (int)(i % CG);
         long n = i / CG;
-        const int ox = (int)(n % p.OW);
-        n /= p.OW;
+        const int q = (int)(n % ncol);
+        n /= ncol;
+        const int ox = PX == 1 ? q : (q / D) * 2 * D + q % D;
+        if (ox >= p.OW)
+            continue; // (a ragged last group of 2 D columns)
         const int seg = (int)(n % segs), b = (int)(n / segs);
         const int oy0 = seg * run, oy1 = min(oy0 + run, p.OH);
         f32x4 w[9];
@@ -472,41 +481,52 @@ __global__ __launch_bounds__(256) void dwconv32_kernel(const dw32_params p, int 
         for (int t = 0; t < 9; ++t)
             w[t] = *reinterpret_cast<const f32x4*>(p.w + t * p.C + cg * 4);
         const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + cg * 4);
-        // input row r of the window = tensor row oy * S - pad_t + r; three taps per row at columns ox * S - pad_l + {0, D, 2 D}
-        const float* const col0 = p.in.p + tv32_off(p.in, b, oy0 * S - p.pad_t, ox * S - p.pad_l) + cg * 4;
-        const long rstride = (long)p.in.wp * p.in.cs, cstride = (long)D * p.in.cs;
-        f32x4 x[NR][3];
+        // input row r of the window = tensor row oy * S - pad_t + r; tap columns at ox * S - pad_l + {0, D, 2 D (, 3 D)}.  A column past the
+        // tensor's halo (the second output of a pair beyond the map) is clamped to it: it only feeds an output that is not stored
+        const int cx0 = ox * S - p.pad_l, cmax = p.W - 1 + (2 * D - p.pad_l);
+        long coff[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            coff[c] = (long)(min(cx0 + c * D, cmax) - cx0) * p.in.cs;
+        const float* const col0 = p.in.p + tv32_off(p.in, b, oy0 * S - p.pad_t, cx0) + cg * 4;
+        const long rstride = (long)p.in.wp * p.in.cs;
+        f32x4 x[NR][NC];
         auto load_row = [&](int r, long row) { // window slot r <- input row `row` (relative to col0)
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                x[r][c] = *reinterpret_cast<const f32x4*>(col0 + row * rstride + c * cstride);
+            for (int c = 0; c < NC; ++c)
+                x[r][c] = *reinterpret_cast<const f32x4*>(col0 + row * rstride + coff[c]);
         };
 #pragma unroll
         for (int r = 0; r < NR; ++r)
             load_row(r, r);
         float* op = p.out.p + tv32_off(p.out, b, oy0, ox) + cg * 4;
-        const long ostride = (long)p.out.wp * p.out.cs;
+        const long ostride = (long)p.out.wp * p.out.cs, o2 = (long)D * p.out.cs;
+        const bool second = PX == 2 && ox + D < p.OW;
         for (int oy = oy0; oy < oy1; ++oy) {
-            f32x4 acc = bias;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int px = 0; px < PX; ++px) {
+                f32x4 acc = bias;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[e] = fmaf(x[ky * D][kx][e], w[ky * 3 + kx][e], acc[e]);
-            f32x4 o;
+                    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                o[e] = act32(acc[e], p.act, p.act_param, 0.f);
-            *reinterpret_cast<f32x4*>(op) = o;
+                        for (int e = 0; e < 4; ++e)
+                            acc[e] = fmaf(x[ky * D][kx + px][e], w[ky * 3 + kx][e], acc[e]);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = act32(acc[e], p.act, p.act_param, 0.f);
+                if (px == 0 || second)
+                    *reinterpret_cast<f32x4*>(op + px * o2) = o;
+            }
             op += ostride;
             // slide the window down by S rows: keep NR - S rows, load S new ones (rows past the tensor's halo are never used: the last
             // outputs of a segment load rows that only the NEXT output would read - clamp them to the window's last valid row)
 #pragma unroll
             for (int r = 0; r + S < NR; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                for (int c = 0; c < NC; ++c)
                     x[r][c] = x[r + S][c];
             if (oy + 1 < oy1) {
 #pragma unroll
@@ -554,14 +574,28 @@ hipError_t launch_dwconv32(const dw32_params& p, hipStream_t s)
         return hipErrorInvalidValue;
     // rows per thread: long runs re-use more, short runs give more threads; 8 keeps > 100 k threads on the 46 x 54 maps of LW-OpenPose
     const int run = p.OH >= 32 ? 8 : 4;
-    const long total = (long)p.B * ((p.OH + run - 1) / run) * p.OW * (p.C / 4);
+    static const bool pairs = !(getenv("HP_DW32_PX") && atoi(getenv("HP_DW32_PX")) == 1); // HP_DW32_PX=1: the A/B switch back to one column per thread
+    // column pairs where they still leave > 120 k threads.  LW-OpenPose @ 8 x 46 x 54, us alone | with a second stream, one column -> pairs: 512 channels
+    // 24.4 | 19.5 -> 20.0 | 16.6, dilation 2 34.0 | 29.4 -> 27.1 | 22.3, 128 channels at 92 x 108 20.5 | 15.4 -> 17.6 | 14.8; 256 channels (83 k pair
+    // threads) 12.0 | 9.0 -> 13.9 | 9.5: those keep one column per thread
+    const long pair_threads = (long)p.B * ((p.OH + run - 1) / run) * ((p.OW + 2 * p.dil - 1) / (2 * p.dil) * p.dil) * (p.C / 4);
+    const bool two = pairs && p.stride == 1 && (p.dil == 1 || p.dil == 2) && pair_threads >= 120000;
+    const int ncol = two ? (p.OW + 2 * p.dil - 1) / (2 * p.dil) * p.dil : p.OW;
+    const long total = (long)p.B * ((p.OH + run - 1) / run) * ncol * (p.C / 4);
     const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 32);
-    if (p.stride == 1 && p.dil == 1)
-        HP_LAUNCH((dwconv32_kernel<1, 1>), dim3(blocks), dim3(256), 0, s, p, run);
-    else if (p.stride == 2 && p.dil == 1)
-        HP_LAUNCH((dwconv32_kernel<2, 1>), dim3(blocks), dim3(256), 0, s, p, run);
-    else if (p.stride == 1 && p.dil == 2)
-        HP_LAUNCH((dwconv32_kernel<1, 2>), dim3(blocks), dim3(256), 0, s, p, run);
+    if (p.stride == 1 && p.dil == 1) {
+        if (two)
+            HP_LAUNCH((dwconv32_kernel<1, 1, 2>), dim3(blocks), dim3(256), 0, s, p, run);
+        else
+            HP_LAUNCH((dwconv32_kernel<1, 1, 1>), dim3(blocks), dim3(256), 0, s, p, run);
+    } else if (p.stride == 2 && p.dil == 1)
+        HP_LAUNCH((dwconv32_kernel<2, 1, 1>), dim3(blocks), dim3(256), 0, s, p, run);
+    else if (p.stride == 1 && p.dil == 2) {
+        if (two)
+            HP_LAUNCH((dwconv32_kernel<1, 2, 2>), dim3(blocks), dim3(256), 0, s, p, run);
+        else
+            HP_LAUNCH((dwconv32_kernel<1, 2, 1>), dim3(blocks), dim3(256), 0, s, p, run);
+    }
     else {
         const long px = (long)p.B * p.OH * p.OW * (p.C / 4);
         HP_LAUNCH(dwconv32_any_kernel, dim3((int)std::min<long>((px + 255) / 256, 256 * 32)), dim3(256), 0, s, p);
