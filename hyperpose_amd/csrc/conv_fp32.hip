@@ -574,12 +574,13 @@ hipError_t launch_dwconv32(const dw32_params& p, hipStream_t s)
         return hipErrorInvalidValue;
     // rows per thread: long runs re-use more, short runs give more threads; 8 keeps > 100 k threads on the 46 x 54 maps of LW-OpenPose
     const int run = p.OH >= 32 ? 8 : 4;
-    static const bool pairs = !(getenv("HP_DW32_PX") && atoi(getenv("HP_DW32_PX")) == 1); // HP_DW32_PX=1: the A/B switch back to one column per thread
+    const int px_env = getenv("HP_DW32_PX") ? atoi(getenv("HP_DW32_PX")) : 0; // A/B switch and test hook: 1 = one column per thread always, 2 = pairs always (read per launch: tests toggle it)
+    const bool pairs = px_env != 1;
     // column pairs where they still leave > 120 k threads.  LW-OpenPose @ 8 x 46 x 54, us alone | with a second stream, one column -> pairs: 512 channels
     // 24.4 | 19.5 -> 20.0 | 16.6, dilation 2 34.0 | 29.4 -> 27.1 | 22.3, 128 channels at 92 x 108 20.5 | 15.4 -> 17.6 | 14.8; 256 channels (83 k pair
     // threads) 12.0 | 9.0 -> 13.9 | 9.5: those keep one column per thread
     const long pair_threads = (long)p.B * ((p.OH + run - 1) / run) * ((p.OW + 2 * p.dil - 1) / (2 * p.dil) * p.dil) * (p.C / 4);
-    const bool two = pairs && p.stride == 1 && (p.dil == 1 || p.dil == 2) && pair_threads >= 120000;
+    const bool two = pairs && p.stride == 1 && (p.dil == 1 || p.dil == 2) && (pair_threads >= 120000 || px_env == 2);
     const int ncol = two ? (p.OW + 2 * p.dil - 1) / (2 * p.dil) * p.dil : p.OW;
     const long total = (long)p.B * ((p.OH + run - 1) / run) * ncol * (p.C / 4);
     const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 32);

@@ -109,6 +109,25 @@ def test_depthwise_pool_upsample(hp, f32dtype):
     _run32(net, [Out("y", y, 0, 24), Out("pooled", mp2, 0, 64), Out("up", up2, 0, 64)], _frames(2, 98, 130, seed=6), 98, 130, dtype=f32dtype)
 
 
+@pytest.mark.parametrize("dil,h,w", [(1, 23, 17), (2, 19, 27), (1, 8, 5), (2, 9, 6)])
+def test_depthwise_column_pairs(hp, dil, h, w, monkeypatch):
+    """dwconv32_kernel<S = 1, D, PX = 2>: a thread owns two output columns D apart (large layers take it by themselves; HP_DW32_PX=2 forces it
+    here).  Odd widths (a ragged last group of 2 D columns, a pair's second column beyond the map), against the oracle and bit for bit
+    against one column per thread (HP_DW32_PX=1): every output is the same chain of fmaf."""
+    def run(px):
+        monkeypatch.setenv("HP_DW32_PX", str(px))
+        net = Net(70 + dil)
+        t0 = net.conv(0, 3, 32, 3, 1)
+        d1 = net.conv(t0, 32, 32, 3, 1, dil, op=E.OP_DWCONV, act=E.ACT_RELU6)
+        d2 = net.conv(d1, 32, 32, 3, 1, 1, op=E.OP_DWCONV, act=E.ACT_LEAKY, act_param=0.1)
+        y = net.conv(d2, 32, 16, 1, 1, act=E.ACT_NONE)
+        return _run32(net, [Out("y", y, 0, 16), Out("d", d2, 0, 32)], _frames(2, h, w, seed=dil + h), h, w, dtype="f32")[1]
+    a, b = run(2), run(1)
+    for f in range(2):
+        for (nm, x), (_, yv) in zip(a[f], b[f]):
+            assert np.array_equal(x, yv), nm
+
+
 @pytest.mark.parametrize("c,cout,dil,dact,h,w", [(64, 128, 1, E.ACT_RELU6, 30, 41), (128, 256, 1, E.ACT_RELU, 23, 17), (256, 512, 2, E.ACT_RELU6, 19, 26),
                                                     (512, 512, 1, E.ACT_RELU6, 16, 24), (64, 64, 2, E.ACT_LEAKY, 11, 9), (192, 128, 1, E.ACT_NONE, 8, 8)])
 def test_fused_separable_blocks(hp, f32dtype, c, cout, dil, dact, h, w, monkeypatch):
