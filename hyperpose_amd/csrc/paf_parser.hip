@@ -37,7 +37,7 @@ constexpr int KR = KSIZE / 2;
 constexpr int PEAK_THREADS = 256;
 constexpr int PEAK_WCOLS = 46;                 // columns a wavefront of the peaks kernel owns (lanes 9 .. 54)
 constexpr int PEAK_BCOLS = 4 * PEAK_WCOLS;       // ... and a block
-constexpr int MAXH = 512;          // humans in flight per frame in the assembly kernel
+constexpr int MAXH = 1024;         // humans (skeleton fragments, alive or merged) in flight per frame in the assembly kernel: 80 KB of its 149 KB of LDS (512 until round 5)
 constexpr int THRESH_VECTOR_CNT1 = 8; // paf.cpp:57
 constexpr int THRESH_PART_CNT = 4;    // paf.cpp:58
 constexpr float THRESH_HUMAN_SCORE = 0.4; // paf.cpp:59
@@ -1309,7 +1309,7 @@ struct hp_paf {
 // that fit every realistic frame (512 peaks per part, 2048 candidates per limb, 128 humans) and hp_paf_collect re-parses a batch
 // with doubled lists when a frame overflowed one.  Hard limits (reported as HP_ERR_CAPACITY, results truncated): 2048 peaks per
 // part (the greedy pass keeps its "used" sets in 64 x 32-bit lane registers), the candidates that fit the CU's LDS next to the two PAF
-// planes (~8000 at 46x54), 512 skeleton fragments alive or merged per frame (MAXH), 1024 humans returned.
+// planes (~8000 at 46x54), 1024 skeleton fragments alive or merged per frame (MAXH), 1024 humans returned.
 constexpr int PEAK_CAP_MAX = 2048, HUMAN_CAP_MAX = 1024;
 int hp_paf::alloc_lists()
 {

@@ -223,6 +223,39 @@ def test_lists_grow_like_the_references_vectors(hp):
     assert len(loader.ref_paf_process(conf[0], paf[0])[2]) >= 66
 
 
+def test_many_skeleton_fragments(hp):
+    """More skeleton fragments in one frame than the assembly kernel held until round 5 (512; now 1024): three limbs that share no part
+    (elbow-wrist right and left, knee-ankle right) as 230 isolated pairs each - the PAF is non-zero only on the two cells between a pair's
+    parts, so no candidate survives but the true ones.  None of the 690 fragments reaches four parts: the reference builds them all
+    (src/paf.cpp:146-231) and removes them; the frame next to it in the batch has ordinary people."""
+    from hyperpose_amd.parser import Paf
+    rows, cols = 46, 54
+    conf = np.zeros((2, 19, rows, cols), np.float32)
+    paf = np.zeros((2, 38, rows, cols), np.float32)
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    limbs = ((3, 4, 16), (6, 7, 24), (9, 10, 4))   # (part a, part b, x channel of the limb's PAF): COCOPAIRS 3, 5, 8
+    n = 0
+    for gy in range(1, rows - 1, 2):
+        for gx in range(1, cols - 3, 5):
+            for a, b, ch in limbs:
+                conf[0, a] += np.exp(-((xx - gx) ** 2 + (yy - gy) ** 2) / 0.5).astype(np.float32)
+                conf[0, b] += np.exp(-((xx - (gx + 2)) ** 2 + (yy - gy) ** 2) / 0.5).astype(np.float32)
+                paf[0, ch, gy, gx:gx + 3] = 1.0
+            n += 1
+    conf[0, 18] = 1 - conf[0, :18].max(0)
+    c1, p1, _ = synth.paf_maps(synth.rng_for(1, salt=73), 1, rows, cols, people=(5,))
+    conf[1], paf[1] = c1[0], p1[0]
+    p = Paf(max_batch=2)
+    humans = p.process_batch(conf, paf)
+    for f in range(2):
+        oh, op, oc = loader.ref_paf_process(conf[f], paf[f], cap_peaks=32768, cap_conns=32768)
+        assert _same(p.debug_peaks(f, cap=32768), op), f
+        assert _same(p.debug_conns(f, cap=32768), oc), f
+        assert _same(humans[f], oh), f
+        if f == 0:
+            assert len(oc) > 512, len(oc)   # every connection of these limbs opens a fragment of its own
+
+
 def _tie_maps(n_necks, rows=46, cols=54, gap=4):
     """Heat-maps in which candidate connections of limb 0 (neck -> right shoulder, COCOPAIRS[0] = (1, 2), PAF channels 12 / 13) TIE
     exactly: every neck has a shoulder `gap` cells to its right and one `gap` cells to its left, the PAF x-field is exactly +1 right of

@@ -5,11 +5,13 @@ import bench
 from hyperpose_amd import _lib, synth
 from hyperpose_amd.parser import Paf
 _lib.init(0)
+cfg = bench.config(1, "f16")   # BASELINE configs[1]: batch 8 @ 368 x 432 -> 46 x 54 maps
+BATCH = cfg["batch"]
 rng = synth.rng_for(1, salt=0)
-conf, paf, _ = synth.paf_maps(rng, bench.BATCH, bench.IN_H // 8, bench.IN_W // 8, people=(1, 2, 4, 8, 16, 3, 5, 6))
+conf, paf, _ = synth.paf_maps(rng, BATCH, cfg["h"] // 8, cfg["w"] // 8, people=cfg["people"])
 cd, pd = _lib.DevBuf.from_numpy(conf), _lib.DevBuf.from_numpy(paf)
-p = Paf(max_batch=bench.BATCH)
+p = Paf(max_batch=BATCH)
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 50):
-    p.enqueue(cd, pd, bench.BATCH, conf.shape[1:], paf.shape[1:])
+    p.enqueue(cd, pd, BATCH, conf.shape[1:], paf.shape[1:])
     h = p.collect()
 print(sum(len(x) for x in h), "humans in the last batch")
