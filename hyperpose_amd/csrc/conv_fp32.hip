@@ -128,9 +128,15 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
                 acc[i][j][r] = 0.f;
 
     const int frow = lane & 31, fh = (lane >> 5) * 4;
+    int dbg_i = 0;
+#define HP_STAMP()                                       \
+    if (p.dbg && blockIdx.x == 9 && tid == 0)            \
+        p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
     gload(0);
     to_lds(0);
     lds_barrier();
+    HP_STAMP();
 #pragma unroll 1
     for (int s = 0; s < steps; ++s) {
         gload(min(s + 1, steps - 1));
@@ -155,6 +161,8 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
         }
         to_lds((s + 1) & 1);
         lds_barrier();
+        if ((s & 7) == 7)
+            HP_STAMP();
     }
 
     // epilogue
@@ -250,6 +258,8 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
         }
     }
     }
+    HP_STAMP();
+#undef HP_STAMP
 }
 
 // Block tile (BM output channels x BN pixels) of a layer.  The fp32 matrix pipe is slow enough (64 cycles per MFMA) that small tiles cost

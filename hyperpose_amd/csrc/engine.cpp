@@ -1389,6 +1389,23 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
                 }
             } else
                 HP_HIP_TRY(hp::launch_conv32(st.cp32, s));
+                static const bool dbg_c32 = getenv("HP_DIRECT_DBG") != nullptr;
+                if (dbg_c32 && st.cp32.Cin >= 256) { // block timeline (s_memtime, block 9, thread 0): start | first tile staged | every 8 K-steps | stored
+                    unsigned long long* dbg = nullptr;
+                    HP_HIP_TRY(hipMalloc(&dbg, 128 * 8));
+                    HP_HIP_TRY(hipMemset(dbg, 0, 128 * 8));
+                    hp::conv32_params q = st.cp32;
+                    q.dbg = dbg;
+                    HP_HIP_TRY(hp::launch_conv32(q, s));
+                    HP_HIP_TRY(hipStreamSynchronize(s));
+                    unsigned long long h[128];
+                    HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "conv32 layer %d %dx%d %d->%d tile %d cycles [start | staged | per 8 K-steps | stored]:", st.layer, q.KH, q.KW, q.Cin, q.Cout, hp::conv32_tile(q));
+                    for (int i = 1; i < 128 && h[i]; ++i)
+                        fprintf(stderr, " %llu", h[i] - h[i - 1]);
+                    fprintf(stderr, "\n");
+                    (void)hipFree(dbg);
+                }
         } else if (st.op == HP_OP_DWCONV) {
             st.dp32.B = n;
             HP_HIP_TRY(hp::launch_dwconv32(st.dp32, s));
