@@ -2,7 +2,8 @@
 //
 // The reference's engine computes in fp32 unless the caller asks for kHALF (include/hyperpose/operator/dnn/tensorrt.hpp:14-21,48;
 // src/tensorrt.cpp:327,353 hand the data type to the TensorRT builder).  An engine created with HP_DTYPE_F32 runs every layer of the
-// exported graphs through the kernels below, one launch per layer:
+// exported graphs through the kernels below, one launch per layer (except where conv32_winograd.hip / conv32_head.hip / conv32_direct.hip take a
+// layer or a pair: conv_fp32.hpp):
 //   conv32_kernel          dense KH x KW convolution, implicit GEMM D[cout][pixel] = sum_{tap,cin} W[tap][cout][cin] * X[pixel@tap][cin]
 //                          on v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, 157 TFLOP/s: MI355X_MICROARCH.md) - exact fp32 products and sums;
 //   first_conv32_kernel    the 3-channel input layer with the u8 -> f32 pre-processing of src/data.cpp:21-51 folded into its load;

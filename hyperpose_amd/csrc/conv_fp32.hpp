@@ -2,8 +2,10 @@
 // HP_DTYPE_F32, i.e. behind `data_type::kFLOAT` of the reference's engine (include/hyperpose/operator/dnn/tensorrt.hpp:14-21,48: fp32 is
 // the reference's default precision; docs/markdown/quick_start/prediction.md:145).  Storage AND arithmetic are fp32: activations NHWC fp32
 // with the same zero halo as the fp16 path (conv_kernels.hpp), weights fp32, products and sums on the fp32 matrix pipe
-// (v_mfma_f32_32x32x2_f32: exact fp32 multiply-add, no TF32-style truncation) or the fp32 vector pipe.  One generic kernel per operator,
-// no fusion: this is the faithful mode, not the fast path (HP_DTYPE_F16 keeps every fused fp16 kernel).
+// (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact fp32 multiply-add, no TF32-style truncation) or the fp32 vector pipe.  The generic
+// kernels are in conv_fp32.hip; since round 5 the 3 x 3 stride-1 layers run in Winograd's F(2 x 2, 3 x 3) form (conv32_winograd.hip), the two-layer
+// heads in one launch (conv32_head.hip), narrow 1 x 1 layers on the barrier-free direct kernel (conv32_direct.hip) - all with exact fp32
+// products; HP_DTYPE_F32S is the same engine with the dense products formed on the fp16 pipe (conv32_direct.hip, SPLIT).
 #pragma once
 #include "conv_kernels.hpp"
 
