@@ -504,7 +504,12 @@ def roofline(pipe, batch, cfg, frames_dev=None):
     peak_tflops = PEAKS[cfg["dtype"]]
     small = cfg["index"] in (0, 1)
     iters = 20 if small else 4
-    prof = pipe.eng.profile(batch, iters=iters, in_sequence=True)
+    # the median of three passes per step: one pass of 4 iterations now and then caught a stall (a 160 us kernel reported at 456 us on one box,
+    # the workload's own throughput unchanged) and the roofline object quoted it
+    passes = [pipe.eng.profile(batch, iters=iters, in_sequence=True) for _ in range(3)]
+    prof = passes[0]
+    for k, p0_ in enumerate(prof):
+        p0_["ms"] = sorted(ps[k]["ms"] for ps in passes)[1]
     warm = pipe.eng.profile(batch, iters=iters) if small else None
     mfma = [p for p in prof if p["tile"] != 0]
     by_tile = {}
