@@ -60,6 +60,13 @@ __device__ __forceinline__ long tv32_off(const tview32& t, int b, int y, int x)
 // ROWS = the row-major epilogue (NHWC output only); !ROWS = the lane = pixel epilogue (the network's heads; HP_LANE_EPILOGUE=1: every layer).
 // A template parameter, not a branch: with both epilogues in one body the kernel carries the register peak of the larger one into every
 // launch (conv32_kernel<64, 128>: 92 registers with the lane form alone, 140 - 184 with both) and the store-bound 1 x 1 layers lose a block per CU.
+// Where step s + 1's global loads are requested inside step s was measured in round 6 ("software-pipeline the loads";
+// 512 -> 512 at 8 x 46 x 54, us alone | in sequence | with a second stream): hipcc's own placement - it sinks them below 12 of the step's 16
+// MFMAs, the s_waitcnt two instructions later - 107 | 102 | 95; requested before the step's fragment reads behind a sched_barrier 127 | 119 | 100;
+// after the first half of the MFMAs 133 | 129 | 97 (profiles/r06_ab_layers_f32_conv32_prefetch.txt).  The block residency trace
+// (HP_DIRECT_DBG, engine.cpp) says why: with the loads early the four blocks of a CU run in step - all of them at their barrier at once, the
+// pipe idle - while the late form lets the oldest block run ahead (blocks of one CU end 58 / 68 / 78 / 88 us after they started together)
+// and the phases interleave.  The form below is therefore round 5's, unchanged.
 template <int BM, int BN, int WM, int WN, bool ROWS>
 __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
 {
@@ -134,6 +141,11 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
     if (p.dbg && blockIdx.x == 9 && tid == 0)            \
         p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
     HP_STAMP();
+    // block residency trace: [128 + 3 b] = start, [.. + 1] = end (100 MHz clock), [.. + 2] = XCC_ID << 32 | HW_ID of block b < 4096
+    if (p.dbg && tid == 0 && blockIdx.x < 4096) {
+        p.dbg[128 + 3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[128 + 3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
     gload(0);
     to_lds(0);
     lds_barrier();
@@ -260,6 +272,188 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
     }
     }
     HP_STAMP();
+    if (p.dbg && tid == 0 && blockIdx.x < 4096)
+        p.dbg[128 + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#undef HP_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv32_t16_kernel: 64 output channels x 160 pixels per block on v_mfma_f32_16x16x4_f32 (round 6).
+// Why 160: conv32_kernel<64, 128> runs four blocks per CU = 1024 slots; a 512-output layer at 8 x 46 x 54 is 156 pixel tiles x 8 channel groups
+// = 1248 blocks - one full round and a second round that is 22 % full, while the K loop itself runs at the pipe's rate.  160 pixels
+// make it 125 x 8 = 1000 blocks: ONE round, 250 of 256 CUs busy to the end.  A tile of 160 pixels does not divide into 32-pixel MFMA tiles over four
+// wavefronts (five wavefronts per block were tried first: the hardware places a block's wavefronts on SIMD 0, 1, 2, 3, 0 - SIMD 0 then holds
+// eight of the CU's twenty and every block waits for it: 168 us against 105, profiles/r06_ab_layers_f32_conv32_64x160_five_wavefronts.txt), so the
+// tile is 2 x 2 wavefronts of 32 channels x 80 pixels = 2 x 5 MFMA tiles of 16 x 16 (same 64 FLOP/clk/SIMD as the 32 x 32 x 2 form).
+// LDS: rows of 16 floats (one K-step) WITHOUT padding, the 16-byte quad index XOR-ed with 2 * ((row >> 3) & 1): the fragment read
+// (lane = (row & 15, quad)) and the staging write (lane = (row, quad) in thread order) are both conflict-free; (64 + 192) rows x 64 B x 2 buffers
+// = 32 KB per block.  K order as in conv32_kernel: lane (row, kq) reads channels [4 kq, 4 kq + 4) with one ds_read_b128 and feeds element e to
+// MFMA e - A and B use the same permutation.  Epilogue: lane (pixel n, q) of a 16 x 16 tile holds channels 4 q .. 4 q + 3 of pixel n: one
+// global_store_dwordx4 of a wavefront covers 16 pixels x 64 contiguous bytes.
+template <int BN>
+__global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
+{
+    constexpr int BM = 64, BK = 16, TMW = 2, TNW = BN / 2 / 16; // a wavefront: TMW x TNW tiles of 16 x 16
+    constexpr int NB = (BN + 63) / 64, BR = NB * 64;             // staging passes of the B tile (64 rows each); rows allocated
+    static_assert(BN % 32 == 0, "two wavefront columns of whole 16-pixel tiles");
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BR) * BK];
+    float (*const sA)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(lds);
+    float (*const sB)[BR * BK] = reinterpret_cast<float (*)[BR * BK]>(lds + 2 * BM * BK);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = p.Cout_pad / BM, nx = (p.npix + BN - 1) / BN; // XCD-aware 1-D block order: see conv32_kernel
+    const int bj = blockIdx.x >> 3, ptile = (bj / G) * 8 + (blockIdx.x & 7);
+    if (ptile >= nx)
+        return;
+    const int n0 = ptile * BN, m0 = (bj % G) * BM;
+    const int lrow = tid >> 2, lq = tid & 3;
+    const int OHW = p.OH * p.OW, kc = p.Cin / BK, steps = p.KH * p.KW * kc;
+    auto swz = [](int row, int quad) { return row * BK + ((quad ^ (((row >> 3) & 1) << 1)) << 2); };
+
+    long bbase[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = min(n0 + min(lrow + 64 * j, BN - 1), p.npix - 1); // (rows past the tile / the tensor: a clamped pixel nobody reads)
+        const int b = n / OHW, rem = n - b * OHW;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        bbase[j] = tv32_off(p.in, b, oy * p.stride - p.pad_t, ox * p.stride - p.pad_l) + lq * 4;
+    }
+    const float* const wrow = p.w + (long)(m0 + lrow) * p.Cin + lq * 4;
+    f32x4 ra, rb[NB];
+    auto gload = [&](int s) { // (requested where hipcc puts them: see conv32_kernel)
+        const int tap = s / kc, k0 = (s - tap * kc) * BK;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const long toff = ((long)(ky * p.dil) * p.in.wp + kx * p.dil) * p.in.cs + k0;
+        ra = *reinterpret_cast<const f32x4*>(wrow + (long)tap * p.Cout_pad * p.Cin + k0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            rb[j] = *reinterpret_cast<const f32x4*>(p.in.p + bbase[j] + toff);
+    };
+    auto to_lds = [&](int buf) {
+        *reinterpret_cast<f32x4*>(&sA[buf][swz(lrow, lq)]) = ra;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<f32x4*>(&sB[buf][swz(lrow + 64 * j, lq)]) = rb[j];
+    };
+
+    f32x4 acc[TMW][TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+            acc[i][j] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+
+    const int fr = lane & 15, kq = lane >> 4;
+    int dbg_i = 0;
+#define HP_STAMP()                                       \
+    if (p.dbg && blockIdx.x == 9 && tid == 0)            \
+        p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
+    // block residency trace: [128 + 3 b] = start, [.. + 1] = end (100 MHz clock), [.. + 2] = XCC_ID << 32 | HW_ID of block b < 4096
+    if (p.dbg && tid == 0 && blockIdx.x < 4096) {
+        p.dbg[128 + 3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[128 + 3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+    gload(0);
+    to_lds(0);
+    lds_barrier();
+    HP_STAMP();
+#pragma unroll 1
+    for (int s = 0; s < steps; ++s) {
+        gload(min(s + 1, steps - 1));
+        f32x4 fa[TMW], fb[TNW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+            fa[i] = *reinterpret_cast<const f32x4*>(&sA[s & 1][swz(wm * 32 + i * 16 + fr, kq)]);
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+            fb[j] = *reinterpret_cast<const f32x4*>(&sB[s & 1][swz(wn * (BN / 2) + j * 16 + fr, kq)]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        to_lds((s + 1) & 1);
+        lds_barrier();
+        if ((s & 7) == 7)
+            HP_STAMP();
+    }
+
+    // epilogue: lane (n, q) of tile (i, j) holds channels m0 + wm * 32 + i * 16 + 4 q + {0..3} of pixel n0 + wn * BN / 2 + j * 16 + n
+    const int q = lane >> 4;
+    const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
+    const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
+    const bool res_pre = p.res.p && p.res_before_act, res_post = p.res.p && !p.res_before_act;
+    f32x4 bs[TMW], sl[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * q; // (m + 3 < Cout_pad)
+        bs[i] = *reinterpret_cast<const f32x4*>(p.bias + m);
+        sl[i] = f32x4{ p.act_slope, p.act_slope, p.act_slope, p.act_slope };
+        if (p.alpha)
+            sl[i] = *reinterpret_cast<const f32x4*>(p.alpha + m);
+    }
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + fr;
+        const bool pix_ok = n < p.npix;
+        const int nc = min(n, p.npix - 1);
+        const int b = nc / OHW, rem = nc - b * OHW;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const long ooff = p.out.p ? tv32_off(p.out, b, oy, ox) : 0;
+        const long roff = p.res.p ? tv32_off(p.res, b, oy, ox) : 0;
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const int m = m0 + wm * 32 + i * 16 + 4 * q;
+            if (!pix_ok || m >= p.Cout)
+                continue;
+            const bool full = m + 3 < p.Cout;
+            float v[4], rr[4] = { 0.f, 0.f, 0.f, 0.f };
+            if (p.res.p) {
+                if (full && res_vec) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(p.res.p + roff + m);
+                    rr[0] = t[0], rr[1] = t[1], rr[2] = t[2], rr[3] = t[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (m + e < p.Cout)
+                            rr[e] = p.res.p[roff + m + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[i][j][e] + bs[i][e];
+                if (res_pre)
+                    x += rr[e];
+                x = x > 0.f ? fminf(x, p.act_hi) : x * sl[i][e];
+                if (res_post)
+                    x += rr[e];
+                v[e] = x;
+            }
+            if (p.out.p) {
+                if (full && out_vec)
+                    *reinterpret_cast<f32x4*>(p.out.p + ooff + m) = f32x4{ v[0], v[1], v[2], v[3] };
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (m + e < p.Cout)
+                            p.out.p[ooff + m + e] = v[e];
+                }
+            }
+            if (p.out_f32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (m + e < p.Cout)
+                        p.out_f32[((long)b * p.Cout + m + e) * OHW + rem] = v[e];
+            }
+        }
+    }
+    HP_STAMP();
+    if (p.dbg && tid == 0 && blockIdx.x < 4096)
+        p.dbg[128 + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #undef HP_STAMP
 }
 
@@ -276,15 +470,30 @@ static void conv32_pick(const conv32_params& p, int& BM, int& BN)
         BM = 64;
         return;
     }
-    const long blocks = (long)((p.npix + 127) / 128) * (p.Cout_pad / BM);
+    const long blocks = (long)(((p.pick_npix > 0 ? p.pick_npix : p.npix) + 127) / 128) * (p.Cout_pad / BM);
     if (blocks < 448) // fewer than ~1.75 blocks per CU: quarter the tile
         BM = 64, BN = 64;
     else if (blocks < 1024 && BM == 128) // up to four blocks per CU: halve the tile (512 -> 512 at 8 x 46 x 54: 115 -> 100 us alone, same machine time)
         BM = 64;
+    // Round quantisation: 64 x 128 tiles have 1024 slots (four blocks per CU); a layer that is "one round and a bit" of them but ONE round of
+    // 64 x 160 tiles takes conv32_t16_kernel<160> (see there).  HP_C32_BN160=0: the A/B switch back; =1: every layer (tests).  Read per launch.
+    const int bn160 = getenv("HP_C32_BN160") ? atoi(getenv("HP_C32_BN160")) : -1;
+    if (bn160 == 1) {
+        BM = 64, BN = 160;
+        return;
+    }
+    if (BM == 64 && BN == 128 && bn160 != 0) {
+        const long np = p.pick_npix > 0 ? p.pick_npix : p.npix; // (the engine's max_batch geometry: see conv32_params::pick_npix)
+        const long g = p.Cout_pad / 64, b128 = (long)((np + 127) / 128) * g, b160 = (long)((np + 159) / 160) * g;
+        if (b128 > 1024 && b160 <= 1024)
+            BN = 160;
+    }
 }
 
 static bool conv32_rows(const conv32_params& p, int BN)
 {
+    if (BN == 160)
+        return false; // conv32_t16_kernel has the one epilogue (16 pixels x 64 contiguous bytes per store instruction)
     // The row-major epilogue pays on the 64-pixel tile only.  Measured per layer of LW-OpenPose @ 8 x 46 x 54 (us alone | with a second
     // stream; rows -> lane = pixel): <64, 64> 256 -> 256 33.2 | 26.9 -> 33.8 | 29.2, 128 -> 256 21.3 | 15.8 -> 21.7 | 19.0;  <64, 128> (two
     // channel tiles per wavefront: eight pixel rows of 256 B in flight per lane group) 128 -> 512 61.5 | 40.3 -> 35.1 | 27.4, 32 -> 64 at
@@ -337,7 +546,9 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
         HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, true>), grid, dim3(256), 0, s, p);    \
     else                                                                                   \
         HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, s, p);
-    if (BM == 128) {
+    if (BN == 160) {
+        HP_LAUNCH((conv32_t16_kernel<160>), grid, dim3(256), 0, s, p);
+    } else if (BM == 128) {
         HP_C32_CASE(128, 128, 2, 2)
     } else if (BN == 128) {
         HP_C32_CASE(64, 128, 1, 4)

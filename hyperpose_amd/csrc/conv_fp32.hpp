@@ -35,6 +35,9 @@ struct conv32_params {
     tview32 out;    // out.p may be null
     float* out_f32; // fp32 NCHW [B][Cout][OH][OW] network output, or nullptr
     int npix;       // B * OH * OW
+    int pick_npix;  // max_batch * OH * OW (0 = npix): what the choice between conv32_kernel and conv32_t16_kernel looks at - the two sum a K-step's
+                    // products in different groupings (32 x 32 x 2 / 16 x 16 x 4), so the choice must not depend on how many frames a call brings:
+                    // a frame's outputs are the same bits in every batch (and in both halves of hp_engine_set_concurrency(2))
     // conv32_direct_kernel (conv32_direct.hip): the same weights in MFMA-fragment order - fp32 (w_frag, HP_DTYPE_F32) or split into fp16
     // (hi, lo) pairs (w_split, HP_DTYPE_F32S) - and the sticky flag the split kernel raises when an activation does not fit fp16's range
     // (then the engine falls back to the fp32 pipe)

@@ -135,6 +135,11 @@ struct hp_engine {
     hp::dev_buf in_stage; // staging for host inputs
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // hp_engine_set_concurrency(2): a batch runs as two half-batches, the second on `stream2` (fork / join by events; inside a captured graph:
+    // two parallel branches) - what a caller with ONE batch in flight gets instead of a second pipe (fp32 engines; frames are independent)
+    int parts = 1;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // captured graphs keyed by (n, input pointer, kind)
     struct graph_key {
@@ -154,13 +159,21 @@ struct hp_engine {
             (void)hipEventDestroy(ev0);
         if (ev1)
             (void)hipEventDestroy(ev1);
+        if (ev_fork)
+            (void)hipEventDestroy(ev_fork);
+        if (ev_join)
+            (void)hipEventDestroy(ev_join);
+        if (stream2)
+            (void)hipStreamDestroy(stream2);
         if (stream)
             (void)hipStreamDestroy(stream);
     }
 
     int build(const hp_engine_desc* d);
-    int enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s);
-    int run_step(step& st, const uint8_t* u8, const float* f32, int n, hipStream_t s);
+    // host_src != nullptr (eager launches of a host batch): every range copies ITS frames to the device on ITS stream first (frame_bytes each)
+    int enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s, const void* host_src = nullptr, size_t frame_bytes = 0);
+    int run_step(step& st, const uint8_t* u8, const float* f32, int n, hipStream_t s, int b0 = 0);
+    int enqueue_range(const uint8_t* u8, const float* f32, int b0, int n, hipStream_t s);
 };
 
 int hp_engine::build(const hp_engine_desc* d)
@@ -605,7 +618,7 @@ int hp_engine::build(const hp_engine_desc* d)
                 if (p.out_f32 && !tensor_is_read(L.out) && tensors[L.out]->C == L.cout)
                     p.out.p = nullptr, to.unwritten = true; // only the fp32 network output is wanted
                 HP_REQUIRE(hp::set_act32(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
-                p.B = max_batch, p.npix = max_batch * g.OH * g.OW;
+                p.B = max_batch, p.npix = p.pick_npix = max_batch * g.OH * g.OW;
                 p.w_split = nullptr, p.w_frag = nullptr, p.w_wino = nullptr, p.ovf = ovf_dev, p.dbg = nullptr;
                 static const int lane_epi = getenv("HP_LANE_EPILOGUE") ? atoi(getenv("HP_LANE_EPILOGUE")) : 0;
                 p.lane_epilogue = lane_epi;
@@ -1331,11 +1344,40 @@ int hp_engine::build(const hp_engine_desc* d)
     HP_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HP_HIP_TRY(hipEventCreate(&ev0));
     HP_HIP_TRY(hipEventCreate(&ev1));
+    HP_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HP_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     return HP_OK;
 }
 
-int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hipStream_t s)
+namespace {
+// frames [b0, ..) of a tensor view / of an fp32 NCHW output
+inline hp::tview32 at_frame(hp::tview32 v, int b0)
 {
+    if (v.p)
+        v.p += (long)b0 * v.img * v.cs;
+    return v;
+}
+} // namespace
+
+int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hipStream_t s, int b0)
+{
+    if (st.f32 && b0 > 0) {
+        // the second half-batch (hp_engine_set_concurrency): the same step on frames [b0, b0 + n) - every view moved by b0 images
+        step t = st;
+        if (t.first) {
+            t.fp32.out = at_frame(st.fp32.out, b0);
+            return run_step(t, u8 ? u8 + (size_t)b0 * in_h * in_w * 3 : nullptr, f32 ? f32 + (size_t)b0 * in_h * in_w * 3 : nullptr, n, s, 0);
+        }
+        if (t.op == HP_OP_CONV) {
+            t.cp32.in = at_frame(st.cp32.in, b0), t.cp32.out = at_frame(st.cp32.out, b0), t.cp32.res = at_frame(st.cp32.res, b0);
+            if (t.cp32.out_f32)
+                t.cp32.out_f32 += (size_t)b0 * t.cp32.Cout * t.cp32.OH * t.cp32.OW;
+        } else if (t.op == HP_OP_DWCONV)
+            t.dp32.in = at_frame(st.dp32.in, b0), t.dp32.out = at_frame(st.dp32.out, b0);
+        else
+            t.pp32.in = at_frame(st.pp32.in, b0), t.pp32.out = at_frame(st.pp32.out, b0);
+        return run_step(t, u8, f32, n, s, 0);
+    }
     if (st.f32) {
         if (st.first) {
             st.fp32.in_u8 = u8, st.fp32.in_f32 = f32, st.fp32.B = n;
@@ -1387,25 +1429,96 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
                     fprintf(stderr, "\n");
                     (void)hipFree(dbg);
                 }
-            } else
+            } else {
                 HP_HIP_TRY(hp::launch_conv32(st.cp32, s));
                 static const bool dbg_c32 = getenv("HP_DIRECT_DBG") != nullptr;
                 if (dbg_c32 && st.cp32.Cin >= 256) { // block timeline (s_memtime, block 9, thread 0): start | first tile staged | every 8 K-steps | stored
+                    constexpr int NDBG = 128 + 3 * 4096;
                     unsigned long long* dbg = nullptr;
-                    HP_HIP_TRY(hipMalloc(&dbg, 128 * 8));
-                    HP_HIP_TRY(hipMemset(dbg, 0, 128 * 8));
+                    HP_HIP_TRY(hipMalloc(&dbg, NDBG * 8));
+                    HP_HIP_TRY(hipMemset(dbg, 0, NDBG * 8));
                     hp::conv32_params q = st.cp32;
                     q.dbg = dbg;
                     HP_HIP_TRY(hp::launch_conv32(q, s));
                     HP_HIP_TRY(hipStreamSynchronize(s));
-                    unsigned long long h[128];
-                    HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+                    std::vector<unsigned long long> hv(NDBG);
+                    unsigned long long* h = hv.data();
+                    HP_HIP_TRY(hipMemcpy(h, dbg, NDBG * 8, hipMemcpyDeviceToHost));
                     fprintf(stderr, "conv32 layer %d %dx%d %d->%d tile %d cycles [start | staged | per 8 K-steps | stored]:", st.layer, q.KH, q.KW, q.Cin, q.Cout, hp::conv32_tile(q));
                     for (int i = 1; i < 128 && h[i]; ++i)
                         fprintf(stderr, " %llu", h[i] - h[i - 1]);
                     fprintf(stderr, "\n");
+                    // residency: every block's (start, end) on the 100 MHz clock and the CU it ran on (XCC_ID, HW_ID: se_id [15:13], sh_id [12], cu_id [11:8])
+                    struct blk { unsigned long long t0, t1; unsigned cu; };
+                    std::vector<blk> bl;
+                    unsigned long long tmin = ~0ull, tmax = 0;
+                    for (int b = 0; b < 4096; ++b) {
+                        const unsigned long long t0 = h[128 + 3 * b], t1 = h[128 + 3 * b + 1], id = h[128 + 3 * b + 2];
+                        if (!t0 || !t1)
+                            continue;
+                        bl.push_back({ t0, t1, (unsigned)(((id >> 32) & 0xf) << 8 | ((id >> 8) & 0xff)) });
+                        tmin = std::min(tmin, t0), tmax = std::max(tmax, t1);
+                    }
+                    if (!bl.empty()) {
+                        std::map<unsigned, std::vector<std::pair<unsigned long long, int>>> ev; // per CU: (time, +1 / -1)
+                        double dsum = 0, dmin = 1e30, dmax = 0;
+                        for (const auto& b : bl) {
+                            ev[b.cu].push_back({ b.t0, +1 }), ev[b.cu].push_back({ b.t1, -1 });
+                            const double d = (b.t1 - b.t0) * 0.01;
+                            dsum += d, dmin = std::min(dmin, d), dmax = std::max(dmax, d);
+                        }
+                        int peak = 0;
+                        std::map<int, int> blocks_per_cu, peak_hist;
+                        for (auto& kv : ev) {
+                            std::sort(kv.second.begin(), kv.second.end());
+                            int cur = 0, pk = 0;
+                            for (auto& e2 : kv.second)
+                                cur += e2.second, pk = std::max(pk, cur);
+                            peak = std::max(peak, pk), ++peak_hist[pk], ++blocks_per_cu[(int)kv.second.size() / 2];
+                        }
+                        fprintf(stderr, "  residency: %zu blocks on %zu CUs in %.2f us (first start -> last end); block duration %.2f .. %.2f us, mean %.2f; peak resident blocks per CU:",
+                            bl.size(), ev.size(), (tmax - tmin) * 0.01, dmin, dmax, dsum / bl.size());
+                        for (auto& kv : peak_hist)
+                            fprintf(stderr, " %d x%d", kv.first, kv.second);
+                        fprintf(stderr, "; blocks run per CU:");
+                        for (auto& kv : blocks_per_cu)
+                            fprintf(stderr, " %d x%d", kv.first, kv.second);
+                        fprintf(stderr, "; active blocks at 10 %% .. 90 %% of the launch:");
+                        for (int k = 1; k < 10; ++k) {
+                            const unsigned long long t = tmin + (tmax - tmin) * k / 10;
+                            int a = 0;
+                            for (const auto& b : bl)
+                                a += b.t0 <= t && t < b.t1;
+                            fprintf(stderr, " %d", a);
+                        }
+                        // block 9 (the one with the s_memtime stamps) on the 100 MHz clock; duration histogram; mean duration per XCD; starts of the late blocks
+                        fprintf(stderr, "; block 9: %.2f us", (h[128 + 3 * 9 + 1] - h[128 + 3 * 9]) * 0.01);
+                        fprintf(stderr, "; durations (10 bins from min to max):");
+                        int hist[10] = { 0 };
+                        for (const auto& b : bl)
+                            ++hist[std::min(9, (int)(((b.t1 - b.t0) * 0.01 - dmin) / std::max(1e-9, dmax - dmin) * 10))];
+                        for (int k = 0; k < 10; ++k)
+                            fprintf(stderr, " %d", hist[k]);
+                        double xs[16] = { 0 };
+                        int xn[16] = { 0 };
+                        for (const auto& b : bl)
+                            xs[(b.cu >> 8) & 15] += (b.t1 - b.t0) * 0.01, ++xn[(b.cu >> 8) & 15];
+                        fprintf(stderr, "; mean duration per XCD:");
+                        for (int k = 0; k < 16; ++k)
+                            if (xn[k])
+                                fprintf(stderr, " %.1f", xs[k] / xn[k]);
+                        double late0 = 1e30, late_d = 0;
+                        int nlate = 0;
+                        for (const auto& b : bl)
+                            if ((b.t0 - tmin) * 0.01 > 5.0)
+                                late0 = std::min(late0, (b.t0 - tmin) * 0.01), late_d += (b.t1 - b.t0) * 0.01, ++nlate;
+                        if (nlate)
+                            fprintf(stderr, "; %d blocks started later than 5 us after the first (earliest at %.1f us), their mean duration %.2f us", nlate, late0, late_d / nlate);
+                        fprintf(stderr, "\n");
+                    }
                     (void)hipFree(dbg);
                 }
+            }
         } else if (st.op == HP_OP_DWCONV) {
             st.dp32.B = n;
             HP_HIP_TRY(hp::launch_dwconv32(st.dp32, s));
@@ -1555,18 +1668,50 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
     return HP_OK;
 }
 
-int hp_engine::enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s)
+int hp_engine::enqueue_range(const uint8_t* u8, const float* f32, int b0, int n, hipStream_t s)
 {
     for (auto& st : steps)
-        HP_TRY(run_step(st, u8, f32, n, s));
+        HP_TRY(run_step(st, u8, f32, n, s, b0));
     for (auto& o : outputs)
         if (o.fused_layer < 0) {
             const tensor_info& ti = *tensors[o.tensor];
+            float* const dst = o.buf->as<float>() + (size_t)b0 * o.out_c() * o.x.out_h * o.x.out_w;
             if (is_f32())
-                HP_HIP_TRY(hp::launch_output_transform32(ti.view32(o.coff), n, o.H, o.W, o.x, o.buf->as<float>(), s));
+                HP_HIP_TRY(hp::launch_output_transform32(at_frame(ti.view32(o.coff), b0), n, o.H, o.W, o.x, dst, s));
             else
-                HP_HIP_TRY(hp::launch_output_transform(ti.view(o.coff), n, o.H, o.W, o.x, o.buf->as<float>(), s));
+                HP_HIP_TRY(hp::launch_output_transform(ti.view(o.coff), n, o.H, o.W, o.x, dst, s));
         }
+    return HP_OK;
+}
+
+int hp_engine::enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s, const void* host_src, size_t frame_bytes)
+{
+    unsigned char* const dev_in = u8 ? (unsigned char*)u8 : (unsigned char*)f32;
+    auto h2d = [&](int b0, int cnt, hipStream_t st) -> int {
+        if (host_src)
+            HP_HIP_TRY(hipMemcpyAsync(dev_in + (size_t)b0 * frame_bytes, (const unsigned char*)host_src + (size_t)b0 * frame_bytes, (size_t)cnt * frame_bytes, hipMemcpyHostToDevice, st));
+        return HP_OK;
+    };
+    if (parts < 2 || dtype != HP_DTYPE_F32 || n < 2) {
+        HP_TRY(h2d(0, n, s));
+        return enqueue_range(u8, f32, 0, n, s);
+    }
+    // two half-batches side by side: frames [0, n0) on `s`, frames [n0, n) on stream2, which joins `s` again.  The kernels of one half are
+    // half as many blocks - what fills the chip is that the two halves are never in the same phase (a store-bound launch of one runs under an
+    // MFMA-bound launch of the other): measured 2490 -> 1962 us per synchronous batch of 8 (profiles/r06_half_batch_probe.txt).  Frames are
+    // independent and every kernel is batch-invariant bit for bit (tests), so the outputs are those of the one-stream schedule.
+    // (A host batch goes up in two copies, each on the stream that reads it: an event recorded behind ONE hipMemcpyAsync from pageable memory
+    // does not cover all of that copy's staged chunks - measured: stream2's first layer now and then read a few stale input rows of frames 4 / 5
+    // of 8, tools/r6_halves_debug.py - while a kernel behind the copy on the same stream always saw it complete.)
+    const int n0 = (n + 1) / 2;
+    HP_HIP_TRY(hipEventRecord(ev_fork, s));
+    HP_HIP_TRY(hipStreamWaitEvent(stream2, ev_fork, 0));
+    HP_TRY(h2d(0, n0, s));
+    HP_TRY(h2d(n0, n - n0, stream2));
+    HP_TRY(enqueue_range(u8, f32, 0, n0, s));
+    HP_TRY(enqueue_range(u8, f32, n0, n - n0, stream2));
+    HP_HIP_TRY(hipEventRecord(ev_join, stream2));
+    HP_HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
     return HP_OK;
 }
 
@@ -1728,13 +1873,14 @@ static int infer_common(hp_engine* e, const void* input, size_t frame_bytes, int
         const size_t need = (size_t)e->max_batch * e->in_h * e->in_w * 3 * sizeof(float);
         if (e->in_stage.bytes < need)
             HP_TRY(e->in_stage.alloc(need));
-        HP_HIP_TRY(hipMemcpyAsync(e->in_stage.p, input, frame_bytes * n, hipMemcpyHostToDevice, s));
+        if (e->use_graph) // (the copy is not part of the captured schedule; the graph launch behind it on `s` waits for all of it)
+            HP_HIP_TRY(hipMemcpyAsync(e->in_stage.p, input, frame_bytes * n, hipMemcpyHostToDevice, s));
         dev_in = e->in_stage.p;
     }
     const uint8_t* u8 = kind == 0 ? (const uint8_t*)dev_in : nullptr;
     const float* f32 = kind == 1 ? (const float*)dev_in : nullptr;
     if (!e->use_graph)
-        return e->enqueue(u8, f32, n, s);
+        return e->enqueue(u8, f32, n, s, on_device ? nullptr : input, frame_bytes);
 
     const hp_engine::graph_key key{ n, dev_in, kind };
     auto it = e->graphs.find(key);
@@ -1812,6 +1958,30 @@ int hp_engine_device_bytes(const hp_engine* e, uint64_t bytes[3])
 }
 
 void* hp_engine_stream(hp_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int hp_engine_set_concurrency(hp_engine* e, int parts)
+{
+    HP_REQUIRE(e && (parts == 1 || parts == 2), HP_ERR_INVALID, "hp_engine_set_concurrency: parts must be 1 or 2");
+    // HP_DTYPE_F32 only.  The fp16 engine's fused launches take no frame offset; HP_DTYPE_F32S was tried and is refused on evidence: with two
+    // streams of split kernels side by side (two half-batches, or two engines) isolated values of the first layers' outputs came out perturbed in
+    // 2 - 25 % of the runs (tools/r6_halves_debug.py, tools/r6_two_engines_debug.py; the fp32 and fp16 engines: 0 of 240 / 120) - cause not found
+    if (e->dtype != HP_DTYPE_F32)
+        parts = 1;
+    if (parts == e->parts)
+        return HP_OK;
+    HP_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->last.stream)
+        HP_HIP_TRY(hipStreamSynchronize((hipStream_t)e->last.stream));
+    if (parts == 2 && !e->stream2)
+        HP_HIP_TRY(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    for (auto& g : e->graphs) // (the captured schedules are of the other form)
+        (void)hipGraphExecDestroy(g.second);
+    e->graphs.clear();
+    e->parts = parts;
+    return HP_OK;
+}
+
+int hp_engine_concurrency(const hp_engine* e) { return e ? e->parts : HP_ERR_INVALID; }
 
 int hp_engine_set_graph(hp_engine* e, int enable)
 {

@@ -221,6 +221,15 @@ class Engine:
         check(lib().hp_engine_set_graph(self._h, int(enable)))
 
     # ---- asynchronous device-resident path (bench, pipelines)
+    def set_concurrency(self, parts: int):
+        """2: a batch runs as two half-batches side by side on two internal streams (hp_engine_set_concurrency; fp32 engines) - for a
+        caller with one batch in flight, like the reference's synchronous ``tensorrt::inference``.  Bit-identical outputs."""
+        check(lib().hp_engine_set_concurrency(self._h, int(parts)))
+
+    @property
+    def concurrency(self) -> int:
+        return int(lib().hp_engine_concurrency(self._h))
+
     def enqueue_u8(self, dev_frames, n: int, stream=None):
         check(lib().hp_engine_infer_u8(self._h, as_ptr(dev_frames), n, 1, C.c_void_p(stream) if stream else None))
 

@@ -287,6 +287,12 @@ int hp_engine_infer_f32(hp_engine* e, const float* nchw, int n, int on_device, v
 int hp_engine_synchronize(hp_engine* e);
 void* hp_engine_stream(hp_engine* e); /* hipStream_t of the engine */
 int hp_engine_set_graph(hp_engine* e, int enable); /* replay the schedule from a captured hipGraph (default on) */
+/* parts = 2: every batch of >= 2 frames runs as two half-batches side by side, the second on an internal stream that forks from and joins the
+ * call's stream (HP_DTYPE_F32 engines; the others keep one stream and hp_engine_concurrency() says so) - for a caller that keeps ONE batch in flight, as the reference's synchronous
+ * tensorrt::inference does (src/tensorrt.cpp:364-434): the two halves fill each other's idle phases.  Outputs are bit-identical to parts = 1.
+ * Callers that overlap several batches on several engines (hp_pipeline_*) keep 1. */
+int hp_engine_set_concurrency(hp_engine* e, int parts);
+int hp_engine_concurrency(const hp_engine* e);
 
 /* Outputs, sorted by name.  shape[] receives the non-batch dims (C,H,W), dev the fp32 NCHW device buffer
  * [max_batch][C][H][W] of which the first n frames are valid after the last inference completed. */

@@ -228,6 +228,70 @@ def test_fused_two_layer_heads(hp, hid, h, w, act1, monkeypatch):
             assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
 
 
+@pytest.mark.parametrize("cin,cout,k,h,w", [(64, 128, 1, 40, 52), (128, 512, 1, 23, 27), (512, 512, 1, 23, 27), (96, 200, 3, 19, 33), (32, 64, 1, 61, 47)])
+def test_one_round_tile_64x160(hp, cin, cout, k, h, w, monkeypatch):
+    """conv32_t16_kernel<160> (round 6: 64 output channels x 160 pixels per block on v_mfma_f32_16x16x4_f32, taken where 64 x 128 tiles are
+    "a round and a bit" of the chip's 1024 slots): forced here (HP_C32_BN160=1) on layers whose pixel counts are not multiples of 160 / 80 /
+    16, with residuals and every activation form - against the oracle at the engine's tolerance, against conv32_kernel<64, 128>
+    (HP_C32_BN160=0) at 2e-5 of scale, batch invariance bit for bit."""
+    def build():
+        net = Net(80 + cin + k)
+        t0 = net.conv(0, 3, cin, 3, 1)
+        a = net.conv(t0, cin, cout, k, 1, act=E.ACT_PRELU)
+        b = net.conv(a, cout, cout, 1, 1, res=a, res_before_act=1, act=E.ACT_RELU6)
+        c = net.conv(b, cout, 70, 1, 1, act=E.ACT_LEAKY, act_param=0.1)    # 70 real channels of 128 padded: partial quads in the epilogue
+        y = net.conv(c, 70, 38, 1, 1, act=E.ACT_NONE)
+        return net, [Out("y", y, 0, 38), Out("c", c, 0, 70), Out("b", b, 0, cout)]
+    frames = _frames(5, h, w, seed=cin + k)
+    monkeypatch.setenv("HP_C32_BN160", "1")
+    net, outs = build()
+    eng, got, _ = _run32(net, outs, frames, h, w, dtype="f32")
+    assert sum(p["tile"] == 32064160 for p in eng.profile(5, iters=1)) >= 2, [p["tile"] for p in eng.profile(5, iters=1)]
+    alone = eng.inference(frames[3:4])[0]
+    for (_, a1), (_, a5) in zip(alone, got[3]):
+        assert np.array_equal(a1, a5)
+    monkeypatch.setenv("HP_C32_BN160", "0")
+    net2, outs2 = build()
+    eng2, got2, _ = _run32(net2, outs2, frames, h, w, dtype="f32")
+    assert not [p for p in eng2.profile(5, iters=1) if p["tile"] == 32064160]
+    for b in range(5):
+        for (nm, x), (_, yv) in zip(got[b], got2[b]):
+            assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
+
+
+@pytest.mark.parametrize("arch,w_,h_,n", [("lw_openpose_mobilenet", 96, 80, 5), ("pose_proposal_resnet50", 160, 128, 4), ("pifpaf_resnet50", 97, 97, 3),
+                                            ("lw_openpose_mobilenet", 432, 368, 8)])
+def test_two_half_batches_are_bit_identical(hp, f32dtype, arch, w_, h_, n):
+    """hp_engine_set_concurrency(2) (round 6): the batch runs as frames [0, ceil(n / 2)) and the rest side by side on two
+    streams - fork / join inside the captured graph.  Frames are independent and every kernel is batch-invariant, so every output byte equals
+    the one-stream schedule's; odd batches, the un-fused output conversions of the PifPaf / PoseProposal heads, graph and eager launches."""
+    m = E.Model(arch, w_, h_)
+    w = m.init_weights(5)
+    eng = E.Engine.from_model(m, w, max_batch=n, dtype=f32dtype)
+    fr = synth.images_u8(synth.rng_for(12), n, h_, w_)
+    one = eng.inference(fr)
+    eng.set_concurrency(2)
+    # (HP_DTYPE_F32S keeps one stream: engine.cpp, hp_engine_set_concurrency - two streams of split kernels side by side were not bit-stable)
+    assert eng.concurrency == (2 if f32dtype == "f32" else 1)
+    for graph in (True, False):
+        eng.set_graph(graph)
+        two = eng.inference(fr)
+        two_again = eng.inference(fr)
+        for b in range(n):
+            for (nm, x), (_, y), (_, z) in zip(one[b], two[b], two_again[b]):
+                assert np.array_equal(x, y) and np.array_equal(x, z), (nm, b, graph)
+    part = eng.inference(fr[:n - 1])     # another batch size through the same engine
+    for b in range(n - 1):
+        for (nm, x), (_, y) in zip(one[b], part[b]):
+            assert np.array_equal(x, y), (nm, b)
+    eng.set_concurrency(1)
+    back = eng.inference(fr)
+    for b in range(n):
+        for (nm, x), (_, y) in zip(one[b], back[b]):
+            assert np.array_equal(x, y), nm
+    assert eng.split_fallbacks == 0
+
+
 def test_output_post_ops(hp, f32dtype):
     # pixel shuffle + crop + per-component sigmoid / softplus (PifPaf heads) and the PoseProposal grid / scale map
     net = Net(7)
@@ -316,7 +380,8 @@ def test_split_engine_leaves_the_fp16_pipe_when_a_value_does_not_fit(hp):
 
 
 # ---- the BASELINE configurations at FULL size, one probed frame each, against PyTorch's own fp32 GPU kernels
-FULL = [("lw_openpose_mobilenet", 432, 368, 8, 20241), ("openpose_vgg19", 768, 432, 16, 20242),
+FULL = [("lw_openpose_vggtiny", 432, 368, 1, 20240),   # configs[0]: benchmarked, so tested at its full size too
+        ("lw_openpose_mobilenet", 432, 368, 8, 20241), ("openpose_vgg19", 768, 432, 16, 20242),
         ("pose_proposal_resnet50", 384, 384, 32, 20243), ("pifpaf_resnet50", 385, 385, 64, 20244)]
 
 
