@@ -80,5 +80,24 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+BENCH_BIN = os.path.join(HERE, "operator_api_bench.bin")
+
+
+def build_operator_bench(verbose: bool = True) -> str:
+    """examples/operator_api_bench.cpp (the reference's operator-API loop, timed) against the C++ mirror headers and libhp_hip.so, with plain
+    g++: a host program, no device code.  bench.py runs it for `operator_api_fps`; the binary travels to the GPU box with the snapshot."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "operator_api_bench.cpp")
+    inc = os.path.join(root, "include")
+    deps = [LIB] + [os.path.join(dp, f) for dp, _, fs in os.walk(inc) for f in fs]
+    if _newer(src, BENCH_BIN, deps):
+        cmd = ["g++", "-std=c++17", "-O2", "-I" + inc, src, "-L" + HERE, "-lhp_hip", "-lpthread", "-Wl,-rpath," + HERE, "-o", BENCH_BIN]
+        if verbose:
+            print("[hyperpose_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return BENCH_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_operator_bench()

@@ -10,6 +10,7 @@
 // the DEVICE exactly as the reference does on the host: cv::resize (INTER_LINEAR) or, with keep_ratio, non_scaling_resize
 // (src/tensorrt.cpp:446-451, src/data.cpp:53-69) through hp_resize_u8c3 / hp_letterbox_u8c3.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -87,6 +88,7 @@ namespace dnn {
                 fatal(hp_last_error());
             if (hp_engine_create_from_model_dtype(&m_engine, m_model, max_batch_size, factor, flip_rgb ? 1 : 0, nullptr, 0, dtype.hp_dtype()) != HP_OK)
                 fatal(hp_last_error());
+            after_create();
         }
 
         explicit tensorrt(const tensorrt_serialized& serialized_model, cv::Size input_size, int max_batch_size = 8, bool keep_ratio = false,
@@ -100,6 +102,7 @@ namespace dnn {
             hp_engine_input_size(m_engine, &w, &h);
             if (w != input_size.width || h != input_size.height)
                 fatal("serialized engine was built for another input size");
+            after_create();
         }
 
         /// Addition: a built-in topology (no model file needed).
@@ -118,6 +121,7 @@ namespace dnn {
             }
             if (hp_engine_create_from_model_dtype(&m_engine, m_model, max_batch_size, factor, flip_rgb ? 1 : 0, w.data(), w.size(), dtype.hp_dtype()) != HP_OK)
                 fatal(hp_last_error());
+            after_create();
         }
 
         /// The builtin_model constructor (an addition of this library) took (model, size, batch, keep_ratio, factor, flip_rgb) before it learned
@@ -130,6 +134,9 @@ namespace dnn {
         tensorrt& operator=(const tensorrt&) = delete;
         ~tensorrt()
         {
+            retire_last_batch(); // maps of the last call that are still alive get their host copy before the buffers go
+            if (m_host_net)
+                hp_free_host(m_host_net);
             if (m_dev_raw)
                 hp_free(m_dev_raw);
             if (m_dev_net)
@@ -152,11 +159,28 @@ namespace dnn {
             const size_t net_frame = (size_t)m_inp_size.width * m_inp_size.height * 3;
             if (!m_dev_net && hp_malloc((void**)&m_dev_net, net_frame * m_max_batch_size) != HP_OK)
                 fatal(hp_last_error());
+            if (!m_host_net && hp_malloc_host((void**)&m_host_net, net_frame * m_max_batch_size) != HP_OK)
+                fatal(hp_last_error());
+            retire_last_batch(); // (the engine is idle here: the previous call was synchronised before it returned)
             std::vector<uint8_t> scratch;
-            for (size_t i = 0; i < inputs.size(); ++i) {
-                const cv::Mat& f = inputs[i];
+            bool all_net_sized = true;
+            for (const cv::Mat& f : inputs) {
                 if (f.empty())
                     fatal("hyperpose::dnn::tensorrt::inference: empty image");
+                all_net_sized = all_net_sized && f.cols == m_inp_size.width && f.rows == m_inp_size.height;
+            }
+            if (all_net_sized) {
+                // resize to the same size is a copy (src/tensorrt.cpp:446-451): the frames are gathered in ONE pinned buffer and go up in one
+                // asynchronous copy per half-batch in front of the network's launches (the reference converts every frame to an f32 NCHW
+                // staging vector on the host and copies 4 x the bytes, src/tensorrt.cpp:380-383)
+                for (size_t i = 0; i < inputs.size(); ++i)
+                    std::memcpy(m_host_net + i * net_frame, detail::mat_bytes(inputs[i], scratch), net_frame);
+                if (hp_engine_infer_u8(m_engine, m_host_net, (int)inputs.size(), 0, nullptr) != HP_OK)
+                    fatal(hp_last_error());
+                return collect(inputs.size());
+            }
+            for (size_t i = 0; i < inputs.size(); ++i) {
+                const cv::Mat& f = inputs[i];
                 const uint8_t* src = detail::mat_bytes(f, scratch);
                 const size_t bytes = (size_t)f.cols * f.rows * 3;
                 uint8_t* dst = m_dev_net + i * net_frame;
@@ -195,6 +219,7 @@ namespace dnn {
                 throw std::logic_error("Input batch size overflow: Yours@" + std::to_string(batch_size) + " Max@" + std::to_string(m_max_batch_size));
             if (float_buffer.size() < batch_size * 3 * (size_t)m_inp_size.area())
                 throw std::logic_error("Input float buffer is smaller than batch_size x 3 x H x W");
+            retire_last_batch();
             if (hp_engine_infer_f32(m_engine, float_buffer.data(), (int)batch_size, 0, nullptr) != HP_OK)
                 fatal(hp_last_error());
             return collect(batch_size);
@@ -210,6 +235,7 @@ namespace dnn {
         // ---- additions for device-resident use (the stream operator and the parsers' process_device forms)
         void inference_device(const uint8_t* dev_hwc_bgr, int n, void* stream = nullptr)
         {
+            retire_last_batch();
             if (hp_engine_infer_u8(m_engine, dev_hwc_bgr, n, 1, stream) != HP_OK)
                 fatal(hp_last_error());
         }
@@ -222,24 +248,48 @@ namespace dnn {
             std::cerr << "[HyperPose::ERROR  ] " << msg << "\n";
             std::exit(-1);
         }
+        // one batch in flight per call, like the reference's synchronous inference: kFLOAT engines run it as two half-batches side by side
+        // (hp_engine_set_concurrency; bit-identical outputs, measured 2490 -> 1962 us per batch of 8 LW-OpenPose frames)
+        void after_create()
+        {
+            m_calls = std::make_shared<std::atomic<uint64_t>>(0);
+            if (!std::getenv("HP_MIRROR_ONE_STREAM"))
+                hp_engine_set_concurrency(m_engine, 2);
+        }
+        // the maps of the previous call lose their device buffers now: those still alive copy themselves to the host first
+        void retire_last_batch()
+        {
+            if (auto last = m_last.lock())
+                last->materialize();
+            m_last.reset();
+            if (m_calls)
+                ++*m_calls;
+        }
+        /// src/tensorrt.cpp:400-433: one internal_t per image, maps sorted by tensor name (:405).  The maps are views of the engine's device
+        /// buffers with a host copy made on demand (utility/data.hpp, detail::device_batch).
         std::vector<internal_t> collect(size_t n)
         {
-            std::vector<internal_t> ret(n);
+            if (hp_engine_synchronize(m_engine) != HP_OK)
+                fatal(hp_last_error());
+            auto rec = std::make_shared<detail::device_batch>();
+            rec->engine = m_engine, rec->live = m_calls, rec->gen = m_calls->load(), rec->n = (int)n;
             const int no = hp_engine_num_outputs(m_engine);
             for (int i = 0; i < no; ++i) { // already sorted by tensor name (src/tensorrt.cpp:405)
                 const char* name = nullptr;
                 int shape[3];
-                hp_engine_output(m_engine, i, &name, shape, nullptr);
-                const size_t per = (size_t)shape[0] * shape[1] * shape[2];
-                std::vector<float> host(per * n);
-                if (hp_engine_output_to_host(m_engine, i, (int)n, host.data()) != HP_OK)
-                    fatal(hp_last_error());
-                for (size_t j = 0; j < n; ++j) {
-                    std::unique_ptr<char[]> data{ new char[per * sizeof(float)] };
-                    std::memcpy(data.get(), host.data() + j * per, per * sizeof(float));
-                    ret[j].emplace_back(name, std::move(data), std::vector<int>{ shape[0], shape[1], shape[2] });
-                }
+                const float* dev = nullptr;
+                hp_engine_output(m_engine, i, &name, shape, &dev);
+                detail::device_batch::out o;
+                o.name = name, o.shape = { shape[0], shape[1], shape[2] }, o.dev = dev, o.per = (size_t)shape[0] * shape[1] * shape[2];
+                rec->outs.push_back(std::move(o));
             }
+            std::vector<internal_t> ret(n);
+            for (size_t j = 0; j < n; ++j)
+                for (int i = 0; i < no; ++i)
+                    ret[j].emplace_back(rec, i, (int)j);
+            m_last = rec;
+            if (std::getenv("HP_MIRROR_EAGER_HOST_COPY")) // (tests: the reference's behaviour, every map on the host before the call returns)
+                rec->materialize();
             return ret;
         }
         const cv::Size m_inp_size; // w, h
@@ -252,6 +302,9 @@ namespace dnn {
         uint8_t* m_dev_raw = nullptr; // one camera-sized frame
         size_t m_raw_bytes = 0;
         uint8_t* m_dev_net = nullptr; // the batch at network size
+        uint8_t* m_host_net = nullptr; // ... and its pinned staging copy on the host
+        std::shared_ptr<std::atomic<uint64_t>> m_calls; // bumped whenever the engine's output buffers are about to be overwritten
+        std::weak_ptr<detail::device_batch> m_last;
     };
 
 } // namespace dnn

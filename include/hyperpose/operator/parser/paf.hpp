@@ -4,7 +4,9 @@
 #pragma once
 #include <cstdlib>
 #include <iostream>
+#include <memory>
 #include <stdexcept>
+#include <vector>
 
 #include "../../../hp_hip.h"
 #include "../../utility/data.hpp"
@@ -32,6 +34,19 @@ namespace parser {
                 fatal("Input of PAF::PROCESS didn't meet requirements: [conf, paf], tensor.dims() == 3\n");
             const int cs[3] = { conf.shape()[0], conf.shape()[1], conf.shape()[2] };
             const int ps[3] = { paf_map.shape()[0], paf_map.shape()[1], paf_map.shape()[2] };
+            // Maps that still lie in their engine's device buffers (utility/data.hpp, detail::device_batch) are read from there - no D2H + H2D
+            // round trip - and, because the reference's callers ask for the frames of a batch one after the other
+            // (examples/operator_api_batched_images_paf.example.cpp:70-73), the WHOLE batch is parsed in one launch the first time one of its
+            // frames is asked for; the other frames' calls return what that launch found.  Per frame the result is process()'s own: the kernels
+            // are the same and frames are independent (tests/cpp/operator_api_paf.cpp compares the two paths).
+            const detail::device_batch* bc = conf.device_batch();
+            if (bc && bc == paf_map.device_batch() && conf.batch_frame() == paf_map.batch_frame() && bc->n <= m_max_batch && !std::getenv("HP_MIRROR_HOST_MAPS")) {
+                if (m_cached.lock().get() != bc || m_cached_gen != bc->gen) {
+                    m_cache = run(bc->n, bc->outs[conf.batch_output()].dev, cs, bc->outs[paf_map.batch_output()].dev, ps, 1);
+                    m_cached = conf.batch_handle(), m_cached_gen = bc->gen;
+                }
+                return m_cache[conf.batch_frame()];
+            }
             std::vector<std::vector<human_t>> r = run(1, conf.view<float>(), cs, paf_map.view<float>(), ps, 0);
             return std::move(r[0]);
         }
@@ -56,12 +71,14 @@ namespace parser {
 
         void set_paf_thresh(float thresh)
         {
+            m_cached.reset();
             m_paf_thresh = thresh;
             if (m_h)
                 hp_paf_set_paf_thresh(m_h, thresh);
         }
         void set_conf_thresh(float thresh)
         {
+            m_cached.reset();
             m_conf_thresh = thresh;
             if (m_h)
                 hp_paf_set_conf_thresh(m_h, thresh);
@@ -98,6 +115,9 @@ namespace parser {
         cv::Size m_resolution_size;
         int m_max_batch;
         hp_paf* m_h = nullptr;
+        std::weak_ptr<detail::device_batch> m_cached; // the batch m_cache holds the humans of
+        uint64_t m_cached_gen = 0;
+        std::vector<std::vector<human_t>> m_cache;
     };
 
 } // namespace parser

@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 int main(int argc, char** argv)
 {
@@ -31,6 +33,54 @@ int main(int argc, char** argv)
             return 3;
         hp::parser::paf p(parser); // copy-construct like the stream API does (stream.hpp:139)
         humans += p.process(packet[0], packet[1]).size();
+    }
+    {   // the maps above never left the device (utility/data.hpp, detail::device_batch): the batch was parsed in one launch at the first
+        // process() call.  The reference's form - every map copied to the host, every frame uploaded again and parsed by itself - must give
+        // the same humans, and a map's host view must be what hp_engine_output_to_host returns
+        setenv("HP_MIRROR_HOST_MAPS", "1", 1);
+        size_t again = 0;
+        for (size_t f = 0; f < packets.size(); ++f) {
+            hp::parser::paf p(parser);
+            const auto a = p.process(packets[f][0], packets[f][1]);
+            unsetenv("HP_MIRROR_HOST_MAPS");
+            hp::parser::paf q(parser);
+            const auto b = q.process(packets[f][0], packets[f][1]);
+            setenv("HP_MIRROR_HOST_MAPS", "1", 1);
+            if (a.size() != b.size())
+                return 20;
+            for (size_t i = 0; i < a.size(); ++i) {
+                if (a[i].score != b[i].score)
+                    return 21;
+                for (int k = 0; k < hp::COCO_N_PARTS; ++k)
+                    if (a[i].parts[k].has_value != b[i].parts[k].has_value || a[i].parts[k].x != b[i].parts[k].x || a[i].parts[k].y != b[i].parts[k].y
+                        || a[i].parts[k].score != b[i].parts[k].score)
+                        return 21;
+            }
+            again += a.size();
+        }
+        unsetenv("HP_MIRROR_HOST_MAPS");
+        if (again != humans)
+            return 22;
+        const auto& cm = packets[1][0];
+        std::vector<float> direct((size_t)3 * cm.shape()[0] * cm.shape()[1] * cm.shape()[2]);
+        if (hp_engine_output_to_host(engine.handle(), 0, 3, direct.data()) != HP_OK)
+            return 23;
+        const size_t per = direct.size() / 3;
+        if (std::memcmp(cm.view<float>(), direct.data() + per, per * sizeof(float)) != 0)
+            return 24;
+        // a map that outlives the next inference call keeps the values of ITS call (the host copy is made just before the buffers are re-used)
+        auto first = engine.inference({ batch[0] });
+        std::vector<float> keep(first[0][1].view<float>(), first[0][1].view<float>() + (size_t)first[0][1].shape()[0] * first[0][1].shape()[1] * first[0][1].shape()[2]);
+        auto held = engine.inference({ batch[1] });          // `held`'s maps stay on the device ...
+        auto other = engine.inference({ batch[0] });         // ... until this call retires them
+        if (std::memcmp(first[0][1].view<float>(), keep.data(), keep.size() * sizeof(float)) != 0)
+            return 25;
+        if (std::memcmp(other[0][1].view<float>(), keep.data(), keep.size() * sizeof(float)) != 0) // same frame, same values
+            return 26;
+        if (std::memcmp(held[0][1].view<float>(), keep.data(), keep.size() * sizeof(float)) == 0)  // another frame: other values, and its own
+            return 27;
+        hp::parser::paf late(parser);
+        (void)late.process(held[0][0], held[0][1]); // maps whose batch has left the device are parsed from their host copies
     }
     {   // the other two parsers through their mirrors, fed by their engines (reduced sizes)
         hp::dnn::tensorrt ppn_engine(hp::dnn::builtin_model{ "pose_proposal_resnet50", {}, 3 }, cv::Size(160, 128), 2);
