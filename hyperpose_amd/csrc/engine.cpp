@@ -34,12 +34,16 @@ struct tensor_info {
     int H = 0, W = 0, C = 0; // C = total channels written
     int cs = 0;              // channel stride of the buffer
     int P = 0;               // zero halo (pixels) around every image: the largest padding any consumer needs
-    hp::dev_buf buf;
+    hp::dev_buf buf;         // the tensor's own allocation, or
+    void* shared = nullptr;  // ... a buffer of the engine's activation arena that tensors of the same geometry take turns in (hp_engine::arena)
+    int arena_slot = -1;
+    template <typename T>
+    T* base() const { return static_cast<T*>(shared ? shared : buf.p); }
     hp::tview view(int coff) const
     {
         hp::tview v;
         const int wp = W + 2 * P;
-        v.p = buf.as<__half>() + ((size_t)P * wp + P) * cs;
+        v.p = base<__half>() + ((size_t)P * wp + P) * cs;
         v.cs = cs, v.coff = coff, v.wp = wp, v.img = (H + 2 * P) * wp;
         return v;
     }
@@ -47,7 +51,7 @@ struct tensor_info {
     {
         hp::tview32 v;
         const int wp = W + 2 * P;
-        v.p = buf.as<float>() + ((size_t)P * wp + P) * cs;
+        v.p = base<float>() + ((size_t)P * wp + P) * cs;
         v.cs = cs, v.coff = coff, v.wp = wp, v.img = (H + 2 * P) * wp;
         return v;
     }
@@ -132,6 +136,16 @@ struct hp_engine {
     std::vector<out_info> outputs; // sorted by name
     std::vector<step> steps;
     std::vector<std::unique_ptr<hp::dev_buf>> weight_bufs;
+    // Activation arena (HP_DTYPE_F32 / F32S engines; HP_NO_ARENA=1 gives every tensor its own allocation, as before round 6).  TensorRT re-uses
+    // activation memory between layers (the reference's engine owns only the binding buffers, src/tensorrt.cpp:255-316); here tensors of ONE
+    // geometry class - same H x W, halo, channel stride and channel count, so that the zero halo and the zero pad channels of a buffer stay valid
+    // for every tenant - take turns in the minimum number of buffers their lifetimes in the schedule need (interval colouring in layer order).
+    struct arena_buf {
+        std::unique_ptr<hp::dev_buf> mem;
+        int tenants = 0;
+    };
+    std::vector<arena_buf> arena;
+    size_t arena_private_bytes = 0; // what the same tensors took with one allocation each
     hp::dev_buf in_stage; // staging for host inputs
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -428,16 +442,6 @@ int hp_engine::build(const hp_engine_desc* d)
             tensors[A.out]->elided = true;
         }
     }
-    for (size_t t = 1; t < tensors.size(); ++t) {
-        tensor_info& ti = *tensors[t];
-        if (!ti.defined || ti.elided)
-            continue;
-        ti.cs = round_up(ti.C, 32);
-        const size_t bytes = (size_t)max_batch * (ti.H + 2 * ti.P) * (ti.W + 2 * ti.P) * ti.cs * (f32 ? sizeof(float) : sizeof(__half));
-        HP_TRY(ti.buf.alloc(bytes));
-        HP_HIP_TRY(hipMemset(ti.buf.p, 0, bytes)); // the halo and the pad channels must read as zero, forever
-    }
-
     // ---- outputs
     HP_REQUIRE(d->n_outputs >= 1 && d->outputs, HP_ERR_INVALID, "engine: no outputs");
     for (int i = 0; i < d->n_outputs; ++i) {
@@ -477,6 +481,77 @@ int hp_engine::build(const hp_engine_desc* d)
         if (writers == 1 && layers[last].op == HP_OP_CONV && layers[last].in != 0 && layers[last].out_coff == o.coff
             && layers[last].cout == o.channels && o.act == HP_ACT_NONE && o.plain())
             o.fused_layer = last;
+    }
+
+    // ---- activation memory.  fp16 engines: one zero-filled allocation per tensor.  fp32 engines: the arena (see hp_engine::arena).
+    {
+        const bool use_arena = f32 && !getenv("HP_NO_ARENA");
+        const int NL = (int)layers.size(), INF = NL + 1;
+        std::vector<int> first(tensors.size(), INF), last(tensors.size(), -1);
+        for (int i = 0; i < NL; ++i) {
+            const hp_layer& L = layers[i];
+            // the step a layer's reads happen in: the first half of a fused pair (depthwise / hidden head layer) runs inside the NEXT layer's launch
+            const int at = (fuse32_with_next[i] || head32_with_next[i]) ? i + 1 : i;
+            first[L.out] = std::min(first[L.out], i);
+            last[L.out] = std::max(last[L.out], i);
+            if (L.in > 0)
+                last[L.in] = std::max(last[L.in], at);
+            if (L.res >= 0)
+                last[L.res] = std::max(last[L.res], at);
+        }
+        for (const auto& o : outputs)
+            if (o.fused_layer < 0)
+                last[o.tensor] = INF; // read by the conversion kernel behind the last layer
+        struct cls_key {
+            int H, W, P, cs, C;
+            bool operator<(const cls_key& o) const { return std::tie(H, W, P, cs, C) < std::tie(o.H, o.W, o.P, o.cs, o.C); }
+        };
+        std::map<cls_key, std::vector<int>> free_slots; // arena slots of a class nobody lives in at the moment
+        std::vector<std::vector<int>> dying(NL + 2);
+        for (size_t t = 1; t < tensors.size(); ++t) {
+            tensor_info& ti = *tensors[t];
+            if (!ti.defined || ti.elided)
+                continue;
+            ti.cs = round_up(ti.C, 32);
+        }
+        auto bytes_of = [&](const tensor_info& ti) { return (size_t)max_batch * (ti.H + 2 * ti.P) * (ti.W + 2 * ti.P) * ti.cs * (f32 ? sizeof(float) : sizeof(__half)); };
+        if (!use_arena) {
+            for (size_t t = 1; t < tensors.size(); ++t) {
+                tensor_info& ti = *tensors[t];
+                if (!ti.defined || ti.elided)
+                    continue;
+                HP_TRY(ti.buf.alloc(bytes_of(ti)));
+                HP_HIP_TRY(hipMemset(ti.buf.p, 0, bytes_of(ti))); // the halo and the pad channels must read as zero, forever
+            }
+        } else {
+            for (int i = 0; i < NL; ++i) {
+                const int t = layers[i].out;
+                tensor_info& ti = *tensors[t];
+                if (first[t] == i && !ti.elided && ti.arena_slot < 0) {
+                    const cls_key key{ ti.H, ti.W, ti.P, ti.cs, ti.C };
+                    auto& fl = free_slots[key];
+                    int slot;
+                    if (!fl.empty()) {
+                        slot = fl.back();
+                        fl.pop_back();
+                    } else {
+                        slot = (int)arena.size();
+                        arena.emplace_back();
+                        arena.back().mem = std::make_unique<hp::dev_buf>();
+                        HP_TRY(arena.back().mem->alloc(bytes_of(ti)));
+                        HP_HIP_TRY(hipMemset(arena.back().mem->p, 0, bytes_of(ti))); // halo and pad channels: zero for every tenant, forever
+                    }
+                    ti.arena_slot = slot, ti.shared = arena[slot].mem->p;
+                    ++arena[slot].tenants;
+                    arena_private_bytes += bytes_of(ti);
+                    dying[std::min(std::max(last[t], i), NL + 1)].push_back(t);
+                }
+                for (int d : dying[i]) { // tensors whose last reader is this step: their buffers are free from the next step on
+                    const tensor_info& td = *tensors[d];
+                    free_slots[cls_key{ td.H, td.W, td.P, td.cs, td.C }].push_back(td.arena_slot);
+                }
+            }
+        }
     }
 
     // a tensor some layer reads (input or residual), or that an un-fused output conversion will read
@@ -1979,11 +2054,22 @@ int hp_engine_device_bytes(const hp_engine* e, uint64_t bytes[3])
     for (const auto& t : e->tensors)
         if (t)
             bytes[0] += t->buf.bytes;
+    for (const auto& a : e->arena)
+        bytes[0] += a.mem->bytes;
     for (const auto& w : e->weight_bufs)
         bytes[1] += w->bytes;
     for (const auto& o : e->outputs)
         if (o.buf)
             bytes[2] += o.buf->bytes;
+    return HP_OK;
+}
+
+int hp_engine_arena_info(const hp_engine* e, uint64_t info[3])
+{
+    HP_REQUIRE(e && info, HP_ERR_INVALID, "hp_engine_arena_info: null argument");
+    info[0] = e->arena.size(), info[1] = 0, info[2] = e->arena_private_bytes;
+    for (const auto& a : e->arena)
+        info[1] += a.tenants;
     return HP_OK;
 }
 
@@ -2049,6 +2135,8 @@ int hp_engine_debug_tensor(hp_engine* e, int tensor, int n, float* host, int sha
     HP_REQUIRE(e && tensor > 0 && tensor < (int)e->tensors.size() && e->tensors[tensor]->defined, HP_ERR_INVALID, "hp_engine_debug_tensor: bad tensor %d", tensor);
     HP_REQUIRE(!e->tensors[tensor]->unwritten, HP_ERR_STATE, "hp_engine_debug_tensor: tensor %d exists only as the fp32 network output", tensor);
     HP_REQUIRE(!e->tensors[tensor]->elided, HP_ERR_STATE, "hp_engine_debug_tensor: tensor %d lives only inside a fused separable block (HP_NO_FUSE=1 materialises it)", tensor);
+    HP_REQUIRE(e->tensors[tensor]->arena_slot < 0 || e->arena[e->tensors[tensor]->arena_slot].tenants == 1, HP_ERR_STATE,
+        "hp_engine_debug_tensor: tensor %d shares its buffer with later tensors of the same geometry (the activation arena); build the engine with HP_NO_ARENA=1 to look at it", tensor);
     const tensor_info& ti = *e->tensors[tensor];
     if (shape)
         shape[0] = ti.C, shape[1] = ti.H, shape[2] = ti.W;

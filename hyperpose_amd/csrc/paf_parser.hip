@@ -544,7 +544,11 @@ __global__ void paf_debug_sort_kernel(const float* __restrict__ scores, int n, c
     }
 }
 
-__global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict__ paf, geom_t g, float paf_thresh,
+// LIMB_THREADS threads per (limb, frame): the pair loop is the kernel's time, a block is alone on its CU (19 x frames blocks), and what a frame of
+// dense maps costs is its LARGEST limb (a part with 300 maxima on both ends is 90 000 pairs): sixteen wavefronts - four per SIMD - walk the pairs
+// four times as wide and cover each other's LDS / division latencies (round 6; four wavefronts before)
+constexpr int LIMB_THREADS = 1024;
+__global__ __launch_bounds__(LIMB_THREADS) void paf_limbs_kernel(const float* __restrict__ paf, geom_t g, float paf_thresh,
     const dpeak* __restrict__ sorted, const int* __restrict__ pcount, int peak_cap, int cand_cap,
     dconn* __restrict__ conns, int* __restrict__ conn_count, int* __restrict__ flags)
 {
@@ -571,6 +575,19 @@ __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict_
     float* s_py = smem + plane;    // PAF y-channel
     cand_t* s_cand = reinterpret_cast<cand_t*>(smem + 2 * plane); // [cand_cap]
     int* s_order = reinterpret_cast<int*>(s_cand + cand_cap);     // [cand_cap] sorted position -> candidate
+    // the up-sampling tables of geom_t, staged once per block (round 6): every sample of every candidate pair used to read seven of them
+    // from global memory - 140 dependent L1 / L2 round trips per pair; a frame of dense maps (the network's own output under random weights:
+    // ~55 peaks per part, ~2 900 pairs per limb) spent 259 us here against 12 us on a frame with people.  Same values, same expressions.
+    int* s_ofs_x = s_order + cand_cap;                 // [UW]
+    float* s_c0_x = reinterpret_cast<float*>(s_ofs_x + g.UW), *s_c1_x = s_c0_x + g.UW;
+    int* s_ofs_y0 = reinterpret_cast<int*>(s_c1_x + g.UW), *s_ofs_y1 = s_ofs_y0 + g.UH; // [UH]
+    float* s_c0_y = reinterpret_cast<float*>(s_ofs_y1 + g.UH), *s_c1_y = s_c0_y + g.UH;
+    if (n1 > 0 && n2 > 0) {
+        for (int i = tid; i < g.UW; i += LIMB_THREADS)
+            s_ofs_x[i] = g.ofs_x[i], s_c0_x[i] = g.c0_x[i], s_c1_x[i] = g.c1_x[i];
+        for (int i = tid; i < g.UH; i += LIMB_THREADS)
+            s_ofs_y0[i] = g.ofs_y0[i], s_ofs_y1[i] = g.ofs_y1[i], s_c0_y[i] = g.c0_y[i], s_c1_y[i] = g.c1_y[i];
+    }
 
     if (tid == 0)
         s_ncand = 0;
@@ -582,17 +599,17 @@ __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict_
         const float* sy = src + (size_t)ch2 * plane;
         if (plane % 4 == 0 && ((size_t)paf & 15) == 0) {
             const int n4 = plane / 4;
-            for (int base = 0; base < n4; base += 4 * 256) {
+            for (int base = 0; base < n4; base += 4 * LIMB_THREADS) {
                 float4 vx[4], vy[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int i = min(base + k * 256 + tid, n4 - 1);
+                    const int i = min(base + k * LIMB_THREADS + tid, n4 - 1);
                     vx[k] = reinterpret_cast<const float4*>(sx)[i];
                     vy[k] = reinterpret_cast<const float4*>(sy)[i];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int i = base + k * 256 + tid;
+                    const int i = base + k * LIMB_THREADS + tid;
                     if (i < n4) {
                         reinterpret_cast<float4*>(s_px)[i] = vx[k];
                         reinterpret_cast<float4*>(s_py)[i] = vy[k];
@@ -600,16 +617,16 @@ __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict_
                 }
             }
         } else {
-            for (int base = 0; base < plane; base += 4 * 256) {
+            for (int base = 0; base < plane; base += 4 * LIMB_THREADS) {
                 float vx[4], vy[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int i = min(base + k * 256 + tid, plane - 1);
+                    const int i = min(base + k * LIMB_THREADS + tid, plane - 1);
                     vx[k] = sx[i], vy[k] = sy[i];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int i = base + k * 256 + tid;
+                    const int i = base + k * LIMB_THREADS + tid;
                     if (i < plane)
                         s_px[i] = vx[k], s_py[i] = vy[k];
                 }
@@ -639,8 +656,19 @@ __global__ __launch_bounds__(256) void paf_limbs_kernel(const float* __restrict_
         for (int i = 0; i < STEP_PAF; ++i) {
             const int lx = static_cast<int>(a.x + i * step_x + 0.5); // roundpaf, paf.cpp:74
             const int ly = static_cast<int>(a.y + i * step_y + 0.5);
-            const float px = up_at(s_px, 0, g, ly, lx);
-            const float py = up_at(s_py, 0, g, ly, lx);
+            // up_at(s_px, 0, g, ly, lx) and up_at(s_py, 0, g, ly, lx) with the tables in LDS and read once for both planes
+            const int sxo = s_ofs_x[lx], r0 = s_ofs_y0[ly] * g.Cc + sxo, r1 = s_ofs_y1[ly] * g.Cc + sxo;
+            const float cy0 = s_c0_y[ly], cy1 = s_c1_y[ly];
+            float px, py;
+            if (lx < g.vmax_x) {
+                const float a0 = s_c0_x[lx], a1 = s_c1_x[lx];
+                const float hx0 = s_px[r0] * a0 + s_px[r0 + 1] * a1, hx1 = s_px[r1] * a0 + s_px[r1 + 1] * a1;
+                const float hy0 = s_py[r0] * a0 + s_py[r0 + 1] * a1, hy1 = s_py[r1] * a0 + s_py[r1 + 1] * a1;
+                px = hx0 * cy0 + hx1 * cy1, py = hy0 * cy0 + hy1 * cy1;
+            } else {
+                const float hx0 = s_px[r0] * 1.f, hx1 = s_px[r1] * 1.f, hy0 = s_py[r0] * 1.f, hy1 = s_py[r1] * 1.f;
+                px = hx0 * cy0 + hx1 * cy1, py = hy0 * cy0 + hy1 * cy1;
+            }
             const float score = vx * px + vy * py;
             scores += score;
             if (score > paf_thresh)
@@ -1313,7 +1341,7 @@ struct hp_paf {
 constexpr int PEAK_CAP_MAX = 2048, HUMAN_CAP_MAX = 1024;
 int hp_paf::alloc_lists()
 {
-    limbs_lds = (size_t)4 * 2 * g.R * g.Cc + (size_t)cand_cap * (sizeof(cand_t) + sizeof(int));
+    limbs_lds = (size_t)4 * 2 * g.R * g.Cc + (size_t)cand_cap * (sizeof(cand_t) + sizeof(int)) + (size_t)4 * (3 * g.UW + 4 * g.UH); // planes, candidates, up-sampling tables
     HP_REQUIRE(limbs_lds <= 160 * 1024, HP_ERR_INVALID, "paf: feature map too large for LDS tiling");
     HP_HIP_TRY(hipFuncSetAttribute((const void*)paf_limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limbs_lds));
     const size_t B = max_batch;
@@ -1472,7 +1500,7 @@ int hp_paf::launch(int n, const float* dev_conf, const float* dev_paf, hipStream
     HP_TRY(launch_peaks(p, n, dev_conf, s, nullptr, nullptr, HP_COCO_N_PARTS));
     hipLaunchKernelGGL(paf_sort_kernel, dim3(HP_COCO_N_PARTS, n), dim3(256), p->peak_cap * sizeof(int), s,
         p->plist.as<dpeak>(), p->pcount.as<int>(), p->peak_cap, p->sorted.as<dpeak>());
-    hipLaunchKernelGGL(paf_limbs_kernel, dim3(HP_COCO_N_PAIRS, n), dim3(256), p->limbs_lds, s, dev_paf, p->g, p->paf_thresh,
+    hipLaunchKernelGGL(paf_limbs_kernel, dim3(HP_COCO_N_PAIRS, n), dim3(LIMB_THREADS), p->limbs_lds, s, dev_paf, p->g, p->paf_thresh,
         p->sorted.as<dpeak>(), p->pcount.as<int>(), p->peak_cap, p->cand_cap, p->conns.as<dconn>(), p->conn_count.as<int>(),
         p->flags.as<int>());
     hipLaunchKernelGGL(paf_assemble_kernel, dim3(n), dim3(64), 0, s, p->sorted.as<dpeak>(), p->pcount.as<int>(), p->peak_cap,
@@ -1514,7 +1542,7 @@ int hp_paf_collect(hp_paf* p, hp_human* out, int cap_per_frame, int* n_out)
             max_h = std::max(max_h, p->h_counts.as<int>()[f]);
         }
         // a list overflowed somewhere in the batch: grow what can grow and parse the batch again (the reference's vectors just grow)
-        const size_t planes = (size_t)4 * 2 * p->g.R * p->g.Cc, per_cand = sizeof(cand_t) + sizeof(int);
+        const size_t planes = (size_t)4 * 2 * p->g.R * p->g.Cc + (size_t)4 * (3 * p->g.UW + 4 * p->g.UH), per_cand = sizeof(cand_t) + sizeof(int); // (+ the up-sampling tables)
         const int cand_max = (int)((156 * 1024 - planes) / per_cand);
         // the new capacities are computed into locals and committed only together with the buffers that match them: leaving the loop
         // (round limit) or failing to allocate must not leave caps larger than plist / sorted / conns / h_humans

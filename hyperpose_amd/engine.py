@@ -203,6 +203,13 @@ class Engine:
         check(lib().hp_engine_device_bytes(self._h, b))
         return {"activations": int(b[0]), "weights": int(b[1]), "outputs": int(b[2]), "total": int(b[0] + b[1] + b[2])}
 
+    @property
+    def arena_info(self) -> dict:
+        """The activation arena of an fp32 engine (hp_engine_arena_info): buffers, tensors living in them, bytes without re-use."""
+        b = (C.c_uint64 * 3)()
+        check(lib().hp_engine_arena_info(self._h, b))
+        return {"buffers": int(b[0]), "tensors": int(b[1]), "bytes_without_reuse": int(b[2])}
+
     def close(self):
         if self._h:
             lib().hp_engine_destroy(self._h)

@@ -363,6 +363,10 @@ int hp_engine_split_fallbacks(const hp_engine* e);
 /* HBM the engine holds for its max_batch, in bytes: bytes[0] activation tensors (with their zero halos), bytes[1] packed weights in every
  * form its kernels read (fragment orders, the Winograd U matrices of an HP_DTYPE_F32 engine ...), bytes[2] the fp32 NCHW network outputs */
 int hp_engine_device_bytes(const hp_engine* e, uint64_t bytes[3]);
+/* The activation arena of an HP_DTYPE_F32 / F32S engine (tensors of one geometry take turns in the fewest buffers their lifetimes in the schedule
+ * allow; HP_NO_ARENA=1 at creation: one allocation per tensor): info = { buffers, tensors living in them, bytes the same tensors would take with one
+ * allocation each }.  All zero for engines without an arena. */
+int hp_engine_arena_info(const hp_engine* e, uint64_t info[3]);
 
 /* ---- hyperpose::stream on the GPU (reference include/hyperpose/stream/stream.hpp:119-390, src/stream.cpp:60-147): host frames of
  * any size in, humans out, in submission order.  Each submit copies one batch (<= max_batch frames, 8-bit BGR HWC, packed rows) to
