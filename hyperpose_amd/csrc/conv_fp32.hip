@@ -488,6 +488,12 @@ static void conv32_pick(const conv32_params& p, int& BM, int& BN)
         if (b128 > 1024 && b160 <= 1024)
             BN = 160;
     }
+    // ResNet's 1 x 1 expansions with few input channels (64 -> 256 at 96 x 96, 128 -> 512 at 48 x 48, batch 32): four to eight K-steps, then 300 MB
+    // of output + residual - the layer is its epilogue.  conv32_t16_kernel's stores cover 16 pixels x 64 contiguous bytes per instruction where
+    // the 32 x 32 accumulator layout covers 64 pixels x 16 bytes: 259 -> 205 us alone, 218 -> 188 with a second stream for 64 -> 256, 146 -> 142 | 130 -> 126
+    // for 128 -> 512; every wider-K layer is slower on it (profiles/r06_ab_layers_f32_config3_t16.txt)
+    if (bn160 != 0 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.Cin <= 128 && p.Cout_pad >= 256 && !p.out_f32 && (BN == 128))
+        BM = 64, BN = 160;
 }
 
 static bool conv32_rows(const conv32_params& p, int BN)

@@ -696,8 +696,7 @@ int hp_engine::build(const hp_engine_desc* d)
                 HP_REQUIRE(hp::set_act32(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
                 p.B = max_batch, p.npix = p.pick_npix = max_batch * g.OH * g.OW;
                 p.w_split = nullptr, p.w_frag = nullptr, p.w_wino = nullptr, p.ovf = ovf_dev, p.dbg = nullptr;
-                static const int lane_epi = getenv("HP_LANE_EPILOGUE") ? atoi(getenv("HP_LANE_EPILOGUE")) : 0;
-                p.lane_epilogue = lane_epi;
+                p.lane_epilogue = getenv("HP_LANE_EPILOGUE") ? atoi(getenv("HP_LANE_EPILOGUE")) : 0; // (A/B switches are read per build: an in-process A/B compares two engines)
                 // The layers conv32_direct_kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the buffer's
                 // channel stride) get their weights in fragment order as well: fp32 for HP_DTYPE_F32 (HP_NO_DIRECT32=1: the A/B switch back
                 // to conv32_kernel), fp16 (hi, lo) pairs for HP_DTYPE_F32S; the others stay on conv32_kernel
@@ -705,9 +704,11 @@ int hp_engine::build(const hp_engine_desc* d)
                 // 72.2 -> 58.7 | 52.6 -> 48.9; the 1 x 1 heads 512 -> 19 / 38 27.9 / 29.3 -> 26.1 / 27.4 | 18.8 / 19.6 -> 17.9 / 18.2; every wider 1 x 1
                 // layer within +-3 % or worse (64 -> 128 22.9 -> 29.0 paired, 512 -> 512 100 -> 100 alone): 1 x 1 layers wider than 64 padded outputs
                 // stay on conv32_kernel (HP_DIRECT32_MAX_1X1 moves the limit, HP_NO_DIRECT32=1 is the A/B switch)
-                static const bool no_direct = getenv("HP_NO_DIRECT32") != nullptr;
-                static const int direct_max_1x1 = getenv("HP_DIRECT32_MAX_1X1") ? atoi(getenv("HP_DIRECT32_MAX_1X1")) : 64;
-                if (dtype == HP_DTYPE_F32S || dw_in_front || (!no_direct && (taps > 1 || cout_pad <= direct_max_1x1))) {
+                const bool no_direct = getenv("HP_NO_DIRECT32") != nullptr;
+                const int direct_max_1x1 = getenv("HP_DIRECT32_MAX_1X1") ? atoi(getenv("HP_DIRECT32_MAX_1X1")) : 64;
+                // (a 3 x 3 layer the Winograd kernel will take needs no direct-form fragments: they doubled its weight bytes in HBM)
+                const bool wino_takes_it = dtype == HP_DTYPE_F32 && !dw_in_front && !getenv("HP_NO_WINOGRAD32") && hp::conv32_winograd_ok(p) && !head_in_front;
+                if (dtype == HP_DTYPE_F32S || dw_in_front || (!no_direct && !wino_takes_it && (taps > 1 || cout_pad <= direct_max_1x1))) {
                     const int ck = taps == 1 ? 64 : 32, cin_s = round_up(L.cin, ck);
                     hp::conv32_params q = p;
                     q.Cin = cin_s;
@@ -721,6 +722,11 @@ int hp_engine::build(const hp_engine_desc* d)
                                     wide.begin() + ((size_t)t * cout_pad + co) * cin_s);
                         void* dws = nullptr;
                         if (dtype == HP_DTYPE_F32S) {
+                            // (a BN-folded weight beyond fp16's range has no (hi, lo) split - hi would be inf - and the run-time flag only watches
+                            // activations: such an engine starts on the fp32 pipe.  ADVICE r5)
+                            for (float v : wide)
+                                if (!(std::fabs(v) <= 65504.f) && !split_off)
+                                    split_off = true, ++split_fallbacks;
                             std::vector<_Float16> ws(wide.size() * 2);
                             hp::conv32_split_pack(wide.data(), taps, cout_pad, cin_s, ws.data());
                             HP_TRY(upload(ws.data(), ws.size() * sizeof(_Float16), &dws));
@@ -2034,7 +2040,9 @@ int hp_engine_synchronize(hp_engine* e)
 {
     HP_REQUIRE(e, HP_ERR_INVALID, "null engine");
     HP_HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->split_overflowed() && e->last.input && true) {
+    if (e->last.stream && (hipStream_t)e->last.stream != e->stream) // the newest call ran on the caller's stream: the flag below is its kernels'
+        HP_HIP_TRY(hipStreamSynchronize((hipStream_t)e->last.stream));
+    if (e->split_overflowed() && e->last.input) {
         // HP_DTYPE_F32S: the batch just finished saw |x| > 65504 somewhere - its outputs are not trustworthy.  Run it again on the fp32
         // pipe before the caller reads them (a host input is copied again from the caller's buffer, which the API keeps valid until the
         // outputs are read)

@@ -101,10 +101,18 @@ def init_for_gpu(device, probe: bool = True, probe_timeout_s: float = 45.0):
     flag = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo: round 2, the agreement
     if int(flag.item()) == 1:
-        try:  # every rank got here with a working RCCL: the data collectives' own group (collective call, same order on all ranks)
-            group = dist.new_group(backend="nccl")
-        except Exception:  # noqa: BLE001 - keep the probe's group rather than fail after the agreement
-            pass
+        # every rank got here with a working RCCL: the data collectives' own group (collective call, same order on all ranks).  Whether that group
+        # exists is AGREED on like the probe was: if new_group failed on some ranks only, the ranks would hold different groups and
+        # the next broadcast would hang until its time-out - so either all ranks use the new group or all keep the probe's.
+        fresh, made = None, 1
+        try:
+            fresh = dist.new_group(backend="nccl")
+        except Exception:  # noqa: BLE001
+            made = 0
+        agreed = torch.tensor([made], dtype=torch.int32)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)  # gloo (the default group)
+        if int(agreed.item()) == 1:
+            group = fresh
         _GROUP, _COLLECTIVE_DEVICE, _BACKEND = group, device, "nccl"
     else:
         if why:

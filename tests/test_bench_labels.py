@@ -63,15 +63,15 @@ def test_ambiguous_or_unknown_kernel_names_give_no_number():
 def _detail():
     """the newest committed full record of a default `python bench.py` run (profiles/r*_bench_detail.json, written by bench.py next to
     the ONE line it prints)"""
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_detail.json")))
+    paths = [p for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_detail.json"))) if os.path.basename(p) >= "r06"]
     if not paths:
-        pytest.skip("no committed bench detail record")
+        pytest.skip("no committed bench detail record of the round-6 form (value = the host-fed leg)")
     return json.load(open(paths[-1]))
 
 
 def _bench_line():
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_final.json")))
-    paths = [p for p in paths if os.path.basename(p) >= "r05"]
+    paths = [p for p in paths if os.path.basename(p) >= "r06"]
     if not paths:
         pytest.skip("no committed bench line of the compact form")
     return open(paths[-1]).read().strip().splitlines()[-1]
@@ -89,6 +89,12 @@ def test_line_is_small_enough_for_the_driver_and_regenerates_from_the_detail_rec
         assert k in out, k
     assert "dropped_for_size" not in out
     assert out["config"]["workload"] and "model" not in out["config"]
+    # round 6: `value` IS the SURVEY 8(d) number - frames from pinned host memory, one H2D per batch, the parser on the
+    # network's own maps - and round 5's headline is kept beside it under its own name
+    assert "frames from pinned host memory" in out["config"]["workload"] and out["config"]["parser_input"] == "the network's own heat-maps"
+    assert out["value"] == d["headline"]["h2d_inclusive"]["value"] == out["value_h2d_inclusive"]
+    assert out["value_resident_injected"] == d["headline"]["value_resident_injected"] > 0 and out["fps_dnn_output"] > 0
+    assert "mfma_busy" in out["roofline"] and "operator_api_fps" in out and "single_pipe_fps" in out
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
     assert out["steps_timed"] % out["steps"] == 0 and out["timed_region_s"] >= 0.45
@@ -162,7 +168,8 @@ def test_dominant_kernel_of_the_headline_has_both_clocks_and_traffic():
     assert cp["source"] and cp["avg_launch_us"] is not None and cp["frac_mfma"] is not None and r["traffic"] is not None
     assert 0.8 < cp["avg_launch_us"] / r["avg_launch_us"] < 1.35
     assert h["cpu_baseline"]["kind"] in ("reference", "port") and h["cpu_baseline"]["value"] > 0
-    assert set(d["workloads"]) == ({f"configs[{i}]/{dt}" for i in range(5) for dt in ("f32", "f16")} | {"configs[1]/f32s"}) - {"configs[1]/f32"}
+    # (HP_DTYPE_F32S left the default run in round 6: single-stream only, bench.py measure())
+    assert set(d["workloads"]) == {f"configs[{i}]/{dt}" for i in range(5) for dt in ("f32", "f16")} - {"configs[1]/f32"}
     f16 = d["workloads"]["configs[1]/f16"]
     assert f16["roofline"]["mfma_peak_tflops"] == 2500.0 and f16["value"] > h["value"] > 0
 
