@@ -10,6 +10,21 @@
 #include <cstdlib>
 #include <cstring>
 
+static bool same_humans(const std::vector<hyperpose::human_t>& a, const std::vector<hyperpose::human_t>& b)
+{
+    if (a.size() != b.size())
+        return false;
+    for (size_t i = 0; i < a.size(); ++i) {
+        if (a[i].score != b[i].score)
+            return false;
+        for (int k = 0; k < hyperpose::COCO_N_PARTS; ++k)
+            if (a[i].parts[k].has_value != b[i].parts[k].has_value || a[i].parts[k].x != b[i].parts[k].x || a[i].parts[k].y != b[i].parts[k].y
+                || a[i].parts[k].score != b[i].parts[k].score)
+                return false;
+    }
+    return true;
+}
+
 int main(int argc, char** argv)
 {
     if (hp_init(0) != HP_OK) {
@@ -88,17 +103,33 @@ int main(int argc, char** argv)
         cv::Mat m(128, 160);
         for (size_t k = 0; k < m.total() * 3; ++k)
             m.data()[k] = (uint8_t)((k * 13) & 255);
-        auto out = ppn_engine.inference({ m });
+        auto out = ppn_engine.inference({ m, m });
         if (out[0].size() != 7)
             return 5;
-        humans += ppn.process(out[0]).size();
+        const auto dev0 = ppn.process(out[0]), dev1 = ppn.process(out[1]); // from the device, both frames in one launch
+        setenv("HP_MIRROR_HOST_MAPS", "1", 1);
+        hp::parser::pose_proposal ppn_host(cv::Size(160, 128));
+        const auto host0 = ppn_host.process(out[0]), host1 = ppn_host.process(out[1]); // the reference's form: host maps, frame by frame
+        unsetenv("HP_MIRROR_HOST_MAPS");
+        if (!same_humans(dev0, host0) || !same_humans(dev1, host1) || !same_humans(dev0, dev1))
+            return 30;
+        humans += dev0.size();
         hp::dnn::tensorrt pp_engine(hp::dnn::builtin_model{ "pifpaf_resnet50", {}, 4 }, cv::Size(97, 97), 2);
         hp::parser::pifpaf pp(97, 97);
         cv::Mat m2(97, 97);
-        auto out2 = pp_engine.inference({ m2 });
+        for (size_t k = 0; k < m2.total() * 3; ++k)
+            m2.data()[k] = (uint8_t)((k * 7) & 255);
+        auto out2 = pp_engine.inference({ m2, m2 });
         if (out2[0].size() != 2)
             return 6;
-        humans += pp.process(out2[0]).size();
+        const auto pdev0 = pp.process(out2[0]), pdev1 = pp.process(out2[1]);
+        setenv("HP_MIRROR_HOST_MAPS", "1", 1);
+        hp::parser::pifpaf pp_host(97, 97);
+        const auto phost0 = pp_host.process(out2[0]), phost1 = pp_host.process(out2[1]);
+        unsetenv("HP_MIRROR_HOST_MAPS");
+        if (!same_humans(pdev0, phost0) || !same_humans(pdev1, phost1))
+            return 31;
+        humans += pdev0.size();
     }
     {   // the stream operator (stream.hpp:119-145): frames of any size in, pose sets out in submission order
         hp::hip_stream stream(hp::dnn::builtin_model{ "lw_openpose_mobilenet", {}, 7 }, cv::Size(96, 80), 4, /*keep_ratio*/ true, /*n_pipes*/ 2,

@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 steps=12
 [ "$cfg" != "1" ] && [ "$cfg" != "0" ] && steps=3
 [ "$dt" != "f16" ] && [ "$cfg" != "1" ] && [ "$cfg" != "0" ] && steps=2
-cmd="python $repo/bench.py --config $cfg --dtype $dt --no-clocks --min-seconds 0 --extra= --steps $steps --warmup 2 --pipes 1 --no-cpu-baseline --no-roofline --no-from-host --no-dnn-output"
+cmd="python $repo/bench.py --config $cfg --dtype $dt --no-clocks --min-seconds 0 --extra= --steps $steps --warmup 2 --pipes 1 --no-cpu-baseline --no-roofline --no-from-host --no-dnn-output --no-operator-api"
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- $cmd > /dev/null 2>&1
 cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats${sfx}.csv
