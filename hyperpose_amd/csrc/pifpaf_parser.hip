@@ -734,7 +734,7 @@ void decode_frame(const pp_geom& g, const int* hdr, const float* arena, float ke
 // within 2^-29 relative of a rounding boundary.
 namespace {
 
-constexpr int PD_MAXA = 256;   // annotations per frame on the device path (more: the frame is decoded by the host tail)
+constexpr int PD_MAXA = 1024;  // annotations per frame on the device path (more: the frame is decoded by the host tail).  256 until round 6: the sort keys (8 KB of LDS now), 272 B per annotation in HBM and 292 B per human in pinned memory are what it costs; a 49 x 49 map has 2 401 cells per joint type
 constexpr int PD_NLINK = 2 * NB;
 
 struct pd_ann {
@@ -1000,7 +1000,7 @@ __device__ __forceinline__ pd_slice pd_load_slice(const float* __restrict__ L, i
     }
     return r;
 }
-constexpr int PD_Q = 256; // entries of one list inside one box (more: the frame goes to the host tail)
+constexpr int PD_Q = 1024; // entries of one list inside one box (more: the frame goes to the host tail); 4 x 20 KB of LDS (256 until round 6)
 struct pd_queue {         // per group of 16 lanes, in LDS: the entries that passed the box test, in list order
     int i[PD_Q];
     float cf[PD_Q], px[PD_Q], py[PD_Q], sc[PD_Q];

@@ -12,7 +12,7 @@
 // wavefront per frame): libstdc++'s std::sort restated step by step (equal limb confidences must come out in ITS order) + the
 // pop-back selection with the root rule (:224-270), the 64x64 hash merge with its stale indices (:275-325), the score filter
 // (:329-332); humans go straight to pinned host memory.  hp_ppn_collect does no per-frame work.  The same statements as host
-// C++ (assemble_frame) remain for the frames the kernel declines (more than 256 skeleton fragments or 2048 hash entries: reported
+// C++ (assemble_frame) remain for the frames the kernel declines (more than 2048 skeleton fragments or 8192 hash entries: reported
 // by hp_ppn_decode_flags) and behind HP_PPN_HOST_TAIL=1, which the tests use to compare the two.
 //
 // Compiled with -ffp-contract=off; the float expressions keep the reference's operand order.
@@ -33,8 +33,10 @@ constexpr int PPN_MAXG = 256;   // grid cells per map supported (12x12 = 144 in 
 constexpr int PPN_MAXB = 144;   // NMS survivors kept per class (a 12x12 grid cannot yield more)
 constexpr int PPN_MAXC = 2048;  // limb candidates kept per limb
 constexpr int HDR = 64;         // ints per frame: [0,18) survivors, [18,35) candidates, [35] flags
-constexpr int PPN_MAXP = 256;   // skeleton fragments (poses before the merge) the device tail holds per frame
-constexpr int PPN_MAXE = 2048;  // entries of the 64 x 64 spatial hash the device tail holds per frame
+constexpr int PPN_MAXP = 256;   // skeleton fragments (poses before the merge) the device tail keeps in LDS per frame
+constexpr int PPN_MAXH = 2048;  // ... and in all: fragment i >= PPN_MAXP lives in a per-frame HBM scratch list (round 6: the reference's vector grows,
+                                // src/pose_proposal.cpp:167-336; until round 6 a 257th fragment sent the frame to the host statements)
+constexpr int PPN_MAXE = 8192;  // entries of the 64 x 64 spatial hash the device tail holds per frame (2048 until round 6)
 constexpr int PPN_FLAG_POSES = 4, PPN_FLAG_HASH = 8, PPN_FLAG_OUT = 16; // device-tail decline reasons (on top of 1 / 2 from the extract kernel)
 
 // pose_proposal.cpp:23-41
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void ppn_extract_kernel(const float* __restric
 // singly linked lists in insertion order (the reference's `std::vector<uint16_t>` buckets, traversed front to back).
 __global__ __launch_bounds__(64) void ppn_assemble_kernel(const int* __restrict__ hdr, const ppn_box* __restrict__ boxes,
     const ppn_cand* __restrict__ cands, int net_w, int net_h, int n_key_points, hp_human* __restrict__ out, int out_cap, int* __restrict__ out_n,
-    int* __restrict__ out_flags)
+    int* __restrict__ out_flags, hp_human* __restrict__ spill)
 {
     __shared__ int s_root[PPN_K][PPN_MAXB];
     __shared__ hp_human s_pose[PPN_MAXP];
@@ -233,10 +235,15 @@ __global__ __launch_bounds__(64) void ppn_assemble_kernel(const int* __restrict_
     __shared__ float s_conf[PPN_MAXC];
     __shared__ unsigned short s_head[64 * 64], s_tail[64 * 64], s_val[PPN_MAXE], s_next[PPN_MAXE];
     __shared__ int s_np, s_flags, s_cmd, s_arg, s_i, s_ne;
-    // ~126 KB of static LDS (the pose list alone is 256 x 292 B): this kernel is written for gfx950's 160 KB per CU (one block per CU)
+    // ~150 KB of static LDS (the first 256 fragments alone are 256 x 292 B): this kernel is written for gfx950's 160 KB per CU (one block per CU)
     static_assert(sizeof(s_root) + sizeof(s_pose) + sizeof(s_ord) + sizeof(s_conf) + sizeof(s_head) + sizeof(s_tail) + sizeof(s_val) + sizeof(s_next) + 64
             <= 160 * 1024, "ppn_assemble_kernel needs the 160 KB LDS of gfx950");
     const int f = blockIdx.x, lane = threadIdx.x;
+    // fragment i: LDS below PPN_MAXP, this frame's slice of the HBM scratch list above (one wavefront works on a frame: program order and the
+    // barriers below order its own reads and writes there).  A spilled slot is zeroed when it is handed out.
+    hp_human* const sp = spill + (size_t)f * (PPN_MAXH - PPN_MAXP);
+    auto pose = [&](int i) -> hp_human& { return i < PPN_MAXP ? s_pose[i] : sp[i - PPN_MAXP]; };
+    auto pose_words = [&](int i) -> unsigned* { return reinterpret_cast<unsigned*>(i < PPN_MAXP ? &s_pose[i] : &sp[i - PPN_MAXP]); };
     const int* const h = hdr + (size_t)f * HDR;
     const ppn_box* const fb = boxes + (size_t)f * PPN_K * PPN_MAXB;
     const ppn_cand* const fc = cands + (size_t)f * PPN_LIMBS * PPN_MAXC;
@@ -279,14 +286,19 @@ __global__ __launch_bounds__(64) void ppn_assemble_kernel(const int* __restrict_
                 int& tr = s_root[p2][cur.to];
                 int root;
                 if ((fr != -1) == (tr != -1)) { // both rooted OR both free -> a new pose (:241-244)
-                    if (np >= PPN_MAXP) {
+                    if (np >= PPN_MAXH) {
                         s_flags |= PPN_FLAG_POSES;
                         break;
                     }
                     root = np++;
+                    if (root >= PPN_MAXP) { // a spilled slot: zero it like the LDS slots were
+                        unsigned* const z = pose_words(root);
+                        for (int k = 0; k < (int)(sizeof(hp_human) / 4); ++k)
+                            z[k] = 0u;
+                    }
                 } else
                     root = fr != -1 ? fr : tr;
-                hp_human& hm = s_pose[root];
+                hp_human& hm = pose(root);
                 if (!hm.parts[p1].has_value) {
                     set_part(hm, p1, fb[(size_t)p1 * PPN_MAXB + cur.from]);
                     fr = root;
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(64) void ppn_assemble_kernel(const int* __restrict_
             int i = s_i;
             int np = s_np;
             for (; i < np && !s_flags; ++i) {
-                hp_human& cur = s_pose[i];
+                hp_human& cur = pose(i);
                 if (cur.score > n_key_points - 0.1)
                     continue;
                 bool remove_cur = false;
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(64) void ppn_assemble_kernel(const int* __restrict_
                         const int pid = s_val[e];
                         if (pid == i || pid >= np) // (an index past the end: the reference reads out of bounds)
                             continue;
-                        hp_human& other = s_pose[pid];
+                        hp_human& other = pose(pid);
                         if (other.parts[j].y != this_part.y || other.parts[j].x != this_part.x)
                             continue;
                         remove_cur = true;
@@ -374,14 +386,15 @@ __global__ __launch_bounds__(64) void ppn_assemble_kernel(const int* __restrict_
         { // erase pose s_arg: shift the tail of the list down by one, word by word, in index order
             const int e = s_arg, np = s_np;
             constexpr int WPP = (int)(sizeof(hp_human) / 4);
-            unsigned* const w = reinterpret_cast<unsigned*>(s_pose);
             // (every lane moves the same two word columns of every row: a row's words are read one iteration before they are
             // overwritten, by the same lane - no cross-lane hazard, no barrier inside the loop)
             for (int k = e; k + 1 < np; ++k) {
+                unsigned* const wd = pose_words(k);
+                const unsigned* const ws = pose_words(k + 1);
                 if (lane < WPP)
-                    w[k * WPP + lane] = w[(k + 1) * WPP + lane];
+                    wd[lane] = ws[lane];
                 if (lane + 64 < WPP)
-                    w[k * WPP + lane + 64] = w[(k + 1) * WPP + lane + 64];
+                    wd[lane + 64] = ws[lane + 64];
             }
             if (lane == 0)
                 s_np = np - 1;
@@ -394,15 +407,15 @@ __global__ __launch_bounds__(64) void ppn_assemble_kernel(const int* __restrict_
     if (!s_flags) {
         const int np = s_np;
         constexpr int WPP = (int)(sizeof(hp_human) / 4);
-        const unsigned* const w = reinterpret_cast<const unsigned*>(s_pose);
         unsigned* const o = reinterpret_cast<unsigned*>(out + (size_t)f * out_cap);
         for (int k = 0; k < np; ++k) {
-            if (!(s_pose[k].score <= 3)) { // uniform
+            if (!(pose(k).score <= 3)) { // uniform
                 if (n_out < out_cap) {
+                    const unsigned* const w = pose_words(k);
                     if (lane < WPP)
-                        o[n_out * WPP + lane] = w[k * WPP + lane];
+                        o[n_out * WPP + lane] = w[lane];
                     if (lane + 64 < WPP)
-                        o[n_out * WPP + lane + 64] = w[k * WPP + lane + 64];
+                        o[n_out * WPP + lane + 64] = w[lane + 64];
                 } else if (lane == 0)
                     s_flags |= PPN_FLAG_OUT;
                 ++n_out;
@@ -531,7 +544,8 @@ struct hp_ppn {
     std::vector<int> h_hdr;
     std::vector<ppn_box> h_boxes;
     std::vector<ppn_cand> h_cands;
-    hp::host_buf h_humans, h_counts; // pinned: [B][PPN_MAXP] humans, [n_humans(B) | flags(B)], written by ppn_assemble_kernel
+    hp::host_buf h_humans, h_counts; // pinned: [B][PPN_MAXH] humans, [n_humans(B) | flags(B)], written by ppn_assemble_kernel
+    hp::dev_buf d_spill;             // [B][PPN_MAXH - PPN_MAXP] fragments beyond the LDS list
     std::vector<int> last_flags;
     bool host_tail = false; // HP_PPN_HOST_TAIL=1: the device tail is not launched, every frame takes the host statements
     int pending = 0;        // frames enqueued and not yet collected
@@ -552,7 +566,8 @@ int hp_ppn_create(hp_ppn** out, int net_w, int net_h, float point_thresh, float 
     HP_TRY(p->d_hdr.alloc(B * HDR * sizeof(int)));
     HP_TRY(p->d_boxes.alloc(B * PPN_K * PPN_MAXB * sizeof(ppn_box)));
     HP_TRY(p->d_cands.alloc(B * PPN_LIMBS * PPN_MAXC * sizeof(ppn_cand)));
-    HP_TRY(p->h_humans.alloc(B * PPN_MAXP * sizeof(hp_human)));
+    HP_TRY(p->h_humans.alloc(B * PPN_MAXH * sizeof(hp_human)));
+    HP_TRY(p->d_spill.alloc(B * (PPN_MAXH - PPN_MAXP) * sizeof(hp_human)));
     HP_TRY(p->h_counts.alloc(2 * B * sizeof(int)));
     p->h_hdr.assign(B * HDR, 0);
     p->last_flags.assign(B, 0);
@@ -623,7 +638,7 @@ static int ppn_launch(hp_ppn* p, int n, const float* const tensors[7], const int
     HP_HIP_TRY(hipGetLastError());
     if (!p->host_tail) {
         hipLaunchKernelGGL(ppn_assemble_kernel, dim3(n), dim3(64), 0, s, p->d_hdr.as<int>(), p->d_boxes.as<ppn_box>(), p->d_cands.as<ppn_cand>(),
-            p->net_w, p->net_h, g.K, p->h_humans.as<hp_human>(), PPN_MAXP, p->h_counts.as<int>(), p->h_counts.as<int>() + p->max_batch);
+            p->net_w, p->net_h, g.K, p->h_humans.as<hp_human>(), PPN_MAXH, p->h_counts.as<int>(), p->h_counts.as<int>() + p->max_batch, p->d_spill.as<hp_human>());
         HP_HIP_TRY(hipGetLastError());
     }
     HP_HIP_TRY(hipEventRecord(p->done, s));
@@ -690,7 +705,7 @@ int hp_ppn_collect(hp_ppn* p, hp_human* out, int cap_per_frame, int* n_out)
         if (nh > cap_per_frame)
             job.rc[f] = 2;
         if (out)
-            memcpy(out + (size_t)f * cap_per_frame, p->h_humans.as<hp_human>() + (size_t)f * PPN_MAXP, sizeof(hp_human) * std::min(nh, cap_per_frame));
+            memcpy(out + (size_t)f * cap_per_frame, p->h_humans.as<hp_human>() + (size_t)f * PPN_MAXH, sizeof(hp_human) * std::min(nh, cap_per_frame));
     }
     if (!job.frames.empty()) {
         // rare path: fetch the compacted lists of the batch and run the reference's statements on the host

@@ -171,7 +171,7 @@ void* hp_ppn_stream(hp_ppn* p);
 int hp_ppn_enqueue(hp_ppn* p, int n, const float* const dev_tensors[7], const int conf_shape[3], const int edge_shape[5], void* stream);
 int hp_ppn_collect(hp_ppn* p, hp_human* out, int cap_per_frame, int* n_out);
 /* Per frame of the last collected batch: 0 = assembled on the device (ppn_assemble_kernel); bits 4 / 8 / 16 = the device tail declined
- * the frame (more than 256 skeleton fragments / 2048 hash entries / 256 humans) and the same statements ran on the host; bits 1 / 2 = a
+ * the frame (more than 2048 skeleton fragments / 8192 hash entries / 2048 humans) and the same statements ran on the host; bits 1 / 2 = a
  * list of the extract kernel overflowed (HP_ERR_CAPACITY); -1 = HP_PPN_HOST_TAIL=1 (tests: every frame on the host). */
 int hp_ppn_decode_flags(hp_ppn* p, int* flags, int n);
 

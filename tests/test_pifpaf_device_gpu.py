@@ -121,3 +121,56 @@ def test_mixed_batch_device_and_host_tail(hp, monkeypatch):
         for b in range(B):
             assert got[b].tobytes() == ref[b].tobytes(), (salt, b, flags[b])
         assert sum(len(r) for r in ref) >= 15
+
+
+def _lattice_maps(B, fh=49, fw=49, step=4, types=(0, 5, 11), scale=0.3):
+    """A frame nobody would film: isolated PIF clusters on a lattice (3 x 3 voting cells every `step` cells, three joint types, small scales so
+    that the occupancy of one annotation does not cover its neighbours) and empty CAF fields - every cluster seeds an annotation of its own:
+    several hundred annotations per frame."""
+    rng = np.random.default_rng(77)
+    yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float64)
+    pif = np.zeros((B, 17, 5, fh, fw))
+    paf = np.zeros((B, 19, 9, fh, fw))
+    pif[:, :, 1], pif[:, :, 2] = xx, yy
+    pif[:, :, 4] = scale
+    for c in (1, 3):
+        paf[:, :, c], paf[:, :, c + 1] = xx, yy
+    paf[:, :, 7:9] = 1.0
+    for b in range(B):
+        for k, t in enumerate(types):
+            for cy in range(2 + k % 2, fh - 2, step):
+                for cx in range(2 + (k + b) % 2, fw - 2, step):
+                    jx, jy = cx + rng.normal(0, 0.05), cy + rng.normal(0, 0.05)
+                    conf = rng.uniform(0.7, 0.95)
+                    for y in range(cy - 1, cy + 2):
+                        for x in range(cx - 1, cx + 2):
+                            pif[b, t, 0, y, x] = conf
+                            pif[b, t, 1, y, x] = jx + rng.normal(0, 0.01)
+                            pif[b, t, 2, y, x] = jy + rng.normal(0, 0.01)
+    return paf.astype(np.float32), pif.astype(np.float32)
+
+
+def test_hundreds_of_annotations_stay_on_the_device(hp):
+    """Round 6: PD_MAXA and PD_Q went from 256 to 1024.  A lattice frame yields 300 - 700 annotations (each seed its own,
+    most of them dropped by the final score filter: the ANNOTATION list is what PD_MAXA bounds); the device decoder keeps every frame (flag 1 =
+    "more than PD_MAXA annotations" is not raised) and equals the host tail and the reference byte for byte."""
+    B = 4
+    dev, host = _parser(False, 385, 385, 0.05, max_batch=B, cap_per_frame=1024), _parser(True, 385, 385, 0.05, max_batch=B, cap_per_frame=1024)
+    paf, pif = _lattice_maps(B)
+    # ... and a few real skeletons among the clusters, so that the frames also return humans (a cluster alone is dropped by the final filter)
+    ppaf, ppif = synth.pifpaf_maps(synth.rng_for(4, salt=55), B, people=(5, 6, 4, 7), noise=0.0)
+    person = ppif[:, :, 0] > 0.05
+    for c in range(5):
+        pif[:, :, c][person] = ppif[:, :, c][person]
+    paf = ppaf.astype(np.float32)
+    got, ref = dev.process_batch(paf, pif), host.process_batch(paf, pif)
+    flags = dev.decode_flags(B)
+    assert all(f in (0, 32) for f in flags), flags
+    assert sum(len(r) for r in ref) >= 10
+    for b in range(B):
+        assert got[b].tobytes() == ref[b].tobytes(), (b, flags[b], len(got[b]), len(ref[b]))
+        if loader.ref_lib() is not None:
+            assert got[b].tobytes() == loader.ref_pifpaf_process(paf[b], pif[b], 385, 385, 0.05, cap=1024).tobytes(), b
+    # (that these frames are beyond the old capacity was checked by building with PD_MAXA = 256: every frame then carries flag 1 and goes to the
+    # host tail - tools/r6_count_ann.py, DESIGN.md section 7B.9)
+    assert all(int((pif[b, :, 0] >= 0.5).sum()) > 9 * 256 for b in range(B))

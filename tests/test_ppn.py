@@ -95,9 +95,10 @@ def test_gpu_device_tail_crowds_ties_and_host_tail(hp, monkeypatch, seed):
         assert _same(got[b], ref), f"frame {b} ({people[b]} people, flags {flags[b]}): {len(got[b])} vs {len(ref)}"
         n_ref += len(ref)
     assert n_ref >= 20
-    # (seed 3 lowers the limb threshold into the clutter: tens to hundreds of candidates per limb; a frame that exceeds 256 skeleton
-    # fragments is declined - flag 4 - and takes the host statements: reported, not hidden)
-    assert (flags == 0).sum() >= (B // 2 if seed == 3 else B), flags
+    # (seed 3 lowers the limb threshold into the clutter: tens to hundreds of candidates per limb and several hundred skeleton fragments per
+    # frame.  Until round 6 a 257th fragment sent the frame to the host statements - flag 4 - and half of these frames went there; the fragments
+    # beyond the 256 kept in LDS now live in an HBM scratch list and every frame is assembled on the device)
+    assert (flags == 0).all(), flags
     monkeypatch.setenv("HP_PPN_HOST_TAIL", "1")
     q = PoseProposal((384, 384), 0.10, 0.02 if seed == 3 else 0.05, 0.3, max_batch=B, cap_per_frame=256)
     host = q.process_batch(t)
