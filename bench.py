@@ -778,10 +778,6 @@ def measure(cfg, args, rank, world, dev, scaling, steps, warmup, headline, light
         coll = {"backend": hd.LAST_BROADCAST.get("backend"), "bcast_bytes": hd.LAST_BROADCAST.get("bytes"), "bcast_ms": hd.LAST_BROADCAST.get("ms"),
                 "what": "one broadcast of the fp32 weight blob from rank 0 at start-up (outside the timed region); the steady state has no collective"}
     n_pipes = args.pipes if args.pipes > 0 else cfg["pipes"]
-    if cfg["dtype"] == "f32s":
-        # HP_DTYPE_F32S (opt-in, `--extra 1/f32s` / `--dtype f32s` only since round 6): ONE pipe.  Two streams of split kernels side by side gave
-        # perturbed values in 1 - 25 % of the runs (tools/r6_two_engines_debug.py), and hp_pipeline_* refuses the type
-        n_pipes = 1
     res = {"workload": cfg["label"], "key": cfg["key"], "dtype": cfg["dtype"], "dtype_long": DTYPE_LONG[cfg["dtype"]],
            "frames_per_gpu_per_step": batch, "global_batch": global_batch, "scaling": scaling,
            "pipes_per_gpu": n_pipes, "gflop_per_frame": round(model.flops_per_frame / 1e9, 2)}
@@ -912,9 +908,9 @@ def measure(cfg, args, rank, world, dev, scaling, steps, warmup, headline, light
     # the host, through the stream operator's device pipeline (hp_pipeline_*) with the same pipes per GPU, on EVERY rank at once (each rank its own
     # pinned frames, all fed from the same host), under the same protocol as above (warm-up, ramp, R x K steps between barriers, MAX over the ranks).
     del pipes[:]
-    if cfg["dtype"] == "f32s":  # (no host-fed pipeline for this type: its value is the one-pipe resident figure, and says so)
+    if cfg["dtype"] == "f32s":  # (hp_pipeline_* refuses this opt-in type - its overflow guard never runs there: its value is the resident figure, and says so)
         res.update({"value": res["value_resident_injected"], "ms_per_step": res["ms_per_step_resident_injected"], "steps_timed": n_res, "timed_region_s": round(dt_res, 4),
-                    "humans_per_step": n_humans / max(1, n_res), "what": res["what_resident_injected"] + "; ONE pipe (HP_DTYPE_F32S is single-stream only)",
+                    "humans_per_step": n_humans / max(1, n_res), "what": res["what_resident_injected"] + " (no host-fed leg: hp_pipeline_* refuses HP_DTYPE_F32S)",
                     "conv_tflops_end_to_end": round(res["value_resident_injected"] * model.flops_per_frame / 1e12, 2),
                     "conv_frac_of_mfma_peak_end_to_end": round(res["value_resident_injected"] * model.flops_per_frame / 1e12 / peak / world, 4)})
         return res
@@ -1098,7 +1094,7 @@ def main():
             extra = ""
         elif world == 1:
             other = "f16" if args.dtype == "f32" else "f32"
-            extra = f"1/{other},0/{args.dtype},2/{args.dtype},3/{args.dtype},4/{args.dtype},0/{other},2/{other},3/{other},4/{other}"
+            extra = f"1/{other},1/f32s,0/{args.dtype},2/{args.dtype},3/{args.dtype},4/{args.dtype},0/{other},2/{other},3/{other},4/{other}"
         else:
             extra = f"3/{args.dtype},4/{args.dtype}"
     for k, dt_ in parse_extra(extra, world, cfg["key"]):

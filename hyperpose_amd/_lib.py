@@ -56,7 +56,7 @@ SYMBOLS = [
     "hp_pifpaf_create", "hp_pifpaf_destroy", "hp_pifpaf_process_batch", "hp_pifpaf_stream", "hp_pifpaf_enqueue", "hp_pifpaf_collect", "hp_pifpaf_decode_flags",
     "hp_ppn_create", "hp_ppn_destroy", "hp_ppn_set_thresholds", "hp_ppn_process_batch", "hp_ppn_stream", "hp_ppn_enqueue", "hp_ppn_collect", "hp_ppn_decode_flags",
     "hp_engine_create", "hp_engine_destroy", "hp_engine_max_batch", "hp_engine_describe", "hp_engine_input_size", "hp_engine_infer_u8",
-    "hp_engine_infer_f32", "hp_engine_synchronize", "hp_engine_stream", "hp_engine_set_graph", "hp_engine_set_concurrency", "hp_engine_arena_info", "hp_engine_concurrency", "hp_engine_num_outputs",
+    "hp_engine_infer_f32", "hp_engine_synchronize", "hp_engine_stream", "hp_engine_set_graph", "hp_engine_set_concurrency", "hp_engine_arena_info", "hp_debug_first_conv_verify", "hp_engine_concurrency", "hp_engine_num_outputs",
     "hp_engine_output", "hp_engine_output_to_host", "hp_engine_debug_tensor", "hp_engine_profile", "hp_engine_profile_sequence", "hp_engine_profile_pair", "hp_model_build", "hp_model_from_onnx", "hp_model_from_onnx_file", "hp_model_weights",
     "hp_model_input_size",
     "hp_model_destroy", "hp_model_archs", "hp_model_layers", "hp_model_outputs", "hp_model_num_weights",

@@ -32,7 +32,11 @@ UNITS = [
     ("conv_kernels.hip", []),
     ("conv_chain.hip", []),
     ("conv_bottleneck.hip", []),
-    ("conv_fp32.hip", []),
+    # -fno-slp-vectorize: no v_pk_fma_f32 in this file's vector kernels.  first_conv32_kernel built with the packed FMAs hipcc's SLP pass forms
+    # (a pixel value broadcast against pairs of weights) returns different bits for the same inputs - recomputed in the same thread - while
+    # fp16-MFMA kernels of another stream share its CUs (an fp16 engine or an HP_DTYPE_F32S engine next to it): DESIGN.md section 7B.8,
+    # tools/r6_two_engines_debug.py, HP_FIRST_CONV_VERIFY.  Without them it is exact; the stem costs 25.3 instead of 24.5 us.
+    ("conv_fp32.hip", ["-fno-slp-vectorize"]),
     ("conv32_direct.hip", []),
     ("conv32_winograd.hip", []),
     ("conv32_head.hip", []),

@@ -572,7 +572,10 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
 // (x - mean) / std; zero outside the image = the convolution's padding of the normalised tensor) - live in LDS; the taps run
 // branch-free in (ky, kx, c) order.  (The first form loaded and converted three bytes per tap and thread behind two bounds checks:
 // 44 us for the 184 x 216 x 32 stem of LW-OpenPose.)
-__global__ __launch_bounds__(256) void first_conv32_kernel(const first_conv32_params p, int tiles_x, int tiles_y, int TH, int GP)
+// HP_FIRST_CONV_VERIFY=1 (diagnostic): after its outputs are computed a block re-reads its staged weights and input patch
+// from LDS and compares them with what global memory holds; [0] = patch words that differ, [1] = weight words, [2] = blocks checked
+__device__ unsigned g_first_conv_verify[4];
+__global__ __launch_bounds__(256) void first_conv32_kernel(const first_conv32_params p, int tiles_x, int tiles_y, int TH, int GP, int verify)
 {
     extern __shared__ __attribute__((aligned(16))) float s_w32[]; // [KH*KW*3][Cout_pad8], then the patch [IH][IW][3]
     constexpr int TW = 8, PX = 4;
@@ -609,12 +612,44 @@ __global__ __launch_bounds__(256) void first_conv32_kernel(const first_conv32_pa
     }
     __syncthreads();
     const int g0 = threadIdx.x % GP, slot = threadIdx.x / GP; // slot = (row of the tile, left / right half of its eight pixels)
-    if (slot >= TH * (TW / PX))
+    auto verify_lds = [&]() {
+        if (!verify)
+            return;
+        unsigned bad_x = 0, bad_w = 0;
+        for (int i = threadIdx.x; i < IH * IW; i += 256) {
+            const int py = i / IW, px = i - py * IW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            float v[3] = { 0.f, 0.f, 0.f };
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && p.in_u8) {
+                const uint8_t* q = p.in_u8 + (((size_t)b * p.H + iy) * p.W + ix) * 3;
+                for (int c = 0; c < 3; ++c)
+                    v[c] = ((float)((double)q[p.flip_rb ? 2 - c : c] * p.factor) - p.mean[c]) * p.inv_std[c];
+            }
+            for (int c = 0; c < 3; ++c)
+                bad_x += __float_as_uint(s_x[i * 3 + c]) != __float_as_uint(v[c]);
+        }
+        for (int i = threadIdx.x; i < taps * 3 * CP; i += 256) {
+            const int co = i % CP, tc = i / CP;
+            const float wv = co < p.Cout ? p.w[(size_t)co * taps * 3 + tc] : 0.f;
+            bad_w += __float_as_uint(s_w32[i]) != __float_as_uint(wv);
+        }
+        if (bad_x)
+            atomicAdd(&g_first_conv_verify[0], bad_x);
+        if (bad_w)
+            atomicAdd(&g_first_conv_verify[1], bad_w);
+        if (threadIdx.x == 0)
+            atomicAdd(&g_first_conv_verify[2], 1u);
+    };
+    if (slot >= TH * (TW / PX)) {
+        verify_lds();
         return;
+    }
     const int ly = slot / (TW / PX), lx0 = (slot % (TW / PX)) * PX;
     const int oy = oy0 + ly;
-    if (oy >= p.OH)
+    if (oy >= p.OH) {
+        verify_lds();
         return;
+    }
     const bool vec_ok = ((p.out.coff | p.out.cs) & 3) == 0;
     for (int g = g0; g < G; g += GP) {
         float acc[PX][8];
@@ -642,6 +677,41 @@ __global__ __launch_bounds__(256) void first_conv32_kernel(const first_conv32_pa
                     }
                 }
             }
+        if (verify) { // the same taps a second time: a difference is arithmetic / register state that changed under the kernel ([3])
+            float acc2[PX][8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float bv = (g * 8 + r < p.Cout) ? p.bias[g * 8 + r] : 0.f;
+#pragma unroll
+                for (int j = 0; j < PX; ++j)
+                    acc2[j][r] = bv;
+            }
+            for (int ky = 0; ky < p.KH; ++ky)
+                for (int kx = 0; kx < p.KW; ++kx) {
+                    const float* xp = s_x + ((ly * p.stride + ky) * IW + lx0 * p.stride + kx) * 3;
+                    const float* wt = s_w32 + (size_t)((ky * p.KW + kx) * 3) * CP + g * 8;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + c * CP);
+                        const f32x4 w1 = *reinterpret_cast<const f32x4*>(wt + c * CP + 4);
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) {
+                            const float xv = xp[j * p.stride * 3 + c];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc2[j][e] = fmaf(xv, w0[e], acc2[j][e]), acc2[j][4 + e] = fmaf(xv, w1[e], acc2[j][4 + e]);
+                        }
+                    }
+                }
+            unsigned bad = 0;
+#pragma unroll
+            for (int j = 0; j < PX; ++j)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    bad += __float_as_uint(acc[j][r]) != __float_as_uint(acc2[j][r]);
+            if (bad)
+                atomicAdd(&g_first_conv_verify[3], bad);
+        }
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             const int ox = ox0 + lx0 + j;
@@ -662,6 +732,16 @@ __global__ __launch_bounds__(256) void first_conv32_kernel(const first_conv32_pa
             }
         }
     }
+    verify_lds();
+}
+
+void first_conv32_verify_counts(unsigned out[4], bool reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_first_conv_verify), 16);
+    if (reset) {
+        const unsigned z[4] = { 0, 0, 0, 0 };
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_first_conv_verify), z, 16);
+    }
 }
 
 hipError_t launch_first_conv32(const first_conv32_params& p, hipStream_t s)
@@ -673,7 +753,7 @@ hipError_t launch_first_conv32(const first_conv32_params& p, hipStream_t s)
     if (lds > 64 * 1024)
         return hipErrorInvalidValue;
     const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + TH - 1) / TH;
-    HP_LAUNCH(first_conv32_kernel, dim3(tiles_x * tiles_y * p.B), dim3(256), lds, s, p, tiles_x, tiles_y, TH, GP);
+    HP_LAUNCH(first_conv32_kernel, dim3(tiles_x * tiles_y * p.B), dim3(256), lds, s, p, tiles_x, tiles_y, TH, GP, getenv("HP_FIRST_CONV_VERIFY") ? 1 : 0);
     return hipGetLastError();
 }
 

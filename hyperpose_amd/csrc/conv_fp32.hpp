@@ -112,6 +112,7 @@ struct first_conv32_params {
 };
 // The 3-channel network input (u8 HWC or f32 NCHW), pre-processing of src/data.cpp:21-51 folded into the load; all-fp32.
 hipError_t launch_first_conv32(const first_conv32_params& p, hipStream_t s);
+void first_conv32_verify_counts(unsigned out[4], bool reset); // HP_FIRST_CONV_VERIFY=1: LDS words that differed from global memory (patch, weights), blocks checked
 
 struct dw32_params {
     tview32 in;

@@ -117,6 +117,8 @@ struct hp_engine {
     int dtype = HP_DTYPE_F16; // HP_DTYPE_F32: fp32 storage and arithmetic (the reference's data_type::kFLOAT), conv_fp32.hip;
                               // HP_DTYPE_F32S: the same engine with the dense layers' products on the fp16 pipe (conv32_direct.hip)
     bool is_f32() const { return dtype == HP_DTYPE_F32 || dtype == HP_DTYPE_F32S; }
+    // which engines may run a batch as two half-batches (hp_engine_set_concurrency): the fp32 engines (their steps take a frame offset)
+    bool halves_ok() const { return is_f32(); }
     // HP_DTYPE_F32S: a pinned host word the split kernels OR into when an activation exceeds fp16's range (|x| > 65504); once seen
     // (hp_engine_synchronize / hp_engine_inference) the engine runs conv32_kernel instead - exact fp32 products, any range
     hp::host_buf ovf_flag;
@@ -708,7 +710,15 @@ int hp_engine::build(const hp_engine_desc* d)
                 const int direct_max_1x1 = getenv("HP_DIRECT32_MAX_1X1") ? atoi(getenv("HP_DIRECT32_MAX_1X1")) : 64;
                 // (a 3 x 3 layer the Winograd kernel will take needs no direct-form fragments: they doubled its weight bytes in HBM)
                 const bool wino_takes_it = dtype == HP_DTYPE_F32 && !dw_in_front && !getenv("HP_NO_WINOGRAD32") && hp::conv32_winograd_ok(p) && !head_in_front;
-                if (dtype == HP_DTYPE_F32S || dw_in_front || (!no_direct && !wino_takes_it && (taps > 1 || cout_pad <= direct_max_1x1))) {
+                // HP_SPLIT_LAYERS="lo hi" (diagnostic, section 7B.8): an HP_DTYPE_F32S engine forms split products in layers lo .. hi only, every other
+                // dense layer runs conv32_kernel
+                bool split_here = dtype == HP_DTYPE_F32S;
+                if (const char* sl = getenv("HP_SPLIT_LAYERS")) {
+                    int lo = 0, hi = 1 << 30;
+                    sscanf(sl, "%d %d", &lo, &hi);
+                    split_here = split_here && ((int)i >= lo && (int)i <= hi);
+                }
+                if (split_here || dw_in_front || (dtype != HP_DTYPE_F32S && !no_direct && !wino_takes_it && (taps > 1 || cout_pad <= direct_max_1x1))) {
                     const int ck = taps == 1 ? 64 : 32, cin_s = round_up(L.cin, ck);
                     hp::conv32_params q = p;
                     q.Cin = cin_s;
@@ -1774,7 +1784,7 @@ int hp_engine::enqueue(const uint8_t* u8, const float* f32, int n, hipStream_t s
             HP_HIP_TRY(hipMemcpyAsync(dev_in + (size_t)b0 * frame_bytes, (const unsigned char*)host_src + (size_t)b0 * frame_bytes, (size_t)cnt * frame_bytes, hipMemcpyHostToDevice, st));
         return HP_OK;
     };
-    if (parts < 2 || dtype != HP_DTYPE_F32 || n < 2) {
+    if (parts < 2 || !halves_ok() || n < 2) {
         HP_TRY(h2d(0, n, s));
         return enqueue_range(u8, f32, 0, n, s);
     }
@@ -1956,7 +1966,7 @@ static int infer_common(hp_engine* e, const void* input, size_t frame_bytes, int
         if (e->in_stage.bytes < need)
             HP_TRY(e->in_stage.alloc(need));
         // (the copy is not part of the captured schedule; two half-batches: each half goes up on the stream that reads it, below)
-        if (e->use_graph && !(e->parts == 2 && e->dtype == HP_DTYPE_F32 && n >= 2))
+        if (e->use_graph && !(e->parts == 2 && e->halves_ok() && n >= 2))
             HP_HIP_TRY(hipMemcpyAsync(e->in_stage.p, input, frame_bytes * n, hipMemcpyHostToDevice, s));
         dev_in = e->in_stage.p;
     }
@@ -1998,7 +2008,7 @@ static int infer_common(hp_engine* e, const void* input, size_t frame_bytes, int
         *out = it->second;
         return HP_OK;
     };
-    if (e->parts == 2 && e->dtype == HP_DTYPE_F32 && n >= 2) {
+    if (e->parts == 2 && e->halves_ok() && n >= 2) {
         // two half-batches side by side (hp_engine::enqueue has the reasoning): ONE graph with two branches is replayed branch after branch by
         // the runtime (measured: 2.27 -> 2.22 ms per call), two graphs on two streams run side by side (the probe's 2.49 -> 1.96 ms)
         const int n0 = (n + 1) / 2;
@@ -2072,6 +2082,13 @@ int hp_engine_device_bytes(const hp_engine* e, uint64_t bytes[3])
     return HP_OK;
 }
 
+int hp_debug_first_conv_verify(unsigned out[4], int reset)
+{
+    HP_REQUIRE(out, HP_ERR_INVALID, "hp_debug_first_conv_verify: null argument");
+    hp::first_conv32_verify_counts(out, reset != 0);
+    return HP_OK;
+}
+
 int hp_engine_arena_info(const hp_engine* e, uint64_t info[3])
 {
     HP_REQUIRE(e && info, HP_ERR_INVALID, "hp_engine_arena_info: null argument");
@@ -2086,10 +2103,9 @@ void* hp_engine_stream(hp_engine* e) { return e ? (void*)e->stream : nullptr; }
 int hp_engine_set_concurrency(hp_engine* e, int parts)
 {
     HP_REQUIRE(e && (parts == 1 || parts == 2), HP_ERR_INVALID, "hp_engine_set_concurrency: parts must be 1 or 2");
-    // HP_DTYPE_F32 only.  The fp16 engine's fused launches take no frame offset; HP_DTYPE_F32S was tried and is refused on evidence: with two
-    // streams of split kernels side by side (two half-batches, or two engines) isolated values of the first layers' outputs came out perturbed in
-    // 2 - 25 % of the runs (tools/r6_halves_debug.py, tools/r6_two_engines_debug.py; the fp32 and fp16 engines: 0 of 240 / 120) - cause not found
-    if (e->dtype != HP_DTYPE_F32)
+    // HP_DTYPE_F32 / F32S only: the fp16 engine's fused launches take no frame offset.  (A split engine failed this in round 6 until the cause was
+    // found in first_conv32_kernel's packed FMAs: DESIGN.md section 7B.8, hyperpose_amd/build.py.)
+    if (!e->halves_ok())
         parts = 1;
     if (parts == e->parts)
         return HP_OK;

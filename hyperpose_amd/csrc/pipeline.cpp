@@ -71,8 +71,7 @@ int hp_pipeline_create_ex(hp_pipeline** out, const hp_engine_desc* desc, const h
     HP_REQUIRE(parser->kind == HP_PARSER_PAF || parser->kind == HP_PARSER_PPN || parser->kind == HP_PARSER_PIFPAF, HP_ERR_INVALID,
         "hp_pipeline_create: unknown parser kind %d", parser->kind);
     // HP_DTYPE_F32S is refused here: its guard against values outside fp16's range (|x| > 65504) runs in hp_engine_synchronize /
-    // hp_engine_output_to_host, which a pipeline never calls - a batch that overflowed would be parsed and returned as humans with no error - and
-    // two streams of split kernels side by side were not bit-stable in round 6's tests (engine.cpp, hp_engine_set_concurrency)
+    // hp_engine_output_to_host, which a pipeline never calls - a batch that overflowed would be parsed and returned as humans with no error
     HP_REQUIRE(desc->dtype != HP_DTYPE_F32S, HP_ERR_INVALID,
         "hp_pipeline_create: HP_DTYPE_F32S engines are for single-stream use (hp_engine_infer_* + hp_engine_synchronize); use HP_DTYPE_F32 or HP_DTYPE_F16 in a pipeline");
     std::unique_ptr<hp_pipeline> pl(new hp_pipeline());

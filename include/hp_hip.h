@@ -288,7 +288,7 @@ int hp_engine_synchronize(hp_engine* e);
 void* hp_engine_stream(hp_engine* e); /* hipStream_t of the engine */
 int hp_engine_set_graph(hp_engine* e, int enable); /* replay the schedule from a captured hipGraph (default on) */
 /* parts = 2: every batch of >= 2 frames runs as two half-batches side by side, the second on an internal stream that forks from and joins the
- * call's stream (HP_DTYPE_F32 engines; the others keep one stream and hp_engine_concurrency() says so) - for a caller that keeps ONE batch in flight, as the reference's synchronous
+ * call's stream (HP_DTYPE_F32 / F32S engines; an fp16 engine keeps one stream and hp_engine_concurrency() says so) - for a caller that keeps ONE batch in flight, as the reference's synchronous
  * tensorrt::inference does (src/tensorrt.cpp:364-434): the two halves fill each other's idle phases.  Outputs are bit-identical to parts = 1.
  * Callers that overlap several batches on several engines (hp_pipeline_*) keep 1. */
 int hp_engine_set_concurrency(hp_engine* e, int parts);
@@ -367,6 +367,9 @@ int hp_engine_device_bytes(const hp_engine* e, uint64_t bytes[3]);
  * allow; HP_NO_ARENA=1 at creation: one allocation per tensor): info = { buffers, tensors living in them, bytes the same tensors would take with one
  * allocation each }.  All zero for engines without an arena. */
 int hp_engine_arena_info(const hp_engine* e, uint64_t info[3]);
+/* Diagnostic (HP_FIRST_CONV_VERIFY=1 at launch time): the fp32 first-layer kernel re-reads its staged weights and input patch from LDS after computing and
+ * compares them with global memory; out = { patch words that differed, weight words that differed, blocks checked, 0 } since the last reset. */
+int hp_debug_first_conv_verify(unsigned out[4], int reset);
 
 /* ---- hyperpose::stream on the GPU (reference include/hyperpose/stream/stream.hpp:119-390, src/stream.cpp:60-147): host frames of
  * any size in, humans out, in submission order.  Each submit copies one batch (<= max_batch frames, 8-bit BGR HWC, packed rows) to

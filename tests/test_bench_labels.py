@@ -168,8 +168,7 @@ def test_dominant_kernel_of_the_headline_has_both_clocks_and_traffic():
     assert cp["source"] and cp["avg_launch_us"] is not None and cp["frac_mfma"] is not None and r["traffic"] is not None
     assert 0.8 < cp["avg_launch_us"] / r["avg_launch_us"] < 1.35
     assert h["cpu_baseline"]["kind"] in ("reference", "port") and h["cpu_baseline"]["value"] > 0
-    # (HP_DTYPE_F32S left the default run in round 6: single-stream only, bench.py measure())
-    assert set(d["workloads"]) == {f"configs[{i}]/{dt}" for i in range(5) for dt in ("f32", "f16")} - {"configs[1]/f32"}
+    assert set(d["workloads"]) == ({f"configs[{i}]/{dt}" for i in range(5) for dt in ("f32", "f16")} | {"configs[1]/f32s"}) - {"configs[1]/f32"}
     f16 = d["workloads"]["configs[1]/f16"]
     assert f16["roofline"]["mfma_peak_tflops"] == 2500.0 and f16["value"] > h["value"] > 0
 

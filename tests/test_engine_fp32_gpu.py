@@ -271,8 +271,7 @@ def test_two_half_batches_are_bit_identical(hp, f32dtype, arch, w_, h_, n):
     fr = synth.images_u8(synth.rng_for(12), n, h_, w_)
     one = eng.inference(fr)
     eng.set_concurrency(2)
-    # (HP_DTYPE_F32S keeps one stream: engine.cpp, hp_engine_set_concurrency - two streams of split kernels side by side were not bit-stable)
-    assert eng.concurrency == (2 if f32dtype == "f32" else 1)
+    assert eng.concurrency == 2
     for graph in (True, False):
         eng.set_graph(graph)
         two = eng.inference(fr)
