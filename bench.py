@@ -1014,7 +1014,7 @@ def compact_line(detail):
     wl = {}
     for key, w in detail.get("workloads", {}).items():
         r = w.get("roofline") or {}
-        wl[key] = {"value": w["value"], "ms_per_step": w["ms_per_step"], "resident": w.get("value_resident_injected"), "bound": r.get("bound"), "frac": r.get("frac")}
+        wl[key] = {"value": w["value"], "resident": w.get("value_resident_injected"), "bound": r.get("bound"), "frac": r.get("frac")}  # (ms_per_step etc.: the detail file)
     if wl:
         out["workloads"] = wl
         # host fall-backs / truncated lists over ALL workloads of the run (per workload: the detail file)
@@ -1029,7 +1029,7 @@ def compact_line(detail):
                 out["value_" + tag] = w["value"]
                 r = compact_roofline(w.get("roofline"))
                 if r:
-                    for k in ("flops_per_launch", "algorithmic_bytes_per_launch", "all_mfma_convs_frac", "traffic", "mfma_busy_source", "note"):
+                    for k in ("flops_per_launch", "algorithmic_bytes_per_launch", "all_mfma_convs_frac", "traffic", "mfma_busy_source", "note", "frac_mfma", "frac_hbm"):
                         r.pop(k, None)
                 out["roofline_" + tag] = r
     out["detail"] = detail.get("detail_file")
@@ -1072,6 +1072,11 @@ def main():
     from hyperpose_amd import _lib
     from hyperpose_amd import dist as hd
 
+    # one rank per GPU.  HP_BENCH_SHARE_DEVICES=1 (tests of the multi-rank path on a box with fewer GPUs than ranks): ranks wrap around the
+    # visible devices - RCCL refuses two ranks on one GPU, the ranks then agree on gloo for the start-up broadcast (hyperpose_amd/dist.py)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and n_dev > 0 and os.environ.get("HP_BENCH_SHARE_DEVICES"):
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     _lib.init(local_rank)
     dev = torch.device("cuda", local_rank)
