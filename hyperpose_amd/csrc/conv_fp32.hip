@@ -290,8 +290,13 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
 // = 32 KB per block.  K order as in conv32_kernel: lane (row, kq) reads channels [4 kq, 4 kq + 4) with one ds_read_b128 and feeds element e to
 // MFMA e - A and B use the same permutation.  Epilogue: lane (pixel n, q) of a 16 x 16 tile holds channels 4 q .. 4 q + 3 of pixel n: one
 // global_store_dwordx4 of a wavefront covers 16 pixels x 64 contiguous bytes.
-template <int BN>
-__global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
+// SK ("short K": the 1 x 1 layers with <= 128 input channels - two to eight K-steps in front of an epilogue that moves far more bytes than the loop):
+// the block's life is its epilogue (64 -> 256 at 32 x 96 x 96 with a residual: 1.2 us staging, 7 us for the four K-steps, 14.3 us epilogue - 6.3 without
+// the residual; profiles/r06_block_timelines_f32_config3.txt), and three things in it wait for memory one after the other: bias / slopes, the residual,
+// the stores.  The SK form requests bias / slopes before the loop and the residual before the LAST K-step's MFMAs (the staging registers are free by
+// then), so that the epilogue only computes and stores.  Same arithmetic in the same order: bit-identical outputs.
+template <int BN, bool SK>
+__device__ __forceinline__ void conv32_t16_body(const conv32_params p)
 {
     constexpr int BM = 64, BK = 16, TMW = 2, TNW = BN / 2 / 16; // a wavefront: TMW x TNW tiles of 16 x 16
     constexpr int NB = (BN + 63) / 64, BR = NB * 64;             // staging passes of the B tile (64 rows each); rows allocated
@@ -300,16 +305,33 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
     float (*const sA)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(lds);
     float (*const sB)[BR * BK] = reinterpret_cast<float (*)[BR * BK]>(lds + 2 * BM * BK);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     const int G = p.Cout_pad / BM, nx = (p.npix + BN - 1) / BN; // XCD-aware 1-D block order: see conv32_kernel
-    const int bj = blockIdx.x >> 3, ptile = (bj / G) * 8 + (blockIdx.x & 7);
-    if (ptile >= nx)
-        return;
-    const int n0 = ptile * BN, m0 = (bj % G) * BM;
-    const int lrow = tid >> 2, lq = tid & 3;
     const int OHW = p.OH * p.OW, kc = p.Cin / BK, steps = p.KH * p.KW * kc;
     auto swz = [](int row, int quad) { return row * BK + ((quad ^ (((row >> 3) & 1) << 1)) << 2); };
+    int dbg_i = 0;
+    // SK: the block is PERSISTENT - it takes tiles vb = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8: vb & 7 = the block's XCD).  A
+    // wavefront's slot is not free before its stores are acknowledged (4-5 us under load: 16 blocks of 15.9 us took 109 us in each of a CU's three
+    // slots, profiles/r06_block_timelines_f32_config3.txt); a block that goes on requests its next tile while they drain.  The other form is
+    // launched with one block per tile: one pass.
+    const int nvb = (nx + 7) / 8 * 8 * G;
+    int vb = blockIdx.x;
+#pragma unroll 1
+    do {
+    const int bj = vb >> 3, ptile = (bj / G) * 8 + (vb & 7);
+    if (ptile >= nx)
+        continue;
+    const bool first = vb == (int)blockIdx.x;
+    if (!first)
+        lds_barrier(); // every wavefront has read the previous tile's last K-step
+    // (everything a lane derives from its index is derived again per tile: hoisted out of the tile loop it would stay live through the epilogue,
+    // where the residual and the accumulators already fill the registers three blocks per CU allow)
+    int tid = threadIdx.x;
+    if (SK)
+        asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 2, lq = tid & 3;
+    const int n0 = ptile * BN, m0 = (bj % G) * BM;
 
     long bbase[NB];
 #pragma unroll
@@ -345,23 +367,53 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
             acc[i][j] = f32x4{ 0.f, 0.f, 0.f, 0.f };
 
     const int fr = lane & 15, kq = lane >> 4;
-    int dbg_i = 0;
-#define HP_STAMP()                                       \
-    if (p.dbg && blockIdx.x == 9 && tid == 0)            \
+#define HP_STAMP()                                                \
+    if (p.dbg && blockIdx.x == 9 && tid == 0 && dbg_i < 120)      \
         p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
     HP_STAMP();
     // block residency trace: [128 + 3 b] = start, [.. + 1] = end (100 MHz clock), [.. + 2] = XCC_ID << 32 | HW_ID of block b < 4096
-    if (p.dbg && tid == 0 && blockIdx.x < 4096) {
+    if (p.dbg && tid == 0 && blockIdx.x < 4096 && first) {
         p.dbg[128 + 3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         p.dbg[128 + 3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
+    // (SK) epilogue operands requested early: bias / slopes now, the residual before the last K-step
+    const int q = lane >> 4;
+    const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
+    const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
+    const bool res_pre = p.res.p && p.res_before_act, res_post = p.res.p && !p.res_before_act;
+    f32x4 bs[TMW], sl[TMW];
+    auto load_bias = [&]() {
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const int m = m0 + wm * 32 + i * 16 + 4 * q; // (m + 3 < Cout_pad)
+            bs[i] = *reinterpret_cast<const f32x4*>(p.bias + m);
+            sl[i] = f32x4{ p.act_slope, p.act_slope, p.act_slope, p.act_slope };
+            if (p.alpha)
+                sl[i] = *reinterpret_cast<const f32x4*>(p.alpha + m);
+        }
+    };
+    f32x4 rr[TMW][TNW];
+    constexpr int JE = (TNW + 1) / 2; // pixel tiles whose residual is requested before the last K-step; the others' when its fragments are dead
+    auto load_res = [&](auto lo, auto hi) { // the vector form only (res_vec and every channel group inside Cout); the epilogue reads the rest itself
+#pragma unroll
+        for (int j = decltype(lo)::value; j < decltype(hi)::value; ++j) {
+            const int nc = min(n0 + wn * (BN / 2) + j * 16 + fr, p.npix - 1);
+            const int b = nc / OHW, rem = nc - b * OHW;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            const long roff = tv32_off(p.res, b, oy, ox);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+                rr[i][j] = *reinterpret_cast<const f32x4*>(p.res.p + roff + min(m0 + wm * 32 + i * 16 + 4 * q, p.Cout_pad - 4));
+        }
+    };
+    const bool res_early = SK && res_vec && p.res.cs >= p.Cout_pad; // (a residual tensor always has the layer's padded channel count; checked, not assumed)
+    if (SK)
+        load_bias();
     gload(0);
     to_lds(0);
     lds_barrier();
     HP_STAMP();
-#pragma unroll 1
-    for (int s = 0; s < steps; ++s) {
-        gload(min(s + 1, steps - 1));
+    auto k_step = [&](int s) {
         f32x4 fa[TMW], fb[TNW];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
@@ -376,28 +428,39 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
 #pragma unroll
                 for (int j = 0; j < TNW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-        to_lds((s + 1) & 1);
-        lds_barrier();
-        if ((s & 7) == 7)
-            HP_STAMP();
+    };
+    if constexpr (SK) {
+#pragma unroll 1
+        for (int s = 0; s + 1 < steps; ++s) {
+            gload(s + 1);
+            k_step(s);
+            to_lds((s + 1) & 1);
+            lds_barrier();
+        }
+        if (res_early)
+            load_res(std::integral_constant<int, 0>{}, std::integral_constant<int, JE>{});
+        k_step(steps - 1);
+        if (res_early)
+            load_res(std::integral_constant<int, JE>{}, std::integral_constant<int, TNW>{});
+    } else {
+#pragma unroll 1
+        for (int s = 0; s < steps; ++s) {
+            gload(min(s + 1, steps - 1));
+            k_step(s);
+            to_lds((s + 1) & 1);
+            lds_barrier();
+            if ((s & 7) == 7)
+                HP_STAMP();
+        }
     }
+    HP_STAMP();
 
     // epilogue: lane (n, q) of tile (i, j) holds channels m0 + wm * 32 + i * 16 + 4 q + {0..3} of pixel n0 + wn * BN / 2 + j * 16 + n
-    const int q = lane >> 4;
-    const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
-    const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
-    const bool res_pre = p.res.p && p.res_before_act, res_post = p.res.p && !p.res_before_act;
-    f32x4 bs[TMW], sl[TMW];
-#pragma unroll
-    for (int i = 0; i < TMW; ++i) {
-        const int m = m0 + wm * 32 + i * 16 + 4 * q; // (m + 3 < Cout_pad)
-        bs[i] = *reinterpret_cast<const f32x4*>(p.bias + m);
-        sl[i] = f32x4{ p.act_slope, p.act_slope, p.act_slope, p.act_slope };
-        if (p.alpha)
-            sl[i] = *reinterpret_cast<const f32x4*>(p.alpha + m);
-    }
+    if (!SK)
+        load_bias();
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
+        HP_STAMP();
         const int n = n0 + wn * (BN / 2) + j * 16 + fr;
         const bool pix_ok = n < p.npix;
         const int nc = min(n, p.npix - 1);
@@ -411,26 +474,28 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
             if (!pix_ok || m >= p.Cout)
                 continue;
             const bool full = m + 3 < p.Cout;
-            float v[4], rr[4] = { 0.f, 0.f, 0.f, 0.f };
+            float v[4], rv[4] = { 0.f, 0.f, 0.f, 0.f };
             if (p.res.p) {
-                if (full && res_vec) {
+                if (res_early) {
+                    rv[0] = rr[i][j][0], rv[1] = rr[i][j][1], rv[2] = rr[i][j][2], rv[3] = rr[i][j][3];
+                } else if (full && res_vec) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(p.res.p + roff + m);
-                    rr[0] = t[0], rr[1] = t[1], rr[2] = t[2], rr[3] = t[3];
+                    rv[0] = t[0], rv[1] = t[1], rv[2] = t[2], rv[3] = t[3];
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (m + e < p.Cout)
-                            rr[e] = p.res.p[roff + m + e];
+                            rv[e] = p.res.p[roff + m + e];
                 }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = acc[i][j][e] + bs[i][e];
                 if (res_pre)
-                    x += rr[e];
+                    x += rv[e];
                 x = x > 0.f ? fminf(x, p.act_hi) : x * sl[i][e];
                 if (res_post)
-                    x += rr[e];
+                    x += rv[e];
                 v[e] = x;
             }
             if (p.out.p) {
@@ -454,7 +519,21 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
     HP_STAMP();
     if (p.dbg && tid == 0 && blockIdx.x < 4096)
         p.dbg[128 + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    } while (SK && (vb += gridDim.x) < nvb); // (next tile of a persistent block)
 #undef HP_STAMP
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
+{
+    conv32_t16_body<BN, false>(p);
+}
+
+// (three blocks per CU = 168 registers: said to the compiler, which otherwise stops at the occupancy the 32 KB of LDS allow and takes 184)
+template <int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv32_t16_sk_kernel(const conv32_params p)
+{
+    conv32_t16_body<BN, true>(p);
 }
 
 // Block tile (BM output channels x BN pixels) of a layer.  The fp32 matrix pipe is slow enough (64 cycles per MFMA) that small tiles cost
@@ -553,7 +632,14 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
     else                                                                                   \
         HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, s, p);
     if (BN == 160) {
-        HP_LAUNCH((conv32_t16_kernel<160>), grid, dim3(256), 0, s, p);
+        static const bool sk_off = getenv("HP_T16_SK") && atoi(getenv("HP_T16_SK")) == 0; // A/B switch
+        if (p.KH == 1 && p.KW == 1 && p.Cin <= 128 && !sk_off) {
+            // persistent: three blocks per CU (166 registers), every block walks the tile list with stride gridDim (a multiple of 8)
+            static const int sk_grid = getenv("HP_T16_SK_GRID") ? atoi(getenv("HP_T16_SK_GRID")) / 8 * 8 : 768;
+            HP_LAUNCH((conv32_t16_sk_kernel<160>), dim3(std::min<unsigned>(grid.x, std::max(8, sk_grid))), dim3(256), 0, s, p);
+        }
+        else
+            HP_LAUNCH((conv32_t16_kernel<160>), grid, dim3(256), 0, s, p);
     } else if (BM == 128) {
         HP_C32_CASE(128, 128, 2, 2)
     } else if (BN == 128) {

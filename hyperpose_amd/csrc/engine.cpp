@@ -1524,7 +1524,8 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
             } else {
                 HP_HIP_TRY(hp::launch_conv32(st.cp32, s));
                 static const bool dbg_c32 = getenv("HP_DIRECT_DBG") != nullptr;
-                if (dbg_c32 && st.cp32.Cin >= 256) { // block timeline (s_memtime, block 9, thread 0): start | first tile staged | every 8 K-steps | stored
+                static const int dbg_min_cin = getenv("HP_DIRECT_DBG_MINCIN") ? atoi(getenv("HP_DIRECT_DBG_MINCIN")) : 256;
+                if (dbg_c32 && st.cp32.Cin >= dbg_min_cin) { // block timeline (s_memtime, block 9, thread 0): start | first tile staged | every 8 K-steps | stored
                     constexpr int NDBG = 128 + 3 * 4096;
                     unsigned long long* dbg = nullptr;
                     HP_HIP_TRY(hipMalloc(&dbg, NDBG * 8));
