@@ -410,6 +410,10 @@ def kernel_label(tile: int):
            20: ("sepconv_pair_kernel<32,64,128>", "the stem's separable blocks 32 -> 64 and 64 -> 128 (stride 2) in one launch, the 64-channel "
                 "tensor between them in LDS only")}
     chain = {1: "false,0", 2: "false,1", 3: "false,2", 10: "true,0", 13: "true,3"}
+    if tile >= 39000000:
+        kt, bn = (tile - 39000000) // 1000, tile % 1000
+        return (f"conv32_wk_kernel<{kt},{bn}>", f"conv32_wk_kernel<K={kt},BN={bn}> (fp32 1x1 layer with {kt} input channels on v_mfma_f32_16x16x4_f32: 64 cout x {bn} pixels per block, weights, "
+                "pixels (all K), residual and bias requested at once, no K-step barriers, whole-line row-major stores through a per-wavefront LDS slab)")
     if tile >= 37000000:
         hid, c2 = (tile - 37000000) // 100, tile % 100
         return (f"conv32_head_kernel<{1 if c2 <= 32 else 2}>", f"conv32_head_kernel (fp32 two-layer head in one launch: 1x1 128 -> {hid} relu -> 1x1 {hid} -> {c2}, 32 pixels per block, "

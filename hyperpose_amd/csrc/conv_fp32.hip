@@ -290,13 +290,8 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
 // = 32 KB per block.  K order as in conv32_kernel: lane (row, kq) reads channels [4 kq, 4 kq + 4) with one ds_read_b128 and feeds element e to
 // MFMA e - A and B use the same permutation.  Epilogue: lane (pixel n, q) of a 16 x 16 tile holds channels 4 q .. 4 q + 3 of pixel n: one
 // global_store_dwordx4 of a wavefront covers 16 pixels x 64 contiguous bytes.
-// SK ("short K": the 1 x 1 layers with <= 128 input channels - two to eight K-steps in front of an epilogue that moves far more bytes than the loop):
-// the block's life is its epilogue (64 -> 256 at 32 x 96 x 96 with a residual: 1.2 us staging, 7 us for the four K-steps, 14.3 us epilogue - 6.3 without
-// the residual; profiles/r06_block_timelines_f32_config3.txt), and three things in it wait for memory one after the other: bias / slopes, the residual,
-// the stores.  The SK form requests bias / slopes before the loop and the residual before the LAST K-step's MFMAs (the staging registers are free by
-// then), so that the epilogue only computes and stores.  Same arithmetic in the same order: bit-identical outputs.
-template <int BN, bool SK>
-__device__ __forceinline__ void conv32_t16_body(const conv32_params p)
+template <int BN>
+__global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
 {
     constexpr int BM = 64, BK = 16, TMW = 2, TNW = BN / 2 / 16; // a wavefront: TMW x TNW tiles of 16 x 16
     constexpr int NB = (BN + 63) / 64, BR = NB * 64;             // staging passes of the B tile (64 rows each); rows allocated
@@ -305,33 +300,16 @@ __device__ __forceinline__ void conv32_t16_body(const conv32_params p)
     float (*const sA)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(lds);
     float (*const sB)[BR * BK] = reinterpret_cast<float (*)[BR * BK]>(lds + 2 * BM * BK);
 
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
     const int G = p.Cout_pad / BM, nx = (p.npix + BN - 1) / BN; // XCD-aware 1-D block order: see conv32_kernel
+    const int bj = blockIdx.x >> 3, ptile = (bj / G) * 8 + (blockIdx.x & 7);
+    if (ptile >= nx)
+        return;
+    const int n0 = ptile * BN, m0 = (bj % G) * BM;
+    const int lrow = tid >> 2, lq = tid & 3;
     const int OHW = p.OH * p.OW, kc = p.Cin / BK, steps = p.KH * p.KW * kc;
     auto swz = [](int row, int quad) { return row * BK + ((quad ^ (((row >> 3) & 1) << 1)) << 2); };
-    int dbg_i = 0;
-    // SK: the block is PERSISTENT - it takes tiles vb = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8: vb & 7 = the block's XCD).  A
-    // wavefront's slot is not free before its stores are acknowledged (4-5 us under load: 16 blocks of 15.9 us took 109 us in each of a CU's three
-    // slots, profiles/r06_block_timelines_f32_config3.txt); a block that goes on requests its next tile while they drain.  The other form is
-    // launched with one block per tile: one pass.
-    const int nvb = (nx + 7) / 8 * 8 * G;
-    int vb = blockIdx.x;
-#pragma unroll 1
-    do {
-    const int bj = vb >> 3, ptile = (bj / G) * 8 + (vb & 7);
-    if (ptile >= nx)
-        continue;
-    const bool first = vb == (int)blockIdx.x;
-    if (!first)
-        lds_barrier(); // every wavefront has read the previous tile's last K-step
-    // (everything a lane derives from its index is derived again per tile: hoisted out of the tile loop it would stay live through the epilogue,
-    // where the residual and the accumulators already fill the registers three blocks per CU allow)
-    int tid = threadIdx.x;
-    if (SK)
-        asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lrow = tid >> 2, lq = tid & 3;
-    const int n0 = ptile * BN, m0 = (bj % G) * BM;
 
     long bbase[NB];
 #pragma unroll
@@ -367,53 +345,23 @@ __device__ __forceinline__ void conv32_t16_body(const conv32_params p)
             acc[i][j] = f32x4{ 0.f, 0.f, 0.f, 0.f };
 
     const int fr = lane & 15, kq = lane >> 4;
-#define HP_STAMP()                                                \
-    if (p.dbg && blockIdx.x == 9 && tid == 0 && dbg_i < 120)      \
+    int dbg_i = 0;
+#define HP_STAMP()                                       \
+    if (p.dbg && blockIdx.x == 9 && tid == 0)            \
         p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
     HP_STAMP();
     // block residency trace: [128 + 3 b] = start, [.. + 1] = end (100 MHz clock), [.. + 2] = XCC_ID << 32 | HW_ID of block b < 4096
-    if (p.dbg && tid == 0 && blockIdx.x < 4096 && first) {
+    if (p.dbg && tid == 0 && blockIdx.x < 4096) {
         p.dbg[128 + 3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         p.dbg[128 + 3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
-    // (SK) epilogue operands requested early: bias / slopes now, the residual before the last K-step
-    const int q = lane >> 4;
-    const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
-    const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
-    const bool res_pre = p.res.p && p.res_before_act, res_post = p.res.p && !p.res_before_act;
-    f32x4 bs[TMW], sl[TMW];
-    auto load_bias = [&]() {
-#pragma unroll
-        for (int i = 0; i < TMW; ++i) {
-            const int m = m0 + wm * 32 + i * 16 + 4 * q; // (m + 3 < Cout_pad)
-            bs[i] = *reinterpret_cast<const f32x4*>(p.bias + m);
-            sl[i] = f32x4{ p.act_slope, p.act_slope, p.act_slope, p.act_slope };
-            if (p.alpha)
-                sl[i] = *reinterpret_cast<const f32x4*>(p.alpha + m);
-        }
-    };
-    f32x4 rr[TMW][TNW];
-    constexpr int JE = (TNW + 1) / 2; // pixel tiles whose residual is requested before the last K-step; the others' when its fragments are dead
-    auto load_res = [&](auto lo, auto hi) { // the vector form only (res_vec and every channel group inside Cout); the epilogue reads the rest itself
-#pragma unroll
-        for (int j = decltype(lo)::value; j < decltype(hi)::value; ++j) {
-            const int nc = min(n0 + wn * (BN / 2) + j * 16 + fr, p.npix - 1);
-            const int b = nc / OHW, rem = nc - b * OHW;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const long roff = tv32_off(p.res, b, oy, ox);
-#pragma unroll
-            for (int i = 0; i < TMW; ++i)
-                rr[i][j] = *reinterpret_cast<const f32x4*>(p.res.p + roff + min(m0 + wm * 32 + i * 16 + 4 * q, p.Cout_pad - 4));
-        }
-    };
-    const bool res_early = SK && res_vec && p.res.cs >= p.Cout_pad; // (a residual tensor always has the layer's padded channel count; checked, not assumed)
-    if (SK)
-        load_bias();
     gload(0);
     to_lds(0);
     lds_barrier();
     HP_STAMP();
-    auto k_step = [&](int s) {
+#pragma unroll 1
+    for (int s = 0; s < steps; ++s) {
+        gload(min(s + 1, steps - 1));
         f32x4 fa[TMW], fb[TNW];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
@@ -428,39 +376,28 @@ __device__ __forceinline__ void conv32_t16_body(const conv32_params p)
 #pragma unroll
                 for (int j = 0; j < TNW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    };
-    if constexpr (SK) {
-#pragma unroll 1
-        for (int s = 0; s + 1 < steps; ++s) {
-            gload(s + 1);
-            k_step(s);
-            to_lds((s + 1) & 1);
-            lds_barrier();
-        }
-        if (res_early)
-            load_res(std::integral_constant<int, 0>{}, std::integral_constant<int, JE>{});
-        k_step(steps - 1);
-        if (res_early)
-            load_res(std::integral_constant<int, JE>{}, std::integral_constant<int, TNW>{});
-    } else {
-#pragma unroll 1
-        for (int s = 0; s < steps; ++s) {
-            gload(min(s + 1, steps - 1));
-            k_step(s);
-            to_lds((s + 1) & 1);
-            lds_barrier();
-            if ((s & 7) == 7)
-                HP_STAMP();
-        }
+        to_lds((s + 1) & 1);
+        lds_barrier();
+        if ((s & 7) == 7)
+            HP_STAMP();
     }
-    HP_STAMP();
 
     // epilogue: lane (n, q) of tile (i, j) holds channels m0 + wm * 32 + i * 16 + 4 q + {0..3} of pixel n0 + wn * BN / 2 + j * 16 + n
-    if (!SK)
-        load_bias();
+    const int q = lane >> 4;
+    const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
+    const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
+    const bool res_pre = p.res.p && p.res_before_act, res_post = p.res.p && !p.res_before_act;
+    f32x4 bs[TMW], sl[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * q; // (m + 3 < Cout_pad)
+        bs[i] = *reinterpret_cast<const f32x4*>(p.bias + m);
+        sl[i] = f32x4{ p.act_slope, p.act_slope, p.act_slope, p.act_slope };
+        if (p.alpha)
+            sl[i] = *reinterpret_cast<const f32x4*>(p.alpha + m);
+    }
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
-        HP_STAMP();
         const int n = n0 + wn * (BN / 2) + j * 16 + fr;
         const bool pix_ok = n < p.npix;
         const int nc = min(n, p.npix - 1);
@@ -474,28 +411,26 @@ __device__ __forceinline__ void conv32_t16_body(const conv32_params p)
             if (!pix_ok || m >= p.Cout)
                 continue;
             const bool full = m + 3 < p.Cout;
-            float v[4], rv[4] = { 0.f, 0.f, 0.f, 0.f };
+            float v[4], rr[4] = { 0.f, 0.f, 0.f, 0.f };
             if (p.res.p) {
-                if (res_early) {
-                    rv[0] = rr[i][j][0], rv[1] = rr[i][j][1], rv[2] = rr[i][j][2], rv[3] = rr[i][j][3];
-                } else if (full && res_vec) {
+                if (full && res_vec) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(p.res.p + roff + m);
-                    rv[0] = t[0], rv[1] = t[1], rv[2] = t[2], rv[3] = t[3];
+                    rr[0] = t[0], rr[1] = t[1], rr[2] = t[2], rr[3] = t[3];
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (m + e < p.Cout)
-                            rv[e] = p.res.p[roff + m + e];
+                            rr[e] = p.res.p[roff + m + e];
                 }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = acc[i][j][e] + bs[i][e];
                 if (res_pre)
-                    x += rv[e];
+                    x += rr[e];
                 x = x > 0.f ? fminf(x, p.act_hi) : x * sl[i][e];
                 if (res_post)
-                    x += rv[e];
+                    x += rr[e];
                 v[e] = x;
             }
             if (p.out.p) {
@@ -519,21 +454,215 @@ __device__ __forceinline__ void conv32_t16_body(const conv32_params p)
     HP_STAMP();
     if (p.dbg && tid == 0 && blockIdx.x < 4096)
         p.dbg[128 + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    } while (SK && (vb += gridDim.x) < nvb); // (next tile of a persistent block)
 #undef HP_STAMP
 }
 
-template <int BN>
-__global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
+// ---------------------------------------------------------------------------------------------------
+// conv32_wk_kernel ("whole K"; round 6): 1 x 1 layers with 32 / 64 input channels whose time is their memory traffic - ResNet's expansions
+// (64 -> 256 at 32 x 96 x 96 with a residual: 75 MB in, 302 MB residual, 302 MB out for 9.7 GFLOP), MobileNet's first pointwise layer (32 -> 64 at
+// 8 x 184 x 216).  On conv32_t16_kernel such a layer is two to four K-steps, each behind a barrier with 14 KB of loads in flight per block, then bias,
+// then the residual, then the stores, one wait after the other: 205 us for 680 MB (3.3 TB/s; a copy reaches 6.3), 172 of them with the MFMAs
+// REMOVED.  What was tried on it, in measured order (profiles/r06_ab_layers_f32_whole_k.txt): bias and residual requested before the
+// last K-step (185), persistent blocks (192), staggered starts (197), a barrier-free per-wavefront stream with the weights in registers (203) - and
+// this form, which gains with the NUMBER of blocks a CU holds (64 x 160 pixels, two per CU: 188; 64 x 96, three: 172; 64 x 64, four: 165):
+//   * a block requests EVERYTHING it will read at once - the weights' 64 rows and its 64 pixels for all K channels (whole pixel rows of K * 4
+//     contiguous bytes), the residual and the bias - waits once, and has no block-wide barrier left;
+//   * a wavefront owns ALL 64 output channels of 16 pixels: it multiplies the K / 16 slices out of LDS, turns the tile through a private LDS slab
+//     (32 channels at a time) into pixel rows - lane = (pixel, 16-byte chunk) - and applies bias / residual / activation there: a store (and a
+//     residual load) instruction covers 8 pixels x 128 contiguous bytes.  (Half-line stores - 16 pixels x 64 bytes, what the accumulator layout
+//     gives - to a tensor beyond the 256 MB Infinity Cache run at 3.3 TB/s against 5.4 when nobody writes the other half, tools/storebench.hip /
+//     profiles/r06_storebench.txt; here the other half follows at once and L2 merges them: whole-line stores measured 168 against 165 us);
+//   * pixel -> address arithmetic (two integer divisions per pixel and tensor) is done once per pixel by 64 threads into an LDS table.
+// Still far from the traffic's 110 us: with parts removed the layer takes 166 (no activation loads), 133 (no stores), 128 us (no MFMAs) - no single
+// resource is the bound, a block's own chain of latencies is, three blocks per CU deep.  What would cover it is a loader that runs tiles ahead
+// (LDS-DMA ring per wavefront); not built.
+//   tile   64 output channels x 64 pixels, four wavefronts side by side over the pixels, MFMA tiles of 16 x 16 x 4
+//   LDS    [K / 16 slices][rows][16 floats] per operand, conv32_t16_kernel's XOR swizzle inside a slice, slices one row apart in bank space
+//   K order, accumulation order and epilogue arithmetic (per element) are conv32_t16_kernel's: the same bits.
+template <int KT, int BN>
+__global__ __launch_bounds__(256) void conv32_wk_kernel(const conv32_params p)
 {
-    conv32_t16_body<BN, false>(p);
+    constexpr int BM = 64, KS = KT / 16, CPR = KT / 4, TMW = 4, TNW = BN / 64, WPX = BN / 4;
+    constexpr int SA = BM * 16 + 16, SB = BN * 16 + 16;   // slice strides in floats (+ 64 B: the slices of one pixel row land in different bank quads)
+    constexpr int SLAB = 16 * 36;                         // a wavefront's slab: 16 pixels x (32 channels + 4) floats
+    constexpr int NA = BM * CPR / 256, NBC = (BN * CPR + 255) / 256; // 16-byte chunks per thread: weights, pixels
+    static_assert(BN % 64 == 0 && KT % 16 == 0 && (BM * CPR) % 256 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[]; // wk_lds_bytes: the two operands, the slabs, then the address table
+    float* const sA = lds;
+    float* const sB = lds + KS * SA;
+    long* const s_in = reinterpret_cast<long*>(lds + KS * (SA + SB) + 4 * SLAB);
+    long* const s_out = s_in + BN;
+    long* const s_res = s_out + BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const slab = lds + KS * (SA + SB) + wave * SLAB;
+    const int G = p.Cout_pad / BM, nx = (p.npix + BN - 1) / BN; // XCD-aware 1-D block order: see conv32_kernel
+    const int bj = blockIdx.x >> 3, ptile = (bj / G) * 8 + (blockIdx.x & 7);
+    if (ptile >= nx)
+        return;
+    const int n0 = ptile * BN, m0 = (bj % G) * BM;
+    const int OHW = p.OH * p.OW;
+    auto swz = [](int row, int quad) { return row * 16 + ((quad ^ (((row >> 3) & 1) << 1)) << 2); };
+
+    if (tid < BN) { // (pixels past the tensor: the last pixel again - read, multiplied, never stored)
+        const int n = min(n0 + tid, p.npix - 1);
+        const int b = n / OHW, rem = n - b * OHW;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        s_in[tid] = tv32_off(p.in, b, oy * p.stride - p.pad_t, ox * p.stride - p.pad_l);
+        s_out[tid] = tv32_off(p.out, b, oy, ox);
+        s_res[tid] = p.res.p ? tv32_off(p.res, b, oy, ox) : 0;
+    }
+    const int fr = lane & 15, kq = lane >> 4;
+    const int rrow = lane >> 3, rc = lane & 7; // row form: lane = (pixel rrow of 8, 16-byte chunk rc of 8) of a half tile
+    const bool out_vec = ((p.out.coff | p.out.cs) & 3) == 0;
+    const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0 && p.res.cs >= p.Cout_pad; // (whole channel quads readable for every group of the padded matrix)
+    const bool res_pre = p.res.p && p.res_before_act, res_post = p.res.p && !p.res_before_act;
+    f32x4 bsr[2], slr[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = m0 + h * 32 + 4 * rc; // (m + 3 < Cout_pad)
+        bsr[h] = *reinterpret_cast<const f32x4*>(p.bias + m);
+        slr[h] = f32x4{ p.act_slope, p.act_slope, p.act_slope, p.act_slope };
+        if (p.alpha)
+            slr[h] = *reinterpret_cast<const f32x4*>(p.alpha + m);
+    }
+    f32x4 va[NA], vb[NBC];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + 256 * i, row = idx / CPR, c = idx % CPR;
+        va[i] = *reinterpret_cast<const f32x4*>(p.w + (long)(m0 + row) * p.Cin + c * 4);
+    }
+    __syncthreads(); // the address table
+#pragma unroll
+    for (int i = 0; i < NBC; ++i) {
+        const int idx = min(tid + 256 * i, BN * CPR - 1), row = idx / CPR, c = idx % CPR;
+        vb[i] = *reinterpret_cast<const f32x4*>(p.in.p + s_in[row] + c * 4);
+    }
+    f32x4 rr[TNW][2][2]; // [tile][half][8-pixel group] in row form
+    if (res_vec) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const long roff = s_res[wave * WPX + j * 16 + 8 * r + rrow] + m0 + 4 * rc;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    rr[j][h][r] = *reinterpret_cast<const f32x4*>(p.res.p + roff + h * 32);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + 256 * i, row = idx / CPR, c = idx % CPR;
+        *reinterpret_cast<f32x4*>(&sA[(c >> 2) * SA + swz(row, c & 3)]) = va[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NBC; ++i) {
+        const int idx = tid + 256 * i, row = idx / CPR, c = idx % CPR;
+        if (idx < BN * CPR)
+            *reinterpret_cast<f32x4*>(&sB[(c >> 2) * SB + swz(row, c & 3)]) = vb[i];
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        f32x4 acc[TMW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+            acc[i] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        const int prow0 = wave * WPX + j * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            f32x4 fa[TMW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+                fa[i] = *reinterpret_cast<const f32x4*>(&sA[s * SA + swz(i * 16 + fr, kq)]);
+            const f32x4 fb = *reinterpret_cast<const f32x4*>(&sB[s * SB + swz(prow0 + fr, kq)]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TMW; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[e], acc[i], 0, 0, 0);
+        }
+        // accumulator form: lane (pixel fr, kq) holds channels i * 16 + 4 kq + {0..3}.  Through the slab, 32 channels at a time, into row form.
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<f32x4*>(&slab[fr * 36 + i * 16 + 4 * kq]) = acc[2 * h + i];
+            __builtin_amdgcn_wave_barrier(); // (a wavefront's LDS operations complete in order: the barrier only pins the compiler's order)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&slab[(8 * r + rrow) * 36 + 4 * rc]);
+                const int prow = prow0 + 8 * r + rrow, m = m0 + h * 32 + 4 * rc;
+                if (n0 + prow >= p.npix || m >= p.Cout)
+                    continue;
+                const bool full = m + 3 < p.Cout;
+                const long ooff = s_out[prow] + m;
+                float v[4], rv[4] = { 0.f, 0.f, 0.f, 0.f };
+                if (p.res.p) {
+                    if (res_vec) {
+                        rv[0] = rr[j][h][r][0], rv[1] = rr[j][h][r][1], rv[2] = rr[j][h][r][2], rv[3] = rr[j][h][r][3];
+                    } else {
+                        const long roff = s_res[prow] + m;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (m + e < p.Cout)
+                                rv[e] = p.res.p[roff + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = a[e] + bsr[h][e];
+                    if (res_pre)
+                        x += rv[e];
+                    x = x > 0.f ? fminf(x, p.act_hi) : x * slr[h][e];
+                    if (res_post)
+                        x += rv[e];
+                    v[e] = x;
+                }
+                if (full && out_vec)
+                    *reinterpret_cast<f32x4*>(p.out.p + ooff) = f32x4{ v[0], v[1], v[2], v[3] };
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (m + e < p.Cout)
+                            p.out.p[ooff + e] = v[e];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
-// (three blocks per CU = 168 registers: said to the compiler, which otherwise stops at the occupancy the 32 KB of LDS allow and takes 184)
-template <int BN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv32_t16_sk_kernel(const conv32_params p)
+template <int KT, int BN>
+static hipError_t launch_wk(const conv32_params& p, dim3 grid, hipStream_t s)
 {
-    conv32_t16_body<BN, true>(p);
+    constexpr int lds = KT / 16 * ((64 * 16 + 16) + (BN * 16 + 16)) * 4 + 4 * 16 * 36 * 4 + 3 * BN * 8;
+    static bool granted = false;
+    if (lds > 64 * 1024 && !granted) {
+        const hipError_t e = hipFuncSetAttribute((const void*)conv32_wk_kernel<KT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess)
+            return e;
+        granted = true;
+    }
+    HP_LAUNCH((conv32_wk_kernel<KT, BN>), grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+// Which layers take conv32_wk_kernel: 1 x 1 (any stride), exactly 32 / 64 / 128 input channels, an NHWC output only, and enough pixel tiles that
+// two blocks per CU stay busy (HP_C32_WK=0: none, the A/B switch; =1: every layer of that shape).  Looks at pick_npix like conv32_pick.
+static int conv32_wk_bn(const conv32_params& p)
+{
+    const int wk = getenv("HP_C32_WK") ? atoi(getenv("HP_C32_WK")) : -1;
+    if (wk == 0 || p.KH != 1 || p.KW != 1 || p.dil != 1 || p.out_f32 || !p.out.p || (p.Cin != 32 && p.Cin != 64 && p.Cin != 128))
+        return 0;
+    // K = 128 (two blocks per CU) wins nothing: ResNet's 128 -> 512 at 32 x 48 x 48 140 -> 135 us, MobileNet's 128 -> 128 at 8 x 92 x 108 38.6 -> 41.6
+    // (profiles/r06_ab_layers_f32_whole_k.txt): forced only (the tests)
+    if (p.Cin == 128 && wk != 1)
+        return 0;
+    const int bn = 64; // (LDS: 27 / 44 / 77 KB per block at K = 32 / 64 / 128: five / three / two blocks per CU)
+    const long np = p.pick_npix > 0 ? p.pick_npix : p.npix, blocks = (np + bn - 1) / bn * (p.Cout_pad / 64);
+    return wk == 1 || blocks >= 768 ? bn : 0;
 }
 
 // Block tile (BM output channels x BN pixels) of a layer.  The fp32 matrix pipe is slow enough (64 cycles per MFMA) that small tiles cost
@@ -589,6 +718,8 @@ static bool conv32_rows(const conv32_params& p, int BN)
 
 int conv32_tile(const conv32_params& p)
 {
+    if (const int bn = conv32_wk_bn(p))
+        return 39000000 + p.Cin * 1000 + bn;
     int BM, BN;
     conv32_pick(p, BM, BN);
     return 32000000 + (conv32_rows(p, BN) ? 400000 : 0) + BM * 1000 + BN;
@@ -622,6 +753,10 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
 {
     if (p.Cin % 16 || p.Cout_pad % 64 || p.npix <= 0)
         return hipErrorInvalidValue;
+    if (const int bn = conv32_wk_bn(p)) {
+        const dim3 g(((p.npix + bn - 1) / bn + 7) / 8 * 8 * (p.Cout_pad / 64));
+        return p.Cin == 32 ? launch_wk<32, 64>(p, g, s) : p.Cin == 64 ? launch_wk<64, 64>(p, g, s) : launch_wk<128, 64>(p, g, s);
+    }
     int BM, BN;
     conv32_pick(p, BM, BN);
     const dim3 grid(((p.npix + BN - 1) / BN + 7) / 8 * 8 * (p.Cout_pad / BM)); // XCD-aware 1-D order: see conv32_kernel
@@ -632,14 +767,7 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
     else                                                                                   \
         HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, s, p);
     if (BN == 160) {
-        static const bool sk_off = getenv("HP_T16_SK") && atoi(getenv("HP_T16_SK")) == 0; // A/B switch
-        if (p.KH == 1 && p.KW == 1 && p.Cin <= 128 && !sk_off) {
-            // persistent: three blocks per CU (166 registers), every block walks the tile list with stride gridDim (a multiple of 8)
-            static const int sk_grid = getenv("HP_T16_SK_GRID") ? atoi(getenv("HP_T16_SK_GRID")) / 8 * 8 : 768;
-            HP_LAUNCH((conv32_t16_sk_kernel<160>), dim3(std::min<unsigned>(grid.x, std::max(8, sk_grid))), dim3(256), 0, s, p);
-        }
-        else
-            HP_LAUNCH((conv32_t16_kernel<160>), grid, dim3(256), 0, s, p);
+        HP_LAUNCH((conv32_t16_kernel<160>), grid, dim3(256), 0, s, p);
     } else if (BM == 128) {
         HP_C32_CASE(128, 128, 2, 2)
     } else if (BN == 128) {

@@ -58,7 +58,7 @@ struct conv32_params {
 bool set_act32(conv32_params& p);
 // Dense KH x KW convolution (any stride / dilation) as an implicit GEMM on v_mfma_f32_32x32x2_f32.
 hipError_t launch_conv32(const conv32_params& p, hipStream_t s);
-int conv32_tile(const conv32_params& p); // profile rows: 32000000 + 400000 (row-major epilogue) + BM * 1000 + BN
+int conv32_tile(const conv32_params& p); // profile rows: 32000000 + 400000 (row-major epilogue) + BM * 1000 + BN; conv32_wk_kernel (1 x 1, 32 / 64 input channels, large maps): 39000000 + Cin * 1000 + pixels per block
 // The barrier-free direct form for square 1 x 1 / 3 x 3, stride 1, dilation 1, SAME padding (conv32_direct.hip): a chunk's halo tile staged in LDS once
 // for all taps, weights in fragment order straight from L2.  split = false: exact fp32 products on v_mfma_f32_32x32x2_f32 (needs w_frag);
 // split = true: every fp32 product formed as three exact fp16 x fp16 products on the fp16 matrix pipe, x = hi + 2^-11 lo,

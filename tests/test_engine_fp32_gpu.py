@@ -259,6 +259,42 @@ def test_one_round_tile_64x160(hp, cin, cout, k, h, w, monkeypatch):
             assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
 
 
+@pytest.mark.parametrize("cin,h,w", [(32, 61, 47), (64, 40, 52), (128, 23, 27), (64, 12, 12)])
+def test_whole_k_tile(hp, cin, h, w, monkeypatch):
+    """conv32_wk_kernel (round 6: 1 x 1 layers with 32 / 64 / 128 input channels; a block reads its 64 weight rows, its pixels for ALL K, the
+    residual and the bias at once, then multiplies and stores 16-pixel tiles without another barrier): forced (HP_C32_WK=1) on maps whose
+    pixel counts are not multiples of the tile, with a residual before the activation, every activation form, 70 real output channels of 128
+    (partial quads) and a stride-2 layer - against the oracle at the engine's tolerance, against the other kernels (HP_C32_WK=0) at 2e-5 of
+    scale, batch invariance bit for bit."""
+    def build():
+        net = Net(300 + cin)
+        t0 = net.conv(0, 3, cin, 3, 1)
+        a = net.conv(t0, cin, 128, 1, 1, act=E.ACT_PRELU)
+        r = net.conv(t0, cin, 128, 1, 1, act=E.ACT_RELU)
+        b = net.conv(a, 128, 128, 1, 1, res=r, res_before_act=1, act=E.ACT_RELU6)
+        c = net.conv(b, 128, 70, 1, 1, act=E.ACT_LEAKY, act_param=0.1)
+        d = net.conv(t0, cin, 64, 1, 2, act=E.ACT_NONE)
+        # (a layer that writes a network output is not this kernel's: every layer under test is read through a 3 x 3 layer behind it)
+        yb, yc, yd = net.conv(b, 128, 32, 3, 1, act=E.ACT_NONE), net.conv(c, 70, 38, 3, 1, act=E.ACT_NONE), net.conv(d, 64, 24, 3, 1, act=E.ACT_NONE)
+        return net, [Out("yb", yb, 0, 32), Out("yc", yc, 0, 38), Out("yd", yd, 0, 24)]
+    frames = _frames(5, h, w, seed=cin)
+    monkeypatch.setenv("HP_C32_WK", "1")
+    net, outs = build()
+    eng, got, _ = _run32(net, outs, frames, h, w, dtype="f32")
+    tiles = [p["tile"] for p in eng.profile(5, iters=1)]
+    assert sum(t // 1000000 == 39 for t in tiles) == 5, tiles
+    alone = eng.inference(frames[3:4])[0]
+    for (_, a1), (_, a5) in zip(alone, got[3]):
+        assert np.array_equal(a1, a5)
+    monkeypatch.setenv("HP_C32_WK", "0")
+    net2, outs2 = build()
+    eng2, got2, _ = _run32(net2, outs2, frames, h, w, dtype="f32")
+    assert not [p for p in eng2.profile(5, iters=1) if p["tile"] // 1000000 == 39]
+    for b in range(5):
+        for (nm, x), (_, yv) in zip(got[b], got2[b]):
+            assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
+
+
 @pytest.mark.parametrize("arch,w_,h_,n", [("lw_openpose_mobilenet", 96, 80, 5), ("pose_proposal_resnet50", 160, 128, 4), ("pifpaf_resnet50", 97, 97, 3),
                                             ("lw_openpose_mobilenet", 432, 368, 8)])
 def test_two_half_batches_are_bit_identical(hp, f32dtype, arch, w_, h_, n):

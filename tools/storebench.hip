@@ -43,11 +43,11 @@ static float time_ms(hipStream_t s, int iters, const std::function<void()>& f)
 int main()
 {
     hipStream_t s; CK(hipStreamCreate(&s));
-    const size_t cap = 1ull << 30;
+    const size_t cap = 5ull << 30;
     u32x4* buf; CK(hipMalloc(&buf, cap));
-    for (size_t mb : { 20, 128 }) {
+    for (size_t mb : { 600 }) {
         const size_t bytes = mb << 20;
-        for (int blocks : { 256, 512, 1024, 2048 }) {
+        for (int blocks : { 2048 }) {
             struct pat { int seg16, stride16; const char* name; };
             for (pat pt : { pat{ 64, 64, "1KB contiguous/instr" }, pat{ 16, 64, "256B per px, 1KB stride (25% dense)" }, pat{ 16, 16, "256B per px dense" },
                             pat{ 8, 8, "128B per px dense" }, pat{ 4, 16, "64B per px, 256B stride" }, pat{ 4, 64, "64B per px, 1KB stride" }, pat{ 8, 64, "128B per px, 1KB stride" } }) {
