@@ -38,14 +38,14 @@ __device__ __forceinline__ long tvh_off(const tview32& t, int b, int y, int x)
 
 // q = the SECOND layer's parameters (bias, activation, out, out_f32, Cout = C2, Cout_pad = 32 TM2, OH / OW / npix) with q.in = the FIRST layer's input;
 // h = the first layer's
+// (the body, with its LDS handed in: xs = HX_BYTES, red_ = 4 x TM2 x 4 x 64 x 4 floats; blk = the block's 32-pixel tile)
 template <int TM2>
-__global__ __launch_bounds__(256, 2) void conv32_head_kernel(const conv32_params q, const head32_hidden h)
+__device__ __forceinline__ void conv32_head_body(const conv32_params& q, const head32_hidden& h, unsigned char* const xs, float* const red_, const int blk)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char xs[HX_BYTES];
-    __shared__ __attribute__((aligned(16))) float red[4][TM2][4][64][4]; // [wavefront][output tile][register quad][lane][4]
+    float (*const red)[TM2][4][64][4] = reinterpret_cast<float (*)[TM2][4][64][4]>(red_); // [wavefront][output tile][register quad][lane][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * 32;
+    const int n0 = blk * 32;
     const int OHW = q.OH * q.OW;
 
     // ---- the 32 pixels' input channels -> LDS: thread = (pixel, quads q0, q0 + 8, q0 + 16, q0 + 24)
@@ -184,6 +184,32 @@ __global__ __launch_bounds__(256, 2) void conv32_head_kernel(const conv32_params
     }
 }
 
+template <int TM2>
+__global__ __launch_bounds__(256, 2) void conv32_head_kernel(const conv32_params q, const head32_hidden h)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char xs[HX_BYTES];
+    __shared__ __attribute__((aligned(16))) float red[4 * TM2 * 4 * 64 * 4];
+    conv32_head_body<TM2>(q, h, xs, red, blockIdx.x);
+}
+
+// Two heads that read the SAME tensor (LW-OpenPose's heat-map and PAF heads of a stage) in ONE launch (round 6): alone each is 621 blocks of 32
+// pixels on 512 slots at 8 x 46 x 54 - 45 + 48 us one after the other, 31 + 33 side by side on two streams; a captured graph cannot run two branches
+// side by side, one grid can.  Block ids b and b + 8 - the same XCD, back to back - are the two heads of one pixel tile: the tile's
+// 16 KB of input come from HBM once.
+template <int TMA, int TMB>
+__global__ __launch_bounds__(256, 2) void conv32_head_pair_kernel(const conv32_params qa, const head32_hidden ha, const conv32_params qb, const head32_hidden hb)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char xs[HX_BYTES];
+    __shared__ __attribute__((aligned(16))) float red[4 * (TMA > TMB ? TMA : TMB) * 4 * 64 * 4];
+    const int blk = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+    if (blk * 32 >= qa.npix)
+        return; // (the grid is padded to whole groups of eight tiles)
+    if ((blockIdx.x >> 3) & 1)
+        conv32_head_body<TMB>(qb, hb, xs, red, blk);
+    else
+        conv32_head_body<TMA>(qa, ha, xs, red, blk);
+}
+
 // The pairs this kernel takes: 1 x 1 / stride 1 / no padding on both layers, 128 input channels (a 4-aligned slice), a hidden width that is a
 // multiple of 128 (32 rows x four wavefronts), at most 64 outputs, no residual on either layer
 bool conv32_head_ok(int k1, int hid, int c2) { return k1 == HK1 && hid >= 128 && hid % 128 == 0 && c2 >= 1 && c2 <= 64; }
@@ -201,6 +227,36 @@ void conv32_head_pack(const float* w2, int tm2, int hid, float* out)
                     for (int e = 0; e < 4; ++e)
                         out[((((size_t)ht * tm2 + m2) * 4 + qd) * 64 + lane) * 4 + e] =
                             w2[(size_t)(m2 * 32 + (lane & 31)) * hid + ht * 32 + e + 8 * qd + 4 * (lane >> 5)];
+}
+
+static bool head_args_ok(const conv32_params& q, const head32_hidden& h)
+{
+    return conv32_head_ok(HK1, h.HID, q.Cout) && h.w1_frag && h.w2_frag && h.bias1 && q.npix > 0 && (q.out.p || q.out_f32);
+}
+
+// whether two head launches may share one grid: the same input view and map
+bool conv32_head_pair_ok(const conv32_params& a, const conv32_params& b)
+{
+    const bool off = getenv("HP_HEAD_PAIR") && atoi(getenv("HP_HEAD_PAIR")) == 0; // A/B switch (read per launch / capture: the tests compare both in one process)
+    return !off && a.in.p == b.in.p && a.in.cs == b.in.cs && a.in.coff == b.in.coff && a.in.wp == b.in.wp && a.in.img == b.in.img && a.OH == b.OH && a.OW == b.OW
+        && a.npix == b.npix;
+}
+
+hipError_t launch_conv32_head_pair(const conv32_params& qa, const head32_hidden& ha, const conv32_params& qb, const head32_hidden& hb, hipStream_t s)
+{
+    if (!head_args_ok(qa, ha) || !head_args_ok(qb, hb) || !conv32_head_pair_ok(qa, qb))
+        return hipErrorInvalidValue;
+    const dim3 grid(((qa.npix + 31) / 32 + 7) / 8 * 8 * 2);
+    const bool a1 = qa.Cout <= 32, b1 = qb.Cout <= 32;
+    if (a1 && b1)
+        HP_LAUNCH((conv32_head_pair_kernel<1, 1>), grid, dim3(256), 0, s, qa, ha, qb, hb);
+    else if (a1)
+        HP_LAUNCH((conv32_head_pair_kernel<1, 2>), grid, dim3(256), 0, s, qa, ha, qb, hb);
+    else if (b1)
+        HP_LAUNCH((conv32_head_pair_kernel<2, 1>), grid, dim3(256), 0, s, qa, ha, qb, hb);
+    else
+        HP_LAUNCH((conv32_head_pair_kernel<2, 2>), grid, dim3(256), 0, s, qa, ha, qb, hb);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv32_head(const conv32_params& q, const head32_hidden& h, hipStream_t s)

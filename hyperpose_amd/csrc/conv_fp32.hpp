@@ -93,6 +93,9 @@ struct head32_hidden {
 };
 bool conv32_head_ok(int k1, int hid, int c2);
 hipError_t launch_conv32_head(const conv32_params& q, const head32_hidden& h, hipStream_t s);
+// two heads that read the same tensor in one grid (LW-OpenPose's heat-map and PAF heads of a stage): same results, the blocks of both side by side
+bool conv32_head_pair_ok(const conv32_params& a, const conv32_params& b);
+hipError_t launch_conv32_head_pair(const conv32_params& qa, const head32_hidden& ha, const conv32_params& qb, const head32_hidden& hb, hipStream_t s);
 int conv32_head_tile(int hid, int c2); // profile rows: 37000000 + 100 * HID + C2
 void conv32_head_pack(const float* w2, int tm2, int hid, float* out);
 

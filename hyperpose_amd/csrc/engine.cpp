@@ -1763,8 +1763,27 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
 
 int hp_engine::enqueue_range(const uint8_t* u8, const float* f32, int b0, int n, hipStream_t s)
 {
-    for (auto& st : steps)
+    for (size_t i = 0; i < steps.size(); ++i) {
+        step& st = steps[i];
+        // two fused heads in a row that read the same tensor (LW-OpenPose's heat-map and PAF heads of a stage): one grid (conv32_head.hip)
+        if (st.f32 && st.head32 && i + 1 < steps.size() && steps[i + 1].f32 && steps[i + 1].head32) {
+            step a = st, b = steps[i + 1];
+            for (step* t : { &a, &b }) {
+                t->cp32.B = n, t->cp32.npix = n * t->cp32.OH * t->cp32.OW;
+                if (b0 > 0) {
+                    t->cp32.in = at_frame(t->cp32.in, b0), t->cp32.out = at_frame(t->cp32.out, b0), t->cp32.res = at_frame(t->cp32.res, b0);
+                    if (t->cp32.out_f32)
+                        t->cp32.out_f32 += (size_t)b0 * t->cp32.Cout * t->cp32.OH * t->cp32.OW;
+                }
+            }
+            if (hp::conv32_head_pair_ok(a.cp32, b.cp32)) {
+                HP_HIP_TRY(hp::launch_conv32_head_pair(a.cp32, a.hh, b.cp32, b.hh, s));
+                ++i;
+                continue;
+            }
+        }
         HP_TRY(run_step(st, u8, f32, n, s, b0));
+    }
     for (auto& o : outputs)
         if (o.fused_layer < 0) {
             const tensor_info& ti = *tensors[o.tensor];

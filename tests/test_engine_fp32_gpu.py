@@ -295,6 +295,29 @@ def test_whole_k_tile(hp, cin, h, w, monkeypatch):
             assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
 
 
+@pytest.mark.parametrize("w_,h_,n", [(96, 80, 5), (432, 368, 8)])
+def test_head_pairs_in_one_grid_are_bit_identical(hp, w_, h_, n, monkeypatch):
+    """conv32_head_pair_kernel (round 6): LW-OpenPose's heat-map and PAF heads of a stage read the same tensor and run as ONE grid (blocks b and
+    b + 8 = the two heads of one 32-pixel tile).  The per-head arithmetic is the single kernel's: every output byte equals the two-launch
+    schedule's (HP_HEAD_PAIR=0), with one stream and with two half-batches, odd batch and full size."""
+    m = E.Model("lw_openpose_mobilenet", w_, h_)
+    w = m.init_weights(9)
+    fr = synth.images_u8(synth.rng_for(21), n, h_, w_)
+    monkeypatch.setenv("HP_HEAD_PAIR", "0")
+    ref_eng = E.Engine.from_model(m, w, max_batch=n, dtype="f32")
+    ref = ref_eng.inference(fr)
+    monkeypatch.delenv("HP_HEAD_PAIR")
+    eng = E.Engine.from_model(m, w, max_batch=n, dtype="f32")
+    for conc in (1, 2):
+        eng.set_concurrency(conc)
+        for graph in (True, False):
+            eng.set_graph(graph)
+            got = eng.inference(fr)
+            for b in range(n):
+                for (nm, x), (_, y) in zip(got[b], ref[b]):
+                    assert np.array_equal(x, y), (nm, b, conc, graph)
+
+
 @pytest.mark.parametrize("arch,w_,h_,n", [("lw_openpose_mobilenet", 96, 80, 5), ("pose_proposal_resnet50", 160, 128, 4), ("pifpaf_resnet50", 97, 97, 3),
                                             ("lw_openpose_mobilenet", 432, 368, 8)])
 def test_two_half_batches_are_bit_identical(hp, f32dtype, arch, w_, h_, n):
