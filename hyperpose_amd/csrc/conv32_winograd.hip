@@ -78,7 +78,7 @@ __device__ __forceinline__ long tvw_off(const tview32& t, int b, int y, int x)
 
 // PIPE: the input transform of chunk c + 1 runs inside the MFMA steps of chunk c (two V buffers): see "K loop" above
 template <int MW, bool PIPE>
-__global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kernel(const conv32_params p, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kernel(const conv32_params p, int tiles_x, int tiles_y, int vh)
 {
     static_assert(!PIPE || MW == 4, "the pipelined form is the four-wavefront one");
     using G = wino_geom<MW>;
@@ -90,7 +90,13 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware block order (1-D grid): block id -> XCD id % 8; the NG channel groups of one pixel tile are ids b, b + 8, .. - back to back on one
     // XCD, whose L2 then serves the tile's halo patch NG - 1 times (conv_fp32.hip has the measurement behind this)
-    const int NG = p.Cout_pad / (16 * MW), ntiles = tiles_x * tiles_y * p.B;
+    // vh > 0, the "tall" form: the batch as ONE image of (B - 1) vh + H rows - an image's rows plus its halo rows are vh (even) rows of the buffer,
+    // the halo rows between two images are zeros, i.e. the padding both of them need.  Tiles then run down the whole batch: a 12 x 12 map is
+    // 14 rows of a 446-row image (28 blocks of 16 rows) instead of one three-quarters-empty block per image (32).  vh is even, so every 2 x 2
+    // Winograd tile covers the same rows of every image: the same bits as the per-image form, whatever the batch.  Output rows that fall on
+    // separator rows are computed and not stored.
+    const int NG = p.Cout_pad / (16 * MW), ntiles = tiles_x * tiles_y * (vh ? 1 : p.B);
+    const int Hin = vh ? (p.B - 1) * vh + p.H : p.H; // rows 0 .. Hin - 1; row Hin = the (last) image's bottom halo row
     const int bj = blockIdx.x >> 3, by = bj % NG;
     int t = (bj / NG) * 8 + (blockIdx.x & 7);
     if (t >= ntiles)
@@ -121,8 +127,8 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
         const int hp = q >> 2, c4 = q & 3;
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        qok[i] = y <= p.H && x <= p.W;
-        goff[i] = tvw_off(p.in, b, min(y, p.H), min(x, p.W)) + c4 * 4;
+        qok[i] = y <= Hin && x <= p.W;
+        goff[i] = tvw_off(p.in, b, min(y, Hin), min(x, p.W)) + c4 * 4;
     }
     f32x4 stage[NQ];
     auto gload = [&](int c) {
@@ -284,11 +290,14 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     constexpr int RPW = 128 / MW;
     conv32_drain_rows<G::TMS, RPW>(p, slab + wave * RPW * SLAB_PITCH, lane, by * 16 * MW, [&](int r, bool& ok, long& ooff, long& roff) {
         const int rr = wave * RPW + r, ab = rr >> 5, tile = rr & 31;
-        const int oy = y0 + 2 * (tile >> 2) + (ab >> 1), ox = x0 + 2 * (tile & 3) + (ab & 1);
-        ok = oy < p.OH && ox < p.OW;
-        const int oyc = min(oy, p.OH - 1), oxc = min(ox, p.OW - 1);
-        ooff = tvw_off(p.out, b, oyc, oxc);
-        roff = p.res.p ? tvw_off(p.res, b, oyc, oxc) : 0;
+        int oy = y0 + 2 * (tile >> 2) + (ab >> 1), ob = b;
+        const int ox = x0 + 2 * (tile & 3) + (ab & 1);
+        if (vh) // tall form: row oy of the batch = row oy % vh of image oy / vh
+            ob = oy / vh, oy -= ob * vh;
+        ok = oy < p.OH && ox < p.OW && ob < p.B;
+        const int oyc = min(oy, p.OH - 1), oxc = min(ox, p.OW - 1), obc = min(ob, p.B - 1);
+        ooff = tvw_off(p.out, obc, oyc, oxc);
+        roff = p.res.p ? tvw_off(p.res, obc, oyc, oxc) : 0;
     });
     HP_STAMP();
 #undef HP_STAMP
@@ -351,7 +360,7 @@ void conv32_winograd_pack(const float* packed, int cout_pad, int cin, float* out
 }
 
 template <int MW, bool PIPE>
-static hipError_t launch_wino_case(const conv32_params& q, dim3 grid, int tiles_x, int tiles_y, hipStream_t s)
+static hipError_t launch_wino_case(const conv32_params& q, dim3 grid, int tiles_x, int tiles_y, int vh, hipStream_t s)
 {
     constexpr int lds = PIPE ? wino_geom<MW>::PLDS_BYTES : wino_geom<MW>::LDS_BYTES;
     static bool granted = false;
@@ -361,8 +370,20 @@ static hipError_t launch_wino_case(const conv32_params& q, dim3 grid, int tiles_
             return e;
         granted = true;
     }
-    HP_LAUNCH((conv32_winograd_kernel<MW, PIPE>), grid, dim3(64 * MW), lds, s, q, tiles_x, tiles_y);
+    HP_LAUNCH((conv32_winograd_kernel<MW, PIPE>), grid, dim3(64 * MW), lds, s, q, tiles_x, tiles_y, vh);
     return hipGetLastError();
+}
+
+// Rows per image of the tall form, or 0 where it does not apply: the input's images must lie vh = even rows apart with at least one (zero) halo
+// row above and below each.  HP_WINO_TALL=0: the A/B switch (read per launch).
+static int winograd_tall(const conv32_params& p)
+{
+    if (getenv("HP_WINO_TALL") && atoi(getenv("HP_WINO_TALL")) == 0)
+        return 0;
+    if (p.B < 2 || p.in.wp <= 0 || p.in.img % p.in.wp)
+        return 0;
+    const int vh = p.in.img / p.in.wp;
+    return (vh & 1) == 0 && vh >= p.H + 2 ? vh : 0;
 }
 
 static bool winograd_pipe() // HP_WINO_PIPE=0: the A/B switch back to the form with the transform between two barriers
@@ -375,11 +396,19 @@ hipError_t launch_conv32_winograd(const conv32_params& p, hipStream_t s)
 {
     if (!conv32_winograd_ok(p) || !p.w_wino || p.npix <= 0)
         return hipErrorInvalidValue;
-    const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 15) / 16, mw = winograd_mw(p);
-    const dim3 grid((tiles_x * tiles_y * p.B + 7) / 8 * 8 * (p.Cout_pad / (16 * mw))); // XCD-aware 1-D order: see the kernel
+    const int tiles_x = (p.OW + 7) / 8, mw = winograd_mw(p);
+    int tiles_y = (p.OH + 15) / 16, vh = winograd_tall(p), images = p.B;
+    if (vh) {
+        const int tall_y = ((p.B - 1) * vh + p.H + 15) / 16;
+        if (tall_y < tiles_y * p.B)
+            tiles_y = tall_y, images = 1;
+        else
+            vh = 0; // (a map that is whole 16-row blocks already: 48 rows + 2 halo rows would only add separator rows)
+    }
+    const dim3 grid((tiles_x * tiles_y * images + 7) / 8 * 8 * (p.Cout_pad / (16 * mw))); // XCD-aware 1-D order: see the kernel
     if (mw == 8)
-        return launch_wino_case<8, false>(p, grid, tiles_x, tiles_y, s);
-    return winograd_pipe() ? launch_wino_case<4, true>(p, grid, tiles_x, tiles_y, s) : launch_wino_case<4, false>(p, grid, tiles_x, tiles_y, s);
+        return launch_wino_case<8, false>(p, grid, tiles_x, tiles_y, vh, s);
+    return winograd_pipe() ? launch_wino_case<4, true>(p, grid, tiles_x, tiles_y, vh, s) : launch_wino_case<4, false>(p, grid, tiles_x, tiles_y, vh, s);
 }
 
 hipError_t conv32_winograd_occupancy(const conv32_params& p, int* blocks_per_cu)

@@ -47,12 +47,15 @@ struct tensor_info {
         v.cs = cs, v.coff = coff, v.wp = wp, v.img = (H + 2 * P) * wp;
         return v;
     }
+    // rows one image takes in an fp32 buffer: H + 2 P, made EVEN when there is a halo - the images of a batch then form one tall image whose
+    // separator rows are zeros and whose 2 x 2 Winograd tiles fall on the same rows in every image (conv32_winograd.hip, "tall" form)
+    int rows32() const { return P > 0 ? (H + 2 * P + 1) / 2 * 2 : H; }
     hp::tview32 view32(int coff) const // the same geometry with 4-byte elements (HP_DTYPE_F32 engines)
     {
         hp::tview32 v;
         const int wp = W + 2 * P;
         v.p = base<float>() + ((size_t)P * wp + P) * cs;
-        v.cs = cs, v.coff = coff, v.wp = wp, v.img = (H + 2 * P) * wp;
+        v.cs = cs, v.coff = coff, v.wp = wp, v.img = rows32() * wp;
         return v;
     }
 };
@@ -516,7 +519,7 @@ int hp_engine::build(const hp_engine_desc* d)
                 continue;
             ti.cs = round_up(ti.C, 32);
         }
-        auto bytes_of = [&](const tensor_info& ti) { return (size_t)max_batch * (ti.H + 2 * ti.P) * (ti.W + 2 * ti.P) * ti.cs * (f32 ? sizeof(float) : sizeof(__half)); };
+        auto bytes_of = [&](const tensor_info& ti) { return (size_t)max_batch * (f32 ? ti.rows32() : ti.H + 2 * ti.P) * (ti.W + 2 * ti.P) * ti.cs * (f32 ? sizeof(float) : sizeof(__half)); };
         if (!use_arena) {
             for (size_t t = 1; t < tensors.size(); ++t) {
                 tensor_info& ti = *tensors[t];

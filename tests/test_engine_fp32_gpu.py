@@ -295,6 +295,34 @@ def test_whole_k_tile(hp, cin, h, w, monkeypatch):
             assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
 
 
+@pytest.mark.parametrize("arch,w_,h_,n", [("pose_proposal_resnet50", 160, 128, 5), ("pifpaf_resnet50", 97, 97, 4), ("openpose_vgg19", 96, 112, 3),
+                                            ("pose_proposal_resnet50", 384, 384, 8)])
+def test_winograd_tall_form_is_bit_identical(hp, arch, w_, h_, n, monkeypatch):
+    """The "tall" Winograd form (round 6): an fp32 tensor's images lie an EVEN number of rows apart (H + 2 halo rows, + 1 if odd), so the batch is
+    one tall image whose separator rows are zeros and whose 2 x 2 tiles cover the same rows of every image; the kernel then tiles the whole batch
+    (a 12 x 12 map: 28 blocks of 16 rows for 32 images instead of 32 three-quarters-empty ones).  Same tiles, same arithmetic: every output byte
+    equals the per-image form's (HP_WINO_TALL=0), a frame alone equals the frame in a batch, and two half-batches equal one batch."""
+    m = E.Model(arch, w_, h_)
+    w = m.init_weights(4)
+    fr = synth.images_u8(synth.rng_for(33), n, h_, w_)
+    monkeypatch.setenv("HP_WINO_TALL", "0")
+    ref_eng = E.Engine.from_model(m, w, max_batch=n, dtype="f32")
+    ref_eng.set_graph(False)
+    ref = ref_eng.inference(fr)
+    monkeypatch.delenv("HP_WINO_TALL")
+    eng = E.Engine.from_model(m, w, max_batch=n, dtype="f32")
+    for conc in (1, 2):
+        eng.set_concurrency(conc)
+        got = eng.inference(fr)
+        for b in range(n):
+            for (nm, x), (_, y) in zip(got[b], ref[b]):
+                assert np.array_equal(x, y), (nm, b, conc)
+    eng.set_concurrency(1)
+    alone = eng.inference(fr[n - 1:n])[0]
+    for (nm, x), (_, y) in zip(alone, ref[n - 1]):
+        assert np.array_equal(x, y), nm
+
+
 @pytest.mark.parametrize("w_,h_,n", [(96, 80, 5), (432, 368, 8)])
 def test_head_pairs_in_one_grid_are_bit_identical(hp, w_, h_, n, monkeypatch):
     """conv32_head_pair_kernel (round 6): LW-OpenPose's heat-map and PAF heads of a stage read the same tensor and run as ONE grid (blocks b and
