@@ -416,8 +416,10 @@ def kernel_label(tile: int):
                 "pixels (all K), residual and bias requested at once, no K-step barriers, whole-line row-major stores through a per-wavefront LDS slab)")
     if tile >= 37000000:
         hid, c2 = (tile - 37000000) // 100, tile % 100
-        return (f"conv32_head_kernel<{1 if c2 <= 32 else 2}>", f"conv32_head_kernel (fp32 two-layer head in one launch: 1x1 128 -> {hid} relu -> 1x1 {hid} -> {c2}, 32 pixels per block, "
-                "the hidden tile's accumulator registers are the second layer's B operand)")
+        # (round 6: two heads that read the same tensor run as ONE grid, conv32_head_pair_kernel<TM2a,TM2b>; a lone head as conv32_head_kernel<TM2>.
+        # The key matches whichever ONE of them a trace holds; a trace with both forms is ambiguous and quotes no committed duration)
+        return ("conv32_head_", f"conv32_head_kernel (fp32 two-layer head in one launch: 1x1 128 -> {hid} relu -> 1x1 {hid} -> {c2}, 32 pixels per block, "
+                "the hidden tile's accumulator registers are the second layer's B operand; the heat-map and PAF heads of a stage share one grid)")
     if tile >= 35000000:
         mw = tile % 1000
         return (f"conv32_winograd_kernel<{mw},{'true' if mw == 4 else 'false'}>", f"conv32_winograd_kernel<MW={mw}> (fp32 3x3 stride-1 convolution in Winograd's F(2x2,3x3) form on v_mfma_f32_16x16x4_f32: 16 MFMA "
@@ -588,6 +590,8 @@ def roofline(pipe, batch, cfg, frames_dev=None):
     tag = profile_tag(cfg)
     traffic, src = pmc_traffic(key, tag)
     prof_us, prof_src = rocprof_avg_us(key, tag)
+    if 39000000 > dom_tile >= 37000000:
+        prof_us, prof_src = None, None  # (a pair launch's duration covers two heads: not this step's)
     busy, wait_any, busy_src = pmc_mfma_busy(key, tag)
     out = {
         # the roof that binds THIS kernel: its arithmetic intensity against the ridge (peak FLOP/s of the engine's matrix pipe / 8 TB/s);
@@ -1019,6 +1023,8 @@ def compact_line(detail):
     for key, w in detail.get("workloads", {}).items():
         r = w.get("roofline") or {}
         wl[key] = {"value": w["value"], "resident": w.get("value_resident_injected"), "bound": r.get("bound"), "frac": r.get("frac")}  # (ms_per_step etc.: the detail file)
+        if "frac_mfma_issued" in r:  # a Winograd kernel dominates: `frac` counts direct-form flops (may pass 1), `issued` what the pipe executes
+            wl[key]["issued"] = r["frac_mfma_issued"]
     if wl:
         out["workloads"] = wl
         # host fall-backs / truncated lists over ALL workloads of the run (per workload: the detail file)

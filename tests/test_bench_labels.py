@@ -32,8 +32,8 @@ CASES = [
     (9002041, "_config3"), (6512009, "_config3"),
     (5202002, "_config4"), (9001311, "_config4"), (9002021, "_config4"), (128128, "_config4"),
     # the fp32 engine (round 5): Winograd, the fused heads, both epilogue forms of conv32_kernel, the direct kernel of the narrow heads' fall-back
-    (35003004, "_config1_fp32"), (37051219, "_config1_fp32"), (37051238, "_config1_fp32"), (32064128, "_config1_fp32"), (32464064, "_config1_fp32"),
-    (35003004, "_config2_fp32"), (32064128, "_config2_fp32"), (32128128, "_config3_fp32"), (32128128, "_config4_fp32"),
+    (35003004, "_config1_fp32"), (37051219, "_config1_fp32"), (37051238, "_config1_fp32"), (39032064, "_config1_fp32"), (32464064, "_config1_fp32"),
+    (35003004, "_config2_fp32"), (32064128, "_config2_fp32"), (32128128, "_config3_fp32"), (32128128, "_config4_fp32"), (39064064, "_config3_fp32"), (39064064, "_config4_fp32"),  # (round 6: conv32_wk_kernel)
     (33003002, "_config1_fp32s"), (33001008, "_config1_fp32s"), (33101008, "_config1_fp32s"),
 ]
 
@@ -185,7 +185,10 @@ def _check_roofline(r):
     t = r["avg_launch_us"] * 1e-6
     assert abs(r["frac_mfma"] - r["flops_per_launch"] / t / (peak * 1e12)) < 5e-3
     assert abs(r["frac_hbm"] - r["algorithmic_bytes_per_launch"] / t / 8e12) < 5e-3
-    assert 0 < r["mfma_frac_ceiling_at_hbm_peak"] <= 1.0 and 0 < r["frac"] < 1
+    # (a Winograd kernel's `frac` is ALGORITHMIC, direct-form flops over time: it may pass 1 - that is the point of the transform; what the
+    # pipe executes, 16 / 36 of them, may not)
+    assert 0 < r["mfma_frac_ceiling_at_hbm_peak"] <= 1.0 and 0 < r["frac"] < (2.25 if "frac_mfma_issued" in r else 1)
+    assert r.get("frac_mfma_issued", 0.5) < 1
 
 
 def test_every_roofline_names_its_binding_roof():
