@@ -48,24 +48,27 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WCK = 16;                        // input channels per chunk
-constexpr int HALO_H = 18, HALO_W = 10;        // halo patch of the 16 x 8 pixel tile
-constexpr int RAW_Q = HALO_H * HALO_W * 4;     // 720 float4 quads (64 bytes per pixel)
+constexpr int HALO_W = 10;                     // halo patch of the 16 NC x 8 pixel tile: (8 NC + 2) x 10 pixels
 constexpr int RAW_PB = WCK * 4;
 constexpr int VP = 24 * 4;                     // V row (one tile, 16 channels) pitch in bytes: 24 floats - the transform's ds_write_b128 and the MFMA's ds_read_b128 are conflict-free
-constexpr int VPOS = 32 * VP, VBUF = 16 * VPOS; // one position (32 tiles), all 16 positions: 49152 bytes
 
-template <int MW>
+// NC = 16-tile MFMA column tiles per block and wavefront: 2 = a block of 16 x 8 pixels (8 x 4 tiles), 1 = 8 x 8 pixels (4 x 4 tiles)
+template <int MW, int NC = 2>
 struct wino_geom {
     static constexpr int NT = 64 * MW;
+    static constexpr int HALO_H = 8 * NC + 2;
+    static constexpr int RAW_Q = HALO_H * HALO_W * 4; // float4 quads of the halo patch (64 bytes per pixel): 720 | 400
     static constexpr int NQ = (RAW_Q + NT - 1) / NT;  // quads per thread and chunk
     static constexpr int RAW_BYTES = NQ * NT * 16;    // + room for the surplus threads' (discarded) quads: the store to LDS has no branch
-    static constexpr int NI = 8 / MW;                 // transform items (row of Bt d B, half of the tiles) per wavefront and chunk
-    static constexpr int TMS = MW / 2;                // the block's output slab: [128 pixel rows][16 MW channels + 4] = rows_geom<TMS>
-    static constexpr int SLAB_PITCH = rows_geom<TMS>::PITCH, SLAB_BYTES = 128 * SLAB_PITCH * 4;
+    static constexpr int NI = 4 * NC / MW;            // transform items (row of Bt d B, 16 tiles) per wavefront and chunk
+    static_assert(NI >= 1, "a transform item per wavefront");
+    static constexpr int TMS = MW / 2;                // the block's output slab: [64 NC pixel rows][16 MW channels + 4] = rows_geom<TMS>
+    static constexpr int SLAB_PITCH = rows_geom<TMS>::PITCH, SLAB_BYTES = 64 * NC * SLAB_PITCH * 4;
+    static constexpr int VPOS = 16 * NC * VP, VBUF = 16 * VPOS; // one position (16 NC tiles), all 16 positions
     static constexpr int LDS_BYTES = RAW_BYTES + (VBUF > SLAB_BYTES ? VBUF : SLAB_BYTES); // MW = 4: 61440 (two blocks per CU), MW = 8: 83968 (one)
     // the pipelined form (MW = 4): two V buffers without padding - 64 bytes per tile, the 16-byte quad index XOR-ed with a function of the
     // tile so that the transform's ds_write_b128 and the MFMA's ds_read_b128 (same lane -> (tile, quad) map) stay conflict-free
-    static constexpr int PVPOS = 32 * 64, PVBUF = 16 * PVPOS;                       // 32768 bytes per buffer
+    static constexpr int PVPOS = 16 * NC * 64, PVBUF = 16 * PVPOS;                  // 32768 | 16384 bytes per buffer
     static constexpr int PLDS_BYTES = RAW_BYTES + (2 * PVBUF > SLAB_BYTES ? 2 * PVBUF : SLAB_BYTES); // 12288 + 65536 = 77824: two blocks per CU
 };
 
@@ -77,12 +80,12 @@ __device__ __forceinline__ long tvw_off(const tview32& t, int b, int y, int x)
 } // namespace
 
 // PIPE: the input transform of chunk c + 1 runs inside the MFMA steps of chunk c (two V buffers): see "K loop" above
-template <int MW, bool PIPE>
-__global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kernel(const conv32_params p, int tiles_x, int tiles_y, int vh)
+template <int MW, bool PIPE, int NC = 2>
+__global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : NC == 1 ? 3 : 2) void conv32_winograd_kernel(const conv32_params p, int tiles_x, int tiles_y, int vh)
 {
     static_assert(!PIPE || MW == 4, "the pipelined form is the four-wavefront one");
-    using G = wino_geom<MW>;
-    constexpr int NT = G::NT, NQ = G::NQ, SLAB_PITCH = G::SLAB_PITCH;
+    using G = wino_geom<MW, NC>;
+    constexpr int NT = G::NT, NQ = G::NQ, SLAB_PITCH = G::SLAB_PITCH, RAW_Q = G::RAW_Q, VPOS = G::VPOS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[]; // G::LDS_BYTES
     unsigned char* const raw = lds;
     unsigned char* const vb = lds + G::RAW_BYTES;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y, b = t / tiles_y;
-    const int y0 = ty * 16, x0 = tx * 8;
+    const int y0 = ty * (8 * NC), x0 = tx * 8;
     const int MT = p.Cout_pad / 16, mt = by * MW + wave;
     const int nch = p.Cin / WCK;
     int dbg_i = 0;
@@ -146,8 +149,8 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     auto transform = [&]() {
 #pragma unroll
         for (int k = 0; k < G::NI; ++k) {
-            const int item = wave + k * MW, i = item >> 1;
-            const int quad = lane >> 4, tile = (item & 1) * 16 + (lane & 15);
+            const int item = wave + k * MW, i = NC == 2 ? item >> 1 : item;
+            const int quad = lane >> 4, tile = (NC == 2 ? (item & 1) * 16 : 0) + (lane & 15);
             const int ra = i == 0 ? 0 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
             const float sg = i == 1 ? 1.f : -1.f;
             const unsigned char* const src = raw + ((2 * (tile >> 2)) * HALO_W + 2 * (tile & 3)) * RAW_PB + quad * 16;
@@ -171,8 +174,10 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     f32x4 ta[4], tb[4];
     auto transform_piece = [&](int pos, int buf) {
         const int k = pos >> 3, ps = pos & 7;
-        const int item = wave + k * MW, i = item >> 1;
-        const int quad = lane >> 4, tile = (item & 1) * 16 + (lane & 15);
+        if (k >= G::NI)
+            return; // (NC = 1: one item per wavefront, in steps 0 - 7)
+        const int item = wave + k * MW, i = NC == 2 ? item >> 1 : item;
+        const int quad = lane >> 4, tile = (NC == 2 ? (item & 1) * 16 : 0) + (lane & 15);
         const int ra = i == 0 ? 0 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
         const unsigned char* const src = raw + ((2 * (tile >> 2)) * HALO_W + 2 * (tile & 3)) * RAW_PB + quad * 16;
         if (ps < 4) {
@@ -198,10 +203,12 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     f32x4 fa[RING];
     auto aload = [&](int slot, int s) { fa[slot] = *reinterpret_cast<const f32x4*>(wp + (long)min(s, nsteps - 1) * step_stride); };
 
-    f32x4 acc[16][2]; // [position][column tile: tile rows 0 - 3 | 4 - 7 of the block]
+    f32x4 acc[16][NC]; // [position][column tile: tile rows 0 - 3 | 4 - 7 of the block]
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-        acc[i][0] = acc[i][1] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc)
+            acc[i][nc] = f32x4{ 0.f, 0.f, 0.f, 0.f };
 
     const int btile = lane & 15, kq = lane >> 4;
     const unsigned char* const vsrc = PIPE ? vb + btile * 64 + ((kq ^ ((4 - (btile >> 2)) & 3)) * 16) : vb + btile * VP + kq * 16;
@@ -232,32 +239,36 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
             HP_STAMP();
         }
         const unsigned char* const vcur = vsrc + (PIPE ? (c & 1) * G::PVBUF : 0);
-        f32x4 fb[2][2];
-        fb[0][0] = *reinterpret_cast<const f32x4*>(vcur);
-        fb[0][1] = *reinterpret_cast<const f32x4*>(vcur + BNT);
+        f32x4 fb[2][NC];
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc)
+            fb[0][nc] = *reinterpret_cast<const f32x4*>(vcur + nc * BNT);
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos) {
             const int cur = pos & 1, npos = pos + 1 < 16 ? pos + 1 : pos;
-            fb[cur ^ 1][0] = *reinterpret_cast<const f32x4*>(vcur + npos * BPOS);
-            fb[cur ^ 1][1] = *reinterpret_cast<const f32x4*>(vcur + npos * BPOS + BNT);
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc)
+                fb[cur ^ 1][nc] = *reinterpret_cast<const f32x4*>(vcur + npos * BPOS + nc * BNT);
             aload((pos + AHEAD) % RING, s + AHEAD); // (16 % RING == 0: the ring position is a compile-time function of pos)
             const int slot = pos % RING;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][e], fb[cur][0][e], acc[pos][0], 0, 0, 0);
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][e], fb[cur][1][e], acc[pos][1], 0, 0, 0);
-            }
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc)
+                    acc[pos][nc] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][e], fb[cur][nc][e], acc[pos][nc], 0, 0, 0);
             if constexpr (PIPE)
                 transform_piece(pos, (c + 1) & 1); // chunk c + 1's transform, one piece per step, under this step's MFMAs
             // issue order of a step: MFMA, LDS read, MFMA, LDS read (the next position's B), MFMA, L2 read (A some steps ahead), 5 MFMAs
             // (the transform's piece - two LDS reads, or a few additions and one LDS write - goes wherever hipcc finds room between them)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if constexpr (NC == 2) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NC == 2 ? 5 : 2, 0);
             __builtin_amdgcn_sched_barrier(0);
             ++s;
         }
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
     HP_STAMP();
     float* const slab = reinterpret_cast<float*>(vb);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NC; ++nt) {
         f32x4 S[2][4]; // At M: S[0][j] = M0j + M1j + M2j, S[1][j] = M1j - M2j - M3j
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -280,16 +291,16 @@ __global__ __launch_bounds__(64 * MW, MW == 8 ? 1 : 2) void conv32_winograd_kern
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const f32x4 y0v = S[a][0] + S[a][1] + S[a][2], y1v = S[a][1] - S[a][2] - S[a][3];
-            *reinterpret_cast<f32x4*>(slab + ((a * 2 + 0) * 32 + nt * 16 + btile) * SLAB_PITCH + wave * 16 + kq * 4) = y0v;
-            *reinterpret_cast<f32x4*>(slab + ((a * 2 + 1) * 32 + nt * 16 + btile) * SLAB_PITCH + wave * 16 + kq * 4) = y1v;
+            *reinterpret_cast<f32x4*>(slab + ((a * 2 + 0) * (16 * NC) + nt * 16 + btile) * SLAB_PITCH + wave * 16 + kq * 4) = y0v;
+            *reinterpret_cast<f32x4*>(slab + ((a * 2 + 1) * (16 * NC) + nt * 16 + btile) * SLAB_PITCH + wave * 16 + kq * 4) = y1v;
         }
     }
     HP_STAMP();
     lds_barrier(); // the slab holds all 16 MW channels of the block's 128 pixels; wavefront w stores rows (128 / MW) w ..
     HP_STAMP();
-    constexpr int RPW = 128 / MW;
+    constexpr int RPW = 64 * NC / MW;
     conv32_drain_rows<G::TMS, RPW>(p, slab + wave * RPW * SLAB_PITCH, lane, by * 16 * MW, [&](int r, bool& ok, long& ooff, long& roff) {
-        const int rr = wave * RPW + r, ab = rr >> 5, tile = rr & 31;
+        const int rr = wave * RPW + r, ab = rr / (16 * NC), tile = rr % (16 * NC);
         int oy = y0 + 2 * (tile >> 2) + (ab >> 1), ob = b;
         const int ox = x0 + 2 * (tile & 3) + (ab & 1);
         if (vh) // tall form: row oy of the batch = row oy % vh of image oy / vh
@@ -359,19 +370,33 @@ void conv32_winograd_pack(const float* packed, int cout_pad, int cin, float* out
             }
 }
 
-template <int MW, bool PIPE>
+template <int MW, bool PIPE, int NC = 2>
 static hipError_t launch_wino_case(const conv32_params& q, dim3 grid, int tiles_x, int tiles_y, int vh, hipStream_t s)
 {
-    constexpr int lds = PIPE ? wino_geom<MW>::PLDS_BYTES : wino_geom<MW>::LDS_BYTES;
+    constexpr int lds = PIPE ? wino_geom<MW, NC>::PLDS_BYTES : wino_geom<MW, NC>::LDS_BYTES;
     static bool granted = false;
     if (lds > 64 * 1024 && !granted) {
-        const hipError_t e = hipFuncSetAttribute((const void*)conv32_winograd_kernel<MW, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t e = hipFuncSetAttribute((const void*)conv32_winograd_kernel<MW, PIPE, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess)
             return e;
         granted = true;
     }
-    HP_LAUNCH((conv32_winograd_kernel<MW, PIPE>), grid, dim3(64 * MW), lds, s, q, tiles_x, tiles_y, vh);
+    HP_LAUNCH((conv32_winograd_kernel<MW, PIPE, NC>), grid, dim3(64 * MW), lds, s, q, tiles_x, tiles_y, vh);
     return hipGetLastError();
+}
+
+// Column tiles per block: 2 (16 x 8 pixels) or 1 (8 x 8 pixels: twice the blocks, half the accumulators, three blocks per CU - and twice the U
+// bytes per MFMA).  A 128 -> 128 layer at 8 x 46 x 54 is 336 blocks of the first form for 256 CUs x 2: 176 CUs run one block, 80 run two and
+// set the launch's time (45.0 us); as 672 blocks of the second it takes 35.9 us alone and the same 27 us next to a second stream's launch -
+// but four pipes lose 1.4 % (5 113 -> 5 042 frames/s, three runs each: the U stream).  So: the small form for a caller with ONE batch in flight
+// (conv32_params::latency, i.e. hp_engine_set_concurrency(e, 2)) when the large form would not fill the chip's 512 slots twice; the same
+// tiles, the same arithmetic: the same bits (tests/test_engine_fp32_gpu.py).  HP_WINO_NC=1 | 2 forces one (read per launch).
+static int winograd_nc(const conv32_params& p, int blocks_nc2)
+{
+    const int force = getenv("HP_WINO_NC") ? atoi(getenv("HP_WINO_NC")) : 0;
+    if (force == 1 || force == 2)
+        return force;
+    return p.latency && blocks_nc2 <= 512 ? 1 : 2;
 }
 
 // Rows per image of the tall form, or 0 where it does not apply: the input's images must lie vh = even rows apart with at least one (zero) halo
@@ -397,9 +422,10 @@ hipError_t launch_conv32_winograd(const conv32_params& p, hipStream_t s)
     if (!conv32_winograd_ok(p) || !p.w_wino || p.npix <= 0)
         return hipErrorInvalidValue;
     const int tiles_x = (p.OW + 7) / 8, mw = winograd_mw(p);
-    int tiles_y = (p.OH + 15) / 16, vh = winograd_tall(p), images = p.B;
+    const int nc = mw == 4 && winograd_pipe() ? winograd_nc(p, tiles_x * ((p.OH + 15) / 16) * p.B * (p.Cout_pad / 64)) : 2, bh = 8 * nc;
+    int tiles_y = (p.OH + bh - 1) / bh, vh = winograd_tall(p), images = p.B;
     if (vh) {
-        const int tall_y = ((p.B - 1) * vh + p.H + 15) / 16;
+        const int tall_y = ((p.B - 1) * vh + p.H + bh - 1) / bh;
         if (tall_y < tiles_y * p.B)
             tiles_y = tall_y, images = 1;
         else
@@ -408,6 +434,8 @@ hipError_t launch_conv32_winograd(const conv32_params& p, hipStream_t s)
     const dim3 grid((tiles_x * tiles_y * images + 7) / 8 * 8 * (p.Cout_pad / (16 * mw))); // XCD-aware 1-D order: see the kernel
     if (mw == 8)
         return launch_wino_case<8, false>(p, grid, tiles_x, tiles_y, vh, s);
+    if (nc == 1)
+        return launch_wino_case<4, true, 1>(p, grid, tiles_x, tiles_y, vh, s);
     return winograd_pipe() ? launch_wino_case<4, true>(p, grid, tiles_x, tiles_y, vh, s) : launch_wino_case<4, false>(p, grid, tiles_x, tiles_y, vh, s);
 }
 

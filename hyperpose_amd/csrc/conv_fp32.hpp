@@ -51,6 +51,8 @@ struct conv32_params {
     const float* dw_w;
     int dw_dil;
     float dw_slope, dw_hi;
+    int latency;       // 1 = the caller has ONE batch in flight (hp_engine_set_concurrency(e, 2)): kernels that have a form for a launch that runs alone take it
+                       // (conv32_winograd_kernel: 8 x 8-pixel blocks); the forms give the same bits
     int lane_epilogue; // HP_LANE_EPILOGUE (A/B switch): 0 = per kernel (launch_conv32: rows on the 64-pixel tile; direct kernels: rows), 1 = the accumulators' lane = pixel layout everywhere, -1 = whole pixel rows everywhere (conv32_epilogue.hpp)
     unsigned long long* dbg; // HP_DIRECT_DBG: s_memtime stamps (shader cycles) of block (0, 0)'s thread 0 - start, chunk staged, chunk multiplied, ..., stored
 };

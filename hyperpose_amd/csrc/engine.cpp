@@ -1482,6 +1482,7 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
             if (st.head32) {
                 HP_HIP_TRY(hp::launch_conv32_head(st.cp32, st.hh, s));
             } else if (st.wino) {
+                st.cp32.latency = parts > 1;
                 HP_HIP_TRY(hp::launch_conv32_winograd(st.cp32, s));
                 static const bool dbg_wino = getenv("HP_DIRECT_DBG") != nullptr;
                 if (dbg_wino) { // block timeline (s_memtime = shader cycles, block (1, 0), thread 0), printed per launch

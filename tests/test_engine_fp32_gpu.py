@@ -323,6 +323,32 @@ def test_winograd_tall_form_is_bit_identical(hp, arch, w_, h_, n, monkeypatch):
         assert np.array_equal(x, y), nm
 
 
+@pytest.mark.parametrize("arch,w_,h_,n", [("lw_openpose_mobilenet", 432, 368, 8), ("lw_openpose_mobilenet", 96, 80, 5), ("pose_proposal_resnet50", 160, 128, 5),
+                                            ("lw_openpose_vggtiny", 432, 368, 1)])
+def test_winograd_small_blocks_are_bit_identical(hp, arch, w_, h_, n, monkeypatch):
+    """conv32_winograd_kernel<4, true, 1> (round 6): blocks of 8 x 8 pixels (one 16-tile MFMA column) instead of 16 x 8 - twice the blocks for a launch
+    that runs alone (a caller with one batch in flight: hp_engine_set_concurrency(e, 2)).  Same tiles, same arithmetic: every output byte equals
+    the large form's (HP_WINO_NC=2), forced (HP_WINO_NC=1) and chosen by the engine's mode."""
+    m = E.Model(arch, w_, h_)
+    w = m.init_weights(6)
+    fr = synth.images_u8(synth.rng_for(44), n, h_, w_)
+    monkeypatch.setenv("HP_WINO_NC", "2")
+    ref_eng = E.Engine.from_model(m, w, max_batch=n, dtype="f32")
+    ref = ref_eng.inference(fr)
+    for force in ("1", None):
+        if force:
+            monkeypatch.setenv("HP_WINO_NC", force)
+        else:
+            monkeypatch.delenv("HP_WINO_NC")
+        eng = E.Engine.from_model(m, w, max_batch=n, dtype="f32")
+        for conc in (1, 2):
+            eng.set_concurrency(conc)
+            got = eng.inference(fr)
+            for b in range(n):
+                for (nm, x), (_, y) in zip(got[b], ref[b]):
+                    assert np.array_equal(x, y), (nm, b, force, conc)
+
+
 @pytest.mark.parametrize("w_,h_,n", [(96, 80, 5), (432, 368, 8)])
 def test_head_pairs_in_one_grid_are_bit_identical(hp, w_, h_, n, monkeypatch):
     """conv32_head_pair_kernel (round 6): LW-OpenPose's heat-map and PAF heads of a stage read the same tensor and run as ONE grid (blocks b and

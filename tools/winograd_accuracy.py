@@ -27,6 +27,10 @@ MATS = {
     2: dict(Bt=[[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]],
             G=[[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]],
             At=[[1, 1, 1, 0], [0, 1, -1, -1]]),
+    # F(3 x 3, 3 x 3): Cook-Toom at the points 0, 1, -1, 2, inf (25 products per 3 x 3 tile; entries up to 3 (Bt), 4 (At), 1/6 .. 2/3 (G))
+    3: dict(Bt=[[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]],
+            G=[[1 / 2, 0, 0], [-1 / 2, -1 / 2, -1 / 2], [-1 / 6, 1 / 6, -1 / 6], [1 / 6, 1 / 3, 2 / 3], [0, 0, 1]],
+            At=[[1, 1, 1, 1, 0], [0, 1, -1, 2, 0], [0, 1, 1, 4, 1]]),
     4: dict(Bt=[[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]],
             G=[[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
             At=[[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]]),
@@ -62,7 +66,7 @@ def run_variant(model, weights, frames, mode):
     def conv2d(xp, wt, b=None, stride=1, dilation=1, groups=1, **kw):
         if mode == "f64":
             return real(xp.double(), wt.double(), None if b is None else b.double(), stride=stride, dilation=dilation, groups=groups).float()
-        if mode in (2, 4) and groups == 1 and wt.shape[2:] == (3, 3) and stride == 1 and dilation == 1 and wt.shape[1] >= 16:
+        if mode in (2, 3, 4) and groups == 1 and wt.shape[2:] == (3, 3) and stride == 1 and dilation == 1 and wt.shape[1] >= 16:
             return winograd_conv(xp, wt, b, mode)
         return real(xp, wt, b, stride=stride, dilation=dilation, groups=groups)
 
@@ -84,7 +88,7 @@ def main():
     frames = np.random.default_rng(21).integers(0, 256, (8, in_h, in_w, 3), dtype=np.uint8)[:B]
     n33 = sum(1 for L in m.layers if L.op == E.OP_CONV and L.kh == 3 and L.stride == 1 and L.dil == 1 and L.cin >= 16)
     print(f"LW-OpenPose @ {in_h}x{in_w}, {B} frames of the drift test, {n33} 3x3 stride-1 layers in the form under test; heads x400 as in the drift test")
-    res = {k: run_variant(m, w, frames, k) for k in ("f64", "direct", 2, 4)}
+    res = {k: run_variant(m, w, frames, k) for k in ("f64", "direct", 2, 3, 4)}
     thr = 0.05
     peaks = {}
     for k, r in res.items():
@@ -94,8 +98,8 @@ def main():
             pk.append({(int(p["part_id"]), int(p["y"]), int(p["x"])) for p in op})
             nh += len(oh)
         peaks[k] = (pk, nh)
-    for k in ("direct", 2, 4):
-        name = {"direct": "direct fp32 (torch CPU)", 2: "F(2x2,3x3) fp32", 4: "F(4x4,3x3) fp32"}[k]
+    for k in ("direct", 2, 3, 4):
+        name = {"direct": "direct fp32 (torch CPU)", 2: "F(2x2,3x3) fp32", 3: "F(3x3,3x3) fp32", 4: "F(4x4,3x3) fp32"}[k]
         for base in ("f64", "direct"):
             if base == k:
                 continue
