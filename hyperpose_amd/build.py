@@ -39,6 +39,7 @@ UNITS = [
     ("conv_fp32.hip", ["-fno-slp-vectorize"]),
     ("conv32_direct.hip", []),
     ("conv32_winograd.hip", []),
+    ("conv32_winograd3.hip", []),
     ("conv32_head.hip", []),
     ("engine.cpp", []),
     ("models.cpp", []),

@@ -41,7 +41,7 @@ __device__ __forceinline__ void conv32_drain_rows(const conv32_params& p, const 
         sl = *reinterpret_cast<const f32x4e*>(p.alpha + m);
     // rows in groups of at most four: the slab reads and residual requests of a group first, then its arithmetic and stores (all eight passes
     // of a two-tile wavefront at once cost conv32_kernel<64, 128> 56 more registers)
-    constexpr int NPASS = NROWS / R::RPP, GRP = NPASS < 4 ? NPASS : 4;
+    constexpr int NPASS = NROWS / R::RPP, GRP = NPASS < 4 ? NPASS : NPASS % 4 == 0 ? 4 : NPASS % 3 == 0 ? 3 : 1;
     static_assert(NROWS % R::RPP == 0 && NPASS % GRP == 0, "slab rows per pass");
 #pragma unroll
     for (int g = 0; g < NPASS; g += GRP) {

@@ -331,7 +331,7 @@ static int winograd_mw(const conv32_params& p)
     return (force == 8 && p.Cout_pad % 128 == 0) ? 8 : 4;
 }
 
-int conv32_winograd_tile(const conv32_params& p) { return 35000000 + 3000 + winograd_mw(p); }
+int conv32_winograd_tile(const conv32_params& p) { return p.w_wino3 ? conv32_winograd3_tile(p) : 35000000 + 3000 + winograd_mw(p); }
 
 // MFMA work of one launch (what the roofline fraction of this kernel is computed from): 16 products per tile and channel pair
 double conv32_winograd_flops(const conv32_params& p)

@@ -46,6 +46,8 @@ struct conv32_params {
     unsigned* ovf;
     // conv32_winograd_kernel (conv32_winograd.hip, HP_DTYPE_F32 only): U = G g Gt of a 3 x 3 stride-1 layer in MFMA-fragment order, or nullptr
     const float* w_wino;
+    // conv32_winograd3_kernel (conv32_winograd3.hip): U = G g Gt of the F(3 x 3, 3 x 3) form (25 positions) in the same fragment order, or nullptr
+    const float* w_wino3;
     // a depthwise 3 x 3 (stride 1, dilation dw_dil = 1 | 2, SAME padding) fused in front of this 1 x 1 convolution (conv32_direct_kernel's DWD
     // forms): `in` is then the DEPTHWISE layer's input; dw_w = [9][Cin] tap-major weights followed by [Cin] biases; y = v > 0 ? min(v, dw_hi) : v * dw_slope
     const float* dw_w;
@@ -78,7 +80,13 @@ void conv32_frag_pack(const float* packed, int taps, int cout_pad, int cin, floa
 // 16 instead of 36 MFMA products per output tile and channel pair.  Needs w_wino (conv32_winograd_pack of the packed matrix).
 bool conv32_winograd_ok(const conv32_params& p);
 hipError_t launch_conv32_winograd(const conv32_params& p, hipStream_t s);
-hipError_t conv32_winograd_occupancy(const conv32_params& p, int* blocks_per_cu); // what the runtime grants this launch's kernel
+hipError_t conv32_winograd_occupancy(const conv32_params& p, int* blocks_per_cu);
+// Winograd F(3 x 3, 3 x 3) for the same layers (conv32_winograd3.hip): 25 products per 3 x 3 output tile and channel pair - 2.78 per pixel against 4.
+// Needs w_wino3 (conv32_winograd3_pack of the packed matrix: 25 * cout_pad * cin floats).
+bool conv32_winograd3_ok(const conv32_params& p);
+hipError_t launch_conv32_winograd3(const conv32_params& p, hipStream_t s);
+int conv32_winograd3_tile(const conv32_params& p);
+void conv32_winograd3_pack(const float* packed, int cout_pad, int cin, float* out); // what the runtime grants this launch's kernel
 int conv32_winograd_tile(const conv32_params& p);     // profile rows: 35000000 + 3000 + wavefronts per block
 double conv32_winograd_flops(const conv32_params& p); // the MFMA work of one launch: 2 * 16 * tiles * Cout * Cin
 void conv32_winograd_pack(const float* packed, int cout_pad, int cin, float* out); // [9][cout_pad][cin] -> 16 * cout_pad * cin floats

@@ -700,7 +700,7 @@ int hp_engine::build(const hp_engine_desc* d)
                     p.out.p = nullptr, to.unwritten = true; // only the fp32 network output is wanted
                 HP_REQUIRE(hp::set_act32(p), HP_ERR_INVALID, "layer %zu: activation %d cannot be fused into a dense conv (use an output post-op)", i, L.act);
                 p.B = max_batch, p.npix = p.pick_npix = max_batch * g.OH * g.OW;
-                p.w_split = nullptr, p.w_frag = nullptr, p.w_wino = nullptr, p.ovf = ovf_dev, p.dbg = nullptr;
+                p.w_split = nullptr, p.w_frag = nullptr, p.w_wino = nullptr, p.w_wino3 = nullptr, p.ovf = ovf_dev, p.dbg = nullptr;
                 p.lane_epilogue = getenv("HP_LANE_EPILOGUE") ? atoi(getenv("HP_LANE_EPILOGUE")) : 0; // (A/B switches are read per build: an in-process A/B compares two engines)
                 // The layers conv32_direct_kernel covers (square 1 x 1 / 3 x 3, stride 1, whole 32- / 64-channel chunks inside the buffer's
                 // channel stride) get their weights in fragment order as well: fp32 for HP_DTYPE_F32 (HP_NO_DIRECT32=1: the A/B switch back
@@ -766,6 +766,20 @@ int hp_engine::build(const hp_engine_desc* d)
                     p.w_wino = (const float*)dwu;
                     st.wino = true;
                     st.bytes += (double)nw * 4 * (16.0 / 9 - 1);
+                    // ... or, opt-in (HP_WINO_F33=1, read per engine), F(3 x 3, 3 x 3): 25 products per 3 x 3 tile - 1.44 x fewer MFMA cycles, same accuracy
+                    // (conv32_winograd3.hip).  Measured: it wins where its 24 x 6-pixel blocks tile the map exactly and the layer is mid-sized (256 -> 256
+                    // at 32 x 24 x 24: 121 -> 87 us) and loses everywhere else - LW-OpenPose's 128 -> 128 at 8 x 46 x 54 48.6 | 28.6 us alone | paired against
+                    // 45.0 (35.9 in 8 x 8 blocks) | 27.0, every layer of PifPaf's 97 / 49 / 25-row maps - because one 16-tile column per wavefront streams
+                    // 3.1 x the U bytes per output pixel.  Not the default.
+                    const bool f33 = getenv("HP_WINO_F33") && atoi(getenv("HP_WINO_F33")) == 1;
+                    if (f33 && hp::conv32_winograd3_ok(p)) {
+                        std::vector<float> wu3((size_t)25 * cout_pad * cin_pad);
+                        hp::conv32_winograd3_pack(packed.data(), cout_pad, cin_pad, wu3.data());
+                        void* dwu3 = nullptr;
+                        HP_TRY(upload(wu3.data(), wu3.size() * sizeof(float), &dwu3));
+                        p.w_wino3 = (const float*)dwu3;
+                        st.bytes += (double)nw * 4 * (25.0 / 9 - 16.0 / 9);
+                    }
                 }
                 if (dw_in_front) // + the depthwise taps; the tensor between the two layers costs no bytes any more
                     st.flops += 2.0 * opix * L.cin * 9, st.bytes += (double)L.cin * 10 * 4;
@@ -1483,9 +1497,12 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
                 HP_HIP_TRY(hp::launch_conv32_head(st.cp32, st.hh, s));
             } else if (st.wino) {
                 st.cp32.latency = parts > 1;
-                HP_HIP_TRY(hp::launch_conv32_winograd(st.cp32, s));
+                if (st.cp32.w_wino3)
+                    HP_HIP_TRY(hp::launch_conv32_winograd3(st.cp32, s));
+                else
+                    HP_HIP_TRY(hp::launch_conv32_winograd(st.cp32, s));
                 static const bool dbg_wino = getenv("HP_DIRECT_DBG") != nullptr;
-                if (dbg_wino) { // block timeline (s_memtime = shader cycles, block (1, 0), thread 0), printed per launch
+                if (dbg_wino && !st.cp32.w_wino3) { // block timeline (s_memtime = shader cycles, block (1, 0), thread 0), printed per launch
                     unsigned long long* dbg = nullptr;
                     HP_HIP_TRY(hipMalloc(&dbg, 128 * 8));
                     HP_HIP_TRY(hipMemset(dbg, 0, 128 * 8));

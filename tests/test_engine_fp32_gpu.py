@@ -190,6 +190,36 @@ def test_winograd_3x3_layers(hp, cin, cout, h, w, act, monkeypatch):
             assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
 
 
+@pytest.mark.parametrize("cin,cout,h,w,act", [(16, 64, 23, 17, E.ACT_RELU), (48, 200, 31, 41, E.ACT_LEAKY), (128, 128, 24, 24, E.ACT_NONE), (256, 64, 25, 25, E.ACT_RELU6)])
+def test_winograd_f33_opt_in(hp, cin, cout, h, w, act, monkeypatch):
+    """conv32_winograd3_kernel (round 6, opt-in HP_WINO_F33=1): the same layers in F(3 x 3, 3 x 3) - 25 products per 3 x 3 output tile.  Ragged 24 x 6
+    pixel blocks, odd maps, one-chunk layers, residuals before / after the activation: against the oracle at the engine's one tolerance, against the
+    F(2 x 2, 3 x 3) engine at 2e-5 of scale, batch invariance bit for bit."""
+    def build():
+        net = Net(40 + cin)
+        t0 = net.conv(0, 3, cin, 3, 1)
+        a = net.conv(t0, cin, cout, 3, 1, act=act, act_param=0.2)
+        b = net.conv(a, cout, cout, 3, 1, res=a, res_before_act=0, act=E.ACT_RELU)
+        c = net.conv(b, cout, cout, 3, 1, res=b, res_before_act=1, act=act, act_param=0.2)
+        y = net.conv(c, cout, 24, 1, 1, act=E.ACT_NONE)
+        return net, [Out("y", y, 0, 24)]
+    frames = _frames(3, h, w, seed=cin + h)
+    monkeypatch.setenv("HP_WINO_F33", "1")
+    net, outs = build()
+    eng, got, _ = _run32(net, outs, frames, h, w, dtype="f32")
+    assert sum(p["tile"] == 35005004 for p in eng.profile(3, iters=1)) == 3
+    alone = eng.inference(frames[2:3])[0]
+    for (_, a1), (_, a3) in zip(alone, got[2]):
+        assert np.array_equal(a1, a3)
+    monkeypatch.delenv("HP_WINO_F33")
+    net2, outs2 = build()
+    eng2, got2, _ = _run32(net2, outs2, frames, h, w, dtype="f32")
+    assert sum(p["tile"] // 1000 == 35003 for p in eng2.profile(3, iters=1)) == 3
+    for b in range(3):
+        for (nm, x), (_, yv) in zip(got[b], got2[b]):
+            assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
+
+
 @pytest.mark.parametrize("hid,h,w,act1", [(512, 23, 27, E.ACT_RELU), (256, 9, 13, E.ACT_RELU6), (128, 16, 32, E.ACT_LEAKY)])
 def test_fused_two_layer_heads(hp, hid, h, w, act1, monkeypatch):
     """HP_DTYPE_F32: 1 x 1 128 -> HID -> 1 x 1 HID -> 19 | 38 | 64 in ONE launch (conv32_head.hip), the hidden tile's accumulator registers
