@@ -110,47 +110,53 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
     const int tile4 = 4 * wave + (lane & 3), quad4 = (lane >> 2) & 3;
     const int tsrc4 = (3 * (tile4 >> 1)) * W3_RP + (3 * (tile4 & 1)) * 64 + quad4 * 16;
     const int vdst4 = tile4 * 64 + ((quad4 ^ ((4 - (tile4 >> 2)) & 3)) * 16);
-    // the transform in ten pieces, one per MFMA step: pieces 0 - 4 read column j of the patch and apply row i of Bt down it, pieces 5 - 9 apply Bt along
-    // the row and store position (i, l)
-    f32x4 T[5];
-    auto piece = [&](int i, int ps, int src, int dstoff, int buf) {
-        if (ps < 5) {
-            const unsigned char* const col = raw + src + ps * 64;
-            auto d = [&](int r) { return *reinterpret_cast<const f32x4*>(col + r * W3_RP); };
-            switch (i) {
-            case 0:
-                T[ps] = ((2.f * d(0) - d(1)) - 2.f * d(2)) + d(3);
-                break;
-            case 1:
-                T[ps] = (d(3) - d(2)) - 2.f * d(1);
-                break;
-            case 2:
-                T[ps] = (2.f * d(1) - 3.f * d(2)) + d(3);
-                break;
-            case 3:
-                T[ps] = d(3) - d(1);
-                break;
-            default:
-                T[ps] = ((2.f * d(1) - d(2)) - 2.f * d(3)) + d(4);
-                break;
-            }
-        } else {
-            const int l = ps - 5;
-            const f32x4 v = l == 0 ? ((2.f * T[0] - T[1]) - 2.f * T[2]) + T[3]
-                : l == 1       ? (T[3] - T[2]) - 2.f * T[1]
-                : l == 2       ? (2.f * T[1] - 3.f * T[2]) + T[3]
-                : l == 3       ? T[3] - T[1]
-                               : ((2.f * T[1] - T[2]) - 2.f * T[3]) + T[4];
-            *reinterpret_cast<f32x4*>(vb + buf * W3_VBUF + (i * 5 + l) * W3_VPOS + dstoff) = v;
+    // The transform in pieces, one per MFMA step, and never a wait inside a step: step k requests column k of the patch (five ds_read_b128), step k + 1
+    // applies the wavefront's row of Bt down it (coefficients in registers: no branch on the row inside the pinned steps - a switch splits the step into
+    // basic blocks and the loads then sit right in front of their use: 48.6 | 28.6 us with it), five more steps apply Bt along the row and store
+    // position (i, l).  Own row: steps 1 - 11; the quarter of row 4: steps 12 - 22.
+    float cw[5]; // row `wave` of Bt
+    {
+        const float bt[4][5] = { { 2.f, -1.f, -2.f, 1.f, 0.f }, { 0.f, -2.f, -1.f, 1.f, 0.f }, { 0.f, 2.f, -3.f, 1.f, 0.f }, { 0.f, -1.f, 0.f, 1.f, 0.f } };
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            cw[k] = wave == 0 ? bt[0][k] : wave == 1 ? bt[1][k] : wave == 2 ? bt[2][k] : bt[3][k];
+    }
+    f32x4 T[5], dc[5];
+    auto col_load = [&](int src, int j) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+            dc[r] = *reinterpret_cast<const f32x4*>(raw + src + j * 64 + r * W3_RP);
+    };
+    auto col_own = [&](int j) { T[j] = (((cw[0] * dc[0] + cw[1] * dc[1]) + cw[2] * dc[2]) + cw[3] * dc[3]) + cw[4] * dc[4]; };
+    auto col_row4 = [&](int j) { T[j] = ((2.f * dc[1] - dc[2]) - 2.f * dc[3]) + dc[4]; };
+    auto v_store = [&](int i, int l, int dstoff, int buf) {
+        const f32x4 v = l == 0 ? ((2.f * T[0] - T[1]) - 2.f * T[2]) + T[3]
+            : l == 1       ? (T[3] - T[2]) - 2.f * T[1]
+            : l == 2       ? (2.f * T[1] - 3.f * T[2]) + T[3]
+            : l == 3       ? T[3] - T[1]
+                           : ((2.f * T[1] - T[2]) - 2.f * T[3]) + T[4];
+        *reinterpret_cast<f32x4*>(vb + buf * W3_VBUF + (i * 5 + l) * W3_VPOS + dstoff) = v;
+    };
+    // piece k = 0 .. 10 of an item: k <= 4 requests column k, 1 <= k <= 5 combines column k - 1, k >= 6 stores position l = k - 6
+    auto piece = [&](bool own, int k, int buf) {
+        if (k >= 1 && k <= 5) {
+            if (own)
+                col_own(k - 1);
+            else
+                col_row4(k - 1);
         }
+        if (k <= 4)
+            col_load(own ? tsrc : tsrc4, k);
+        if (k >= 6)
+            v_store(own ? wave : 4, k - 6, own ? vdst : vdst4, buf);
     };
     auto transform_all = [&](int buf) { // chunk 0: nothing to hide it under
 #pragma unroll
-        for (int ps = 0; ps < 10; ++ps)
-            piece(wave, ps, tsrc, vdst, buf);
+        for (int k = 0; k < 11; ++k)
+            piece(true, k, buf);
 #pragma unroll
-        for (int ps = 0; ps < 10; ++ps)
-            piece(4, ps, tsrc4, vdst4, buf);
+        for (int k = 0; k < 11; ++k)
+            piece(false, k, buf);
     };
 
     // ---- A fragments: [chunk][pos][16-row tile][lane][4 floats]; step s = chunk * 25 + pos
@@ -194,11 +200,11 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][e], fb[cur][e], acc[pos], 0, 0, 0);
-            // chunk c + 1's transform under this chunk's MFMAs, a piece per step: the wavefront's own row in steps 1 - 10, its quarter of row 4 in 12 - 21
-            if (pos >= 1 && pos <= 10)
-                piece(wave, pos - 1, tsrc, vdst, (c + 1) & 1);
-            if (pos >= 12 && pos <= 21)
-                piece(4, pos - 12, tsrc4, vdst4, (c + 1) & 1);
+            // chunk c + 1's transform under this chunk's MFMAs, a piece per step: the wavefront's own row in steps 1 - 11, its quarter of row 4 in 12 - 22
+            if (pos >= 1 && pos <= 11)
+                piece(true, pos - 1, (c + 1) & 1);
+            if (pos >= 12 && pos <= 22)
+                piece(false, pos - 12, (c + 1) & 1);
             // issue order of a step (hipcc otherwise sinks every load to just before its use): MFMA, LDS read (the next position's B), MFMA, L2 read (A four
             // steps ahead), two MFMAs; the transform's piece goes wherever hipcc finds room between them
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
