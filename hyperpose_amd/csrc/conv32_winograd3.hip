@@ -73,6 +73,11 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
     const int y0 = ty * W3_BH, x0 = tx * W3_BW;
     const int MT = p.Cout_pad / 16, mt = by * 4 + wave;
     const int nch = p.Cin / W3_CK;
+    int dbg_i = 0;
+#define HP_STAMP()                                                          \
+    if (p.dbg && blockIdx.x == 9 && tid == 0 && dbg_i < 60)                \
+        p.dbg[dbg_i++] = __builtin_amdgcn_s_memtime();
+    HP_STAMP();
 
     // ---- staging geometry: quad q of a chunk = (halo pixel q / 4, channels 4 (q % 4) ..); halo pixel (hy, hx) = image pixel (y0 - 1 + hy, x0 - 1 + hx).
     // The tensor's zero halo is the convolution's padding; pixels further out (ragged last tiles) are clamped to it and zeroed
@@ -102,33 +107,29 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
     };
 
     // ---- input transform: item i = row i of Bt d B for the block's 16 tiles; lane (tile, quad) like the MFMA's B read.  Wavefront w forms row w;
-    // row 4 is cut in four: wavefront w forms it for tiles 4 w .. 4 w + 3 (lane & 15 = (tile & 3, quad); the other lanes repeat lanes 0 - 15 - the same
-    // values to the same addresses - rather than branch inside the pinned MFMA steps).
+    // row 4 is formed by wavefront (chunk & 3).
     const int btile = lane & 15, kq = lane >> 4;
     const int vdst = btile * 64 + ((kq ^ ((4 - (btile >> 2)) & 3)) * 16); // (quad index XOR-ed with a function of the tile: ds_write_b128 / ds_read_b128 conflict-free)
     const int tsrc = (3 * (btile >> 1)) * W3_RP + (3 * (btile & 1)) * 64 + kq * 16;
-    const int tile4 = 4 * wave + (lane & 3), quad4 = (lane >> 2) & 3;
-    const int tsrc4 = (3 * (tile4 >> 1)) * W3_RP + (3 * (tile4 & 1)) * 64 + quad4 * 16;
-    const int vdst4 = tile4 * 64 + ((quad4 ^ ((4 - (tile4 >> 2)) & 3)) * 16);
     // The transform in pieces, one per MFMA step, and never a wait inside a step: step k requests column k of the patch (five ds_read_b128), step k + 1
     // applies the wavefront's row of Bt down it (coefficients in registers: no branch on the row inside the pinned steps - a switch splits the step into
     // basic blocks and the loads then sit right in front of their use: 48.6 | 28.6 us with it), five more steps apply Bt along the row and store
-    // position (i, l).  Own row: steps 1 - 11; the quarter of row 4: steps 12 - 22.
-    float cw[5]; // row `wave` of Bt
+    // position (i, l).  Own row: steps 1 - 11; row 4 (one wavefront per chunk): steps 12 - 22.
+    float cw[4]; // row `wave` of Bt (rows 0 - 3 of Bt have no fifth entry: patch rows 0 - 3 are all they read)
     {
-        const float bt[4][5] = { { 2.f, -1.f, -2.f, 1.f, 0.f }, { 0.f, -2.f, -1.f, 1.f, 0.f }, { 0.f, 2.f, -3.f, 1.f, 0.f }, { 0.f, -1.f, 0.f, 1.f, 0.f } };
+        const float bt[4][4] = { { 2.f, -1.f, -2.f, 1.f }, { 0.f, -2.f, -1.f, 1.f }, { 0.f, 2.f, -3.f, 1.f }, { 0.f, -1.f, 0.f, 1.f } };
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
+        for (int k = 0; k < 4; ++k)
             cw[k] = wave == 0 ? bt[0][k] : wave == 1 ? bt[1][k] : wave == 2 ? bt[2][k] : bt[3][k];
     }
-    f32x4 T[5], dc[5];
-    auto col_load = [&](int src, int j) {
+    f32x4 T[5], dc[4];
+    auto col_load = [&](int row0, int j) { // patch rows row0 .. row0 + 3 of column j
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
-            dc[r] = *reinterpret_cast<const f32x4*>(raw + src + j * 64 + r * W3_RP);
+        for (int r = 0; r < 4; ++r)
+            dc[r] = *reinterpret_cast<const f32x4*>(raw + tsrc + j * 64 + (row0 + r) * W3_RP);
     };
-    auto col_own = [&](int j) { T[j] = (((cw[0] * dc[0] + cw[1] * dc[1]) + cw[2] * dc[2]) + cw[3] * dc[3]) + cw[4] * dc[4]; };
-    auto col_row4 = [&](int j) { T[j] = ((2.f * dc[1] - dc[2]) - 2.f * dc[3]) + dc[4]; };
+    auto col_own = [&](int j) { T[j] = ((cw[0] * dc[0] + cw[1] * dc[1]) + cw[2] * dc[2]) + cw[3] * dc[3]; };
+    auto col_row4 = [&](int j) { T[j] = ((2.f * dc[0] - dc[1]) - 2.f * dc[2]) + dc[3]; }; // (dc = patch rows 1 .. 4)
     auto v_store = [&](int i, int l, int dstoff, int buf) {
         const f32x4 v = l == 0 ? ((2.f * T[0] - T[1]) - 2.f * T[2]) + T[3]
             : l == 1       ? (T[3] - T[2]) - 2.f * T[1]
@@ -146,17 +147,20 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
                 col_row4(k - 1);
         }
         if (k <= 4)
-            col_load(own ? tsrc : tsrc4, k);
+            col_load(own ? 0 : 1, k);
         if (k >= 6)
-            v_store(own ? wave : 4, k - 6, own ? vdst : vdst4, buf);
+            v_store(own ? wave : 4, k - 6, vdst, buf);
     };
+    // row 4 of a chunk is formed by ONE wavefront, in turn: wavefront (chunk & 3) (a branch on the wavefront's index, around whole pieces only)
     auto transform_all = [&](int buf) { // chunk 0: nothing to hide it under
 #pragma unroll
         for (int k = 0; k < 11; ++k)
             piece(true, k, buf);
+        if (wave == 0) {
 #pragma unroll
-        for (int k = 0; k < 11; ++k)
-            piece(false, k, buf);
+            for (int k = 0; k < 11; ++k)
+                piece(false, k, buf);
+        }
     };
 
     // ---- A fragments: [chunk][pos][16-row tile][lane][4 floats]; step s = chunk * 25 + pos
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
     gload(1);
     lds_barrier();
     transform_all(0);
+    HP_STAMP();
     int s = 0;
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
         to_lds();      // chunk c + 1's patch
         gload(c + 2);  // (past the last chunk: a harmless re-read of it)
         lds_barrier(); // the patch is complete
+        HP_STAMP();
         const unsigned char* const vcur = vsrc + (c & 1) * W3_VBUF;
         f32x4 fb[2];
         fb[0] = *reinterpret_cast<const f32x4*>(vcur);
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
             // chunk c + 1's transform under this chunk's MFMAs, a piece per step: the wavefront's own row in steps 1 - 11, its quarter of row 4 in 12 - 22
             if (pos >= 1 && pos <= 11)
                 piece(true, pos - 1, (c + 1) & 1);
-            if (pos >= 12 && pos <= 22)
+            if (pos >= 12 && pos <= 22 && wave == ((c + 1) & 3))
                 piece(false, pos - 12, (c + 1) & 1);
             // issue order of a step (hipcc otherwise sinks every load to just before its use): MFMA, LDS read (the next position's B), MFMA, L2 read (A four
             // steps ahead), two MFMAs; the transform's piece goes wherever hipcc finds room between them
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
             __builtin_amdgcn_sched_barrier(0);
             ++s;
         }
+        HP_STAMP();
     }
 
     // ---- output transform Y = At M A, per lane: tile btile, channels 16 wave + 4 kq + r; then whole pixel rows through the block's slab.
@@ -241,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
             *reinterpret_cast<f32x4*>(row + 2 * W3_SLAB_PITCH) = y2v;
         }
     }
+    HP_STAMP();
     lds_barrier(); // the slab holds all 64 channels of the block's 144 pixels; wavefront w stores rows 36 w ..
     constexpr int RPW = W3_BH * W3_BW / 4;
     conv32_drain_rows<2, RPW>(p, slab + wave * RPW * W3_SLAB_PITCH, lane, by * 64, [&](int r, bool& ok, long& ooff, long& roff) {
@@ -251,6 +259,8 @@ __global__ __launch_bounds__(256, 2) void conv32_winograd3_kernel(const conv32_p
         ooff = tv3_off(p.out, b, oyc, oxc);
         roff = p.res.p ? tv3_off(p.res, b, oyc, oxc) : 0;
     });
+    HP_STAMP();
+#undef HP_STAMP
 }
 
 // 3 x 3, stride 1, dilation 1, SAME padding, input slice readable in whole 16-channel chunks, NHWC output only

@@ -1497,9 +1497,26 @@ int hp_engine::run_step(step& st, const uint8_t* u8, const float* f32, int n, hi
                 HP_HIP_TRY(hp::launch_conv32_head(st.cp32, st.hh, s));
             } else if (st.wino) {
                 st.cp32.latency = parts > 1;
-                if (st.cp32.w_wino3)
+                if (st.cp32.w_wino3) {
                     HP_HIP_TRY(hp::launch_conv32_winograd3(st.cp32, s));
-                else
+                    static const bool dbg_w3 = getenv("HP_DIRECT_DBG") != nullptr;
+                    if (dbg_w3) { // block timeline (s_memtime, block 9, thread 0): start | chunk 0 transformed | per chunk: patch stored, multiplied | transformed out | stored
+                        unsigned long long* dbg = nullptr;
+                        HP_HIP_TRY(hipMalloc(&dbg, 64 * 8));
+                        HP_HIP_TRY(hipMemset(dbg, 0, 64 * 8));
+                        hp::conv32_params q = st.cp32;
+                        q.dbg = dbg;
+                        HP_HIP_TRY(hp::launch_conv32_winograd3(q, s));
+                        HP_HIP_TRY(hipStreamSynchronize(s));
+                        unsigned long long h[64];
+                        HP_HIP_TRY(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+                        fprintf(stderr, "winograd3 layer %d %d->%d cycles [start | chunk 0 transformed | per chunk: patch stored, multiplied | output transformed | stored]:", st.layer, q.Cin, q.Cout);
+                        for (int i = 1; i < 60 && h[i]; ++i)
+                            fprintf(stderr, " %llu", h[i] - h[i - 1]);
+                        fprintf(stderr, "\n");
+                        (void)hipFree(dbg);
+                    }
+                } else
                     HP_HIP_TRY(hp::launch_conv32_winograd(st.cp32, s));
                 static const bool dbg_wino = getenv("HP_DIRECT_DBG") != nullptr;
                 if (dbg_wino && !st.cp32.w_wino3) { // block timeline (s_memtime = shader cycles, block (1, 0), thread 0), printed per launch
