@@ -767,6 +767,8 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
     else                                                                                   \
         HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, s, p);
     if (BN == 160) {
+        // (three blocks per CU instead of four - 12 KB of unused dynamic LDS, to leave registers and LDS to the other pipes' depthwise kernels - cost four
+        // pipes 1.3 %: 1.466 -> 1.485 ms of conv stack per batch, two runs each)
         HP_LAUNCH((conv32_t16_kernel<160>), grid, dim3(256), 0, s, p);
     } else if (BM == 128) {
         HP_C32_CASE(128, 128, 2, 2)
