@@ -422,7 +422,11 @@ def kernel_label(tile: int):
                 "the hidden tile's accumulator registers are the second layer's B operand; the heat-map and PAF heads of a stage share one grid)")
     if tile >= 35000000:
         mw = tile % 1000
-        return (f"conv32_winograd_kernel<{mw},{'true' if mw == 4 else 'false'}>", f"conv32_winograd_kernel<MW={mw}> (fp32 3x3 stride-1 convolution in Winograd's F(2x2,3x3) form on v_mfma_f32_16x16x4_f32: 16 MFMA "
+        if tile // 1000 == 35005:
+            return ("conv32_winograd3_kernel", "conv32_winograd3_kernel (opt-in HP_WINO_F33=1: fp32 3x3 stride-1 convolution in Winograd's F(3x3,3x3) form on v_mfma_f32_16x16x4_f32: 25 MFMA products "
+                    "per 3x3 output tile and channel pair instead of 81; 64 cout x 24x6 px per block)")
+        # (third template argument: 16-tile MFMA columns per block - 2 = the 16 x 8-pixel form of every pipelined run, 1 = the 8 x 8-pixel form a caller with one batch in flight gets)
+        return (f"conv32_winograd_kernel<{mw},{'true' if mw == 4 else 'false'},2>", f"conv32_winograd_kernel<MW={mw}> (fp32 3x3 stride-1 convolution in Winograd's F(2x2,3x3) form on v_mfma_f32_16x16x4_f32: 16 MFMA "
                 f"products per output tile and channel pair instead of 36; {16 * mw} cout x 16x8 px per block, input transform through LDS, U = G g Gt in fragment order from L2; "
                 "flops = the MFMA work issued)")
     if 35000000 > tile >= 33000000 and (tile // 100000) % 10:  # a depthwise 3 x 3 fused in front of the 1 x 1 layer
