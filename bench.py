@@ -447,8 +447,11 @@ def kernel_label(tile: int):
         bm, bn = v // 1000, v % 1000
         wm, wn = (1, 4) if (bm, bn) == (64, 128) else (2, 2)
         if bn == 160:
-            return ("conv32_t16_kernel<160>", "conv32_t16_kernel<BN=160> (fp32 implicit GEMM on v_mfma_f32_16x16x4_f32: 64 cout x 160 pixels per block = ONE round of "
+            return ("conv32_t16_kernel<160,2>", "conv32_t16_kernel<BN=160> (fp32 implicit GEMM on v_mfma_f32_16x16x4_f32: 64 cout x 160 pixels per block = ONE round of "
                     "four blocks per CU where 64 x 128 tiles need a round and a bit; 2 x 2 wavefronts of 32 x 80, A and B staged through swizzled LDS, K-steps of 16 channels)")
+        if bn == 176:
+            return ("conv32_t16_kernel<176,1>", "conv32_t16_kernel<BN=176> (fp32 implicit GEMM on v_mfma_f32_16x16x4_f32: 64 cout x 176 pixels per block = ONE round of "
+                    "four blocks per CU where 64 x 160 tiles are a few blocks more than the chip's 1024 slots; four wavefronts of 16 x 176, swizzled LDS, K-steps of 16 channels)")
         return (f"conv32_kernel<{bm},{bn},{wm},{wn},{'true' if rows else 'false'}>", f"conv32_kernel<BM={bm},BN={bn}> (fp32 implicit GEMM on v_mfma_f32_32x32x2_f32: {bm} cout x {bn} pixels per block, "
                 f"A and B staged through LDS in fp32, K-steps of 16 channels, {'row-major' if rows else 'lane = pixel'} epilogue)")
     if tile >= 9000000:

@@ -290,18 +290,21 @@ __global__ __launch_bounds__(256) void conv32_kernel(const conv32_params p)
 // = 32 KB per block.  K order as in conv32_kernel: lane (row, kq) reads channels [4 kq, 4 kq + 4) with one ds_read_b128 and feeds element e to
 // MFMA e - A and B use the same permutation.  Epilogue: lane (pixel n, q) of a 16 x 16 tile holds channels 4 q .. 4 q + 3 of pixel n: one
 // global_store_dwordx4 of a wavefront covers 16 pixels x 64 contiguous bytes.
-template <int BN>
+// WN = wavefronts side by side over the pixels (2: 2 x 2 wavefronts of 32 channels x BN / 2 pixels; 1: four wavefronts of 16 channels x all BN pixels -
+// any multiple of 16 pixels per block, e.g. 176: OpenPose-VGG19's 7 x 7 layers at 16 x 54 x 96 are 1 296 tiles of 64 x 128, 1 038 of 64 x 160 - 14 more
+// than the chip's 1 024 slots - and 944 of 64 x 176: one round).
+template <int BN, int WN = 2>
 __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
 {
-    constexpr int BM = 64, BK = 16, TMW = 2, TNW = BN / 2 / 16; // a wavefront: TMW x TNW tiles of 16 x 16
+    constexpr int BM = 64, BK = 16, WM = 4 / WN, TMW = BM / 16 / WM, TNW = BN / WN / 16; // a wavefront: TMW x TNW tiles of 16 x 16
     constexpr int NB = (BN + 63) / 64, BR = NB * 64;             // staging passes of the B tile (64 rows each); rows allocated
-    static_assert(BN % 32 == 0, "two wavefront columns of whole 16-pixel tiles");
+    static_assert(BN % (16 * WN) == 0 && (WN == 1 || WN == 2), "wavefront columns of whole 16-pixel tiles");
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BR) * BK];
     float (*const sA)[BM * BK] = reinterpret_cast<float (*)[BM * BK]>(lds);
     float (*const sB)[BR * BK] = reinterpret_cast<float (*)[BR * BK]>(lds + 2 * BM * BK);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int G = p.Cout_pad / BM, nx = (p.npix + BN - 1) / BN; // XCD-aware 1-D block order: see conv32_kernel
     const int bj = blockIdx.x >> 3, ptile = (bj / G) * 8 + (blockIdx.x & 7);
     if (ptile >= nx)
@@ -365,10 +368,10 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
         f32x4 fa[TMW], fb[TNW];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
-            fa[i] = *reinterpret_cast<const f32x4*>(&sA[s & 1][swz(wm * 32 + i * 16 + fr, kq)]);
+            fa[i] = *reinterpret_cast<const f32x4*>(&sA[s & 1][swz(wm * (16 * TMW) + i * 16 + fr, kq)]);
 #pragma unroll
         for (int j = 0; j < TNW; ++j)
-            fb[j] = *reinterpret_cast<const f32x4*>(&sB[s & 1][swz(wn * (BN / 2) + j * 16 + fr, kq)]);
+            fb[j] = *reinterpret_cast<const f32x4*>(&sB[s & 1][swz(wn * (BN / WN) + j * 16 + fr, kq)]);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
             HP_STAMP();
     }
 
-    // epilogue: lane (n, q) of tile (i, j) holds channels m0 + wm * 32 + i * 16 + 4 q + {0..3} of pixel n0 + wn * BN / 2 + j * 16 + n
+    // epilogue: lane (n, q) of tile (i, j) holds channels m0 + wm * 16 TMW + i * 16 + 4 q + {0..3} of pixel n0 + wn * BN / WN + j * 16 + n
     const int q = lane >> 4;
     const bool out_vec = p.out.p && ((p.out.coff | p.out.cs) & 3) == 0;
     const bool res_vec = p.res.p && ((p.res.coff | p.res.cs) & 3) == 0;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
     f32x4 bs[TMW], sl[TMW];
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
-        const int m = m0 + wm * 32 + i * 16 + 4 * q; // (m + 3 < Cout_pad)
+        const int m = m0 + wm * (16 * TMW) + i * 16 + 4 * q; // (m + 3 < Cout_pad)
         bs[i] = *reinterpret_cast<const f32x4*>(p.bias + m);
         sl[i] = f32x4{ p.act_slope, p.act_slope, p.act_slope, p.act_slope };
         if (p.alpha)
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
     }
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + fr;
+        const int n = n0 + wn * (BN / WN) + j * 16 + fr;
         const bool pix_ok = n < p.npix;
         const int nc = min(n, p.npix - 1);
         const int b = nc / OHW, rem = nc - b * OHW;
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256) void conv32_t16_kernel(const conv32_params p)
         const long roff = p.res.p ? tv32_off(p.res, b, oy, ox) : 0;
 #pragma unroll
         for (int i = 0; i < TMW; ++i) {
-            const int m = m0 + wm * 32 + i * 16 + 4 * q;
+            const int m = m0 + wm * (16 * TMW) + i * 16 + 4 * q;
             if (!pix_ok || m >= p.Cout)
                 continue;
             const bool full = m + 3 < p.Cout;
@@ -686,8 +689,8 @@ static void conv32_pick(const conv32_params& p, int& BM, int& BN)
     // Round quantisation: 64 x 128 tiles have 1024 slots (four blocks per CU); a layer that is "one round and a bit" of them but ONE round of
     // 64 x 160 tiles takes conv32_t16_kernel<160> (see there).  HP_C32_BN160=0: the A/B switch back; =1: every layer (tests).  Read per launch.
     const int bn160 = getenv("HP_C32_BN160") ? atoi(getenv("HP_C32_BN160")) : -1;
-    if (bn160 == 1) {
-        BM = 64, BN = 160;
+    if (bn160 == 1 || bn160 == 176) { // (tests: every layer on the 64 x 160 | 64 x 176 tile)
+        BM = 64, BN = bn160 == 1 ? 160 : 176;
         return;
     }
     if (BM == 64 && BN == 128 && bn160 != 0) {
@@ -695,6 +698,9 @@ static void conv32_pick(const conv32_params& p, int& BM, int& BN)
         const long g = p.Cout_pad / 64, b128 = (long)((np + 127) / 128) * g, b160 = (long)((np + 159) / 160) * g;
         if (b128 > 1024 && b160 <= 1024)
             BN = 160;
+        // (b160 a few blocks over the 1 024 slots - OpenPose-VGG19's 7 x 7 layers at 16 x 54 x 96: 1 296 tiles of 64 x 128, 1 038 of 64 x 160, 944 of
+        // 64 x 176 = conv32_t16_kernel<176, 1>, one round: 1 272 -> 1 172 us alone, but 1 039 -> 1 053 with a second stream, whose blocks fill the
+        // second round's empty slots anyway: not taken; HP_C32_BN160=176 forces it, tests/test_engine_fp32_gpu.py::test_one_round_tile_64x160)
     }
     // ResNet's 1 x 1 expansions with few input channels (64 -> 256 at 96 x 96, 128 -> 512 at 48 x 48, batch 32): four to eight K-steps, then 300 MB
     // of output + residual - the layer is its epilogue.  conv32_t16_kernel's stores cover 16 pixels x 64 contiguous bytes per instruction where
@@ -706,7 +712,7 @@ static void conv32_pick(const conv32_params& p, int& BM, int& BN)
 
 static bool conv32_rows(const conv32_params& p, int BN)
 {
-    if (BN == 160)
+    if (BN == 160 || BN == 176)
         return false; // conv32_t16_kernel has the one epilogue (16 pixels x 64 contiguous bytes per store instruction)
     // The row-major epilogue pays on the 64-pixel tile only.  Measured per layer of LW-OpenPose @ 8 x 46 x 54 (us alone | with a second
     // stream; rows -> lane = pixel): <64, 64> 256 -> 256 33.2 | 26.9 -> 33.8 | 29.2, 128 -> 256 21.3 | 15.8 -> 21.7 | 19.0;  <64, 128> (two
@@ -766,7 +772,9 @@ hipError_t launch_conv32(const conv32_params& p, hipStream_t s)
         HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, true>), grid, dim3(256), 0, s, p);    \
     else                                                                                   \
         HP_LAUNCH((conv32_kernel<BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, s, p);
-    if (BN == 160) {
+    if (BN == 176) {
+        HP_LAUNCH((conv32_t16_kernel<176, 1>), grid, dim3(256), 0, s, p);
+    } else if (BN == 160) {
         // (three blocks per CU instead of four - 12 KB of unused dynamic LDS, to leave registers and LDS to the other pipes' depthwise kernels - cost four
         // pipes 1.3 %: 1.466 -> 1.485 ms of conv stack per batch, two runs each)
         HP_LAUNCH((conv32_t16_kernel<160>), grid, dim3(256), 0, s, p);

@@ -258,8 +258,9 @@ def test_fused_two_layer_heads(hp, hid, h, w, act1, monkeypatch):
             assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
 
 
-@pytest.mark.parametrize("cin,cout,k,h,w", [(64, 128, 1, 40, 52), (128, 512, 1, 23, 27), (512, 512, 1, 23, 27), (96, 200, 3, 19, 33), (32, 64, 1, 61, 47)])
-def test_one_round_tile_64x160(hp, cin, cout, k, h, w, monkeypatch):
+@pytest.mark.parametrize("force,tile", [("1", 32064160), ("176", 32064176)])
+@pytest.mark.parametrize("cin,cout,k,h,w", [(64, 128, 1, 40, 52), (128, 512, 1, 23, 27), (512, 512, 1, 23, 27), (96, 200, 3, 19, 33), (32, 64, 1, 61, 47), (128, 128, 7, 20, 23)])
+def test_one_round_tile_64x160(hp, cin, cout, k, h, w, force, tile, monkeypatch):
     """conv32_t16_kernel<160> (round 6: 64 output channels x 160 pixels per block on v_mfma_f32_16x16x4_f32, taken where 64 x 128 tiles are
     "a round and a bit" of the chip's 1024 slots): forced here (HP_C32_BN160=1) on layers whose pixel counts are not multiples of 160 / 80 /
     16, with residuals and every activation form - against the oracle at the engine's tolerance, against conv32_kernel<64, 128>
@@ -273,17 +274,18 @@ def test_one_round_tile_64x160(hp, cin, cout, k, h, w, monkeypatch):
         y = net.conv(c, 70, 38, 1, 1, act=E.ACT_NONE)
         return net, [Out("y", y, 0, 38), Out("c", c, 0, 70), Out("b", b, 0, cout)]
     frames = _frames(5, h, w, seed=cin + k)
-    monkeypatch.setenv("HP_C32_BN160", "1")
+    monkeypatch.setenv("HP_C32_BN160", force)  # "1": conv32_t16_kernel<160, 2>; "176": conv32_t16_kernel<176, 1> (four wavefronts of 16 channels x 176 pixels)
+    monkeypatch.setenv("HP_C32_WK", "0")
     net, outs = build()
     eng, got, _ = _run32(net, outs, frames, h, w, dtype="f32")
-    assert sum(p["tile"] == 32064160 for p in eng.profile(5, iters=1)) >= 2, [p["tile"] for p in eng.profile(5, iters=1)]
+    assert sum(p["tile"] == tile for p in eng.profile(5, iters=1)) >= 2, [p["tile"] for p in eng.profile(5, iters=1)]
     alone = eng.inference(frames[3:4])[0]
     for (_, a1), (_, a5) in zip(alone, got[3]):
         assert np.array_equal(a1, a5)
     monkeypatch.setenv("HP_C32_BN160", "0")
     net2, outs2 = build()
     eng2, got2, _ = _run32(net2, outs2, frames, h, w, dtype="f32")
-    assert not [p for p in eng2.profile(5, iters=1) if p["tile"] == 32064160]
+    assert not [p for p in eng2.profile(5, iters=1) if p["tile"] in (32064160, 32064176)]
     for b in range(5):
         for (nm, x), (_, yv) in zip(got[b], got2[b]):
             assert np.abs(x - yv).max() <= 2e-5 * np.abs(yv).max() + 1e-6, nm
