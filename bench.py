@@ -643,6 +643,8 @@ def roofline(pipe, batch, cfg, frames_dev=None):
                             "avg_launch_us": round(d2["ms"] / d2["n"] * 1e3, 2),
                             "share_of_serial_step": round(d2["ms"] / tot_ms, 4), "intensity_flop_per_byte": round(in2, 1),
                             "bound": "mfma" if in2 >= ridge else "hbm", "frac_mfma": round(tf2 / peak_tflops, 4), "frac_hbm": round(gb2 / PEAK_HBM_GBS, 4)}
+        busy2, _, _ = pmc_mfma_busy(kernel_label(t2)[0], tag)  # (from the committed SQ pass, like the dominant kernel's)
+        out["runner_up"]["mfma_busy"] = busy2
     out["share_of_serial_step"] = round(dom["ms"] / tot_ms, 4)
     if warm is not None:
         out["back_to_back_us"] = round(sum(p["ms"] for p in warm if p["tile"] == dom_tile) / dom["n"] * 1e3, 2)
@@ -990,7 +992,11 @@ def compact_roofline(r):
             "all_mfma_convs_frac": r["all_mfma_convs"]["frac"],
             **({"frac_mfma_issued": r["frac_mfma_issued"], "note": "Winograd F(2x2,3x3): frac = algorithmic (direct-form) flops / time / peak; frac_mfma_issued = the 16/36 of them the pipe executes"}
                if "frac_mfma_issued" in r else {}),
-            "committed_profile": {"source": cp.get("source"), "avg_launch_us": cp.get("avg_launch_us"), "frac": cp.get(frac_key)}}
+            "committed_profile": {"source": cp.get("source"), "avg_launch_us": cp.get("avg_launch_us"), "frac": cp.get(frac_key)},
+            # the kernel with the second-largest share of the step, in four numbers (the rest: the detail file)
+            **({"runner_up": {"kernel": _short((r["runner_up"].get("kernel_symbol") or ""), 40), "share": r["runner_up"].get("share_of_serial_step"),
+                              "frac": r["runner_up"].get("frac_mfma" if r["runner_up"].get("bound") == "mfma" else "frac_hbm"),
+                              "mfma_busy": r["runner_up"].get("mfma_busy")}} if r.get("runner_up") else {})}
 
 
 def compact_line(detail):
@@ -1046,7 +1052,7 @@ def compact_line(detail):
                 out["value_" + tag] = w["value"]
                 r = compact_roofline(w.get("roofline"))
                 if r:
-                    for k in ("flops_per_launch", "algorithmic_bytes_per_launch", "all_mfma_convs_frac", "traffic", "mfma_busy_source", "note", "frac_mfma", "frac_hbm"):
+                    for k in ("flops_per_launch", "algorithmic_bytes_per_launch", "all_mfma_convs_frac", "traffic", "mfma_busy_source", "note", "frac_mfma", "frac_hbm", "runner_up"):
                         r.pop(k, None)
                 out["roofline_" + tag] = r
     out["detail"] = detail.get("detail_file")
