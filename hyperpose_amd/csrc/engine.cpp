@@ -770,7 +770,8 @@ int hp_engine::build(const hp_engine_desc* d)
                     // (conv32_winograd3.hip).  Measured: it wins where its 24 x 6-pixel blocks tile the map exactly and the layer is mid-sized (256 -> 256
                     // at 32 x 24 x 24: 121 -> 87 us) and loses everywhere else - LW-OpenPose's 128 -> 128 at 8 x 46 x 54 48.6 | 28.6 us alone | paired against
                     // 45.0 (35.9 in 8 x 8 blocks) | 27.0, every layer of PifPaf's 97 / 49 / 25-row maps - because one 16-tile column per wavefront streams
-                    // 3.1 x the U bytes per output pixel.  Not the default.
+                    // 3.1 x the U bytes per output pixel.  Not the default: taken by itself only on PoseProposal's exactly tiled 48 x 48 / 24 x 24
+                    // stages it made configs[3] 0.6 % faster (4 353 -> 4 380 frames/s resident, two runs each) - not worth a second numeric path.
                     const bool f33 = getenv("HP_WINO_F33") && atoi(getenv("HP_WINO_F33")) == 1;
                     if (f33 && hp::conv32_winograd3_ok(p)) {
                         std::vector<float> wu3((size_t)25 * cout_pad * cin_pad);
